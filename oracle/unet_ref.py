@@ -1,0 +1,234 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY. Never imported by the product path.
+
+CPU restatement (torch-CPU autograd, fp32 or fp64) of the reference's 2-D U-Net
+train / predict step:
+
+  topology, layer order, names ........ mpunet/models/unet.py:114-216
+  Keras layer defaults ................ SURVEY.md section 8a row a6 (TF 2.3 API)
+  loss / optimizer constants .......... mpunet/bin/defaults/MultiPlanar/train_hparams.yaml:108-126
+  compile (reduction=NONE) ............ mpunet/train/trainer.py:78-97, mpunet/bin/train.py:357
+  fusion layer ........................ mpunet/models/fusion_model.py:38-39
+
+PARITY UNPINNED for this file: the arithmetic lives in tensorflow==2.3.2
+(requirements.txt:10), which is absent from /root/reference and from this
+image, and the reference's own tests hold no vectors for it. The
+restatement is anchored on hand-computable known-answer tests
+(tests/test_oracle_unet_kat.py).
+
+Weights are a dict keyed "<keras layer name>/<var>" with Keras layouts:
+conv kernel HWIO (kh,kw,Cin,Cout), bias (Cout,), BN gamma/beta/moving_mean/
+moving_variance (C,). The unnamed 1x1 head is Keras' auto-name "conv2d".
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3          # keras BatchNormalization default epsilon
+BN_MOMENTUM = 0.99     # keras default momentum
+CE_EPS = 1e-7          # keras.backend.epsilon()
+
+
+def filters_at(level, cf):
+    """int(64 * 2**level * sqrt(cf)); unet.py:91,120,132,195."""
+    return int(64 * (2 ** level) * np.sqrt(cf))
+
+
+def layer_specs(n_classes, n_channels=1, depth=4, complexity_factor=1):
+    """Ordered (name, kind, shape) list in unet.py creation order."""
+    specs = []
+    cin = n_channels
+    for i in range(depth):
+        f = filters_at(i, complexity_factor)
+        specs.append(("encoder_L%d_conv1" % i, "conv", (3, 3, cin, f)))
+        specs.append(("encoder_L%d_conv2" % i, "conv", (3, 3, f, f)))
+        specs.append(("encoder_L%d_BN" % i, "bn", (f,)))
+        cin = f
+    f = filters_at(depth, complexity_factor)
+    specs.append(("bottom_conv1", "conv", (3, 3, cin, f)))
+    specs.append(("bottom_conv2", "conv", (3, 3, f, f)))
+    specs.append(("bottom_BN", "bn", (f,)))
+    cin = f
+    for i in range(depth):
+        f = filters_at(depth - 1 - i, complexity_factor)
+        specs.append(("upsample_L%d_conv1" % i, "conv", (2, 2, cin, f)))
+        specs.append(("upsample_L%d_BN1" % i, "bn", (f,)))
+        specs.append(("upsample_L%d_conv2" % i, "conv", (3, 3, 2 * f, f)))
+        specs.append(("upsample_L%d_conv3" % i, "conv", (3, 3, f, f)))
+        specs.append(("upsample_L%d_BN2" % i, "bn", (f,)))
+        cin = f
+    specs.append(("conv2d", "conv", (1, 1, cin, n_classes)))
+    return specs
+
+
+def init_weights(n_classes, n_channels=1, depth=4, complexity_factor=1, seed=0):
+    """Keras defaults: glorot_uniform kernels, zero bias, BN 1/0/0/1."""
+    rng = np.random.RandomState(seed)
+    w = {}
+    for name, kind, shp in layer_specs(n_classes, n_channels, depth,
+                                       complexity_factor):
+        if kind == "conv":
+            kh, kw, ci, co = shp
+            lim = np.sqrt(6.0 / (kh * kw * ci + kh * kw * co))
+            w[name + "/kernel"] = rng.uniform(-lim, lim, shp).astype(np.float32)
+            w[name + "/bias"] = np.zeros(co, np.float32)
+        else:
+            c = shp[0]
+            w[name + "/gamma"] = np.ones(c, np.float32)
+            w[name + "/beta"] = np.zeros(c, np.float32)
+            w[name + "/moving_mean"] = np.zeros(c, np.float32)
+            w[name + "/moving_variance"] = np.ones(c, np.float32)
+    return w
+
+
+def trainable_names(w):
+    return [k for k in w if not k.split("/")[1].startswith("moving")]
+
+
+def _conv(x, k, b, relu=True):
+    """Keras Conv2D(padding='same'), x NCHW, k HWIO. 2x2 SAME pads 0 top/left, 1 bottom/right."""
+    kh, kw = k.shape[0], k.shape[1]
+    wt = k.permute(3, 2, 0, 1)
+    pt, pl = (kh - 1) // 2, (kw - 1) // 2
+    pb, pr = kh - 1 - pt, kw - 1 - pl
+    x = F.pad(x, (pl, pr, pt, pb))
+    y = F.conv2d(x, wt, b)
+    return torch.relu(y) if relu else y
+
+
+def _bn(x, p, name, training, new_stats):
+    g, b = p[name + "/gamma"], p[name + "/beta"]
+    if training:
+        mean = x.mean(dim=(0, 2, 3))
+        var = x.var(dim=(0, 2, 3), unbiased=False)
+        n = x.shape[0] * x.shape[2] * x.shape[3]
+        if new_stats is not None:
+            mm, mv = p[name + "/moving_mean"], p[name + "/moving_variance"]
+            ub = var.detach() * (n / max(n - 1, 1))
+            new_stats[name + "/moving_mean"] = \
+                mm * BN_MOMENTUM + mean.detach() * (1 - BN_MOMENTUM)
+            new_stats[name + "/moving_variance"] = \
+                mv * BN_MOMENTUM + ub * (1 - BN_MOMENTUM)
+    else:
+        mean, var = p[name + "/moving_mean"], p[name + "/moving_variance"]
+    inv = torch.rsqrt(var + BN_EPS) * g
+    return x * inv[None, :, None, None] + (b - mean * inv)[None, :, None, None]
+
+
+def forward(p, x_nhwc, depth=4, training=False, out_activation="softmax",
+            new_stats=None, taps=None):
+    """U-Net forward on torch params p (same keys as init_weights). Returns NHWC."""
+    x = x_nhwc.permute(0, 3, 1, 2)
+    skips = []
+    for i in range(depth):
+        n = "encoder_L%d" % i
+        x = _conv(x, p[n + "_conv1/kernel"], p[n + "_conv1/bias"])
+        x = _conv(x, p[n + "_conv2/kernel"], p[n + "_conv2/bias"])
+        x = _bn(x, p, n + "_BN", training, new_stats)
+        skips.append(x)
+        x = F.max_pool2d(x, 2, 2)
+    x = _conv(x, p["bottom_conv1/kernel"], p["bottom_conv1/bias"])
+    x = _conv(x, p["bottom_conv2/kernel"], p["bottom_conv2/bias"])
+    x = _bn(x, p, "bottom_BN", training, new_stats)
+    for i in range(depth):
+        n = "upsample_L%d" % i
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        x = _conv(x, p[n + "_conv1/kernel"], p[n + "_conv1/bias"])
+        x = _bn(x, p, n + "_BN1", training, new_stats)
+        x = torch.cat([skips[depth - 1 - i], x], dim=1)      # skip first
+        x = _conv(x, p[n + "_conv2/kernel"], p[n + "_conv2/bias"])
+        x = _conv(x, p[n + "_conv3/kernel"], p[n + "_conv3/bias"])
+        x = _bn(x, p, n + "_BN2", training, new_stats)
+        if taps is not None:
+            taps[n + "_BN2"] = x.permute(0, 2, 3, 1)
+    z = _conv(x, p["conv2d/kernel"], p["conv2d/bias"], relu=False)
+    z = z.permute(0, 2, 3, 1)
+    if taps is not None:
+        taps["logits"] = z
+    if out_activation == "softmax":
+        return torch.softmax(z, dim=-1)
+    return z
+
+
+def to_torch(w, dtype=torch.float32, requires_grad=False):
+    out = {}
+    for k, v in w.items():
+        t = torch.tensor(np.asarray(v), dtype=dtype)
+        if requires_grad and not k.split("/")[1].startswith("moving"):
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+def predict(w, x, depth=4, dtype=torch.float32, out_activation="softmax"):
+    with torch.no_grad():
+        p = to_torch(w, dtype)
+        y = forward(p, torch.tensor(x, dtype=dtype), depth, False, out_activation)
+    return y.numpy().astype(np.float32)
+
+
+def keras_sparse_ce(probs, y, sample_w):
+    """
+    SparseCategoricalCrossentropy(reduction=NONE) on a softmax output that went
+    through a Reshape (train.py:288 forces flatten_output) -- Keras cannot
+    back-track to the logits, so it clips the probabilities to [eps, 1-eps],
+    takes the log and feeds that to sparse_softmax_cross_entropy_with_logits
+    (TF 2.3 keras/backend.py sparse_categorical_crossentropy). The per-pixel
+    loss is multiplied by the per-image sample weight; the tape differentiates
+    the SUM of the unreduced loss. probs [B,H,W,K]; y [B,H,W] int; w [B].
+    """
+    q = torch.clamp(probs, CE_EPS, 1 - CE_EPS)
+    logq = torch.log(q)
+    K = probs.shape[-1]
+    l = F.cross_entropy(logq.reshape(-1, K), y.reshape(-1).long(),
+                        reduction="none").reshape(y.shape)
+    return l * sample_w.reshape(-1, 1, 1).to(l.dtype)
+
+
+def adam_update(theta, g, m, v, t, lr=5e-5, b1=0.9, b2=0.999, eps=1e-8):
+    """
+    TF ApplyAdam kernel form (Keras Adam, non-amsgrad), t = 1-based step:
+      alpha = lr*sqrt(1-b2^t)/(1-b1^t); m += (g-m)(1-b1); v += (g^2-v)(1-b2);
+      theta -= m*alpha/(sqrt(v)+eps)
+    YAML :126 -> lr 5e-5, b1 .9, b2 .999, eps 1e-8, decay 0.
+    """
+    alpha = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    m = m + (g - m) * (1 - b1)
+    v = v + (g * g - v) * (1 - b2)
+    theta = theta - (m * alpha) / (np.sqrt(v) + eps)
+    return theta, m, v
+
+
+def train_step(w, x, y, sample_w, opt=None, depth=4, dtype=torch.float32,
+               lr=5e-5, b1=0.9, b2=0.999, eps=1e-8, grad_scale_replicas=None):
+    """
+    One Keras Model.fit inner step. x [B,H,W,C] f32,
+    y [B,H,W] (or [B,H*W,1]) u8, sample_w [B]. Returns dict(loss [B,H,W],
+    grads {name: np}, weights (updated, incl. BN moving stats), opt state).
+    """
+    p = to_torch(w, dtype, requires_grad=True)
+    B, H, W = x.shape[:3]
+    yt = torch.tensor(np.asarray(y).reshape(B, H, W).astype(np.int64))
+    new_stats = {}
+    probs = forward(p, torch.tensor(x, dtype=dtype), depth, True, "softmax",
+                    new_stats)
+    loss = keras_sparse_ce(probs, yt, torch.tensor(np.asarray(sample_w), dtype=dtype))
+    loss.sum().backward()
+    names = trainable_names(w)
+    grads = {k: p[k].grad.numpy().astype(np.float64 if dtype == torch.float64
+                                         else np.float32) for k in names}
+    if opt is None:
+        opt = {"t": 0, "m": {k: np.zeros_like(grads[k]) for k in names},
+               "v": {k: np.zeros_like(grads[k]) for k in names}}
+    t = opt["t"] + 1
+    new_w = dict(w)
+    new_opt = {"t": t, "m": {}, "v": {}}
+    for k in names:
+        th, m, v = adam_update(np.asarray(w[k], grads[k].dtype), grads[k],
+                               opt["m"][k], opt["v"][k], t, lr, b1, b2, eps)
+        new_w[k] = th.astype(np.float32)
+        new_opt["m"][k], new_opt["v"][k] = m, v
+    for k, v in new_stats.items():
+        new_w[k] = v.numpy().astype(np.float32)
+    return {"loss": loss.detach().numpy(), "probs": probs.detach().numpy(),
+            "grads": grads, "weights": new_w, "opt": new_opt}

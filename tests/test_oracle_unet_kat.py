@@ -1,0 +1,177 @@
+"""
+Known-answer tests anchoring the U-Net oracle (oracle/unet_ref.py): the
+reference's own tests hold no vectors for this part of the path,
+and TensorFlow is absent, so the restatement is checked against independent
+naive NumPy loops on hand-sized cases. CPU only.
+"""
+import numpy as np
+import torch
+from oracle import unet_ref as U
+
+
+def naive_conv_same(x, k, b, relu=True):
+    """x [H,W,Ci], k HWIO; TF SAME: pad_total=k-1, before=pad_total//2."""
+    H, W, Ci = x.shape
+    kh, kw, _, Co = k.shape
+    pt, pl = (kh - 1) // 2, (kw - 1) // 2
+    y = np.zeros((H, W, Co))
+    for i in range(H):
+        for j in range(W):
+            for a in range(kh):
+                for c in range(kw):
+                    ii, jj = i + a - pt, j + c - pl
+                    if 0 <= ii < H and 0 <= jj < W:
+                        y[i, j] += x[ii, jj] @ k[a, c]
+    y += b
+    return np.maximum(y, 0) if relu else y
+
+
+def naive_bn(x, g, b, mean, var):
+    g, b, mean, var = (np.asarray(t, np.float64) for t in (g, b, mean, var))
+    return (x - mean) / np.sqrt(var + 1e-3) * g + b
+
+
+def naive_unet_depth1(w, x, training):
+    """x [B,H,W,C] float64; returns probs, batch stats."""
+    B = x.shape[0]
+    def conv(t, n, relu=True):
+        return np.stack([naive_conv_same(t[i], w[n + "/kernel"].astype(np.float64),
+                                         w[n + "/bias"].astype(np.float64), relu)
+                         for i in range(B)])
+    def bn(t, n):
+        if training:
+            m, v = t.mean((0, 1, 2)), t.var((0, 1, 2))
+        else:
+            m, v = w[n + "/moving_mean"], w[n + "/moving_variance"]
+        return naive_bn(t, w[n + "/gamma"], w[n + "/beta"], m, v)
+    c = conv(conv(x, "encoder_L0_conv1"), "encoder_L0_conv2")
+    skip = bn(c, "encoder_L0_BN")
+    Bn, H, W, F = skip.shape
+    p = skip.reshape(Bn, H // 2, 2, W // 2, 2, F).max((2, 4))
+    bt = bn(conv(conv(p, "bottom_conv1"), "bottom_conv2"), "bottom_BN")
+    up = np.repeat(np.repeat(bt, 2, 1), 2, 2)
+    u1 = bn(conv(up, "upsample_L0_conv1"), "upsample_L0_BN1")
+    cat = np.concatenate([skip, u1], -1)
+    o = bn(conv(conv(cat, "upsample_L0_conv2"), "upsample_L0_conv3"),
+           "upsample_L0_BN2")
+    z = conv(o, "conv2d", relu=False)
+    e = np.exp(z - z.max(-1, keepdims=True))
+    return e / e.sum(-1, keepdims=True)
+
+
+def small_weights(seed=3):
+    w = U.init_weights(3, n_channels=2, depth=1, complexity_factor=1 / 64., seed=seed)
+    rng = np.random.RandomState(seed)
+    for k in w:
+        if k.endswith("kernel"):
+            w[k] = rng.randint(-2, 3, w[k].shape).astype(np.float32) * 0.25
+        elif k.endswith("bias"):
+            w[k] = rng.randint(-1, 2, w[k].shape).astype(np.float32) * 0.5
+        elif k.endswith("gamma"):
+            w[k] = rng.uniform(0.5, 1.5, w[k].shape).astype(np.float32)
+            w[k][0] = -0.75      # negative gamma: pool must follow the affine
+        elif k.endswith("beta") or k.endswith("moving_mean"):
+            w[k] = rng.uniform(-.5, .5, w[k].shape).astype(np.float32)
+        elif k.endswith("moving_variance"):
+            w[k] = rng.uniform(0.5, 2, w[k].shape).astype(np.float32)
+    return w
+
+
+def test_filter_counts_and_param_count():
+    assert [U.filters_at(i, 2) for i in range(5)] == [90, 181, 362, 724, 1448]
+    specs = U.layer_specs(3, 1, 4, 1)
+    n_conv = sum(int(np.prod(s)) + s[-1] for _, k, s in specs if k == "conv")
+    n_bn = sum(4 * s[0] for _, k, s in specs if k == "bn")
+    assert n_conv == 31030723 and n_bn == 15616
+
+
+def test_conv_same_asymmetric_2x2():
+    x = np.arange(9, dtype=np.float64).reshape(1, 3, 3, 1)
+    k = np.array([[1., 10.], [100., 1000.]]).reshape(2, 2, 1, 1)
+    y = U._conv(torch.tensor(x).permute(0, 3, 1, 2), torch.tensor(k),
+                torch.zeros(1, dtype=torch.float64), relu=False)[0, 0].numpy()
+    # out[i,j] = x[i,j] + 10 x[i,j+1] + 100 x[i+1,j] + 1000 x[i+1,j+1], 0 beyond
+    assert y[0, 0] == 0 + 10 * 1 + 100 * 3 + 1000 * 4
+    assert y[2, 2] == 8 and y[0, 2] == 2 + 100 * 5 and y[2, 0] == 6 + 10 * 7
+
+
+def test_depth1_forward_matches_naive_loops():
+    w = small_weights()
+    x = np.random.RandomState(1).randn(2, 4, 4, 2)
+    for training in (False, True):
+        p = U.to_torch(w, torch.float64)
+        got = U.forward(p, torch.tensor(x), depth=1, training=training).numpy()
+        ref = naive_unet_depth1(w, x, training)
+        np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-11)
+
+
+def test_bn_moving_stats_update():
+    w = small_weights()
+    x = np.random.RandomState(2).randn(2, 4, 4, 2).astype(np.float32)
+    y = np.zeros((2, 4, 4), np.uint8)
+    r = U.train_step(w, x, y, np.ones(2), depth=1, dtype=torch.float64)
+    c = np.stack([naive_conv_same(naive_conv_same(
+        x[i].astype(np.float64), w["encoder_L0_conv1/kernel"], w["encoder_L0_conv1/bias"]),
+        w["encoder_L0_conv2/kernel"], w["encoder_L0_conv2/bias"]) for i in range(2)])
+    n = 2 * 4 * 4
+    np.testing.assert_allclose(
+        r["weights"]["encoder_L0_BN/moving_mean"],
+        0.99 * w["encoder_L0_BN/moving_mean"] + 0.01 * c.mean((0, 1, 2)), rtol=1e-6)
+    np.testing.assert_allclose(
+        r["weights"]["encoder_L0_BN/moving_variance"],
+        0.99 * w["encoder_L0_BN/moving_variance"] + 0.01 * c.var((0, 1, 2)) * n / (n - 1),
+        rtol=1e-6)
+
+
+def test_ce_sum_gradient_finite_difference():
+    w = small_weights(5)
+    rng = np.random.RandomState(4)
+    x = rng.randn(2, 4, 4, 2)
+    y = rng.randint(0, 3, (2, 4, 4)).astype(np.uint8)
+    sw = np.array([1.0, 0.33])
+    r = U.train_step(w, x, y, sw, depth=1, dtype=torch.float64)
+
+    def total(wd):
+        p = U.to_torch(wd, torch.float64)
+        pr = U.forward(p, torch.tensor(x), 1, True)
+        return float(U.keras_sparse_ce(pr, torch.tensor(y.astype(np.int64)),
+                                       torch.tensor(sw)).sum())
+    for name, idx in (("conv2d/kernel", (0, 0, 0, 1)), ("upsample_L0_conv1/kernel", (1, 0, 0, 0)),
+                      ("encoder_L0_conv1/bias", (0,)), ("bottom_BN/gamma", (0,)),
+                      ("upsample_L0_BN1/beta", (0,))):
+        h = 1e-6
+        wp = {k: np.array(v, np.float64) for k, v in w.items()}
+        wm = {k: np.array(v, np.float64) for k, v in w.items()}
+        wp[name][idx] += h
+        wm[name][idx] -= h
+        fd = (total(wp) - total(wm)) / (2 * h)
+        np.testing.assert_allclose(r["grads"][name][idx], fd, rtol=2e-5, atol=1e-7)
+
+
+def test_keras_ce_value_and_weighting():
+    probs = torch.tensor([[[[0.7, 0.2, 0.1], [1.0, 0.0, 0.0]]]], dtype=torch.float64)
+    y = torch.tensor([[[1, 1]]])
+    l = U.keras_sparse_ce(probs, y, torch.tensor([0.33], dtype=torch.float64)).numpy()
+    q = np.clip(np.array([1.0, 0.0, 0.0]), 1e-7, 1 - 1e-7)
+    np.testing.assert_allclose(l[0, 0, 0], -0.33 * np.log(0.2), rtol=1e-12)
+    np.testing.assert_allclose(l[0, 0, 1], 0.33 * (-np.log(q[1]) + np.log(q.sum())), rtol=1e-12)
+
+
+def test_adam_three_step_trajectory():
+    th, m, v = np.float64(1.0), 0.0, 0.0
+    gs = [0.5, -0.25, 2.0]
+    out = []
+    for t, g in enumerate(gs, 1):
+        th, m, v = U.adam_update(th, g, m, v, t)
+        out.append(th)
+    # hand: step 1: m=.05 v=.00025 alpha=5e-5*sqrt(.001)/.1 -> th = 1 - 5e-5*(.5/(.5+~0))
+    lr, b1, b2, eps = 5e-5, .9, .999, 1e-8
+    th2, m2, v2 = 1.0, 0.0, 0.0
+    ref = []
+    for t, g in enumerate(gs, 1):
+        m2 = b1 * m2 + (1 - b1) * g
+        v2 = b2 * v2 + (1 - b2) * g * g
+        th2 -= lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m2 / (np.sqrt(v2) + eps)
+        ref.append(th2)
+    np.testing.assert_allclose(out, ref, rtol=1e-13)
+    np.testing.assert_allclose(out[0], 1 - 5e-5 * 0.5 / (0.5 + 1e-8 / np.sqrt(1e-3) * 1.0), rtol=1e-9)
