@@ -1,0 +1,136 @@
+/*
+ * mpunet_hip.h -- C ABI of libmpunet_hip.so: the MI355X (gfx950) hot path of
+ * perslev/MultiPlanarUNet (mpunet 0.2.12).
+ *
+ * The reference reaches its arithmetic through tf.keras / NumPy; it has no FFI
+ * of its own. Each entry point below therefore cites the reference call site
+ * (file:line under /root/reference) whose work it replaces. INTEGRATION.md
+ * shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer named d_* is DEVICE memory owned by the caller;
+ *     everything else is host memory read before the call returns;
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues
+ *     work on it (no synchronisation, no allocation) unless stated;
+ *   - return 0 on success, negative mpu_status otherwise; the message of the
+ *     last failure on the calling thread is mpu_last_error();
+ *   - activations are NHWC; `dtype` selects storage/arithmetic:
+ *       MPU_F32  : f32 storage, exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
+ *       MPU_BF16 : bf16 storage, v_mfma_f32_32x32x16_bf16, f32 accumulate.
+ */
+#ifndef MPUNET_HIP_H
+#define MPUNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { MPU_OK = 0, MPU_EINVAL = -1, MPU_EHIP = -2, MPU_EUNSUPPORTED = -3 } mpu_status;
+typedef enum { MPU_F32 = 0, MPU_BF16 = 1 } mpu_dtype;
+
+int         mpu_abi_version(void);
+const char* mpu_last_error(void);
+
+/* ------------------------------------------------------------------------ *
+ * Predict-time geometry (HBM-bound kernels)
+ * ------------------------------------------------------------------------ */
+
+/* One view of IsotrophicLiveViewSequence2D.get_view_from
+ * (mpunet/sequences/isotrophic_live_view_sequence_2d.py:29-117) expressed as
+ * numbers: the plane basis of sample_plane_at (mpunet/interpolation/
+ * sample_grid.py:192-244), the in-plane mgrid axis, and the optional rot_mat of
+ * ViewInterpolator.apply_rotation (mpunet/interpolation/view_interpolator.py:54-60).
+ * Matrices are row-major 3x3. */
+typedef struct {
+    double  basis[9];      /* columns u, v, n_hat                              */
+    double  rot[9];        /* rot_mat; ignored unless has_rot                  */
+    int32_t has_rot;
+    int32_t dim;           /* sample_dim                                       */
+    int32_t n_planes;      /* P = len(offsets)                                 */
+    int32_t _pad;
+    double  g_start;       /* np.mgrid[-hd:hd:dim*1j]: value(i) = i*g_step+g_start */
+    double  g_step;
+} mpu_view_geom;
+
+/* get_view_from / sample_at: trilinear image planes (+ nearest label planes)
+ * for every offset of one view, then MultiChannelScaler.transform.
+ *   d_vol      f32 [X,Y,Z,C]            ImagePair.image
+ *   d_labels   u8  [X,Y,Z] or NULL      ImagePair.labels
+ *   d_ax,d_ay,d_az  f64 voxel axes of get_voxel_axes_real_space (sample_grid.py:63-98)
+ *   d_offsets  f64 [P]                  np.linspace(-bounds, bounds, P)
+ *   d_bg       f32 [C]                  RegularGridInterpolator fill_value per channel
+ *   d_center,d_scale f64 [C] or NULL    sklearn scaler center_/scale_ (NULL = identity)
+ *   d_out      f32 [P,dim,dim,C]        == np.moveaxis(Xs, 2, 0) of the reference
+ *   d_out_lab  u8  [P,dim,dim] or NULL
+ * Replaces isotrophic_live_view_sequence_2d.py:64-101 + view_interpolator.py:62-133
+ * + regular_grid_interpolator.py:152-270 + preprocessing/scaling.py:75-89. */
+int mpu_sample_view_planes(const float* d_vol, const uint8_t* d_labels,
+                           const int32_t vol_shape[4],
+                           const double* d_ax, const double* d_ay, const double* d_az,
+                           const mpu_view_geom* geom, const double* d_offsets,
+                           const float* d_bg, uint8_t bg_class,
+                           const double* d_center, const double* d_scale,
+                           float* d_out, uint8_t* d_out_lab, void* stream);
+
+/* One view's prediction volume as seen by the back-mapping
+ * (mpunet/utils/fusion/fuse_and_predict.py:92-137). */
+typedef struct {
+    double       inv_basis[9];   /* np.linalg.inv(basis) of the view            */
+    const float* d_pred;         /* f32 [P,dim,dim,K] (model.predict output order) */
+    const double* d_g;           /* f64 [dim]  real_axis = np.linspace(-hd,hd,dim) */
+    const double* d_offsets;     /* f64 [P]                                     */
+    int32_t      dim;
+    int32_t      n_planes;
+} mpu_view_pred;
+
+/* Voxel grid of get_voxel_grid_real_space (sample_grid.py:101-130), computed on
+ * the fly: p = A*(i,j,k) - center. */
+typedef struct {
+    double  A[9];          /* affine[:3,:3]                                     */
+    double  center[3];     /* mean over all voxels of A*(i,j,k)                 */
+    int32_t shape[3];      /* X, Y, Z                                           */
+    int32_t _pad;
+} mpu_voxel_grid;
+
+/* map_real_space_pred(method="nearest") for ONE view: d_mapped f32 [X,Y,Z,K],
+ * OOB voxels -> [1,0,...,0] (fuse_and_predict.py:99-100). */
+int mpu_map_view_nearest(const mpu_voxel_grid* grid, const mpu_view_pred* view,
+                         int32_t n_classes, float* d_mapped, void* stream);
+
+/* Fused _multi_view_predict_on + merge_multi_view_preds
+ * (mpunet/bin/predict.py:294-366): for every voxel, nearest lookup in each of
+ * the V view predictions, FusionLayer.call = softmax_k(sum_v W[v,k] x[v,k] + b[k])
+ * (mpunet/models/fusion_model.py:38-39) or, with sum_fusion, sum_v x[v,k]
+ * (predict.py:364); then pred_to_class argmax -> uint8 (utils/utils.py:326-328).
+ * Nothing of `combined[V,X,Y,Z,K]` is materialised.
+ *   views      host array of V mpu_view_pred
+ *   d_W f32 [V,K], d_b f32 [K]  (ignored when sum_fusion)
+ *   d_probs    f32 [X,Y,Z,K] or NULL ; d_labels u8 [X,Y,Z] or NULL */
+int mpu_map_fuse_views(const mpu_voxel_grid* grid, const mpu_view_pred* views,
+                       int32_t n_views, int32_t n_classes,
+                       const float* d_W, const float* d_b, int32_t sum_fusion,
+                       float* d_probs, uint8_t* d_labels, void* stream);
+
+/* FusionModel.predict on an explicit x[N,V,K] (predict.py:358-361 layout). */
+int mpu_fusion_forward(const float* d_x, int64_t n, int32_t n_views, int32_t n_classes,
+                       const float* d_W, const float* d_b,
+                       float* d_probs, uint8_t* d_labels, void* stream);
+
+/* Multi-GPU predict: accumulate W[v,:] * nearest(x_v) of one
+ * view's plane chunk [p_lo, p_hi) into d_z f32 [X,Y,Z,K]; the rank that owns
+ * p_lo == 0 also adds the OOB contribution W[v,:]*[1,0..]. Then
+ * mpu_fusion_finalize applies +b, softmax, argmax on a voxel slab. */
+int mpu_map_accumulate_view(const mpu_voxel_grid* grid, const mpu_view_pred* view,
+                            int32_t n_classes, const float* d_Wv,
+                            int32_t p_lo, int32_t p_hi, int32_t owns_oob,
+                            float* d_z, void* stream);
+int mpu_fusion_finalize(const float* d_z, int64_t n, int32_t n_classes,
+                        const float* d_b, int32_t sum_fusion,
+                        float* d_probs, uint8_t* d_labels, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPUNET_HIP_H */

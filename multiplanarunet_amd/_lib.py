@@ -1,0 +1,93 @@
+"""
+ctypes binding of libmpunet_hip.so (include/mpunet_hip.h). There is no CPU
+fallback anywhere in this package: if the shared library is missing the import
+of any compute entry point raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmpunet_hip.so")
+
+c_p = C.c_void_p
+i32, i64, f32, f64, u8 = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint8
+
+MPU_F32, MPU_BF16 = 0, 1
+
+
+class ViewGeom(C.Structure):            # mpu_view_geom
+    _fields_ = [("basis", f64 * 9), ("rot", f64 * 9), ("has_rot", i32), ("dim", i32),
+                ("n_planes", i32), ("_pad", i32), ("g_start", f64), ("g_step", f64)]
+
+
+class ViewPred(C.Structure):            # mpu_view_pred
+    _fields_ = [("inv_basis", f64 * 9), ("d_pred", c_p), ("d_g", c_p), ("d_offsets", c_p),
+                ("dim", i32), ("n_planes", i32)]
+
+
+class VoxelGrid(C.Structure):           # mpu_voxel_grid
+    _fields_ = [("A", f64 * 9), ("center", f64 * 3), ("shape", i32 * 3), ("_pad", i32)]
+
+
+class MpuError(RuntimeError):
+    pass
+
+
+_SIGS = {
+    "mpu_abi_version": (C.c_int, []),
+    "mpu_last_error": (C.c_char_p, []),
+    "mpu_sample_view_planes": (C.c_int, [c_p, c_p, C.POINTER(i32), c_p, c_p, c_p,
+                                         C.POINTER(ViewGeom), c_p, c_p, u8, c_p, c_p,
+                                         c_p, c_p, c_p]),
+    "mpu_map_view_nearest": (C.c_int, [C.POINTER(VoxelGrid), C.POINTER(ViewPred), i32, c_p, c_p]),
+    "mpu_map_accumulate_view": (C.c_int, [C.POINTER(VoxelGrid), C.POINTER(ViewPred), i32, c_p,
+                                          i32, i32, i32, c_p, c_p]),
+    "mpu_map_fuse_views": (C.c_int, [C.POINTER(VoxelGrid), C.POINTER(ViewPred), i32, i32,
+                                     c_p, c_p, i32, c_p, c_p, c_p]),
+    "mpu_fusion_forward": (C.c_int, [c_p, i64, i32, i32, c_p, c_p, c_p, c_p, c_p]),
+    "mpu_fusion_finalize": (C.c_int, [c_p, i64, i32, c_p, i32, c_p, c_p, c_p]),
+}
+
+_lib = None
+
+
+def declared_symbols():
+    """Every extern "C" symbol include/mpunet_hip.h declares."""
+    return sorted(_SIGS)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MpuError(
+                "libmpunet_hip.so not found at %s -- build it with "
+                "`python -m multiplanarunet_amd.build` (hipcc, gfx950). "
+                "There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)         # AttributeError if a symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().mpu_last_error()
+        raise MpuError("%s failed (%d): %s" % (what, status, (msg or b"").decode()))
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,137 @@
+"""
+GPU parity: HIP resampling / back-mapping / fusion kernels (through the C ABI)
+against the reference goldens and the oracle. Tolerances: sampled image values
+atol 2e-6 (fp64 accumulate -> f32; expected bit-exact), labels / mapped
+vectors exact except fp64-tie voxels (<= 1e-3 of voxels), fusion probabilities
+atol 1e-6.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+AFFS = ("ident", "aniso", "rot")
+
+
+def _vol(golden, an):
+    from multiplanarunet_amd.interpolation import Volume
+    return Volume(golden["g3_vol"], golden["g3_lab"], golden["aff_" + an], bg_value=[12.5],
+                  scaler=(golden["g3_center"], golden["g3_scale"]))
+
+
+@pytest.mark.parametrize("an", AFFS)
+@pytest.mark.parametrize("dim", (16, 32))
+def test_get_view_from_vs_reference_golden(golden, an, dim):
+    from multiplanarunet_amd.interpolation import ViewSampler
+    span = {16: 30.0, 32: 33.0}[dim]
+    vol = _vol(golden, an)
+    seq = ViewSampler(golden["views"], dim, span, n_classes=3)
+    for v in golden["g3_views"]:
+        key = "%s_%d_%d" % (an, dim, v)
+        Xs, ys, grid, ib = seq.get_view_from(vol, golden["views"][v], "same+20")
+        assert tuple(Xs.shape) == golden["g3_X_" + key].shape
+        X = Xs.cpu().numpy()
+        y = ys.cpu().numpy()
+        np.testing.assert_allclose(X, golden["g3_X_" + key], rtol=0, atol=2e-6)
+        assert (X != golden["g3_X_" + key]).mean() <= 1e-4
+        assert (y != golden["g3_y_" + key]).mean() <= 1e-3
+        np.testing.assert_array_equal(ib, golden["g3_invb_" + key])
+
+
+@pytest.mark.parametrize("an", AFFS)
+def test_two_channel_planes_vs_reference_golden(golden, an):
+    from multiplanarunet_amd.interpolation import Volume, ViewGeometry, sample_view
+    vol = Volume(golden["g2_vol"], golden["g2_lab"], golden["aff_" + an], bg_value=list(golden["g2_bg"]))
+    for pi, (v, dim, span, off) in enumerate(golden["g2_planes"]):
+        g = ViewGeometry(golden["views"][int(v)], int(dim), span, "same")
+        g.offsets = np.array([off]); g.n_planes = 1
+        X, y = sample_view(vol, g)
+        np.testing.assert_allclose(X[0].cpu().numpy(), golden["g2_im_%s_%d" % (an, pi)], rtol=0, atol=2e-6)
+        assert (y[0].cpu().numpy() != golden["g2_lab_%s_%d" % (an, pi)]).mean() <= 1e-3
+
+
+@pytest.mark.parametrize("an", AFFS)
+def test_map_real_space_pred_vs_reference_golden(golden, an):
+    from multiplanarunet_amd.interpolation import map_real_space_pred
+    vol = _vol(golden, an)
+    for v in golden["g3_views"]:
+        key = "%s_16_%d" % (an, v)
+        grid = (golden["g3_g_" + key], golden["g3_g_" + key], golden["g3_off_" + key])
+        for K in (1, 3, 5):
+            pr = torch.tensor(golden["g5_pred_%s_%d_%d" % (an, v, K)], device="cuda")
+            ref = golden["g5_map_%s_%d_%d" % (an, v, K)]
+            mp = map_real_space_pred(pr, grid, golden["g3_invb_" + key], vol).cpu().numpy()
+            assert mp.shape == ref.shape
+            assert np.any(mp != ref, axis=-1).mean() <= 1e-3
+
+
+@pytest.mark.parametrize("an", AFFS)
+@pytest.mark.parametrize("sum_fusion", (False, True))
+def test_fused_map_fuse_vs_oracle(golden, an, sum_fusion):
+    """combined[V,...] from the reference goldens -> oracle merge vs the fused HIP kernel."""
+    from multiplanarunet_amd.interpolation import map_and_fuse, map_accumulate, fusion_finalize
+    from oracle import geometry as G
+    vol = _vol(golden, an)
+    K = 3
+    rng = np.random.RandomState(5)
+    W = rng.uniform(0.5, 1.5, (len(golden["g3_views"]), K)).astype(np.float32)
+    b = rng.uniform(-0.2, 0.2, (K,)).astype(np.float32)
+    combined, vps = [], []
+    for v in golden["g3_views"]:
+        key = "%s_16_%d" % (an, v)
+        grid = (golden["g3_g_" + key], golden["g3_g_" + key], golden["g3_off_" + key])
+        pr = golden["g5_pred_%s_%d_%d" % (an, v, K)]
+        combined.append(golden["g5_map_%s_%d_%d" % (an, v, K)])
+        vps.append((torch.tensor(np.moveaxis(pr, 2, 0).copy(), device="cuda"), grid,
+                    golden["g3_invb_" + key]))
+    merged_ref, map_ref = G.merge_multi_view_preds(np.stack(combined), W, b, sum_fusion)
+    probs, labels = map_and_fuse(vol, vps, W, b, sum_fusion=sum_fusion)
+    torch.cuda.synchronize()
+    p = probs.cpu().numpy()
+    bad = np.abs(p - merged_ref).max(-1) > 2e-6
+    assert bad.mean() <= 1e-3, bad.mean()
+    assert (labels.cpu().numpy() != map_ref).mean() <= 2e-3
+    # plane-sharded accumulate path (multi-GPU predict) == fused path
+    z = torch.zeros_like(probs)
+    for vi, (pr, grid, ib) in enumerate(vps):
+        P = pr.shape[0]
+        cuts = [0, 7, 20, P]
+        Wv = np.ones(K, np.float32) if sum_fusion else W[vi]
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            map_accumulate(vol, pr[lo:hi].contiguous(), grid, ib, Wv, lo, hi, lo == 0, z)
+    p2, l2 = fusion_finalize(z, b, sum_fusion=sum_fusion)
+    np.testing.assert_allclose(p2.cpu().numpy(), p, rtol=0, atol=2e-6)
+    assert (l2 != labels).float().mean().item() <= 1e-3
+
+
+def test_fusion_forward_vs_oracle():
+    import ctypes as C
+    from multiplanarunet_amd import _lib
+    from oracle import geometry as G
+    rng = np.random.RandomState(0)
+    for (N, V, K) in ((1000, 6, 3), (777, 3, 5), (64, 1, 1), (4096, 6, 16)):
+        x = rng.rand(N, V, K).astype(np.float32)
+        x /= x.sum(-1, keepdims=True)
+        W = rng.uniform(.5, 1.5, (V, K)).astype(np.float32)
+        b = rng.uniform(-.2, .2, (K,)).astype(np.float32)
+        ref = G.fusion_layer(x, W, b)
+        xd, Wd, bd = (torch.tensor(t, device="cuda") for t in (x, W, b))
+        probs = torch.empty((N, K), device="cuda")
+        lab = torch.empty((N,), dtype=torch.uint8, device="cuda")
+        _lib.call("mpu_fusion_forward", _lib.ptr(xd), N, V, K, _lib.ptr(Wd), _lib.ptr(bd),
+                  _lib.ptr(probs), _lib.ptr(lab), _lib.stream_ptr())
+        np.testing.assert_allclose(probs.cpu().numpy(), ref, rtol=0, atol=1e-6)
+        assert (lab.cpu().numpy() != ref.argmax(-1)).mean() <= 1e-3
+
+
+def test_error_behaviour():
+    import ctypes as C
+    from multiplanarunet_amd import _lib
+    x = torch.zeros(4, device="cuda")
+    with pytest.raises(_lib.MpuError):
+        _lib.call("mpu_fusion_forward", _lib.ptr(x), 1, 1, 17, _lib.ptr(x), _lib.ptr(x),
+                  _lib.ptr(x), None, _lib.stream_ptr())
+    with pytest.raises(_lib.MpuError):
+        _lib.call("mpu_fusion_forward", None, 1, 1, 3, _lib.ptr(x), _lib.ptr(x),
+                  _lib.ptr(x), None, _lib.stream_ptr())

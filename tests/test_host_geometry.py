@@ -1,0 +1,79 @@
+"""Host-side view geometry (multiplanarunet_amd.interpolation) against the reference goldens. CPU only."""
+import re
+import os
+import ctypes
+import numpy as np
+import pytest
+from multiplanarunet_amd import interpolation as I
+from multiplanarunet_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_plane_basis_and_axes_match_reference(golden):
+    for vi, v in enumerate(golden["views"]):
+        for ci, (dim, span, off) in enumerate(golden["g1_cfg"]):
+            g = I.ViewGeometry(v, int(dim), span, "same+20")
+            np.testing.assert_array_equal(g.inv_basis, golden["g1_invb_%d_%d" % (vi, ci)])
+            np.testing.assert_array_equal(g.real_axis, golden["g1_g_%d_%d" % (vi, ci)])
+            # in-plane coordinates: basis @ (i*step+start, j*step+start, off)
+            ax = np.arange(int(dim), dtype=np.float64) * g.g_step + g.g_start
+            gx, gy = np.meshgrid(ax, ax, indexing="ij")
+            pts = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, off)], 1)
+            real = g.basis.dot(pts.T).T
+            ref = golden["g1_grid_%d_%d" % (vi, ci)]
+            for k in range(3):
+                np.testing.assert_array_equal(real[:, k].reshape(ref[k].shape), ref[k])
+
+
+def test_offsets_match_reference(golden):
+    for an in ("ident", "rot"):
+        for dim, span in ((16, 30.0), (32, 33.0)):
+            for v in golden["g3_views"]:
+                key = "%s_%d_%d" % (an, dim, v)
+                g = I.ViewGeometry(golden["views"][v], dim, span, "same+20")
+                np.testing.assert_array_equal(g.offsets, golden["g3_off_" + key])
+                np.testing.assert_array_equal(g.real_axis, golden["g3_g_" + key])
+                np.testing.assert_array_equal(g.inv_basis, golden["g3_invb_" + key])
+                assert g.n_planes == dim + 20
+
+
+def test_volume_axes_and_voxel_grid(golden):
+    from oracle import geometry as G
+    for an in ("ident", "aniso", "rot"):
+        aff = golden["aff_" + an]
+        vol = I.Volume(golden["g3_vol"], golden["g3_lab"], aff, bg_value=[12.5], device="cpu")
+        axes, rot = G.voxel_axes_real_space(golden["g3_vol"].shape[:3], aff)
+        for a, b in zip(vol.axes, axes):
+            np.testing.assert_array_equal(a, b)
+        assert (rot is None) == (vol.rot_mat is None)
+        if rot is not None:
+            np.testing.assert_array_equal(rot, vol.rot_mat)
+        vg = vol.voxel_grid()
+        A = np.array(vg.A[:]).reshape(3, 3)
+        X, Y, Z = vg.shape[:]
+        ref = golden["g4_vgrid_" + an]
+        for (i, j, k) in ((0, 0, 0), (X - 1, 2, 5), (3, Y - 1, Z - 1)):
+            p = A.dot(np.array([i, j, k], float)) - np.array(vg.center[:])
+            np.testing.assert_allclose(p, ref[:, i, j, k], rtol=0, atol=1e-11)
+
+
+def test_volume_argument_errors():
+    with pytest.raises(ValueError):
+        I.Volume(np.zeros((4, 4, 4), np.float32), device="cpu")
+    with pytest.raises(ValueError):
+        I.Volume(np.zeros((4, 4, 4, 2), np.float32), bg_value=[0, 1, 2], device="cpu")
+
+
+def test_capi_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mpunet_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(mpu_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == _lib.declared_symbols()
+    lib = _lib.load()                      # raises if the .so or a symbol is missing
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.mpu_abi_version() >= 1
+    assert ctypes.sizeof(_lib.ViewGeom) == 9 * 8 * 2 + 4 * 4 + 16
+    assert ctypes.sizeof(_lib.ViewPred) == 72 + 24 + 8
+    assert ctypes.sizeof(_lib.VoxelGrid) == 72 + 24 + 16
