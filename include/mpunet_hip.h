@@ -130,6 +130,105 @@ int mpu_fusion_finalize(const float* d_z, int64_t n, int32_t n_classes,
                         const float* d_b, int32_t sum_fusion,
                         float* d_probs, uint8_t* d_labels, void* stream);
 
+
+/* ------------------------------------------------------------------------ *
+ * 2-D U-Net (MFMA-bound): mpunet.models.UNet (mpunet/models/unet.py:20-251)
+ * ------------------------------------------------------------------------ */
+
+/* conv modes of the implicit-GEMM kernels */
+enum { MPU_CONV3 = 0,      /* Conv2D(k=3, padding="same")                 unet.py:120-179 */
+       MPU_UPCONV2 = 1,    /* UpSampling2D(2) + Conv2D(k=2, "same")       unet.py:159-163 */
+       MPU_CONV3S2 = 2,    /* 3x3 stride-2 pad-1: data gradient of MPU_UPCONV2           */
+       MPU_CONV1 = 3 };    /* Conv2D(k=1)                                 unet.py:211     */
+
+/* What UNet.__init__ / init_model (unet.py:26-112,182-216) derive from the
+ * constructor arguments. filters[l] = int(64 * 2^l * sqrt(complexity_factor)),
+ * l = 0..depth (unet.py:91,120,132). padding="same", activation="relu",
+ * kernel_size=3 are the only supported values. */
+typedef struct {
+    int32_t n_classes;     /* 1..8                                              */
+    int32_t n_channels;
+    int32_t depth;         /* 1..6                                              */
+    int32_t H, W;          /* img_rows, img_cols: multiples of 2^depth          */
+    int32_t dtype;         /* mpu_dtype of activations / MFMA operands          */
+    int32_t softmax;       /* out_activation: 1 = "softmax", 0 = "linear"       */
+    int32_t filters[8];
+} mpu_unet_config;
+
+typedef struct mpu_unet mpu_unet;   /* host-only layer table; owns no device memory */
+
+mpu_unet* mpu_unet_create(const mpu_unet_config* cfg);      /* NULL + mpu_last_error() on bad config */
+void      mpu_unet_destroy(mpu_unet* m);
+
+/* Flat fp32 buffers the caller allocates (channel counts are padded to multiples
+ * of 8; padded entries are zero and stay zero under training):
+ *   params / grads / adam m / adam v : mpu_unet_param_floats()   floats each
+ *   BN moving statistics             : mpu_unet_bn_state_floats() floats
+ *   packed MFMA weight operands      : mpu_unet_packed_bytes()    bytes
+ *   activations + scratch            : mpu_unet_workspace_bytes(batch) bytes
+ * mpu_unet_tensor_info enumerates "<keras layer name>/<kernel|bias|gamma|beta|
+ * moving_mean|moving_variance>" with its offset, stored (padded) and logical
+ * Keras shape (kernels are HWIO), kind 0 = params buffer, 1 = BN-state buffer. */
+int64_t mpu_unet_param_floats(const mpu_unet* m);
+int64_t mpu_unet_bn_state_floats(const mpu_unet* m);
+int64_t mpu_unet_packed_bytes(const mpu_unet* m);
+int64_t mpu_unet_logical_param_count(const mpu_unet* m);   /* trainable, unpadded */
+int64_t mpu_unet_workspace_bytes(const mpu_unet* m, int32_t batch);
+int32_t mpu_unet_num_tensors(const mpu_unet* m);
+int     mpu_unet_tensor_info(const mpu_unet* m, int32_t idx, char* name, int32_t name_cap,
+                             int32_t* kind, int64_t* offset,
+                             int32_t stored_shape[4], int32_t logical_shape[4]);
+
+/* fp32 master weights -> MFMA operands (forward [tap][co][ci], data-gradient
+ * [tap][ci][co] incl. the tap-combined 3x3 stride-2 form of the up-conv).
+ * Call after every change of d_params (set_weights, load_weights, Adam). */
+int mpu_unet_pack_weights(const mpu_unet* m, const float* d_params, void* d_packed, void* stream);
+
+/* model.predict_on_batch / the forward half of a Model.fit step
+ * (mpunet/utils/fusion/fuse_and_predict.py:88, mpunet/train/trainer.py:246).
+ *   d_x   f32 [B,H,W,n_channels] ; d_out f32 [B,H,W,n_classes] (probabilities or
+ *   logits). training != 0: BatchNormalization uses batch statistics and updates
+ *   the moving statistics in d_bn_state; activations stay in d_workspace for
+ *   mpu_unet_backward. */
+int mpu_unet_forward(const mpu_unet* m, int32_t batch, const float* d_x, const float* d_params,
+                     const void* d_packed, float* d_bn_state, void* d_workspace,
+                     int32_t training, float* d_out, void* stream);
+
+/* Backward half of the Keras train step compiled at mpunet/train/trainer.py:78-97
+ * (SparseCategoricalCrossentropy(reduction=NONE) on clipped probabilities,
+ * per-image sample weights, gradient of the SUM over batch and pixels).
+ *   d_y u8 [B,H*W] ; d_sample_weight f32 [B] ; d_grads f32 [param_floats]
+ *   d_loss f32 [B,H*W] per-pixel weighted loss or NULL.
+ * Must follow mpu_unet_forward(training=1) on the same workspace. */
+int mpu_unet_backward(const mpu_unet* m, int32_t batch, const uint8_t* d_y,
+                      const float* d_sample_weight, const float* d_params, const void* d_packed,
+                      float* d_bn_state, void* d_workspace, float* d_grads, float* d_loss,
+                      void* stream);
+
+/* Keras Adam (TF ApplyAdam form), t = 1-based step; YAML defaults
+ * lr 5e-5, beta_1 .9, beta_2 .999, epsilon 1e-8
+ * (mpunet/bin/defaults/MultiPlanar/train_hparams.yaml:126). */
+int mpu_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n,
+                  int64_t t, double lr, double beta1, double beta2, double eps, void* stream);
+
+/* Single-layer entry points (unit tests / layer-wise integration). Channels
+ * must be multiples of 8. d_w is the fp32 Keras HWIO kernel; d_w_dgrad may be
+ * NULL; sizes: fwd taps*Cin*Cout elements, dgrad 9*Cin*Cout elements.
+ * mpu_conv2d_igemm computes out[m][n] = act(sum_k in[m@tap][k] w[tap][n][k] + bias[n])
+ * (* (mask[m][n] > 0) when d_mask is given) over the channel-concatenation of
+ * in0 and in1. */
+int mpu_conv2d_pack_weights(int32_t dtype, int32_t mode, const float* d_w, int32_t Cin, int32_t Cout,
+                            void* d_w_fwd, void* d_w_dgrad, void* stream);
+int mpu_conv2d_igemm(int32_t dtype, int32_t mode, const void* d_in0, int32_t C0,
+                     const void* d_in1, int32_t C1, const void* d_w_packed,
+                     int64_t w_tap_stride, int32_t w_row_stride, const float* d_bias,
+                     const void* d_mask, void* d_out, int32_t B, int32_t Ho, int32_t Wo,
+                     int32_t Cout, int32_t relu, void* stream);
+int64_t mpu_conv2d_wgrad_workspace_floats(int32_t mode, int32_t Cin, int32_t Cout, int64_t M);
+int mpu_conv2d_wgrad(int32_t dtype, int32_t mode, const void* d_x0, int32_t C0, const void* d_x1,
+                     int32_t C1, const void* d_dz, int32_t Cout, int32_t B, int32_t Ho, int32_t Wo,
+                     float* d_workspace, float* d_dW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,11 @@ class VoxelGrid(C.Structure):           # mpu_voxel_grid
     _fields_ = [("A", f64 * 9), ("center", f64 * 3), ("shape", i32 * 3), ("_pad", i32)]
 
 
+class UNetConfig(C.Structure):         # mpu_unet_config
+    _fields_ = [("n_classes", i32), ("n_channels", i32), ("depth", i32), ("H", i32), ("W", i32),
+                ("dtype", i32), ("softmax", i32), ("filters", i32 * 8)]
+
+
 class MpuError(RuntimeError):
     pass
 
@@ -46,6 +51,25 @@ _SIGS = {
                                      c_p, c_p, i32, c_p, c_p, c_p]),
     "mpu_fusion_forward": (C.c_int, [c_p, i64, i32, i32, c_p, c_p, c_p, c_p, c_p]),
     "mpu_fusion_finalize": (C.c_int, [c_p, i64, i32, c_p, i32, c_p, c_p, c_p]),
+    "mpu_unet_create": (c_p, [C.POINTER(UNetConfig)]),
+    "mpu_unet_destroy": (None, [c_p]),
+    "mpu_unet_param_floats": (i64, [c_p]),
+    "mpu_unet_bn_state_floats": (i64, [c_p]),
+    "mpu_unet_packed_bytes": (i64, [c_p]),
+    "mpu_unet_logical_param_count": (i64, [c_p]),
+    "mpu_unet_workspace_bytes": (i64, [c_p, i32]),
+    "mpu_unet_num_tensors": (i32, [c_p]),
+    "mpu_unet_tensor_info": (C.c_int, [c_p, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i64),
+                                       C.POINTER(i32), C.POINTER(i32)]),
+    "mpu_unet_pack_weights": (C.c_int, [c_p, c_p, c_p, c_p]),
+    "mpu_unet_forward": (C.c_int, [c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, c_p, c_p]),
+    "mpu_unet_backward": (C.c_int, [c_p, i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "mpu_adam_step": (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, f64, f64, f64, f64, c_p]),
+    "mpu_conv2d_pack_weights": (C.c_int, [i32, i32, c_p, i32, i32, c_p, c_p, c_p]),
+    "mpu_conv2d_igemm": (C.c_int, [i32, i32, c_p, i32, c_p, i32, c_p, i64, i32, c_p, c_p, c_p,
+                                   i32, i32, i32, i32, i32, c_p]),
+    "mpu_conv2d_wgrad_workspace_floats": (i64, [i32, i32, i32, i64]),
+    "mpu_conv2d_wgrad": (C.c_int, [i32, i32, c_p, i32, c_p, i32, c_p, i32, i32, i32, i32, c_p, c_p, c_p]),
 }
 
 _lib = None

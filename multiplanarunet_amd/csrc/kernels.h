@@ -1,0 +1,71 @@
+// Internal C++ launch API shared by the translation units of libmpunet_hip.so.
+#pragma once
+#include "common.h"
+
+namespace mpu {
+
+enum { CONV3 = 0, UPCONV2 = 1, CONV3S2 = 2, CONV1 = 3 };
+
+struct ConvArgs {
+    const void* in0; const void* in1; int C0, C1;
+    const void* w; long w_tap_stride; int w_row_stride;
+    const float* bias; const void* mask; void* out;
+    int B, Ho, Wo, Cout, relu;
+};
+struct WgradArgs {
+    const void* x0; const void* x1; int C0, C1;
+    const void* dz; int Cout;
+    float* partial;
+    int B, Ho, Wo, ksplit, mchunk;
+};
+
+int  launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st);
+long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out);
+int  launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st);
+
+// ---- unet_ops.hip ---------------------------------------------------------
+constexpr int RED_MAX_BLOCKS = 1024;
+
+// fp32 master [taps][Cin][Cout] -> packed operands in T
+int launch_pack_weights(int dtype, int mode, const float* W, int Cin, int Cout,
+                        void* w_fwd, void* w_dgrad, hipStream_t st);
+int launch_cast_pad(int dtype, const float* x, long M, int Cin, int Cpad, void* out, hipStream_t st);
+
+// BatchNormalization, training: batch statistics of x [M][C]
+//   partial: [RED_MAX_BLOCKS][2][C] floats scratch
+//   writes mean, invstd, scale = gamma*invstd, shift = beta - mean*scale and
+//   updates moving_mean / moving_var in place (momentum .99, Bessel-corrected var)
+int launch_bn_stats(int dtype, const void* x, long M, int C, float* partial,
+                    const float* gamma, const float* beta, float* moving_mean, float* moving_var,
+                    float* mean, float* invstd, float* scale, float* shift, float eps, float momentum,
+                    hipStream_t st);
+// inference: scale/shift from the moving statistics
+int launch_bn_infer_coeffs(const float* gamma, const float* beta, const float* moving_mean,
+                           const float* moving_var, int C, float eps, float* scale, float* shift, hipStream_t st);
+// y = x*scale + shift (and optionally 2x2 max-pool of y)
+int launch_bn_apply(int dtype, const void* x, int B, int H, int W, int C, const float* scale,
+                    const float* shift, void* y, void* pooled, hipStream_t st);
+// BN backward: dgamma, dbeta and dz = (x>0) * d(x) where x is the post-ReLU BN input
+int launch_bn_backward(int dtype, const void* dn, const void* x, long M, int C, float* partial,
+                       const float* gamma, const float* mean, const float* invstd,
+                       float* dgamma, float* dbeta, float* coeffs /*[3][C]*/, void* dz, hipStream_t st);
+// dn = dskip + unpool(dp) (gradient of MaxPooling2D routed to the first max of each window)
+int launch_maxpool_bwd_add(int dtype, const void* n, const void* dskip, const void* dp,
+                           int B, int H, int W, int C, void* dn, hipStream_t st);
+// db[c] = sum_m dz[m][c]
+int launch_colsum(int dtype, const void* dz, long M, int C, float* partial, float* out, hipStream_t st);
+
+// 1x1 head: logits = n @ Wh + bh ; probs = softmax (or linear)
+int launch_head_forward(int dtype, const void* n, long M, int C, int K, const float* Wh, int ldw,
+                        const float* bh, int softmax, float* out, hipStream_t st);
+// Keras sparse CE (clipped probabilities, see oracle/unet_ref.py keras_sparse_ce), sum-gradient:
+// dn = dlogits @ Wh^T, dWh, dbh, per-pixel loss
+int launch_head_backward(int dtype, const void* n, const float* probs, const uint8_t* y,
+                         const float* sample_w, long M, long pix_per_image, int C, int K,
+                         const float* Wh, int ldw, float* partial, void* dn, float* dWh, float* dbh,
+                         float* loss, hipStream_t st);
+
+int launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha, float b1, float b2,
+                float eps, hipStream_t st);
+
+}  // namespace mpu

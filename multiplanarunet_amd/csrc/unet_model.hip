@@ -1,0 +1,466 @@
+// Host-side orchestration of the 2-D U-Net (mpunet/models/unet.py:114-216) on
+// top of the HIP kernels, plus the U-Net part of the C ABI. The model object
+// is a host-only description (layer table, parameter / workspace layout); every
+// device buffer belongs to the caller.
+#include <string>
+#include <vector>
+#include <cmath>
+#include "kernels.h"
+
+using namespace mpu;
+
+namespace {
+
+constexpr float BN_EPS = 1e-3f, BN_MOM = 0.99f;      // Keras BatchNormalization defaults
+
+inline int pad8(int c) { return (c + 7) / 8 * 8; }
+inline long align64(long e) { return (e + 63) / 64 * 64; }
+
+struct Tensor {                 // one entry of the flat parameter / BN-state tables
+    std::string name;           // "<keras layer>/<var>"
+    int kind;                   // 0 = trainable (params/grads/m/v), 1 = BN moving statistic
+    long offset;                // floats, into d_params (kind 0) or d_bn_state (kind 1)
+    int pshape[4];              // stored (channel-padded) shape, 0-terminated
+    int lshape[4];              // logical Keras shape
+};
+
+struct Conv { int mode, Cin, Cout; long w, b; long wf, wd; };        // offsets
+struct BN { int C; long g, b, mm, mv; long st; };                    // st: mean,invstd,scale,shift (4*C)
+
+}  // namespace
+
+struct mpu_unet {
+    mpu_unet_config cfg;
+    int cin_pad = 0;
+    std::vector<int> F, Fl;                 // padded / logical filters per level (depth+1)
+    std::vector<Conv> conv;                 // creation order
+    std::vector<BN> bn;
+    std::vector<Tensor> tensors;
+    long n_params = 0, n_state = 0, n_packed = 0, n_stats = 0, n_logical = 0;
+    int head_C = 0; long head_w = 0, head_b = 0;
+    int cmax = 0;
+
+    // indices into conv / bn
+    int enc_c1(int i) const { return 2 * i; }
+    int enc_c2(int i) const { return 2 * i + 1; }
+    int bot_c1() const { return 2 * cfg.depth; }
+    int bot_c2() const { return 2 * cfg.depth + 1; }
+    int up_c(int j, int k) const { return 2 * cfg.depth + 2 + 3 * j + k; }       // k = 0,1,2
+    int enc_bn(int i) const { return i; }
+    int bot_bn() const { return cfg.depth; }
+    int up_bn(int j, int k) const { return cfg.depth + 1 + 2 * j + k; }          // k = 0,1
+};
+
+namespace {
+
+void add_tensor(mpu_unet* m, const std::string& name, int kind, long off, std::initializer_list<int> p,
+                std::initializer_list<int> l) {
+    Tensor t; t.name = name; t.kind = kind; t.offset = off;
+    int i = 0; for (int v : p) t.pshape[i++] = v; for (; i < 4; ++i) t.pshape[i] = 0;
+    i = 0; for (int v : l) t.lshape[i++] = v; for (; i < 4; ++i) t.lshape[i] = 0;
+    m->tensors.push_back(t);
+}
+
+void add_conv(mpu_unet* m, const std::string& name, int mode, int Cin, int Cout, int lCin, int lCout) {
+    const int esz = 1;
+    const int k = mode == UPCONV2 ? 2 : (mode == CONV1 ? 1 : 3);
+    Conv c; c.mode = mode; c.Cin = Cin; c.Cout = Cout;
+    c.w = m->n_params; m->n_params += (long)k * k * Cin * Cout;
+    c.b = m->n_params; m->n_params += Cout;
+    add_tensor(m, name + "/kernel", 0, c.w, {k, k, Cin, Cout}, {k, k, lCin, lCout});
+    add_tensor(m, name + "/bias", 0, c.b, {Cout}, {lCout});
+    m->n_logical += (long)k * k * lCin * lCout + lCout;
+    c.wf = c.wd = -1;
+    if (mode != CONV1) {
+        c.wf = m->n_packed; m->n_packed = align64(m->n_packed + (long)k * k * Cin * Cout * esz);
+        c.wd = m->n_packed; m->n_packed = align64(m->n_packed + 9L * Cin * Cout * esz);
+    }
+    m->conv.push_back(c);
+}
+
+void add_bn(mpu_unet* m, const std::string& name, int C, int lC) {
+    BN b; b.C = C;
+    b.g = m->n_params; m->n_params += C;
+    b.b = m->n_params; m->n_params += C;
+    b.mm = m->n_state; m->n_state += C;
+    b.mv = m->n_state; m->n_state += C;
+    b.st = m->n_stats; m->n_stats += 4L * C;
+    add_tensor(m, name + "/gamma", 0, b.g, {C}, {lC});
+    add_tensor(m, name + "/beta", 0, b.b, {C}, {lC});
+    add_tensor(m, name + "/moving_mean", 1, b.mm, {C}, {lC});
+    add_tensor(m, name + "/moving_variance", 1, b.mv, {C}, {lC});
+    m->n_logical += 2L * lC;
+    m->bn.push_back(b);
+    if (C > m->cmax) m->cmax = C;
+}
+
+// ---- workspace plan --------------------------------------------------------
+struct Plan {
+    long xin;
+    std::vector<long> c1, c2, n, p, dskip;          // encoder levels
+    long c1b, c2b, nb;
+    std::vector<long> u1, n1, c2u, c3u, n2;         // up levels
+    long probs, gA, gB, gC, partial, wpartial, coeffs, stats, total;
+};
+
+Plan make_plan(const mpu_unet* m, int B) {
+    const int D = m->cfg.depth, esz = m->cfg.dtype == MPU_BF16 ? 2 : 4;
+    Plan P; long off = 0;
+    auto take = [&](long bytes) { long o = off; off += (bytes + 255) / 256 * 256; return o; };
+    auto act = [&](int lvl, int C) { return take((long)B * (m->cfg.H >> lvl) * (m->cfg.W >> lvl) * C * esz); };
+    P.xin = act(0, m->cin_pad);
+    for (int i = 0; i < D; ++i) {
+        P.c1.push_back(act(i, m->F[i])); P.c2.push_back(act(i, m->F[i])); P.n.push_back(act(i, m->F[i]));
+        P.p.push_back(act(i + 1, m->F[i])); P.dskip.push_back(act(i, m->F[i]));
+    }
+    P.c1b = act(D, m->F[D]); P.c2b = act(D, m->F[D]); P.nb = act(D, m->F[D]);
+    for (int j = 0; j < D; ++j) {
+        const int lvl = D - 1 - j;
+        P.u1.push_back(act(lvl, m->F[lvl])); P.n1.push_back(act(lvl, m->F[lvl]));
+        P.c2u.push_back(act(lvl, m->F[lvl])); P.c3u.push_back(act(lvl, m->F[lvl]));
+        P.n2.push_back(act(lvl, m->F[lvl]));
+    }
+    const long M0 = (long)B * m->cfg.H * m->cfg.W;
+    P.probs = take(M0 * m->cfg.n_classes * 4);
+    long gmax = 0;
+    for (int l = 0; l <= D; ++l) {
+        const long e = (long)B * (m->cfg.H >> l) * (m->cfg.W >> l) * m->F[l];
+        if (e > gmax) gmax = e;
+    }
+    P.gA = take(gmax * esz); P.gB = take(gmax * esz); P.gC = take(gmax * esz);
+    long pe = (long)RED_MAX_BLOCKS * 2 * m->cmax;
+    const long he = (long)RED_MAX_BLOCKS * (m->head_C * m->cfg.n_classes + m->cfg.n_classes);
+    if (he > pe) pe = he;
+    P.partial = take(pe * 4);
+    long we = 0;
+    for (size_t i = 0; i < m->conv.size(); ++i) {
+        const Conv& c = m->conv[i];
+        if (c.mode == CONV1) continue;
+        // the layer's output resolution: find from the tables below (upper bound: try all levels)
+        for (int l = 0; l <= D; ++l) {
+            const long M = (long)B * (m->cfg.H >> l) * (m->cfg.W >> l);
+            const long e = wgrad_partial_elems(c.mode, c.Cin, c.Cout, M, nullptr, nullptr);
+            if (e > we) we = e;
+        }
+    }
+    P.wpartial = take(we * 4);
+    P.coeffs = take(3L * m->cmax * 4);
+    P.stats = take(m->n_stats * 4);
+    P.total = off;
+    return P;
+}
+
+struct Run {
+    const mpu_unet* m; int B; hipStream_t st; unsigned char* ws; Plan P;
+    const float* params; const unsigned char* packed; float* state; float* grads;
+    int esz;
+    void* at(long off) const { return ws + off; }
+    const void* wf(const Conv& c) const { return packed + c.wf * esz; }
+    const void* wd(const Conv& c) const { return packed + c.wd * esz; }
+    float* stat(const BN& b, int k) const { return (float*)(ws + P.stats) + b.st + (long)k * b.C; }
+};
+
+int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* in1, int C1, void* out, int lvl) {
+    ConvArgs a;
+    a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1;
+    a.w = r.wf(c); a.w_tap_stride = (long)c.Cin * c.Cout; a.w_row_stride = c.Cin;
+    a.bias = r.params + c.b; a.mask = nullptr; a.out = out;
+    a.B = r.B; a.Ho = r.m->cfg.H >> lvl; a.Wo = r.m->cfg.W >> lvl; a.Cout = c.Cout; a.relu = 1;
+    return launch_conv(r.m->cfg.dtype, c.mode, a, r.st);
+}
+
+// data gradient of conv `c` w.r.t. input channels [n_off, n_off + n_cnt); out_lvl = resolution of the result
+int conv_dgrad(const Run& r, const Conv& c, const void* dz, const void* mask, void* out, int out_lvl,
+               int n_off, int n_cnt) {
+    ConvArgs a;
+    a.in0 = dz; a.in1 = nullptr; a.C0 = c.Cout; a.C1 = 0;
+    a.w = (const unsigned char*)r.wd(c) + (long)n_off * c.Cout * r.esz;
+    a.w_tap_stride = (long)c.Cin * c.Cout; a.w_row_stride = c.Cout;
+    a.bias = nullptr; a.mask = mask; a.out = out;
+    a.B = r.B; a.Ho = r.m->cfg.H >> out_lvl; a.Wo = r.m->cfg.W >> out_lvl; a.Cout = n_cnt; a.relu = 0;
+    return launch_conv(r.m->cfg.dtype, c.mode == UPCONV2 ? CONV3S2 : CONV3, a, r.st);
+}
+
+int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* x1, int C1, const void* dz, int lvl) {
+    WgradArgs a;
+    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.dz = dz; a.Cout = c.Cout;
+    a.partial = (float*)r.at(r.P.wpartial);
+    a.B = r.B; a.Ho = r.m->cfg.H >> lvl; a.Wo = r.m->cfg.W >> lvl;
+    const long M = (long)a.B * a.Ho * a.Wo;
+    wgrad_partial_elems(c.mode, c.Cin, c.Cout, M, &a.ksplit, &a.mchunk);
+    int rc = launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st);
+    if (rc) return rc;
+    return launch_colsum(r.m->cfg.dtype, dz, M, c.Cout, (float*)r.at(r.P.partial), r.grads + c.b, r.st);
+}
+
+int bn_fwd(const Run& r, const BN& b, const void* x, int lvl, int training, void* y, void* pooled) {
+    const int H = r.m->cfg.H >> lvl, W = r.m->cfg.W >> lvl;
+    const long M = (long)r.B * H * W;
+    int rc;
+    if (training)
+        rc = launch_bn_stats(r.m->cfg.dtype, x, M, b.C, (float*)r.at(r.P.partial), r.params + b.g, r.params + b.b,
+                             r.state + b.mm, r.state + b.mv, r.stat(b, 0), r.stat(b, 1), r.stat(b, 2), r.stat(b, 3),
+                             BN_EPS, BN_MOM, r.st);
+    else
+        rc = launch_bn_infer_coeffs(r.params + b.g, r.params + b.b, r.state + b.mm, r.state + b.mv, b.C, BN_EPS,
+                                    r.stat(b, 2), r.stat(b, 3), r.st);
+    if (rc) return rc;
+    return launch_bn_apply(r.m->cfg.dtype, x, r.B, H, W, b.C, r.stat(b, 2), r.stat(b, 3), y, pooled, r.st);
+}
+
+int bn_bwd(const Run& r, const BN& b, const void* dn, const void* x, int lvl, void* dz) {
+    const long M = (long)r.B * (r.m->cfg.H >> lvl) * (r.m->cfg.W >> lvl);
+    return launch_bn_backward(r.m->cfg.dtype, dn, x, M, b.C, (float*)r.at(r.P.partial), r.params + b.g, r.stat(b, 0),
+                              r.stat(b, 1), r.grads + b.g, r.grads + b.b, (float*)r.at(r.P.coeffs), dz, r.st);
+}
+
+#define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+int run_forward(const Run& r, const float* d_x, int training, float* d_out) {
+    const mpu_unet* m = r.m; const int D = m->cfg.depth; const Plan& P = r.P;
+    const long M0 = (long)r.B * m->cfg.H * m->cfg.W;
+    RC(launch_cast_pad(m->cfg.dtype, d_x, M0, m->cfg.n_channels, m->cin_pad, r.at(P.xin), r.st));
+    const void* cur = r.at(P.xin); int Ccur = m->cin_pad;
+    for (int i = 0; i < D; ++i) {
+        RC(conv_fwd(r, m->conv[m->enc_c1(i)], cur, Ccur, nullptr, 0, r.at(P.c1[i]), i));
+        RC(conv_fwd(r, m->conv[m->enc_c2(i)], r.at(P.c1[i]), m->F[i], nullptr, 0, r.at(P.c2[i]), i));
+        RC(bn_fwd(r, m->bn[m->enc_bn(i)], r.at(P.c2[i]), i, training, r.at(P.n[i]), r.at(P.p[i])));
+        cur = r.at(P.p[i]); Ccur = m->F[i];
+    }
+    RC(conv_fwd(r, m->conv[m->bot_c1()], cur, Ccur, nullptr, 0, r.at(P.c1b), D));
+    RC(conv_fwd(r, m->conv[m->bot_c2()], r.at(P.c1b), m->F[D], nullptr, 0, r.at(P.c2b), D));
+    RC(bn_fwd(r, m->bn[m->bot_bn()], r.at(P.c2b), D, training, r.at(P.nb), nullptr));
+    const void* prev = r.at(P.nb); int Cprev = m->F[D];
+    for (int j = 0; j < D; ++j) {
+        const int lvl = D - 1 - j, f = m->F[lvl];
+        RC(conv_fwd(r, m->conv[m->up_c(j, 0)], prev, Cprev, nullptr, 0, r.at(P.u1[j]), lvl));
+        RC(bn_fwd(r, m->bn[m->up_bn(j, 0)], r.at(P.u1[j]), lvl, training, r.at(P.n1[j]), nullptr));
+        RC(conv_fwd(r, m->conv[m->up_c(j, 1)], r.at(P.n[lvl]), f, r.at(P.n1[j]), f, r.at(P.c2u[j]), lvl));
+        RC(conv_fwd(r, m->conv[m->up_c(j, 2)], r.at(P.c2u[j]), f, nullptr, 0, r.at(P.c3u[j]), lvl));
+        RC(bn_fwd(r, m->bn[m->up_bn(j, 1)], r.at(P.c3u[j]), lvl, training, r.at(P.n2[j]), nullptr));
+        prev = r.at(P.n2[j]); Cprev = f;
+    }
+    float* out = d_out ? d_out : (float*)r.at(P.probs);
+    RC(launch_head_forward(m->cfg.dtype, prev, M0, m->head_C, m->cfg.n_classes, r.params + m->head_w,
+                           m->cfg.n_classes, r.params + m->head_b, m->cfg.softmax, out, r.st));
+    if (training && d_out)     // keep a copy for the backward pass
+        MPU_CHECK_HIP(hipMemcpyAsync(r.at(P.probs), d_out, M0 * m->cfg.n_classes * 4, hipMemcpyDeviceToDevice, r.st));
+    return MPU_OK;
+}
+
+int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_loss) {
+    const mpu_unet* m = r.m; const int D = m->cfg.depth; const Plan& P = r.P;
+    const int dt = m->cfg.dtype;
+    const long M0 = (long)r.B * m->cfg.H * m->cfg.W;
+    void* gA = r.at(P.gA); void* gB = r.at(P.gB); void* gC = r.at(P.gC);
+    const void* last = D > 0 ? r.at(P.n2[D - 1]) : r.at(P.nb);
+    RC(launch_head_backward(dt, last, (const float*)r.at(P.probs), d_y, d_sw, M0, (long)m->cfg.H * m->cfg.W,
+                            m->head_C, m->cfg.n_classes, r.params + m->head_w, m->cfg.n_classes,
+                            (float*)r.at(P.partial), gA, r.grads + m->head_w, r.grads + m->head_b, d_loss, r.st));
+    for (int j = D - 1; j >= 0; --j) {
+        const int lvl = D - 1 - j, f = m->F[lvl];
+        const Conv& cu = m->conv[m->up_c(j, 0)]; const Conv& c2 = m->conv[m->up_c(j, 1)];
+        const Conv& c3 = m->conv[m->up_c(j, 2)];
+        const void* prev = j > 0 ? r.at(P.n2[j - 1]) : r.at(P.nb);
+        const int Cprev = j > 0 ? m->F[lvl + 1] : m->F[D];
+        RC(bn_bwd(r, m->bn[m->up_bn(j, 1)], gA, r.at(P.c3u[j]), lvl, gB));                 // dz3
+        RC(conv_wgrad(r, c3, r.at(P.c2u[j]), f, nullptr, 0, gB, lvl));
+        RC(conv_dgrad(r, c3, gB, r.at(P.c2u[j]), gA, lvl, 0, f));                          // dz2
+        RC(conv_wgrad(r, c2, r.at(P.n[lvl]), f, r.at(P.n1[j]), f, gA, lvl));
+        RC(conv_dgrad(r, c2, gA, nullptr, r.at(P.dskip[lvl]), lvl, 0, f));                 // d skip
+        RC(conv_dgrad(r, c2, gA, nullptr, gB, lvl, f, f));                                 // d n1
+        RC(bn_bwd(r, m->bn[m->up_bn(j, 0)], gB, r.at(P.u1[j]), lvl, gC));                  // dz up-conv
+        RC(conv_wgrad(r, cu, prev, Cprev, nullptr, 0, gC, lvl));
+        RC(conv_dgrad(r, cu, gC, nullptr, gA, lvl + 1, 0, Cprev));                         // d prev
+    }
+    {   // bottom
+        const Conv& c1 = m->conv[m->bot_c1()]; const Conv& c2 = m->conv[m->bot_c2()];
+        const void* xin = D > 0 ? r.at(P.p[D - 1]) : r.at(P.xin);
+        const int Cx = D > 0 ? m->F[D - 1] : m->cin_pad;
+        RC(bn_bwd(r, m->bn[m->bot_bn()], gA, r.at(P.c2b), D, gB));
+        RC(conv_wgrad(r, c2, r.at(P.c1b), m->F[D], nullptr, 0, gB, D));
+        RC(conv_dgrad(r, c2, gB, r.at(P.c1b), gA, D, 0, m->F[D]));
+        RC(conv_wgrad(r, c1, xin, Cx, nullptr, 0, gA, D));
+        if (D > 0) RC(conv_dgrad(r, c1, gA, nullptr, gB, D, 0, Cx));                       // d pooled
+    }
+    for (int i = D - 1; i >= 0; --i) {
+        const Conv& c1 = m->conv[m->enc_c1(i)]; const Conv& c2 = m->conv[m->enc_c2(i)];
+        const int H = m->cfg.H >> i, W = m->cfg.W >> i;
+        RC(launch_maxpool_bwd_add(dt, r.at(P.n[i]), r.at(P.dskip[i]), gB, r.B, H, W, m->F[i], gA, r.st));
+        RC(bn_bwd(r, m->bn[m->enc_bn(i)], gA, r.at(P.c2[i]), i, gB));
+        RC(conv_wgrad(r, c2, r.at(P.c1[i]), m->F[i], nullptr, 0, gB, i));
+        RC(conv_dgrad(r, c2, gB, r.at(P.c1[i]), gA, i, 0, m->F[i]));
+        const void* xin = i > 0 ? r.at(P.p[i - 1]) : r.at(P.xin);
+        const int Cx = i > 0 ? m->F[i - 1] : m->cin_pad;
+        RC(conv_wgrad(r, c1, xin, Cx, nullptr, 0, gA, i));
+        if (i > 0) RC(conv_dgrad(r, c1, gA, nullptr, gB, i, 0, Cx));
+    }
+    return MPU_OK;
+}
+
+int make_run(Run& r, const mpu_unet* m, int batch, const float* params, const void* packed, float* state,
+             float* grads, void* ws, void* stream) {
+    MPU_REQUIRE(m && params && packed && state && ws, "unet: null argument");
+    MPU_REQUIRE(batch >= 1, "unet: batch must be >= 1");
+    r.m = m; r.B = batch; r.st = (hipStream_t)stream; r.ws = (unsigned char*)ws; r.P = make_plan(m, batch);
+    r.params = params; r.packed = (const unsigned char*)packed; r.state = state; r.grads = grads;
+    r.esz = m->cfg.dtype == MPU_BF16 ? 2 : 4;
+    return MPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+mpu_unet* mpu_unet_create(const mpu_unet_config* cfg) {
+    if (!cfg) { fail(MPU_EINVAL, "%s", "mpu_unet_create: null config"); return nullptr; }
+    const int D = cfg->depth;
+    if (cfg->n_classes < 1 || cfg->n_classes > 8 || cfg->n_channels < 1 || D < 1 || D > 6 || cfg->H < 1 || cfg->W < 1 ||
+        (cfg->H % (1 << D)) || (cfg->W % (1 << D)) || (cfg->dtype != MPU_F32 && cfg->dtype != MPU_BF16)) {
+        fail(MPU_EINVAL, "%s", "mpu_unet_create: unsupported configuration (need 1<=n_classes<=8, 1<=depth<=6, "
+                               "H and W multiples of 2^depth, dtype f32|bf16)");
+        return nullptr;
+    }
+    mpu_unet* m = new mpu_unet();
+    m->cfg = *cfg;
+    m->cin_pad = pad8(cfg->n_channels);
+    for (int l = 0; l <= D; ++l) {
+        const int fl = cfg->filters[l];
+        if (fl < 1) { delete m; fail(MPU_EINVAL, "%s", "mpu_unet_create: filters[] must be positive"); return nullptr; }
+        m->Fl.push_back(fl); m->F.push_back(pad8(fl));
+    }
+    char buf[64];
+    int cin = m->cin_pad, lcin = cfg->n_channels;
+    for (int i = 0; i < D; ++i) {
+        snprintf(buf, sizeof(buf), "encoder_L%d", i);
+        add_conv(m, std::string(buf) + "_conv1", CONV3, cin, m->F[i], lcin, m->Fl[i]);
+        add_conv(m, std::string(buf) + "_conv2", CONV3, m->F[i], m->F[i], m->Fl[i], m->Fl[i]);
+        cin = m->F[i]; lcin = m->Fl[i];
+    }
+    add_conv(m, "bottom_conv1", CONV3, cin, m->F[D], lcin, m->Fl[D]);
+    add_conv(m, "bottom_conv2", CONV3, m->F[D], m->F[D], m->Fl[D], m->Fl[D]);
+    cin = m->F[D]; lcin = m->Fl[D];
+    for (int j = 0; j < D; ++j) {
+        const int lvl = D - 1 - j;
+        snprintf(buf, sizeof(buf), "upsample_L%d", j);
+        add_conv(m, std::string(buf) + "_conv1", UPCONV2, cin, m->F[lvl], lcin, m->Fl[lvl]);
+        add_conv(m, std::string(buf) + "_conv2", CONV3, 2 * m->F[lvl], m->F[lvl], 2 * m->Fl[lvl], m->Fl[lvl]);
+        add_conv(m, std::string(buf) + "_conv3", CONV3, m->F[lvl], m->F[lvl], m->Fl[lvl], m->Fl[lvl]);
+        cin = m->F[lvl]; lcin = m->Fl[lvl];
+    }
+    add_conv(m, "conv2d", CONV1, cin, cfg->n_classes, lcin, cfg->n_classes);
+    m->head_C = cin; m->head_w = m->conv.back().w; m->head_b = m->conv.back().b;
+    // BN layers are appended after the convs in the flat tables (order inside the
+    // tables is irrelevant to callers: they address tensors by name)
+    for (int i = 0; i < D; ++i) { snprintf(buf, sizeof(buf), "encoder_L%d_BN", i); add_bn(m, buf, m->F[i], m->Fl[i]); }
+    add_bn(m, "bottom_BN", m->F[D], m->Fl[D]);
+    for (int j = 0; j < D; ++j) {
+        const int lvl = D - 1 - j;
+        snprintf(buf, sizeof(buf), "upsample_L%d_BN1", j); add_bn(m, buf, m->F[lvl], m->Fl[lvl]);
+        snprintf(buf, sizeof(buf), "upsample_L%d_BN2", j); add_bn(m, buf, m->F[lvl], m->Fl[lvl]);
+    }
+    return m;
+}
+
+void mpu_unet_destroy(mpu_unet* m) { delete m; }
+
+int64_t mpu_unet_param_floats(const mpu_unet* m) { return m ? m->n_params : 0; }
+int64_t mpu_unet_bn_state_floats(const mpu_unet* m) { return m ? m->n_state : 0; }
+int64_t mpu_unet_packed_bytes(const mpu_unet* m) { return m ? m->n_packed * (m->cfg.dtype == MPU_BF16 ? 2 : 4) : 0; }
+int64_t mpu_unet_logical_param_count(const mpu_unet* m) { return m ? m->n_logical : 0; }
+int32_t mpu_unet_num_tensors(const mpu_unet* m) { return m ? (int32_t)m->tensors.size() : 0; }
+
+int mpu_unet_tensor_info(const mpu_unet* m, int32_t idx, char* name, int32_t name_cap, int32_t* kind,
+                         int64_t* offset, int32_t stored_shape[4], int32_t logical_shape[4]) {
+    MPU_REQUIRE(m && name && kind && offset && stored_shape && logical_shape, "mpu_unet_tensor_info: null argument");
+    MPU_REQUIRE(idx >= 0 && idx < (int)m->tensors.size(), "mpu_unet_tensor_info: index out of range");
+    const Tensor& t = m->tensors[idx];
+    snprintf(name, name_cap, "%s", t.name.c_str());
+    *kind = t.kind; *offset = t.offset;
+    for (int i = 0; i < 4; ++i) { stored_shape[i] = t.pshape[i]; logical_shape[i] = t.lshape[i]; }
+    return MPU_OK;
+}
+
+int64_t mpu_unet_workspace_bytes(const mpu_unet* m, int32_t batch) {
+    if (!m || batch < 1) return 0;
+    return make_plan(m, batch).total;
+}
+
+int mpu_unet_pack_weights(const mpu_unet* m, const float* d_params, void* d_packed, void* stream) {
+    MPU_REQUIRE(m && d_params && d_packed, "mpu_unet_pack_weights: null argument");
+    const int esz = m->cfg.dtype == MPU_BF16 ? 2 : 4;
+    for (const Conv& c : m->conv) {
+        if (c.mode == CONV1) continue;
+        RC(launch_pack_weights(m->cfg.dtype, c.mode, d_params + c.w, c.Cin, c.Cout,
+                               (unsigned char*)d_packed + c.wf * esz, (unsigned char*)d_packed + c.wd * esz,
+                               (hipStream_t)stream));
+    }
+    return MPU_OK;
+}
+
+int mpu_unet_forward(const mpu_unet* m, int32_t batch, const float* d_x, const float* d_params, const void* d_packed,
+                     float* d_bn_state, void* d_workspace, int32_t training, float* d_out, void* stream) {
+    MPU_REQUIRE(d_x, "mpu_unet_forward: null input");
+    Run r;
+    RC(make_run(r, m, batch, d_params, d_packed, d_bn_state, nullptr, d_workspace, stream));
+    return run_forward(r, d_x, training, d_out);
+}
+
+int mpu_unet_backward(const mpu_unet* m, int32_t batch, const uint8_t* d_y, const float* d_sample_weight,
+                      const float* d_params, const void* d_packed, float* d_bn_state, void* d_workspace,
+                      float* d_grads, float* d_loss, void* stream) {
+    MPU_REQUIRE(d_y && d_sample_weight && d_grads, "mpu_unet_backward: null argument");
+    MPU_REQUIRE(m && m->cfg.softmax, "mpu_unet_backward: training needs out_activation='softmax'");
+    Run r;
+    RC(make_run(r, m, batch, d_params, d_packed, d_bn_state, d_grads, d_workspace, stream));
+    return run_backward(r, d_y, d_sample_weight, d_loss);
+}
+
+int mpu_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n, int64_t t,
+                  double lr, double beta1, double beta2, double eps, void* stream) {
+    MPU_REQUIRE(d_params && d_grads && d_m && d_v && n >= 0 && t >= 1, "mpu_adam_step: bad argument");
+    const double alpha = lr * std::sqrt(1.0 - std::pow(beta2, (double)t)) / (1.0 - std::pow(beta1, (double)t));
+    return launch_adam(d_params, d_grads, d_m, d_v, n, (float)alpha, (float)beta1, (float)beta2, (float)eps,
+                       (hipStream_t)stream);
+}
+
+// ---- op-level entry points (unit tests, integration of single layers) ------
+int mpu_conv2d_pack_weights(int32_t dtype, int32_t mode, const float* d_w, int32_t Cin, int32_t Cout,
+                            void* d_w_fwd, void* d_w_dgrad, void* stream) {
+    MPU_REQUIRE(d_w && d_w_fwd, "mpu_conv2d_pack_weights: null argument");
+    MPU_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "mpu_conv2d_pack_weights: channels must be multiples of 8");
+    return launch_pack_weights(dtype, mode, d_w, Cin, Cout, d_w_fwd, d_w_dgrad, (hipStream_t)stream);
+}
+
+int mpu_conv2d_igemm(int32_t dtype, int32_t mode, const void* d_in0, int32_t C0, const void* d_in1, int32_t C1,
+                     const void* d_w_packed, int64_t w_tap_stride, int32_t w_row_stride, const float* d_bias,
+                     const void* d_mask, void* d_out, int32_t B, int32_t Ho, int32_t Wo, int32_t Cout, int32_t relu,
+                     void* stream) {
+    MPU_REQUIRE(d_in0 && d_w_packed && d_out, "mpu_conv2d_igemm: null argument");
+    MPU_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && Cout % 8 == 0 && C0 > 0, "mpu_conv2d_igemm: channels must be multiples of 8");
+    MPU_REQUIRE((C1 == 0) == (d_in1 == nullptr), "mpu_conv2d_igemm: in1 / C1 mismatch");
+    MPU_REQUIRE(mode != UPCONV2 || (Ho % 2 == 0 && Wo % 2 == 0), "mpu_conv2d_igemm: UPCONV2 needs even output size");
+    ConvArgs a;
+    a.in0 = d_in0; a.in1 = d_in1; a.C0 = C0; a.C1 = C1; a.w = d_w_packed; a.w_tap_stride = w_tap_stride;
+    a.w_row_stride = w_row_stride; a.bias = d_bias; a.mask = d_mask; a.out = d_out;
+    a.B = B; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.relu = relu;
+    return launch_conv(dtype, mode, a, (hipStream_t)stream);
+}
+
+int64_t mpu_conv2d_wgrad_workspace_floats(int32_t mode, int32_t Cin, int32_t Cout, int64_t M) {
+    return wgrad_partial_elems(mode, Cin, Cout, M, nullptr, nullptr);
+}
+
+int mpu_conv2d_wgrad(int32_t dtype, int32_t mode, const void* d_x0, int32_t C0, const void* d_x1, int32_t C1,
+                     const void* d_dz, int32_t Cout, int32_t B, int32_t Ho, int32_t Wo, float* d_workspace,
+                     float* d_dW, void* stream) {
+    MPU_REQUIRE(d_x0 && d_dz && d_workspace && d_dW, "mpu_conv2d_wgrad: null argument");
+    MPU_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && Cout % 8 == 0, "mpu_conv2d_wgrad: channels must be multiples of 8");
+    WgradArgs a;
+    a.x0 = d_x0; a.x1 = d_x1; a.C0 = C0; a.C1 = C1; a.dz = d_dz; a.Cout = Cout; a.partial = d_workspace;
+    a.B = B; a.Ho = Ho; a.Wo = Wo;
+    wgrad_partial_elems(mode, C0 + C1, Cout, (long)B * Ho * Wo, &a.ksplit, &a.mchunk);
+    return launch_wgrad(dtype, mode, a, d_dW, (hipStream_t)stream);
+}
+
+}  // extern "C"

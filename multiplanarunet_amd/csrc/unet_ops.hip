@@ -1,0 +1,637 @@
+// Memory-bound U-Net kernels around the MFMA convolutions: weight packing,
+// BatchNormalization (train statistics / apply / backward), 2x2 max-pool and its
+// gradient, bias-gradient column sums, the 1x1 softmax head with the Keras
+// sparse-CE gradient, and Adam. All activations are [M][C] (NHWC flattened),
+// C a multiple of 8; every kernel moves 16 B per lane.
+//
+// Reference semantics: mpunet/models/unet.py:114-216 (layer order), Keras
+// defaults restated in SURVEY.md section 8a rows a6/a7, oracle/unet_ref.py.
+#include "kernels.h"
+
+namespace mpu {
+
+template <typename T> struct Vec;   // one 16-byte chunk of T as floats
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct Vec<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        const uint4 t = *(const uint4*)p;
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+        *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+static inline int ew_grid(long work) {
+    long b = (work + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+// ------------------------------------------------------------------------- //
+// weight packing: fp32 master (Keras HWIO = [tap][ci][co]) -> MFMA operands
+// ------------------------------------------------------------------------- //
+template <typename T>
+__global__ void pack_weights_kernel(int mode, const float* __restrict__ W, int Cin, int Cout,
+                                    T* __restrict__ wf, T* __restrict__ wd) {
+    const int ntaps = mode == UPCONV2 ? 4 : (mode == CONV1 ? 1 : 9);
+    const long per_tap = (long)Cin * Cout;
+    // forward operand [tap][co][ci]
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < ntaps * per_tap;
+         e += (long)gridDim.x * blockDim.x) {
+        const int tap = (int)(e / per_tap); const long r = e % per_tap;
+        const int co = (int)(r / Cin), ci = (int)(r % Cin);
+        wf[e] = from_f32<T>(W[(long)tap * per_tap + (long)ci * Cout + co]);
+    }
+    if (!wd) return;
+    // data-gradient operand [tap'][ci][co]
+    const int dtaps = 9;
+    if (mode == CONV1) {
+        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < per_tap; e += (long)gridDim.x * blockDim.x)
+            wd[e] = from_f32<T>(W[e]);
+        return;
+    }
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < dtaps * per_tap;
+         e += (long)gridDim.x * blockDim.x) {
+        const int tp = (int)(e / per_tap); const long r = e % per_tap;
+        float v;
+        if (mode == CONV3) {
+            v = W[(long)(8 - tp) * per_tap + r];                 // 180-degree rotated taps
+        } else {                                                  // UPCONV2 -> 3x3 stride-2 combined taps
+            const int dy = tp / 3 - 1, dx = tp % 3 - 1;           // S(-1)={1}, S(0)={0,1}, S(1)={0}
+            v = 0.f;
+            for (int ky = 0; ky < 2; ++ky) {
+                if ((dy == -1 && ky != 1) || (dy == 1 && ky != 0)) continue;
+                for (int kx = 0; kx < 2; ++kx) {
+                    if ((dx == -1 && kx != 1) || (dx == 1 && kx != 0)) continue;
+                    v += W[(long)(ky * 2 + kx) * per_tap + r];
+                }
+            }
+        }
+        wd[e] = from_f32<T>(v);
+    }
+}
+
+int launch_pack_weights(int dtype, int mode, const float* W, int Cin, int Cout, void* wf, void* wd, hipStream_t st) {
+    const long n = 9L * Cin * Cout;
+    if (dtype == MPU_BF16) pack_weights_kernel<bf16_t><<<ew_grid(n), 256, 0, st>>>(mode, W, Cin, Cout, (bf16_t*)wf, (bf16_t*)wd);
+    else pack_weights_kernel<float><<<ew_grid(n), 256, 0, st>>>(mode, W, Cin, Cout, (float*)wf, (float*)wd);
+    return launch_ok();
+}
+
+template <typename T>
+__global__ void cast_pad_kernel(const float* __restrict__ x, long M, int Cin, int Cpad, T* __restrict__ out) {
+    const long n = M * Cpad;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long m = e / Cpad; const int c = (int)(e % Cpad);
+        out[e] = from_f32<T>(c < Cin ? x[m * Cin + c] : 0.f);
+    }
+}
+int launch_cast_pad(int dtype, const float* x, long M, int Cin, int Cpad, void* out, hipStream_t st) {
+    if (dtype == MPU_BF16) cast_pad_kernel<bf16_t><<<ew_grid(M * Cpad), 256, 0, st>>>(x, M, Cin, Cpad, (bf16_t*)out);
+    else cast_pad_kernel<float><<<ew_grid(M * Cpad), 256, 0, st>>>(x, M, Cin, Cpad, (float*)out);
+    return launch_ok();
+}
+
+// ------------------------------------------------------------------------- //
+// per-channel reductions over the M rows of [M][C]: two deterministic stages
+//   OP 0: (sum x, sum x^2)                      BN statistics
+//   OP 1: (sum dn, sum dn*(x-mean)*invstd)      BN backward
+//   OP 2: (sum x)                               bias gradient
+// partial layout [nblk][NS][C]
+// ------------------------------------------------------------------------- //
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a, const T* __restrict__ b, long M, int C,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        int rows_per_blk, float* __restrict__ partial) {
+    constexpr int N = Vec<T>::N;
+    constexpr int NS = OP == 2 ? 1 : 2;
+    __shared__ float red[256 * N * NS];
+    const int cpr = C / N;
+    int TX = 1; while (TX < cpr && TX < 256) TX <<= 1;
+    const int TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const long r_beg = (long)blockIdx.x * rows_per_blk;
+    long r_end = r_beg + rows_per_blk; if (r_end > M) r_end = M;
+    for (int cg = 0; cg < cpr; cg += TX) {
+        const int c = cg + tx;
+        float s0[N], s1[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+        if (c < cpr) {
+            float mu[N], is[N];
+            if (OP == 1) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) { mu[i] = mean[c * N + i]; is[i] = invstd[c * N + i]; }
+            }
+            for (long r = r_beg + ty; r < r_end; r += TY) {
+                float va[N];
+                Vec<T>::load(a + r * C + (long)c * N, va);
+                if (OP == 0) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) { s0[i] += va[i]; s1[i] += va[i] * va[i]; }
+                } else if (OP == 1) {
+                    float vb[N];
+                    Vec<T>::load(b + r * C + (long)c * N, vb);
+#pragma unroll
+                    for (int i = 0; i < N; ++i) { s0[i] += va[i]; s1[i] += va[i] * ((vb[i] - mu[i]) * is[i]); }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) s0[i] += va[i];
+                }
+            }
+        }
+        // reduce over ty through LDS
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            red[(threadIdx.x * NS + 0) * N + i] = s0[i];
+            if (NS == 2) red[(threadIdx.x * NS + 1) * N + i] = s1[i];
+        }
+        __syncthreads();
+        if (ty == 0 && c < cpr) {
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    float acc = 0.f;
+                    for (int y = 0; y < TY; ++y) acc += red[((y * TX + tx) * NS + s) * N + i];
+                    partial[((long)blockIdx.x * NS + s) * C + c * N + i] = acc;
+                }
+        }
+        __syncthreads();
+    }
+}
+
+static int red_blocks(long M, int* rows_per_blk) {
+    long rpb = (M + RED_MAX_BLOCKS - 1) / RED_MAX_BLOCKS;
+    if (rpb < 64) rpb = 64;
+    *rows_per_blk = (int)rpb;
+    return (int)((M + rpb - 1) / rpb);
+}
+
+template <int OP>
+static int launch_colreduce(int dtype, const void* a, const void* b, long M, int C, const float* mean,
+                            const float* invstd, float* partial, int* nblk_out, hipStream_t st) {
+    int rpb; const int nblk = red_blocks(M, &rpb);
+    *nblk_out = nblk;
+    if (dtype == MPU_BF16)
+        colreduce_kernel<bf16_t, OP><<<nblk, 256, 0, st>>>((const bf16_t*)a, (const bf16_t*)b, M, C, mean, invstd, rpb, partial);
+    else
+        colreduce_kernel<float, OP><<<nblk, 256, 0, st>>>((const float*)a, (const float*)b, M, C, mean, invstd, rpb, partial);
+    return launch_ok();
+}
+
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
+                                         const float* gamma, const float* beta, float* mmean, float* mvar,
+                                         float* mean, float* invstd, float* scale, float* shift, float eps, float mom) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < nblk; ++k) { s += partial[((long)k * 2) * C + c]; ss += partial[((long)k * 2 + 1) * C + c]; }
+    const double mu = s / (double)M;
+    double var = ss / (double)M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * is;
+    mean[c] = (float)mu; invstd[c] = is; scale[c] = sc; shift[c] = beta[c] - (float)mu * sc;
+    const double ub = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+    mmean[c] = mmean[c] * mom + (float)mu * (1.f - mom);
+    mvar[c] = mvar[c] * mom + (float)ub * (1.f - mom);
+}
+
+int launch_bn_stats(int dtype, const void* x, long M, int C, float* partial, const float* gamma, const float* beta,
+                    float* mmean, float* mvar, float* mean, float* invstd, float* scale, float* shift,
+                    float eps, float momentum, hipStream_t st) {
+    int nblk;
+    int rc = launch_colreduce<0>(dtype, x, nullptr, M, C, nullptr, nullptr, partial, &nblk, st);
+    if (rc) return rc;
+    bn_stats_finalize_kernel<<<cdiv(C, 128), 128, 0, st>>>(partial, nblk, C, M, gamma, beta, mmean, mvar, mean,
+                                                           invstd, scale, shift, eps, momentum);
+    return launch_ok();
+}
+
+__global__ void bn_infer_coeffs_kernel(const float* gamma, const float* beta, const float* mm, const float* mv,
+                                       int C, float eps, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * (1.f / sqrtf(mv[c] + eps));
+    scale[c] = sc; shift[c] = beta[c] - mm[c] * sc;
+}
+int launch_bn_infer_coeffs(const float* gamma, const float* beta, const float* mm, const float* mv, int C, float eps,
+                           float* scale, float* shift, hipStream_t st) {
+    bn_infer_coeffs_kernel<<<cdiv(C, 128), 128, 0, st>>>(gamma, beta, mm, mv, C, eps, scale, shift);
+    return launch_ok();
+}
+
+// y = x*scale + shift ; POOL: also 2x2 max of y (taken after the affine: gamma may be negative)
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int B, int H, int W, int C,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       T* __restrict__ y, T* __restrict__ pooled) {
+    constexpr int N = Vec<T>::N;
+    const int cpr = C / N;
+    if (!POOL) {
+        const long total = (long)B * H * W * cpr;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+            const int c = (int)(e % cpr);
+            float v[N];
+            Vec<T>::load(x + e * N, v);
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = v[i] * scale[c * N + i] + shift[c * N + i];
+            Vec<T>::store(y + e * N, v);
+        }
+    } else {
+        const int Hp = H / 2, Wp = W / 2;
+        const long total = (long)B * Hp * Wp * cpr;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+            const int c = (int)(e % cpr); long t = e / cpr;
+            const int px = (int)(t % Wp); t /= Wp;
+            const int py = (int)(t % Hp); const int b = (int)(t / Hp);
+            float sc[N], sh[N], mx[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) { sc[i] = scale[c * N + i]; sh[i] = shift[c * N + i]; }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const long o = ((((long)b * H + 2 * py + (d >> 1)) * W + 2 * px + (d & 1)) * cpr + c) * N;
+                float v[N];
+                Vec<T>::load(x + o, v);
+#pragma unroll
+                for (int i = 0; i < N; ++i) v[i] = v[i] * sc[i] + sh[i];
+                Vec<T>::store(y + o, v);
+                // the pooled value is the max of the STORED (rounded) values
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const float r = to_f32<T>(from_f32<T>(v[i]));
+                    mx[i] = d == 0 ? r : fmaxf(mx[i], r);
+                }
+            }
+            Vec<T>::store(pooled + e * N, mx);
+        }
+    }
+}
+
+int launch_bn_apply(int dtype, const void* x, int B, int H, int W, int C, const float* scale, const float* shift,
+                    void* y, void* pooled, hipStream_t st) {
+    const long work = (long)B * H * W * C / 8 / (pooled ? 4 : 1);
+#define MPU_BNA(TT)                                                                                      \
+    if (pooled) bn_apply_kernel<TT, true><<<ew_grid(work), 256, 0, st>>>((const TT*)x, B, H, W, C, scale, shift, (TT*)y, (TT*)pooled); \
+    else bn_apply_kernel<TT, false><<<ew_grid(work), 256, 0, st>>>((const TT*)x, B, H, W, C, scale, shift, (TT*)y, nullptr);
+    if (dtype == MPU_BF16) { MPU_BNA(bf16_t) } else { MPU_BNA(float) }
+#undef MPU_BNA
+    return launch_ok();
+}
+
+// BN backward finalize: dgamma, dbeta and the per-channel coefficients of
+// dx = k1*dn + k2*x + k3  (dx = scale*(dn - mean(dn) - xhat*mean(dn*xhat)))
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
+                                       const float* gamma, const float* mean, const float* invstd,
+                                       float* dgamma, float* dbeta, float* coeffs) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, sx = 0.0;
+    for (int k = 0; k < nblk; ++k) { s += partial[((long)k * 2) * C + c]; sx += partial[((long)k * 2 + 1) * C + c]; }
+    dgamma[c] = (float)sx; dbeta[c] = (float)s;
+    const double sc = (double)gamma[c] * (double)invstd[c];
+    const double mdn = s / (double)M, mdx = sx / (double)M;
+    const double k2 = -sc * mdx * (double)invstd[c];
+    coeffs[c] = (float)sc;
+    coeffs[C + c] = (float)k2;
+    coeffs[2 * C + c] = (float)(-sc * mdn - k2 * (double)mean[c]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dn, const T* __restrict__ x, long M, int C,
+                                                           const float* __restrict__ k, T* __restrict__ dz) {
+    constexpr int N = Vec<T>::N;
+    const int cpr = C / N;
+    const long total = M * cpr;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % cpr);
+        float g[N], v[N], o[N];
+        Vec<T>::load(dn + e * N, g);
+        Vec<T>::load(x + e * N, v);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int ch = c * N + i;
+            o[i] = v[i] > 0.f ? (k[ch] * g[i] + k[C + ch] * v[i] + k[2 * C + ch]) : 0.f;
+        }
+        Vec<T>::store(dz + e * N, o);
+    }
+}
+
+int launch_bn_backward(int dtype, const void* dn, const void* x, long M, int C, float* partial, const float* gamma,
+                       const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coeffs, void* dz,
+                       hipStream_t st) {
+    int nblk;
+    int rc = launch_colreduce<1>(dtype, dn, x, M, C, mean, invstd, partial, &nblk, st);
+    if (rc) return rc;
+    bn_bwd_finalize_kernel<<<cdiv(C, 128), 128, 0, st>>>(partial, nblk, C, M, gamma, mean, invstd, dgamma, dbeta, coeffs);
+    rc = launch_ok();
+    if (rc) return rc;
+    const long work = M * C / 8;
+    if (dtype == MPU_BF16)
+        bn_bwd_apply_kernel<bf16_t><<<ew_grid(work), 256, 0, st>>>((const bf16_t*)dn, (const bf16_t*)x, M, C, coeffs, (bf16_t*)dz);
+    else
+        bn_bwd_apply_kernel<float><<<ew_grid(work), 256, 0, st>>>((const float*)dn, (const float*)x, M, C, coeffs, (float*)dz);
+    return launch_ok();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const T* __restrict__ n, const T* __restrict__ dskip,
+                                                              const T* __restrict__ dp, int B, int H, int W, int C,
+                                                              T* __restrict__ dn) {
+    constexpr int N = Vec<T>::N;
+    const int cpr = C / N, Hp = H / 2, Wp = W / 2;
+    const long total = (long)B * Hp * Wp * cpr;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % cpr); long t = e / cpr;
+        const int px = (int)(t % Wp); t /= Wp;
+        const int py = (int)(t % Hp); const int b = (int)(t / Hp);
+        float g[N];
+        Vec<T>::load(dp + e * N, g);
+        float v[4][N];
+        long o[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            o[d] = ((((long)b * H + 2 * py + (d >> 1)) * W + 2 * px + (d & 1)) * cpr + c) * N;
+            Vec<T>::load(n + o[d], v[d]);
+        }
+        int arg[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            int a = 0; float m = v[0][i];
+#pragma unroll
+            for (int d = 1; d < 4; ++d) if (v[d][i] > m) { m = v[d][i]; a = d; }
+            arg[i] = a;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float s[N];
+            if (dskip) Vec<T>::load(dskip + o[d], s);
+#pragma unroll
+            for (int i = 0; i < N; ++i) s[i] = (dskip ? s[i] : 0.f) + (arg[i] == d ? g[i] : 0.f);
+            Vec<T>::store(dn + o[d], s);
+        }
+    }
+}
+
+int launch_maxpool_bwd_add(int dtype, const void* n, const void* dskip, const void* dp, int B, int H, int W, int C,
+                           void* dn, hipStream_t st) {
+    const long work = (long)B * (H / 2) * (W / 2) * C / 8;
+    if (dtype == MPU_BF16)
+        maxpool_bwd_add_kernel<bf16_t><<<ew_grid(work), 256, 0, st>>>((const bf16_t*)n, (const bf16_t*)dskip, (const bf16_t*)dp, B, H, W, C, (bf16_t*)dn);
+    else
+        maxpool_bwd_add_kernel<float><<<ew_grid(work), 256, 0, st>>>((const float*)n, (const float*)dskip, (const float*)dp, B, H, W, C, (float*)dn);
+    return launch_ok();
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += partial[(long)k * C + c];
+    out[c] = (float)s;
+}
+int launch_colsum(int dtype, const void* dz, long M, int C, float* partial, float* out, hipStream_t st) {
+    int nblk;
+    int rc = launch_colreduce<2>(dtype, dz, nullptr, M, C, nullptr, nullptr, partial, &nblk, st);
+    if (rc) return rc;
+    colsum_finalize_kernel<<<cdiv(C, 128), 128, 0, st>>>(partial, nblk, C, out);
+    return launch_ok();
+}
+
+// ------------------------------------------------------------------------- //
+// 1x1 head (unet.py:211): K <= 16 classes, direct (HBM-bound) kernels.
+// G = C/N lanes cooperate on one pixel (each owns one 16-B chunk of channels).
+// ------------------------------------------------------------------------- //
+constexpr int HEAD_MAXC = 512;     // channels the head kernels stage in LDS
+
+template <typename T, int K>
+__global__ __launch_bounds__(256) void head_forward_kernel(const T* __restrict__ n, long M, int C, const float* __restrict__ Wh,
+                                                           int ldw, const float* __restrict__ bh, int softmax,
+                                                           float* __restrict__ out) {
+    constexpr int N = Vec<T>::N;
+    __shared__ float w[HEAD_MAXC * K];
+    for (int i = threadIdx.x; i < C * K; i += 256) w[i] = Wh[(i / K) * ldw + (i % K)];
+    __syncthreads();
+    const int cpr = C / N;
+    int G = 1; while (G < cpr && G < 64) G <<= 1;        // lanes per pixel (power of two)
+    const int sub = threadIdx.x % G;
+    const long ppb = 256 / G;
+    for (long m = (long)blockIdx.x * ppb + threadIdx.x / G; m < M; m += (long)gridDim.x * ppb) {
+        // the G lanes of a group share m, so a group is active or idle as a whole
+        float z[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) z[k] = 0.f;
+        for (int c = sub; c < cpr; c += G) {
+            float v[N];
+            Vec<T>::load(n + m * C + (long)c * N, v);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int k = 0; k < K; ++k) z[k] += v[i] * w[(c * N + i) * K + k];
+        }
+        for (int off = G >> 1; off > 0; off >>= 1)
+#pragma unroll
+            for (int k = 0; k < K; ++k) z[k] += __shfl_xor(z[k], off, 64);
+        if (sub == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) z[k] += bh[k];
+            if (softmax) {
+                float mx = z[0];
+#pragma unroll
+                for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) { z[k] = expf(z[k] - mx); s += z[k]; }
+#pragma unroll
+                for (int k = 0; k < K; ++k) z[k] = z[k] / s;
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) out[m * K + k] = z[k];
+        }
+    }
+}
+
+#define MPU_HEAD_DISPATCH_K(K_, CALL)                                       \
+    switch (K_) {                                                           \
+        case 1: { constexpr int KK = 1; CALL; } break;                      \
+        case 2: { constexpr int KK = 2; CALL; } break;                      \
+        case 3: { constexpr int KK = 3; CALL; } break;                      \
+        case 4: { constexpr int KK = 4; CALL; } break;                      \
+        case 5: { constexpr int KK = 5; CALL; } break;                      \
+        case 6: { constexpr int KK = 6; CALL; } break;                      \
+        case 7: { constexpr int KK = 7; CALL; } break;                      \
+        case 8: { constexpr int KK = 8; CALL; } break;                      \
+        default: return fail(MPU_EUNSUPPORTED, "%s", "U-Net head supports 1..8 classes"); \
+    }
+
+int launch_head_forward(int dtype, const void* n, long M, int C, int K, const float* Wh, int ldw, const float* bh,
+                        int softmax, float* out, hipStream_t st) {
+    if (C > HEAD_MAXC) return fail(MPU_EUNSUPPORTED, "%s", "head: more than 512 input channels");
+    const int N = dtype == MPU_BF16 ? 8 : 4;
+    int G = 1; while (G < C / N && G < 64) G <<= 1;
+    const long ppb = 256 / G;
+    long blocks = (M + ppb - 1) / ppb; if (blocks > 4096) blocks = 4096;
+    if (dtype == MPU_BF16) {
+        MPU_HEAD_DISPATCH_K(K, (head_forward_kernel<bf16_t, KK><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)n, M, C, Wh, ldw, bh, softmax, out)))
+    } else {
+        MPU_HEAD_DISPATCH_K(K, (head_forward_kernel<float, KK><<<(unsigned)blocks, 256, 0, st>>>((const float*)n, M, C, Wh, ldw, bh, softmax, out)))
+    }
+    return launch_ok();
+}
+
+// Gradient of the Keras sparse CE on clipped probabilities through the softmax
+// (oracle/unet_ref.py keras_sparse_ce). Per pixel:
+//   q = clip(p, eps, 1-eps); S = sum q; L = (-log q_y + log S) * w
+//   g_k = 1[eps <= p_k <= 1-eps] * (-[k==y]/q_y + 1/S) * w ;  dz_j = p_j (g_j - sum_k g_k p_k)
+// then dn = dz @ Wh^T, dWh += n^T dz, dbh += dz.
+// partial layout: [nblk][C*K + K]
+template <typename T, int K>
+__global__ __launch_bounds__(256) void head_backward_kernel(const T* __restrict__ n, const float* __restrict__ probs,
+                                                            const uint8_t* __restrict__ y, const float* __restrict__ sw,
+                                                            long M, long ppi, int C, const float* __restrict__ Wh, int ldw,
+                                                            float* __restrict__ partial, T* __restrict__ dn,
+                                                            float* __restrict__ loss) {
+    constexpr int N = Vec<T>::N;
+    constexpr float EPS = 1e-7f;
+    __shared__ float w[HEAD_MAXC * K];
+    __shared__ float red[HEAD_MAXC * K + K];
+    for (int i = threadIdx.x; i < C * K; i += 256) w[i] = Wh[(i / K) * ldw + (i % K)];
+    for (int i = threadIdx.x; i < C * K + K; i += 256) red[i] = 0.f;
+    __syncthreads();
+    const int cpr = C / N;           // host guarantees cpr <= 64
+    int G = 1; while (G < cpr) G <<= 1;
+    const int sub = threadIdx.x % G;
+    const bool act = sub < cpr;
+    const long ppb = 256 / G;
+    float aw[N][K], ab[K];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int k = 0; k < K; ++k) aw[i][k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) ab[k] = 0.f;
+    for (long m = (long)blockIdx.x * ppb + threadIdx.x / G; m < M; m += (long)gridDim.x * ppb) {
+        float p[K], g[K], dzv[K];
+        const int yy = y[m];
+        const float wt = sw[m / ppi];
+        float S = 0.f, qy = 1.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            p[k] = probs[m * K + k];
+            const float q = fminf(fmaxf(p[k], EPS), 1.f - EPS);
+            S += q;
+            if (k == yy) qy = q;
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool pass = p[k] >= EPS && p[k] <= 1.f - EPS;
+            g[k] = pass ? ((k == yy ? -1.f / qy : 0.f) + 1.f / S) * wt : 0.f;
+            dot += g[k] * p[k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) dzv[k] = p[k] * (g[k] - dot);
+        if (sub == 0) {
+            if (loss) loss[m] = (-logf(qy) + logf(S)) * wt;
+#pragma unroll
+            for (int k = 0; k < K; ++k) ab[k] += dzv[k];
+        }
+        if (act) {
+            float v[N], d[N];
+            Vec<T>::load(n + m * C + (long)sub * N, v);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    acc += dzv[k] * w[(sub * N + i) * K + k];
+                    aw[i][k] += v[i] * dzv[k];
+                }
+                d[i] = acc;
+            }
+            Vec<T>::store(dn + m * C + (long)sub * N, d);
+        }
+    }
+    // block reduction through LDS atomics-free: serialise by pixel-slot
+    for (int slot = 0; slot < (int)ppb; ++slot) {
+        if ((int)(threadIdx.x / G) == slot && act) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int k = 0; k < K; ++k) red[(sub * N + i) * K + k] += aw[i][k];
+            if (sub == 0)
+#pragma unroll
+                for (int k = 0; k < K; ++k) red[C * K + k] += ab[k];
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < C * K + K; i += 256) partial[(long)blockIdx.x * (C * K + K) + i] = red[i];
+}
+
+__global__ void head_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int K, int ldw,
+                                         float* dWh, float* dbh) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tot = C * K + K;
+    if (i >= tot) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[(long)b * tot + i];
+    if (i < C * K) dWh[(i / K) * ldw + (i % K)] = (float)s; else dbh[i - C * K] = (float)s;
+}
+
+int launch_head_backward(int dtype, const void* n, const float* probs, const uint8_t* y, const float* sw, long M,
+                         long ppi, int C, int K, const float* Wh, int ldw, float* partial, void* dn, float* dWh,
+                         float* dbh, float* loss, hipStream_t st) {
+    const int N = dtype == MPU_BF16 ? 8 : 4;
+    const int cpr = C / N;
+    if (C > HEAD_MAXC || cpr > 64 || C % N != 0)
+        return fail(MPU_EUNSUPPORTED, "%s", "head backward: at most 64 16-byte channel chunks");
+    int G = 1; while (G < cpr) G <<= 1;
+    const long ppb = 256 / G;
+    long blocks = (M + ppb - 1) / ppb; if (blocks > RED_MAX_BLOCKS) blocks = RED_MAX_BLOCKS;
+    if (dtype == MPU_BF16) {
+        MPU_HEAD_DISPATCH_K(K, (head_backward_kernel<bf16_t, KK><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)n, probs, y, sw, M, ppi, C, Wh, ldw, partial, (bf16_t*)dn, loss)))
+    } else {
+        MPU_HEAD_DISPATCH_K(K, (head_backward_kernel<float, KK><<<(unsigned)blocks, 256, 0, st>>>((const float*)n, probs, y, sw, M, ppi, C, Wh, ldw, partial, (float*)dn, loss)))
+    }
+    int rc = launch_ok();
+    if (rc) return rc;
+    head_bwd_finalize_kernel<<<cdiv(C * K + K, 128), 128, 0, st>>>(partial, (int)blocks, C, K, ldw, dWh, dbh);
+    return launch_ok();
+}
+
+// TF ApplyAdam: m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= m*alpha/(sqrt(v)+eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float alpha, float b1, float b2, float eps) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const float gg = g[e];
+        const float mm = m[e] + (gg - m[e]) * (1.f - b1);
+        const float vv = v[e] + (gg * gg - v[e]) * (1.f - b2);
+        m[e] = mm; v[e] = vv;
+        p[e] = p[e] - (mm * alpha) / (sqrtf(vv) + eps);
+    }
+}
+int launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha, float b1, float b2, float eps,
+                hipStream_t st) {
+    adam_kernel<<<ew_grid(n), 256, 0, st>>>(p, g, m, v, n, alpha, b1, b2, eps);
+    return launch_ok();
+}
+
+}  // namespace mpu

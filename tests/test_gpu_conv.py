@@ -1,0 +1,106 @@
+"""
+GPU parity of the implicit-GEMM convolution kernels (forward, data gradient,
+weight gradient; f32 and bf16) against torch-CPU convolutions with Keras/TF
+padding semantics. Tolerances: f32 path rtol 1e-5 (+atol 1e-5*|scale|); bf16
+path compares against a reference fed the same bf16-rounded operands, so only
+accumulation order and the final bf16 rounding differ: atol/rtol 1.2e-2.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CONV3, UPCONV2, CONV3S2, CONV1 = 0, 1, 2, 3
+
+
+def ref_forward(mode, x, w, b=None):
+    """x [B,H,W,C] f64, w HWIO f64 -> NHWC f64 (pre-activation)."""
+    xt = x.permute(0, 3, 1, 2)
+    wt = w.permute(3, 2, 0, 1)
+    if mode == CONV3:
+        y = F.conv2d(xt, wt, b, padding=1)
+    elif mode == UPCONV2:
+        up = F.interpolate(xt, scale_factor=2, mode="nearest")
+        y = F.conv2d(F.pad(up, (0, 1, 0, 1)), wt, b)
+    elif mode == CONV1:
+        y = F.conv2d(xt, wt, b)
+    return y.permute(0, 2, 3, 1)
+
+
+def tol(dtype, ref):
+    s = float(ref.abs().max())
+    return (1e-5, 1e-5 * s) if dtype == torch.float32 else (1.2e-2, 1.2e-2 * s)
+
+
+def rnd(t, dtype):
+    """round to the storage dtype, return f64"""
+    return t.to(dtype).to(torch.float64)
+
+
+CASES = [
+    # mode,   B, H,  W,  C0, C1, Cout
+    (CONV3,   2, 16, 16, 64, 0, 64),
+    (CONV3,   1, 12, 20, 8, 0, 72),        # ragged M / N, tiny Cin
+    (CONV3,   2, 8, 8, 64, 64, 128),       # concat of two sources
+    (CONV3,   3, 32, 32, 128, 0, 136),     # 128-wide tiles with ragged N
+    (UPCONV2, 2, 16, 16, 128, 0, 64),
+    (UPCONV2, 1, 8, 12, 72, 0, 40),
+    (CONV1,   2, 16, 16, 64, 0, 8),
+]
+
+
+@pytest.mark.parametrize("dtype", (torch.float32, torch.bfloat16))
+@pytest.mark.parametrize("case", CASES)
+def test_conv_forward_dgrad_wgrad(case, dtype):
+    from multiplanarunet_amd import ops
+    mode, B, H, W, C0, C1, Cout = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    k = {CONV3: 3, UPCONV2: 2, CONV1: 1}[mode]
+    Hi, Wi = (H // 2, W // 2) if mode == UPCONV2 else (H, W)
+    Cin = C0 + C1
+    x = rnd(torch.randn(B, Hi, Wi, Cin, generator=g), dtype)
+    w = rnd(torch.randn(k, k, Cin, Cout, generator=g) / np.sqrt(k * k * Cin), dtype)
+    b = torch.randn(Cout, generator=g).to(torch.float64) * 0.1
+    dz = rnd(torch.randn(B, H, W, Cout, generator=g), dtype)
+
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    pre = ref_forward(mode, xr, wr, b)
+    y_ref = torch.relu(pre)
+    pre.backward(dz)
+    dx_ref, dw_ref = xr.grad, wr.grad
+
+    dev = "cuda"
+    xd = x.to(dev, dtype)
+    x0 = xd[..., :C0].contiguous()
+    x1 = xd[..., C0:].contiguous() if C1 else None
+    wf, wd = ops.pack_weights(w.to(dev, torch.float32), mode, dtype)
+    y = ops.conv2d(mode, x0, wf, Cout, (H, W), bias=b.to(dev, torch.float32), x1=x1, relu=True)
+    rt, at = tol(dtype, y_ref)
+    np.testing.assert_allclose(y.cpu().double().numpy(), y_ref.detach().numpy(), rtol=rt, atol=at)
+
+    # data gradient (+ ReLU mask of the consumer's input)
+    dzd = dz.to(dev, dtype)
+    dmode = CONV3S2 if mode == UPCONV2 else (CONV1 if mode == CONV1 else CONV3)
+    wdg = wd if mode != CONV1 else w.to(dev, dtype).reshape(-1)
+    mask = (torch.rand(B, Hi, Wi, Cin, generator=g) > 0.3).to(torch.float64)
+    dx = ops.conv2d(dmode, dzd, wdg, Cin, (Hi, Wi), mask=mask.to(dev, dtype),
+                    w_tap_stride=Cin * Cout, w_row_stride=Cout)
+    ref = dx_ref * mask
+    rt, at = tol(dtype, ref)
+    np.testing.assert_allclose(dx.cpu().double().numpy(), ref.numpy(), rtol=rt, atol=at)
+    if C1:   # channel-sliced data gradient (how the concat gradient is split)
+        import ctypes
+        esz = 2 if dtype == torch.bfloat16 else 4
+        dx1 = ops.conv2d(dmode, dzd, wdg[C0 * Cout:], C1, (Hi, Wi), w_tap_stride=Cin * Cout, w_row_stride=Cout)
+        np.testing.assert_allclose(dx1.cpu().double().numpy(), dx_ref[..., C0:].numpy(), rtol=rt, atol=at)
+
+    # weight gradient
+    dW = ops.conv2d_wgrad(mode, x0, dzd, x1=x1)
+    ref = dw_ref.reshape(k * k, Cin, Cout)
+    rt, at = tol(dtype, ref)
+    if dtype == torch.bfloat16:
+        rt, at = 2e-3, 2e-3 * float(ref.abs().max())      # f32 accumulate of exact bf16 products
+    np.testing.assert_allclose(dW.cpu().double().numpy(), ref.numpy(), rtol=rt, atol=at)
