@@ -1,0 +1,426 @@
+"""
+mpunet.models.UNet on MI355X: same constructor, attributes and Keras-Model call
+surface as the reference (mpunet/models/unet.py:20-251), with every tensor
+operation executed by libmpunet_hip.so (hand-written gfx950 kernels).
+
+Host code here only owns buffers (torch device tensors), converts weights
+between Keras layouts and the library's flat parameter buffer, and drives the
+C ABI: mpu_unet_forward / mpu_unet_backward / mpu_adam_step /
+mpu_unet_pack_weights. There is no eager / CPU fallback.
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class _ScreenLogger:
+    def __call__(self, *args, **kwargs):
+        print(*args)
+
+
+class _OutputLayerShim:
+    """What mpunet/utils/utils.py:190-241 (set_bias_weights) needs from the last layer."""
+
+    class _Act:
+        def __init__(self, name):
+            self.__name__ = name
+
+    def __init__(self, model):
+        self._m = model
+        self.activation = self._Act(model.out_activation)
+        self.name = "conv2d"
+
+    def get_weights(self):
+        d = self._m.get_weights_dict()
+        return [d["conv2d/kernel"], d["conv2d/bias"]]
+
+    def set_weights(self, weights):
+        self._m.set_weights_dict({"conv2d/kernel": weights[0], "conv2d/bias": weights[1]})
+
+
+class UNet:
+    """
+    2D UNet implementation with batch normalization and complexity factor adj.
+    See mpunet/models/unet.py:26-79 for the meaning of the arguments. Extra
+    keyword arguments (model_class_name, l1_reg, biased_output_layer, ...) are
+    accepted and ignored, as the reference does (unet.py:41).
+
+    Additions that have no counterpart in the reference:
+      dtype  : "bf16" (default; bf16 storage + MFMA, f32 accumulate) or "f32"
+               (exact-f32 MFMA; the parity mode)
+      device : torch device of all buffers
+      seed   : seed of the glorot-uniform initialisation
+    """
+
+    def __init__(self, n_classes, img_rows=None, img_cols=None, dim=None, n_channels=1, depth=4,
+                 out_activation="softmax", activation="relu", kernel_size=3, padding="same",
+                 complexity_factor=1, flatten_output=False, l2_reg=None, logger=None,
+                 dtype="bf16", device="cuda", seed=None, **kwargs):
+        if not ((img_rows and img_cols) or dim):
+            raise ValueError("Must specify either img_rows and img_col or dim")
+        if dim:
+            img_rows, img_cols = dim, dim
+        self.logger = logger or _ScreenLogger()
+        self.img_shape = (img_rows, img_cols, n_channels)
+        self.n_classes = n_classes
+        self.cf = np.sqrt(complexity_factor)
+        self.kernel_size = kernel_size
+        self.activation = activation
+        self.out_activation = out_activation
+        self.l2_reg = l2_reg
+        self.padding = padding
+        self.depth = depth
+        self.flatten_output = flatten_output
+        self.label_crop = np.array([[0, 0], [0, 0]])
+        self.stop_training = False
+        if padding != "same" or activation != "relu" or kernel_size != 3:
+            raise NotImplementedError("only padding='same', activation='relu', kernel_size=3 "
+                                      "are on the MI355X path")
+        if out_activation not in ("softmax", "linear"):
+            raise NotImplementedError("out_activation must be 'softmax' or 'linear'")
+        if l2_reg:
+            raise NotImplementedError("l2_reg is not supported (default YAML: False)")
+        if img_rows % (2 ** depth) or img_cols % (2 ** depth):
+            raise NotImplementedError("image dims must be multiples of 2**depth (no cropping path)")
+        self.dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "float32": torch.float32,
+                      "bfloat16": torch.bfloat16}[dtype] if isinstance(dtype, str) else dtype
+        self.device = torch.device(device)
+
+        cfg = _lib.UNetConfig()
+        cfg.n_classes, cfg.n_channels, cfg.depth = n_classes, n_channels, depth
+        cfg.H, cfg.W = img_rows, img_cols
+        cfg.dtype = _lib.MPU_BF16 if self.dtype == torch.bfloat16 else _lib.MPU_F32
+        cfg.softmax = 1 if out_activation == "softmax" else 0
+        self.filters = [int(64 * (2 ** l) * self.cf) for l in range(depth + 1)]      # unet.py:91,120
+        for l, f in enumerate(self.filters):
+            cfg.filters[l] = f
+        lib = _lib.load()
+        self._h = lib.mpu_unet_create(C.byref(cfg))
+        if not self._h:
+            raise ValueError("mpu_unet_create: " + (lib.mpu_last_error() or b"").decode())
+        self._h = C.c_void_p(self._h)
+
+        # tensor table
+        self._tensors = {}
+        self._order = []
+        name = C.create_string_buffer(96)
+        kind, off = C.c_int32(), C.c_int64()
+        ps, ls = (C.c_int32 * 4)(), (C.c_int32 * 4)()
+        for i in range(lib.mpu_unet_num_tensors(self._h)):
+            _lib.check(lib.mpu_unet_tensor_info(self._h, i, name, 96, C.byref(kind), C.byref(off), ps, ls),
+                       "mpu_unet_tensor_info")
+            nm = name.value.decode()
+            self._tensors[nm] = (kind.value, off.value, tuple(v for v in ps if v), tuple(v for v in ls if v))
+            self._order.append(nm)
+        n_par = lib.mpu_unet_param_floats(self._h)
+        n_st = lib.mpu_unet_bn_state_floats(self._h)
+        dev = self.device
+        self.params = torch.zeros(n_par, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(n_par, dtype=torch.float32, device=dev)
+        self.bn_state = torch.zeros(n_st, dtype=torch.float32, device=dev)
+        self.packed = torch.zeros(lib.mpu_unet_packed_bytes(self._h), dtype=torch.uint8, device=dev)
+        self._adam_m = self._adam_v = None
+        self._ws = None
+        self._ws_batch = 0
+        self.optimizer_kwargs = dict(lr=5e-5, beta_1=0.9, beta_2=0.999, epsilon=1e-8)
+        self.iterations = 0
+        self._grad_hook = None         # e.g. an all-reduce over RCCL (multiplanarunet_amd.distributed)
+        self._init_weights(seed)
+
+        # receptive field of the contracting path (unet.py:104-109, utils/conv_arithmetics.py:57)
+        rf, jump = 1, 1
+        for _ in range(depth):
+            rf += 2 * jump; rf += 2 * jump          # two 3x3 convs
+            jump *= 2; rf += jump                   # 2x2 max-pool, stride 2
+        rf += 2 * jump; rf += 2 * jump              # bottom convs
+        self.receptive_field = np.array([rf, rf])
+        self.layers = [_OutputLayerShim(self)]
+        self.metrics_names = ["loss"]
+        self.log()
+
+    # ------------------------------------------------------------------ #
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.load().mpu_unet_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _init_weights(self, seed):
+        """Keras defaults: glorot_uniform kernels, zero biases, BN gamma=1 beta=0 mean=0 var=1."""
+        rng = np.random.RandomState(seed)
+        w = {}
+        for nm in self._order:
+            kind, off, ps, ls = self._tensors[nm]
+            var = nm.split("/")[1]
+            if var == "kernel":
+                kh, kw, ci, co = ls
+                lim = np.sqrt(6.0 / (kh * kw * ci + kh * kw * co))
+                w[nm] = rng.uniform(-lim, lim, ls).astype(np.float32)
+            elif var in ("gamma", "moving_variance"):
+                w[nm] = np.ones(ls, np.float32)
+            else:
+                w[nm] = np.zeros(ls, np.float32)
+        self.set_weights_dict(w)
+
+    # ---- weights ------------------------------------------------------ #
+    def _buf(self, kind):
+        return self.params if kind == 0 else self.bn_state
+
+    def get_weights_dict(self):
+        """{'<layer>/<var>': ndarray} in Keras layouts (kernels HWIO), padding stripped."""
+        out = {}
+        host = {0: self.params.cpu().numpy(), 1: self.bn_state.cpu().numpy()}
+        for nm in self._order:
+            kind, off, ps, ls = self._tensors[nm]
+            a = host[kind][off:off + int(np.prod(ps))].reshape(ps)
+            out[nm] = self._from_stored(nm, a, ps, ls)
+        return out
+
+    @staticmethod
+    def _is_concat_kernel(nm):
+        return nm.startswith("upsample_L") and nm.endswith("_conv2/kernel")
+
+    def _from_stored(self, nm, a, ps, ls):
+        """Strip the channel padding. The conv after the skip-concat reads [skip(F_p), up(F_p)]:
+        its input-channel padding sits after EACH half (unet.py:168-169 concat order: skip first)."""
+        if self._is_concat_kernel(nm):
+            F, Fp = ls[3], ps[3]
+            return np.ascontiguousarray(np.concatenate([a[:, :, :F, :F], a[:, :, Fp:Fp + F, :F]], axis=2))
+        return np.ascontiguousarray(a[tuple(slice(0, s) for s in ls)])
+
+    def _to_stored(self, nm, val, ps, ls):
+        a = np.zeros(ps, np.float32)
+        if self._is_concat_kernel(nm):
+            F, Fp = ls[3], ps[3]
+            a[:, :, :F, :F] = val[:, :, :F, :]
+            a[:, :, Fp:Fp + F, :F] = val[:, :, F:, :]
+        else:
+            a[tuple(slice(0, s) for s in ls)] = val
+        return a
+
+    def set_weights_dict(self, weights, strict=False):
+        host = {0: self.params.cpu().numpy(), 1: self.bn_state.cpu().numpy()}
+        for nm, val in weights.items():
+            if nm not in self._tensors:
+                if strict:
+                    raise KeyError(nm)
+                continue
+            kind, off, ps, ls = self._tensors[nm]
+            val = np.asarray(val, np.float32)
+            if tuple(val.shape) != tuple(ls):
+                raise ValueError("shape mismatch for %s: got %s expected %s" % (nm, val.shape, ls))
+            a = self._to_stored(nm, val, ps, ls)
+            host[kind][off:off + a.size] = a.ravel()
+        self.params.copy_(torch.from_numpy(host[0]))
+        self.bn_state.copy_(torch.from_numpy(host[1]))
+        self._repack()
+
+    _KERAS_VARS = {"kernel": 0, "bias": 1, "gamma": 0, "beta": 1, "moving_mean": 2, "moving_variance": 3}
+
+    def _keras_order(self):
+        """Layer creation order of unet.py (encoder, bottom, upsample, head)."""
+        names = []
+        for i in range(self.depth):
+            names += ["encoder_L%d_conv1" % i, "encoder_L%d_conv2" % i, "encoder_L%d_BN" % i]
+        names += ["bottom_conv1", "bottom_conv2", "bottom_BN"]
+        for i in range(self.depth):
+            p = "upsample_L%d" % i
+            names += [p + "_conv1", p + "_BN1", p + "_conv2", p + "_conv3", p + "_BN2"]
+        names += ["conv2d"]
+        out = []
+        for n in names:
+            vs = ("gamma", "beta", "moving_mean", "moving_variance") if "BN" in n else ("kernel", "bias")
+            out += [n + "/" + v for v in vs]
+        return out
+
+    def get_weights(self):
+        d = self.get_weights_dict()
+        return [d[n] for n in self._keras_order()]
+
+    def set_weights(self, weights):
+        names = self._keras_order()
+        if len(weights) != len(names):
+            raise ValueError("expected %d arrays" % len(names))
+        self.set_weights_dict(dict(zip(names, weights)), strict=True)
+
+    def save_weights(self, path):
+        """.npz keyed by Keras layer/variable names (h5py is not available here)."""
+        d = self.get_weights_dict()
+        with open(path, "wb") as f:
+            np.savez(f, **{k.replace("/", "__"): v for k, v in d.items()})
+
+    def load_weights(self, path, by_name=True):
+        with np.load(path) as z:
+            d = {k.replace("__", "/"): z[k] for k in z.files}
+        self.set_weights_dict(d, strict=not by_name)
+
+    def count_params(self):
+        """Keras count_params(): trainable + BN moving statistics, unpadded."""
+        return int(sum(int(np.prod(ls)) for (_, _, _, ls) in self._tensors.values()))
+
+    def _repack(self):
+        if self.device.type != "cuda":
+            return          # host-only introspection (layout, weight I/O); nothing can run without a GPU
+        _lib.call("mpu_unet_pack_weights", self._h, _lib.ptr(self.params), _lib.ptr(self.packed),
+                  _lib.stream_ptr())
+
+    # ---- execution ---------------------------------------------------- #
+    def _workspace(self, batch):
+        if self._ws is None or self._ws_batch < batch:
+            n = _lib.load().mpu_unet_workspace_bytes(self._h, batch)
+            self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._ws_batch = batch
+        return self._ws
+
+    def _as_input(self, X):
+        if not torch.is_tensor(X):
+            X = torch.from_numpy(np.ascontiguousarray(X))
+        X = X.to(device=self.device, dtype=torch.float32).contiguous()
+        if X.ndim != 4 or tuple(X.shape[1:]) != tuple(self.img_shape):
+            raise ValueError("expected input [B,%d,%d,%d], got %s" % (self.img_shape + (tuple(X.shape),)))
+        return X
+
+    def _forward(self, X, training, out=None):
+        if self.device.type != "cuda":
+            raise _lib.MpuError("UNet needs a HIP device (MI355X); there is no CPU execution path")
+        B = X.shape[0]
+        # the workspace layout depends on the batch it was planned for
+        ws = self._workspace_exact(B)
+        if out is None:
+            out = torch.empty((B, self.img_shape[0], self.img_shape[1], self.n_classes),
+                              dtype=torch.float32, device=self.device)
+        _lib.call("mpu_unet_forward", self._h, B, _lib.ptr(X), _lib.ptr(self.params), _lib.ptr(self.packed),
+                  _lib.ptr(self.bn_state), _lib.ptr(ws), 1 if training else 0, _lib.ptr(out), _lib.stream_ptr())
+        return out
+
+    def _workspace_exact(self, batch):
+        # plans for smaller batches fit inside a larger allocation
+        return self._workspace(batch)
+
+    def predict_on_batch(self, X):
+        out = self._forward(self._as_input(X), training=False)
+        return out.reshape(out.shape[0], -1, self.n_classes) if self.flatten_output else out
+
+    def predict(self, X, batch_size=8, verbose=0):
+        """model.predict: inference-mode forward in chunks of batch_size; returns a device tensor."""
+        numpy_in = not torch.is_tensor(X)
+        n = X.shape[0]
+        out = torch.empty((n, self.img_shape[0], self.img_shape[1], self.n_classes),
+                          dtype=torch.float32, device=self.device)
+        for s in range(0, n, batch_size):
+            xb = self._as_input(X[s:s + batch_size])
+            self._forward(xb, training=False, out=out[s:s + xb.shape[0]])
+        if self.flatten_output:
+            out = out.reshape(n, -1, self.n_classes)
+        return out.cpu().numpy() if numpy_in else out
+
+    __call__ = predict_on_batch
+
+    # ---- training ------------------------------------------------------ #
+    def compile(self, optimizer="Adam", loss=None, metrics=None, optimizer_kwargs=None, **kwargs):
+        """
+        Trainer.compile_model (mpunet/train/trainer.py:51-97): only the reference
+        default is on the path -- Adam + SparseCategoricalCrossentropy(reduction=NONE).
+        """
+        name = optimizer if isinstance(optimizer, str) else type(optimizer).__name__
+        if name.lower() != "adam":
+            raise NotImplementedError("only the Adam optimizer is supported")
+        if loss is not None:
+            lname = loss if isinstance(loss, str) else getattr(loss, "__name__", type(loss).__name__)
+            if isinstance(loss, (list, tuple)):
+                lname = loss[0] if isinstance(loss[0], str) else type(loss[0]).__name__
+            if "sparsecategoricalcrossentropy" not in lname.lower().replace("_", ""):
+                raise NotImplementedError("only SparseCategoricalCrossentropy is supported")
+        if optimizer_kwargs:
+            kw = dict(optimizer_kwargs)
+            if "learning_rate" in kw:
+                kw["lr"] = kw.pop("learning_rate")
+            if kw.get("decay"):
+                raise NotImplementedError("Adam decay != 0 is not supported")
+            kw.pop("decay", None)
+            self.optimizer_kwargs.update(kw)
+        return self
+
+    def _ensure_adam(self):
+        if self._adam_m is None:
+            self._adam_m = torch.zeros_like(self.params)
+            self._adam_v = torch.zeros_like(self.params)
+
+    def forward_backward(self, x, y, sample_weight=None, want_loss=True):
+        """Train-mode forward + backward; fills self.grads (sum-gradient). Returns (probs, loss[B,H*W] or None)."""
+        X = self._as_input(x)
+        B = X.shape[0]
+        if not torch.is_tensor(y):
+            y = torch.from_numpy(np.ascontiguousarray(y))
+        y = y.to(device=self.device, dtype=torch.uint8).reshape(B, -1).contiguous()
+        if y.shape[1] != self.img_shape[0] * self.img_shape[1]:
+            raise ValueError("labels must have H*W entries per image")
+        if sample_weight is None:
+            sw = torch.ones(B, dtype=torch.float32, device=self.device)
+        else:
+            sw = torch.as_tensor(np.asarray(sample_weight, np.float32) if not torch.is_tensor(sample_weight)
+                                 else sample_weight).to(device=self.device, dtype=torch.float32).contiguous()
+        probs = self._forward(X, training=True)
+        loss = torch.empty((B, y.shape[1]), dtype=torch.float32, device=self.device) if want_loss else None
+        _lib.call("mpu_unet_backward", self._h, B, _lib.ptr(y), _lib.ptr(sw), _lib.ptr(self.params),
+                  _lib.ptr(self.packed), _lib.ptr(self.bn_state), _lib.ptr(self._ws), _lib.ptr(self.grads),
+                  _lib.ptr(loss), _lib.stream_ptr())
+        return probs, loss
+
+    def apply_gradients(self):
+        """Keras Adam on the flat parameter buffer, then refresh the packed MFMA operands."""
+        self._ensure_adam()
+        self.iterations += 1
+        k = self.optimizer_kwargs
+        _lib.call("mpu_adam_step", _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self._adam_m),
+                  _lib.ptr(self._adam_v), self.params.numel(), self.iterations, float(k["lr"]),
+                  float(k["beta_1"]), float(k["beta_2"]), float(k["epsilon"]), _lib.stream_ptr())
+        self._repack()
+
+    def train_step(self, x, y, sample_weight=None, want_loss=True):
+        """One Model.fit inner step. Returns the per-pixel loss [B,H*W] (device) or None."""
+        _, loss = self.forward_backward(x, y, sample_weight, want_loss)
+        if self._grad_hook is not None:
+            self._grad_hook(self.grads)          # data-parallel: SUM of replica gradients
+        self.apply_gradients()
+        return loss
+
+    def train_on_batch(self, x, y, sample_weight=None):
+        return float(self.train_step(x, y, sample_weight).mean().item())
+
+    def fit(self, data, steps_per_epoch, epochs=1, callbacks=None, initial_epoch=0, verbose=0, **kwargs):
+        """Minimal Model.fit over an iterator of (x, y, w) batches (trainer.py:246-257)."""
+        it = iter(data)
+        history = []
+        for ep in range(initial_epoch, epochs):
+            tot = 0.0
+            for _ in range(steps_per_epoch):
+                x, y, w = next(it)
+                tot += self.train_on_batch(x, y, w)
+            history.append(tot / steps_per_epoch)
+            if verbose:
+                self.logger("epoch %d: loss %.5f" % (ep + 1, history[-1]))
+            if self.stop_training:
+                break
+        return history
+
+    def log(self):
+        self.logger("UNet Model Summary\n------------------")
+        self.logger("Image rows:        %i" % self.img_shape[0])
+        self.logger("Image cols:        %i" % self.img_shape[1])
+        self.logger("Image channels:    %i" % self.img_shape[2])
+        self.logger("N classes:         %i" % self.n_classes)
+        self.logger("CF factor:         %.3f" % self.cf ** 2)
+        self.logger("Depth:             %i" % self.depth)
+        self.logger("l2 reg:            %s" % self.l2_reg)
+        self.logger("Padding:           %s" % self.padding)
+        self.logger("Conv activation:   %s" % self.activation)
+        self.logger("Out activation:    %s" % self.out_activation)
+        self.logger("Receptive field:   %s" % self.receptive_field)
+        self.logger("N params:          %i" % self.count_params())
+        self.logger("Compute dtype:     %s (MI355X / gfx950 HIP kernels)" % str(self.dtype))
+        self.logger("Crop:              None")

