@@ -229,6 +229,15 @@ int mpu_conv2d_wgrad(int32_t dtype, int32_t mode, const void* d_x0, int32_t C0, 
                      int32_t C1, const void* d_dz, int32_t Cout, int32_t B, int32_t Ho, int32_t Wo,
                      float* d_workspace, float* d_dW, void* stream);
 
+/* Measurement aid (bench.py roofline leg; no reference counterpart): when
+ * enabled, every MFMA convolution launch is bracketed by HIP events recorded on
+ * its own stream. mpu_profile_summary synchronises on them and returns the summed
+ * kernel time, the summed ALGORITHMIC FLOPs (2*M*N*K of the reference's layer,
+ * SURVEY.md 8d) and the launch count. kind 0 = conv_igemm (forward + data
+ * gradient), 1 = wgrad_igemm. mpu_profile_enable(0|1) also clears the records. */
+int mpu_profile_enable(int32_t on);
+int mpu_profile_summary(int32_t kind, double* total_ms, double* total_flops, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

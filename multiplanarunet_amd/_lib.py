@@ -6,6 +6,10 @@ of any compute entry point raises.
 import ctypes as C
 import os
 
+# torch bundles its own HIP runtime (libamdhip64); it must be the one already loaded when
+# libmpunet_hip.so resolves its dependency, so that streams / device pointers are shared.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmpunet_hip.so")
 
@@ -69,6 +73,8 @@ _SIGS = {
     "mpu_conv2d_igemm": (C.c_int, [i32, i32, c_p, i32, c_p, i32, c_p, i64, i32, c_p, c_p, c_p,
                                    i32, i32, i32, i32, i32, c_p]),
     "mpu_conv2d_wgrad_workspace_floats": (i64, [i32, i32, i32, i64]),
+    "mpu_profile_enable": (C.c_int, [i32]),
+    "mpu_profile_summary": (C.c_int, [i32, C.POINTER(f64), C.POINTER(f64), C.POINTER(i64)]),
     "mpu_conv2d_wgrad": (C.c_int, [i32, i32, c_p, i32, c_p, i32, c_p, i32, i32, i32, i32, c_p, c_p, c_p]),
 }
 

@@ -417,7 +417,12 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t st) {
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const long tiles = (long)cdiv(a.Cout, BN) * cdiv(M, BM);
+    if (prof_on()) {
+        const int taps = MODE == UPCONV2 ? 4 : (MODE == CONV1 ? 1 : 9);
+        prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * taps * (a.C0 + a.C1), st);
+    }
     kern<<<dim3((unsigned)tiles), dim3(256), SMEM, st>>>(a);
+    if (prof_on()) prof_end(st);
     return launch_ok();
 }
 
@@ -469,6 +474,8 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
     const int Cin = a.C0 + a.C1;
     const int ntaps = ModeTraits<MODE>::NTAPS;
     const long n = (long)ntaps * Cin * a.Cout;
+    if (prof_on())
+        prof_begin(PROF_WGRAD, a.flops > 0 ? a.flops : 2.0 * a.B * a.Ho * a.Wo * (double)n, st);
     bool big = false;
     if constexpr (sizeof(T) == 2) {
         if (Cin >= 128 && a.Cout >= 128) {
@@ -481,6 +488,7 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
         dim3 g((unsigned)(cdiv(Cin, 64) * cdiv(a.Cout, 64)), ntaps, a.ksplit);
         wgrad_igemm_kernel<T, MODE, 64, 64><<<g, dim3(256), 0, st>>>(a);
     }
+    if (prof_on()) prof_end(st);
     int rc = launch_ok();
     if (rc) return rc;
     long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;

@@ -11,20 +11,28 @@ struct ConvArgs {
     const void* w; long w_tap_stride; int w_row_stride;
     const float* bias; const void* mask; void* out;
     int B, Ho, Wo, Cout, relu;
+    double flops;                // algorithmic FLOPs of this launch (profiling only; 0 = derive)
 };
 struct WgradArgs {
     const void* x0; const void* x1; int C0, C1;
     const void* dz; int Cout;
     float* partial;
     int B, Ho, Wo, ksplit, mchunk;
+    double flops;
 };
+
+// ---- profile.hip: optional per-launch HIP-event timing of the MFMA kernels ----
+enum { PROF_CONV = 0, PROF_WGRAD = 1, PROF_KINDS = 2 };
+bool prof_on();
+void prof_begin(int kind, double flops, hipStream_t st);
+void prof_end(hipStream_t st);
 
 int  launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st);
 long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out);
 int  launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st);
 
 // ---- unet_ops.hip ---------------------------------------------------------
-constexpr int RED_MAX_BLOCKS = 1024;
+constexpr int RED_MAX_BLOCKS = 256;
 
 // fp32 master [taps][Cin][Cout] -> packed operands in T
 int launch_pack_weights(int dtype, int mode, const float* W, int Cin, int Cout,

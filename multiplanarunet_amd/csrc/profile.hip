@@ -1,0 +1,56 @@
+// Optional per-launch timing of the MFMA kernels with HIP events recorded on the
+// launch stream (bench.py's roofline leg). Off by default: zero overhead.
+#include <vector>
+#include "kernels.h"
+
+namespace mpu {
+namespace {
+struct Rec { hipEvent_t a, b; int kind; double flops; };
+bool g_on = false;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t take_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+}  // namespace
+
+bool prof_on() { return g_on; }
+void prof_begin(int kind, double flops, hipStream_t st) {
+    Rec r; r.a = take_event(); r.b = take_event(); r.kind = kind; r.flops = flops;
+    (void)hipEventRecord(r.a, st);
+    g_recs.push_back(r);
+}
+void prof_end(hipStream_t st) { (void)hipEventRecord(g_recs.back().b, st); }
+}  // namespace mpu
+
+using namespace mpu;
+
+extern "C" {
+
+int mpu_profile_enable(int32_t on) {
+    for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+    g_recs.clear();
+    g_on = on != 0;
+    return MPU_OK;
+}
+
+// Synchronises on the recorded events. kind: 0 = conv_igemm (forward + data gradient),
+// 1 = wgrad_igemm. Any output pointer may be NULL.
+int mpu_profile_summary(int32_t kind, double* total_ms, double* total_flops, int64_t* launches) {
+    MPU_REQUIRE(kind >= 0 && kind < PROF_KINDS, "mpu_profile_summary: bad kind");
+    double ms = 0, fl = 0; int64_t n = 0;
+    for (auto& r : g_recs) {
+        if (r.kind != kind) continue;
+        MPU_CHECK_HIP(hipEventSynchronize(r.b));
+        float t = 0.f;
+        MPU_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        ms += t; fl += r.flops; ++n;
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    if (launches) *launches = n;
+    return MPU_OK;
+}
+
+}  // extern "C"

@@ -24,7 +24,7 @@ struct Tensor {                 // one entry of the flat parameter / BN-state ta
     int lshape[4];              // logical Keras shape
 };
 
-struct Conv { int mode, Cin, Cout; long w, b; long wf, wd; };        // offsets
+struct Conv { int mode, Cin, Cout; long w, b; long wf, wd; int lCin, lCout; };        // offsets
 struct BN { int C; long g, b, mm, mv; long st; };                    // st: mean,invstd,scale,shift (4*C)
 
 }  // namespace
@@ -64,7 +64,7 @@ void add_tensor(mpu_unet* m, const std::string& name, int kind, long off, std::i
 void add_conv(mpu_unet* m, const std::string& name, int mode, int Cin, int Cout, int lCin, int lCout) {
     const int esz = 1;
     const int k = mode == UPCONV2 ? 2 : (mode == CONV1 ? 1 : 3);
-    Conv c; c.mode = mode; c.Cin = Cin; c.Cout = Cout;
+    Conv c; c.mode = mode; c.Cin = Cin; c.Cout = Cout; c.lCin = lCin; c.lCout = lCout;
     c.w = m->n_params; m->n_params += (long)k * k * Cin * Cout;
     c.b = m->n_params; m->n_params += Cout;
     add_tensor(m, name + "/kernel", 0, c.w, {k, k, Cin, Cout}, {k, k, lCin, lCout});
@@ -160,8 +160,17 @@ struct Run {
     float* stat(const BN& b, int k) const { return (float*)(ws + P.stats) + b.st + (long)k * b.C; }
 };
 
+// algorithmic FLOPs of one pass over conv `c` at its OUTPUT resolution level `lvl`
+// (2*M*N*K with the logical channel counts; the 2x2 up-conv counted at output resolution)
+double conv_flops(const Run& r, const Conv& c, int lvl, int n_cnt_logical = -1) {
+    const double M = (double)r.B * (r.m->cfg.H >> lvl) * (r.m->cfg.W >> lvl);
+    const int taps = c.mode == UPCONV2 ? 4 : (c.mode == CONV1 ? 1 : 9);
+    return 2.0 * M * taps * c.lCin * c.lCout;
+}
+
 int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* in1, int C1, void* out, int lvl) {
     ConvArgs a;
+    a.flops = conv_flops(r, c, lvl);
     a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1;
     a.w = r.wf(c); a.w_tap_stride = (long)c.Cin * c.Cout; a.w_row_stride = c.Cin;
     a.bias = r.params + c.b; a.mask = nullptr; a.out = out;
@@ -178,6 +187,8 @@ int conv_dgrad(const Run& r, const Conv& c, const void* dz, const void* mask, vo
     a.w_tap_stride = (long)c.Cin * c.Cout; a.w_row_stride = c.Cout;
     a.bias = nullptr; a.mask = mask; a.out = out;
     a.B = r.B; a.Ho = r.m->cfg.H >> out_lvl; a.Wo = r.m->cfg.W >> out_lvl; a.Cout = n_cnt; a.relu = 0;
+    // the data gradient costs the forward's FLOPs (at the conv's own output level), pro rata of the slice
+    a.flops = conv_flops(r, c, c.mode == UPCONV2 ? out_lvl - 1 : out_lvl) * ((double)n_cnt / c.Cin);
     return launch_conv(r.m->cfg.dtype, c.mode == UPCONV2 ? CONV3S2 : CONV3, a, r.st);
 }
 
@@ -186,6 +197,7 @@ int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* 
     a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.dz = dz; a.Cout = c.Cout;
     a.partial = (float*)r.at(r.P.wpartial);
     a.B = r.B; a.Ho = r.m->cfg.H >> lvl; a.Wo = r.m->cfg.W >> lvl;
+    a.flops = conv_flops(r, c, lvl);
     const long M = (long)a.B * a.Ho * a.Wo;
     wgrad_partial_elems(c.mode, c.Cin, c.Cout, M, &a.ksplit, &a.mchunk);
     int rc = launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st);
@@ -443,7 +455,7 @@ int mpu_conv2d_igemm(int32_t dtype, int32_t mode, const void* d_in0, int32_t C0,
     ConvArgs a;
     a.in0 = d_in0; a.in1 = d_in1; a.C0 = C0; a.C1 = C1; a.w = d_w_packed; a.w_tap_stride = w_tap_stride;
     a.w_row_stride = w_row_stride; a.bias = d_bias; a.mask = d_mask; a.out = d_out;
-    a.B = B; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.relu = relu;
+    a.B = B; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.relu = relu; a.flops = 0;
     return launch_conv(dtype, mode, a, (hipStream_t)stream);
 }
 
@@ -458,7 +470,7 @@ int mpu_conv2d_wgrad(int32_t dtype, int32_t mode, const void* d_x0, int32_t C0, 
     MPU_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && Cout % 8 == 0, "mpu_conv2d_wgrad: channels must be multiples of 8");
     WgradArgs a;
     a.x0 = d_x0; a.x1 = d_x1; a.C0 = C0; a.C1 = C1; a.dz = d_dz; a.Cout = Cout; a.partial = d_workspace;
-    a.B = B; a.Ho = Ho; a.Wo = Wo;
+    a.B = B; a.Ho = Ho; a.Wo = Wo; a.flops = 0;
     wgrad_partial_elems(mode, C0 + C1, Cout, (long)B * Ho * Wo, &a.ksplit, &a.mchunk);
     return launch_wgrad(dtype, mode, a, d_dW, (hipStream_t)stream);
 }

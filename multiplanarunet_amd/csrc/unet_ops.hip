@@ -197,13 +197,32 @@ static int launch_colreduce(int dtype, const void* a, const void* b, long M, int
     return launch_ok();
 }
 
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
+
+// Second stage of the two-stage reductions: block = 32 columns x 8 k-lanes; returns (to the
+// k-lane-0 thread of each column) sum_k partial[k*stride + col] in double, fixed order.
+__device__ __forceinline__ double partial_sum(const float* __restrict__ partial, int nblk, long stride, int col,
+                                              bool valid, double* red /*[256]*/) {
+    const int kl = threadIdx.x >> 5;             // 0..7
+    double s = 0.0;
+    if (valid)
+        for (int k = kl; k < nblk; k += 8) s += (double)partial[(long)k * stride + col];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    double t = 0.0;
+    if (kl == 0)
+        for (int j = 0; j < 8; ++j) t += red[j * 32 + (threadIdx.x & 31)];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
                                          const float* gamma, const float* beta, float* mmean, float* mvar,
                                          float* mean, float* invstd, float* scale, float* shift, float eps, float mom) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < nblk; ++k) { s += partial[((long)k * 2) * C + c]; ss += partial[((long)k * 2 + 1) * C + c]; }
+    __shared__ double red[256];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const double s = partial_sum(partial, nblk, 2L * C, c, c < C, red);
+    const double ss = partial_sum(partial + C, nblk, 2L * C, c, c < C, red);
+    if (c >= C || threadIdx.x >= 32) return;
     const double mu = s / (double)M;
     double var = ss / (double)M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -221,7 +240,7 @@ int launch_bn_stats(int dtype, const void* x, long M, int C, float* partial, con
     int nblk;
     int rc = launch_colreduce<0>(dtype, x, nullptr, M, C, nullptr, nullptr, partial, &nblk, st);
     if (rc) return rc;
-    bn_stats_finalize_kernel<<<cdiv(C, 128), 128, 0, st>>>(partial, nblk, C, M, gamma, beta, mmean, mvar, mean,
+    bn_stats_finalize_kernel<<<cdiv(C, 32), 256, 0, st>>>(partial, nblk, C, M, gamma, beta, mmean, mvar, mean,
                                                            invstd, scale, shift, eps, momentum);
     return launch_ok();
 }
@@ -299,13 +318,14 @@ int launch_bn_apply(int dtype, const void* x, int B, int H, int W, int C, const 
 
 // BN backward finalize: dgamma, dbeta and the per-channel coefficients of
 // dx = k1*dn + k2*x + k3  (dx = scale*(dn - mean(dn) - xhat*mean(dn*xhat)))
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
                                        const float* gamma, const float* mean, const float* invstd,
                                        float* dgamma, float* dbeta, float* coeffs) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, sx = 0.0;
-    for (int k = 0; k < nblk; ++k) { s += partial[((long)k * 2) * C + c]; sx += partial[((long)k * 2 + 1) * C + c]; }
+    __shared__ double red[256];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const double s = partial_sum(partial, nblk, 2L * C, c, c < C, red);
+    const double sx = partial_sum(partial + C, nblk, 2L * C, c, c < C, red);
+    if (c >= C || threadIdx.x >= 32) return;
     dgamma[c] = (float)sx; dbeta[c] = (float)s;
     const double sc = (double)gamma[c] * (double)invstd[c];
     const double mdn = s / (double)M, mdx = sx / (double)M;
@@ -341,7 +361,7 @@ int launch_bn_backward(int dtype, const void* dn, const void* x, long M, int C, 
     int nblk;
     int rc = launch_colreduce<1>(dtype, dn, x, M, C, mean, invstd, partial, &nblk, st);
     if (rc) return rc;
-    bn_bwd_finalize_kernel<<<cdiv(C, 128), 128, 0, st>>>(partial, nblk, C, M, gamma, mean, invstd, dgamma, dbeta, coeffs);
+    bn_bwd_finalize_kernel<<<cdiv(C, 32), 256, 0, st>>>(partial, nblk, C, M, gamma, mean, invstd, dgamma, dbeta, coeffs);
     rc = launch_ok();
     if (rc) return rc;
     const long work = M * C / 8;
@@ -401,18 +421,17 @@ int launch_maxpool_bwd_add(int dtype, const void* n, const void* dskip, const vo
     return launch_ok();
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int k = 0; k < nblk; ++k) s += partial[(long)k * C + c];
-    out[c] = (float)s;
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* out) {
+    __shared__ double red[256];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const double s = partial_sum(partial, nblk, C, c, c < C, red);
+    if (c < C && threadIdx.x < 32) out[c] = (float)s;
 }
 int launch_colsum(int dtype, const void* dz, long M, int C, float* partial, float* out, hipStream_t st) {
     int nblk;
     int rc = launch_colreduce<2>(dtype, dz, nullptr, M, C, nullptr, nullptr, partial, &nblk, st);
     if (rc) return rc;
-    colsum_finalize_kernel<<<cdiv(C, 128), 128, 0, st>>>(partial, nblk, C, out);
+    colsum_finalize_kernel<<<cdiv(C, 32), 256, 0, st>>>(partial, nblk, C, out);
     return launch_ok();
 }
 
@@ -586,13 +605,13 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const T* __restrict_
     for (int i = threadIdx.x; i < C * K + K; i += 256) partial[(long)blockIdx.x * (C * K + K) + i] = red[i];
 }
 
-__global__ void head_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int K, int ldw,
+__global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int K, int ldw,
                                          float* dWh, float* dbh) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double red[256];
+    const int i = blockIdx.x * 32 + (threadIdx.x & 31);
     const int tot = C * K + K;
-    if (i >= tot) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[(long)b * tot + i];
+    const double s = partial_sum(partial, nblk, tot, i, i < tot, red);
+    if (i >= tot || threadIdx.x >= 32) return;
     if (i < C * K) dWh[(i / K) * ldw + (i % K)] = (float)s; else dbh[i - C * K] = (float)s;
 }
 
@@ -613,7 +632,7 @@ int launch_head_backward(int dtype, const void* n, const float* probs, const uin
     }
     int rc = launch_ok();
     if (rc) return rc;
-    head_bwd_finalize_kernel<<<cdiv(C * K + K, 128), 128, 0, st>>>(partial, (int)blocks, C, K, ldw, dWh, dbh);
+    head_bwd_finalize_kernel<<<cdiv(C * K + K, 32), 256, 0, st>>>(partial, (int)blocks, C, K, ldw, dWh, dbh);
     return launch_ok();
 }
 

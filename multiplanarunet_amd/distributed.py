@@ -1,0 +1,174 @@
+"""
+One process per GPU over torch.distributed (backend "nccl" == RCCL over xGMI on
+ROCm; "gloo" on CPU for the tests). Replaces the reference's only multi-GPU
+mechanism, tf.distribute.MirroredStrategy (mpunet/bin/train.py:349,
+mpunet/bin/predict.py:214), for the two phases of the hot path:
+
+  training : pure data parallelism over slices; one SUM all-reduce of the flat
+             gradient buffer per step (the Keras loss is unreduced, so replica
+             gradients are summed, not averaged); BatchNorm statistics stay
+             per-replica as under MirroredStrategy.
+  predict  : (view, plane-chunk) work items dealt over ranks; each rank
+             accumulates W_v * nearest(x_v) for its planes into z_partial, then
+             reduce-scatter(SUM) over X-slabs -> +b, softmax, argmax on the slab
+             -> all-gather of the uint8 label slabs. Exact (fusion is linear in
+             the views before the softmax, fusion_model.py:39) and V times less
+             traffic than all-gathering per-view logits.
+"""
+import os
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise from torchrun's RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; returns (rank, world, device)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_cuda = torch.cuda.is_available()
+    if use_cuda:
+        torch.cuda.set_device(local)
+    device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
+    return rank, world, device
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def allreduce_sum_(flat, bucket_bytes=64 << 20):
+    """
+    In-place SUM all-reduce of a flat gradient buffer in buckets issued back to
+    back as async collectives (RCCL pipelines them over the xGMI links) and
+    waited on together. 124 MB of fp32 gradients = 2 buckets at the default size.
+    """
+    if world_size() == 1:
+        return flat
+    n = flat.numel()
+    step = max(1, bucket_bytes // flat.element_size())
+    works = [dist.all_reduce(flat[s:s + step], op=dist.ReduceOp.SUM, async_op=True)
+             for s in range(0, n, step)]
+    for w in works:
+        w.wait()
+    return flat
+
+
+class DataParallelTrainer:
+    """Wires the gradient all-reduce into UNet.train_step (model._grad_hook)."""
+
+    def __init__(self, model, bucket_bytes=64 << 20, broadcast_weights=True):
+        self.model = model
+        self.bucket_bytes = bucket_bytes
+        model._grad_hook = self._hook
+        if broadcast_weights and world_size() > 1:
+            dist.broadcast(model.params, src=0)
+            dist.broadcast(model.bn_state, src=0)
+            model._repack()
+
+    def _hook(self, grads):
+        allreduce_sum_(grads, self.bucket_bytes)
+
+
+# --------------------------------------------------------------------------- #
+# predict sharding
+# --------------------------------------------------------------------------- #
+def plane_work_items(n_views, n_planes, world, chunks_per_view=None):
+    """
+    Deal contiguous plane chunks of every view round-robin over ranks. Returns
+    per rank a list of (view, p_lo, p_hi). With V=6 plain view sharding would
+    leave 2 of 8 GPUs idle; chunking planes keeps all ranks busy.
+    """
+    if chunks_per_view is None:
+        chunks_per_view = world // np.gcd(world, n_views) if world > 1 else 1
+        while n_views * chunks_per_view < world:
+            chunks_per_view += 1
+    items = []
+    for v in range(n_views):
+        cuts = np.linspace(0, n_planes, chunks_per_view + 1).round().astype(int)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            if hi > lo:
+                items.append((v, int(lo), int(hi)))
+    per_rank = [[] for _ in range(world)]
+    for i, it in enumerate(items):
+        per_rank[i % world].append(it)
+    return per_rank
+
+
+def slab_bounds(X, world):
+    cuts = np.linspace(0, X, world + 1).round().astype(int)
+    return [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:])]
+
+
+def reduce_scatter_slabs(z_partial):
+    """
+    SUM over ranks of z_partial [X,...]; each rank keeps its X-slab
+    (slab_bounds). Equal slabs -> one reduce_scatter_tensor (RCCL); otherwise,
+    or on gloo (no reduce-scatter), all-reduce + slice.
+    """
+    world = world_size()
+    if world == 1:
+        return z_partial, (0, z_partial.shape[0])
+    rank = dist.get_rank()
+    X = z_partial.shape[0]
+    lo, hi = slab_bounds(X, world)[rank]
+    if X % world == 0 and dist.get_backend() == "nccl":
+        out = torch.empty((X // world,) + tuple(z_partial.shape[1:]), dtype=z_partial.dtype,
+                          device=z_partial.device)
+        dist.reduce_scatter_tensor(out, z_partial.contiguous(), op=dist.ReduceOp.SUM)
+        return out, (lo, hi)
+    dist.all_reduce(z_partial, op=dist.ReduceOp.SUM)
+    return z_partial[lo:hi].contiguous(), (lo, hi)
+
+
+def all_gather_slabs(slab, X):
+    """Concatenate every rank's slab along axis 0 (ragged slabs padded to the widest)."""
+    world = world_size()
+    if world == 1:
+        return slab
+    bounds = slab_bounds(X, world)
+    wmax = max(b - a for a, b in bounds)
+    pad = torch.zeros((wmax,) + tuple(slab.shape[1:]), dtype=slab.dtype, device=slab.device)
+    pad[:slab.shape[0]] = slab
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[:b - a] for p, (a, b) in zip(parts, bounds)], dim=0)
+
+
+def multi_view_predict_sharded(model, volume, views, dim, real_space_span, fusion_model=None,
+                               sum_fusion=False, batch_size=16, n_planes="same+20"):
+    """
+    multiplanarunet_amd.predict.multi_view_predict over all ranks. Every rank
+    holds the full input volume; returns the full uint8 label volume on every rank.
+    """
+    from .interpolation import ViewGeometry, sample_view, map_accumulate, fusion_finalize
+    world = world_size()
+    rank = dist.get_rank() if world > 1 else 0
+    K = model.n_classes
+    X, Y, Z = (int(v) for v in volume.image.shape[:3])
+    z = torch.zeros((X, Y, Z, K), dtype=torch.float32, device=volume.device)
+    geoms = [ViewGeometry(v, dim, real_space_span, n_planes) for v in views]
+    items = plane_work_items(len(views), geoms[0].n_planes, world)[rank]
+    for (vi, lo, hi) in items:
+        g = geoms[vi]
+        sub = ViewGeometry(views[vi], dim, real_space_span, n_planes)
+        sub.offsets = g.offsets[lo:hi]
+        sub.n_planes = hi - lo
+        Xs, _ = sample_view(volume, sub, want_labels=False)
+        pred = model.predict(Xs, batch_size=batch_size)
+        if pred.ndim == 3:
+            pred = pred.reshape(Xs.shape[0], dim, dim, -1)
+        if sum_fusion:
+            Wv = torch.ones(K, dtype=torch.float32, device=volume.device)
+        else:
+            Wv = fusion_model.W[vi]
+        map_accumulate(volume, pred, (g.real_axis, g.real_axis, g.offsets), g.inv_basis, Wv,
+                       lo, hi, owns_oob=(lo == 0), z=z)
+    zs, (lo, hi) = reduce_scatter_slabs(z)
+    b = None if sum_fusion else fusion_model.b
+    _, labels = fusion_finalize(zs, b, sum_fusion=sum_fusion, want_probs=False)
+    return all_gather_slabs(labels, X)

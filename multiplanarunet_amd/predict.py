@@ -1,0 +1,53 @@
+"""
+The 6-view predict+fuse loop of `mp predict` (mpunet/bin/predict.py:294-366) on
+one GPU: per view sample planes (HIP) -> U-Net forward (HIP) -> after all views one
+fused nearest-map + weighted-softmax + argmax kernel. `combined[V,X,Y,Z,K]` and
+the fp64 voxel grid of the reference are never materialised.
+"""
+import numpy as np
+import torch
+
+from .interpolation import ViewGeometry, sample_view, map_and_fuse
+
+
+def multi_view_predict(model, volume, views, dim, real_space_span, fusion_model=None,
+                       sum_fusion=False, batch_size=16, n_planes="same+20",
+                       want_probs=True, timings=None):
+    """
+    Returns (merged f32 [X,Y,Z,K] or None, merged_map u8 [X,Y,Z]).
+    fusion_model: object with .W (V,K) and .b (1,K) device tensors (FusionModel) or None with sum_fusion.
+    """
+    if fusion_model is None and not sum_fusion:
+        raise ValueError("need a fusion model unless sum_fusion")
+    view_preds = []
+    ev = []
+    for view in views:
+        geom = ViewGeometry(view, dim, real_space_span, n_planes)
+        if timings is not None:
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+        X, _ = sample_view(volume, geom, want_labels=False)
+        if timings is not None:
+            e1.record()
+        pred = model.predict(X, batch_size=batch_size)
+        if pred.ndim == 3:                                  # flatten_output models
+            pred = pred.reshape(X.shape[0], dim, dim, -1)
+        if timings is not None:
+            e2.record()
+            ev.append((e0, e1, e2))
+        view_preds.append((pred, (geom.real_axis, geom.real_axis, geom.offsets), geom.inv_basis))
+    if timings is not None:
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record()
+    W = b = None
+    if not sum_fusion:
+        W, b = fusion_model.W, fusion_model.b
+    probs, labels = map_and_fuse(volume, view_preds, W, b, sum_fusion=sum_fusion,
+                                 want_probs=want_probs, want_labels=True)
+    if timings is not None:
+        f1.record()
+        torch.cuda.synchronize()
+        timings["sample_ms"] = sum(a.elapsed_time(b_) for a, b_, _ in ev)
+        timings["unet_ms"] = sum(b_.elapsed_time(c) for _, b_, c in ev)
+        timings["map_fuse_ms"] = f0.elapsed_time(f1)
+    return probs, labels

@@ -1,0 +1,80 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU orchestration: gradient SUM all-reduce, plane sharding, slab exchange."""
+import os
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from multiplanarunet_amd import distributed as D
+
+
+def test_plane_work_items_cover_every_plane_once():
+    for V, P, world in ((6, 276, 8), (6, 532, 8), (6, 276, 4), (6, 276, 2), (3, 37, 8), (6, 276, 1), (1, 5, 8)):
+        per_rank = D.plane_work_items(V, P, world)
+        assert len(per_rank) == world
+        seen = np.zeros((V, P), int)
+        for items in per_rank:
+            for v, lo, hi in items:
+                assert 0 <= lo < hi <= P
+                seen[v, lo:hi] += 1
+        assert (seen == 1).all()
+        if V * P >= world * 8:
+            loads = [sum(hi - lo for _, lo, hi in it) for it in per_rank]
+            assert min(loads) > 0 and max(loads) <= 1.35 * (V * P / world) + 1, (V, P, world, loads)
+        owners = [sum(1 for it in per_rank for v, lo, hi in it if v == vv and lo == 0) for vv in range(V)]
+        assert owners == [1] * V          # exactly one rank adds each view's OOB term
+
+
+def test_slab_bounds():
+    for X, w in ((256, 8), (30, 4), (7, 8)):
+        b = D.slab_bounds(X, w)
+        assert b[0][0] == 0 and b[-1][1] == X and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, dev = D.init_from_env("gloo")
+    assert (r, w) == (rank, world) and dev.type == "cpu"
+    # 1. bucketed gradient SUM all-reduce (sum, not mean: Keras reduction=NONE)
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    D.allreduce_sum_(g, bucket_bytes=1024)
+    ok1 = torch.equal(g, torch.arange(1000, dtype=torch.float32) * sum(range(1, world + 1)))
+    # 2. DataParallelTrainer hook + weight broadcast on a stand-in model
+    class M:
+        pass
+    m = M()
+    m.params = torch.full((10,), float(rank)); m.bn_state = torch.full((4,), float(rank))
+    m._repack = lambda: None
+    t = D.DataParallelTrainer(m, bucket_bytes=16)
+    ok2 = bool((m.params == 0).all() and (m.bn_state == 0).all())
+    gg = torch.ones(10) * (rank + 1)
+    m._grad_hook(gg)
+    ok2 = ok2 and bool((gg == 3).all())
+    # 3. reduce-scatter over X slabs + all-gather (ragged X)
+    X = 7
+    z = torch.ones((X, 2, 3, 2)) * (rank + 1) + torch.arange(X).reshape(X, 1, 1, 1)
+    zs, (lo, hi) = D.reduce_scatter_slabs(z.clone())
+    exp = (torch.ones((X, 2, 3, 2)) * 3 + 2 * torch.arange(X).reshape(X, 1, 1, 1))[lo:hi]
+    ok3 = torch.equal(zs, exp)
+    lab = zs[..., 0].to(torch.uint8)
+    full = D.all_gather_slabs(lab, X)
+    ok3 = ok3 and full.shape == (X, 2, 3) and torch.equal(full, (3 + 2 * torch.arange(X)).reshape(X, 1, 1).expand(X, 2, 3).to(torch.uint8))
+    q.put((rank, ok1, ok2, ok3))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_collectives():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(r[0] for r in res) == [0, 1]
+    for r in res:
+        assert r[1] and r[2] and r[3], r
