@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-predict", action="store_true")
+    ap.add_argument("--predict-only", action="store_true", help="only the 6-view predict+fuse leg (profiling aid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -76,6 +77,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     quiet = lambda *a, **k: None
     B, dim = args.batch, args.dim
+    if args.predict_only:
+        print(json.dumps({"predict_fuse": bench_predict(device, quiet)}), flush=True)
+        return
 
     model = UNet(n_classes=3, dim=dim, n_channels=1, depth=4, complexity_factor=1,
                  flatten_output=True, dtype=args.dtype, logger=quiet, seed=0, device=device)

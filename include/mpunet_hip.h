@@ -37,6 +37,18 @@ const char* mpu_last_error(void);
  * Predict-time geometry (HBM-bound kernels)
  * ------------------------------------------------------------------------ */
 
+/* A strictly increasing coordinate axis that also lives in device memory as an f64 array.
+ * When the host has verified that a closed form reproduces the array BIT FOR BIT it says so
+ * here and the kernels evaluate the form in registers instead of loading the array:
+ *   kind 0: no closed form; only `step` is used (to seed the cell search)
+ *   kind 1: value(i) = (i == n-1) ? last : fl(fl(i*step) + start)        (np.linspace)
+ *   kind 2: value(i) = fl((i - start) * step)      (voxel axes: (arange(n)-(n-1)/2)*pixdim) */
+typedef struct {
+    int32_t kind;
+    int32_t n;
+    double  start, step, last;
+} mpu_axis;
+
 /* One view of IsotrophicLiveViewSequence2D.get_view_from
  * (mpunet/sequences/isotrophic_live_view_sequence_2d.py:29-117) expressed as
  * numbers: the plane basis of sample_plane_at (mpunet/interpolation/
@@ -52,6 +64,7 @@ typedef struct {
     int32_t _pad;
     double  g_start;       /* np.mgrid[-hd:hd:dim*1j]: value(i) = i*g_step+g_start */
     double  g_step;
+    mpu_axis vol_axis[3];  /* closed forms / spacings of the voxel axes d_ax, d_ay, d_az */
 } mpu_view_geom;
 
 /* get_view_from / sample_at: trilinear image planes (+ nearest label planes)
@@ -83,6 +96,8 @@ typedef struct {
     const double* d_offsets;     /* f64 [P]                                     */
     int32_t      dim;
     int32_t      n_planes;
+    mpu_axis     g_axis;         /* closed form / spacing of d_g       */
+    mpu_axis     o_axis;         /* closed form / spacing of d_offsets */
 } mpu_view_pred;
 
 /* Voxel grid of get_voxel_grid_real_space (sample_grid.py:101-130), computed on

@@ -19,14 +19,46 @@ i32, i64, f32, f64, u8 = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint8
 MPU_F32, MPU_BF16 = 0, 1
 
 
+class Axis(C.Structure):                # mpu_axis
+    _fields_ = [("kind", i32), ("n", i32), ("start", f64), ("step", f64), ("last", f64)]
+
+
+def make_axis(values):
+    """mpu_axis for a host f64 axis array: picks a closed form only if it reproduces the array bit for bit."""
+    import numpy as np
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    n = int(v.shape[0])
+    a = Axis()
+    a.n = n
+    a.kind = 0
+    a.step = float(v[1] - v[0]) if n > 1 else 1.0
+    a.start = float(v[0])
+    a.last = float(v[-1])
+    if n > 2:
+        i = np.arange(n, dtype=np.float64)
+        step1 = (v[-1] - v[0]) / float(n - 1)                     # np.linspace: arange*step + start, last = stop
+        lin = i * step1 + v[0]
+        lin[-1] = v[-1]
+        if np.array_equal(lin, v):
+            a.kind, a.start, a.step, a.last = 1, float(v[0]), float(step1), float(v[-1])
+            return a
+        half = (n - 1) / 2.0                                       # voxel axes: (arange(n) - (n-1)/2) * pixdim
+        pd = (v[-1] - v[0]) / float(n - 1)
+        for cand in (pd, float(v[1] - v[0]), float(v[-1] / half) if half else pd):
+            if np.array_equal((i - half) * cand, v):
+                a.kind, a.start, a.step, a.last = 2, float(half), float(cand), float(v[-1])
+                return a
+    return a
+
+
 class ViewGeom(C.Structure):            # mpu_view_geom
     _fields_ = [("basis", f64 * 9), ("rot", f64 * 9), ("has_rot", i32), ("dim", i32),
-                ("n_planes", i32), ("_pad", i32), ("g_start", f64), ("g_step", f64)]
+                ("n_planes", i32), ("_pad", i32), ("g_start", f64), ("g_step", f64), ("vol_axis", Axis * 3)]
 
 
 class ViewPred(C.Structure):            # mpu_view_pred
     _fields_ = [("inv_basis", f64 * 9), ("d_pred", c_p), ("d_g", c_p), ("d_offsets", c_p),
-                ("dim", i32), ("n_planes", i32)]
+                ("dim", i32), ("n_planes", i32), ("g_axis", Axis), ("o_axis", Axis)]
 
 
 class VoxelGrid(C.Structure):           # mpu_voxel_grid

@@ -34,11 +34,11 @@ inline int launch_ok() {
 // bf16 <-> f32 (round-to-nearest-even, as torch.bfloat16)
 typedef uint16_t bf16_t;
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {      // branch-free RNE; NaN stays NaN
+    const uint32_t u = __float_as_uint(f);
+    const uint32_t r = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    const uint32_t nan = (u >> 16) | 0x40u;
+    return (bf16_t)(((u & 0x7fffffffu) > 0x7f800000u) ? nan : r);
 }
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }

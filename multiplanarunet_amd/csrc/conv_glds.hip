@@ -1,0 +1,592 @@
+// conv_glds_kernel: the implicit-GEMM convolution of conv_igemm.hip with the operand tiles
+// DMA'd straight from HBM/L2 into LDS (buffer_load_dwordx4 ... lds), no VGPR staging and no
+// ds_write pass.
+//
+//  * one wave-instruction moves 64 lanes x 16 B = 8 K-rows of 128 B into 1 KiB of LDS
+//    (destination = wave-uniform base + lane*16, so LDS rows are unpadded);
+//  * bank conflicts are removed by an XOR swizzle applied on the SOURCE side: LDS slot p of row r
+//    holds channel chunk p ^ ((r>>1)&7); a fragment read of chunk q goes to slot q ^ ((r>>1)&7).
+//    For the non-contiguous 16-lane groups of ds_read_b128 on gfx950 this hits 16 distinct
+//    16-byte slots of the 256-byte bank row (checked on paper and with SQ_LDS_BANK_CONFLICT);
+//  * zero padding (image border, ragged tiles, channel tails, concat boundaries) costs nothing:
+//    a buffer descriptor bounds the tensor and out-of-range lanes get an offset beyond
+//    num_records, for which the DMA writes zeros (verified on hardware, tools/probe_glds3.hip).
+//
+// Pipeline: NSTAGE LDS stages; the loads of tile t+NSTAGE-1 are issued before the MFMAs of tile t.
+#include "kernels.h"
+
+namespace mpu {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+template <int MODE> struct GModeTraits;
+template <> struct GModeTraits<CONV3>   { static constexpr int NTAPS = 9, KW = 3; };
+template <> struct GModeTraits<UPCONV2> { static constexpr int NTAPS = 4, KW = 2; };
+template <> struct GModeTraits<CONV3S2> { static constexpr int NTAPS = 9, KW = 3; };
+template <> struct GModeTraits<CONV1>   { static constexpr int NTAPS = 1, KW = 1; };
+
+template <int MODE>
+__device__ __forceinline__ bool g_tap_src(int oy, int ox, int ky, int kx, int Ho, int Wo, int& iy, int& ix) {
+    if (MODE == CONV3) {
+        iy = oy + ky - 1; ix = ox + kx - 1;
+        return (unsigned)iy < (unsigned)Ho && (unsigned)ix < (unsigned)Wo;
+    } else if (MODE == UPCONV2) {
+        const int uy = oy + ky, ux = ox + kx;
+        iy = uy >> 1; ix = ux >> 1;
+        return uy < Ho && ux < Wo;
+    } else if (MODE == CONV3S2) {
+        iy = 2 * oy + ky - 1; ix = 2 * ox + kx - 1;
+        return (unsigned)iy < (unsigned)(2 * Ho) && (unsigned)ix < (unsigned)(2 * Wo);
+    } else {
+        iy = oy; ix = ox;
+        return true;
+    }
+}
+template <int MODE> __device__ __forceinline__ int g_in_h(int Ho) {
+    return MODE == UPCONV2 ? Ho / 2 : (MODE == CONV3S2 ? Ho * 2 : Ho);
+}
+
+template <typename T> struct GMma;
+template <> struct GMma<bf16_t> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct GMma<float> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// raw buffer descriptor (stride 0, byte-granular range check) in four SGPRs
+__device__ __forceinline__ i32x4 make_rsrc(const void* p, long bytes) {
+    const unsigned long long pa = (unsigned long long)p;
+    i32x4 r;
+    r.x = (int)(unsigned)pa;
+    r.y = (int)((unsigned)(pa >> 32) & 0xffffu);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+// One LDS-DMA piece: 64 lanes x 16 B -> LDS[lds_addr + lane*16]. Issued as inline asm so that the
+// compiler does not treat it as a pending LDS write (it would drain vmcnt(0) before every ds_read);
+// completion is tracked by the caller's counted s_waitcnt vmcnt(N) + s_barrier.
+__device__ __forceinline__ void dma16(const i32x4& rsrc, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
+                 :: "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
+}
+
+__device__ __forceinline__ int g_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <typename T, int BN, int BM>
+struct GldsCfg {
+    static constexpr int STAGE = (BN + BM) * 128;
+    static constexpr int OROW = BN * (int)sizeof(T) + 16;
+    static constexpr int EPI = BM * OROW + BN * 4;
+    // three stages (prefetch distance 2) only where three workgroups still fit one CU's 160 KiB:
+    // measured, workgroups per CU matter more than prefetch depth (64x128: 2 stages/3 WGs 42.9 us
+    // vs 3 stages/2 WGs 52.1 us on the 64-filter full-resolution layer)
+    static constexpr int NSTAGE = (3 * STAGE <= 53 * 1024) ? 3 : 2;
+    static constexpr int SMEM = (NSTAGE * STAGE > EPI) ? NSTAGE * STAGE : EPI;
+};
+
+template <typename T, int MODE, int BN, int BM, int WN, int WM>
+__global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
+    using Cfg = GldsCfg<T, BN, BM>;
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int BKE = 128 / sizeof(T);
+    constexpr int TN = WN / 32, TM = WM / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int NTAPS = GModeTraits<MODE>::NTAPS, KW = GModeTraits<MODE>::KW;
+    constexpr int STAGE = Cfg::STAGE;
+    constexpr int GW = BN / 32, GP = BM / 32;        // 8-row groups per wave (weights / pixels)
+    static_assert((BN / WN) * (BM / WM) == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WAVES_N, wm = wave / WAVES_N;
+    const int tiles_n = (a.Cout + BN - 1) / BN;
+    const int logical = g_xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (logical % tiles_n) * BN;
+    const long m0 = (long)(logical / tiles_n) * BM;
+    const int nch0 = (a.C0 + BKE - 1) / BKE, nch1 = (a.C1 + BKE - 1) / BKE;
+    const int nchunks = nch0 + nch1;
+    const int nit = NTAPS * nchunks;
+    const int Hi = g_in_h<MODE>(a.Ho), Wi = g_in_h<MODE>(a.Wo);
+    const long M = (long)a.B * a.Ho * a.Wo;
+    constexpr unsigned OOB = 0xfffffff0u;
+    const long npix = (long)a.B * Hi * Wi;
+    const i32x4 rs0 = make_rsrc(a.in0, npix * a.C0 * (long)sizeof(T));
+    const i32x4 rs1 = make_rsrc(a.in1 ? a.in1 : a.in0, a.in1 ? npix * a.C1 * (long)sizeof(T) : 0);
+    const i32x4 rsw = make_rsrc(a.w, a.w_elems * (long)sizeof(T));
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;      // LDS byte address of the staging area
+
+    // DMA roles: wave w moves weight rows [w*BN/4, (w+1)*BN/4) and pixel rows [w*BM/4, (w+1)*BM/4),
+    // 8 rows per instruction; lane -> (row = lane>>3, LDS slot = lane&7), source chunk = slot ^ swz(row)
+    const int lrow = lane >> 3, slot = lane & 7;
+    unsigned wrow[GW]; int wchunk[GW];
+#pragma unroll
+    for (int g = 0; g < GW; ++g) {
+        const int rl = wave * (BN / 4) + g * 8 + lrow;           // tile-local weight row
+        const int n = n0 + rl;
+        wrow[g] = n < a.Cout ? (unsigned)((long)n * a.w_row_stride * (long)sizeof(T)) : OOB;
+        wchunk[g] = slot ^ ((rl >> 1) & 7);
+    }
+    int pb[GP], py[GP], px[GP], pchunk[GP];
+#pragma unroll
+    for (int g = 0; g < GP; ++g) {
+        const int rl = wave * (BM / 4) + g * 8 + lrow;           // tile-local pixel row
+        const long m = m0 + rl;
+        pchunk[g] = slot ^ ((rl >> 1) & 7);
+        if (m < M) {
+            const int ox = (int)(m % a.Wo); const long t = m / a.Wo;
+            const int oy = (int)(t % a.Ho); const int b = (int)(t / a.Ho);
+            pb[g] = b * Hi * Wi; py[g] = oy; px[g] = ox;
+        } else { pb[g] = -1; py[g] = 0; px[g] = 0; }
+    }
+
+    auto issue = [&](int tap, int cc, int stage) {
+        const bool s1 = cc >= nch0;
+        const int cbase = (s1 ? cc - nch0 : cc) * BKE;
+        const int Cs = s1 ? a.C1 : a.C0;
+        const long wkbase = (long)tap * a.w_tap_stride + (s1 ? a.C0 : 0) + cbase;
+        const unsigned sbase = lds0 + stage * STAGE;
+#pragma unroll
+        for (int g = 0; g < GW; ++g) {
+            const int ch = wchunk[g] * EPC;
+            const unsigned off = (cbase + ch < Cs && wrow[g] != OOB)
+                                     ? wrow[g] + (unsigned)((wkbase + ch) * (long)sizeof(T)) : OOB;
+            dma16(rsw, off, sbase + (wave * (BN / 4) + g * 8) * 128);
+        }
+        const int ky = tap / KW, kx = tap % KW;
+#pragma unroll
+        for (int g = 0; g < GP; ++g) {
+            int iy, ix;
+            const int ch = cbase + pchunk[g] * EPC;
+            const bool v = g_tap_src<MODE>(py[g], px[g], ky, kx, a.Ho, a.Wo, iy, ix) && ch < Cs && pb[g] >= 0;
+            const unsigned off = v ? (unsigned)(((pb[g] + iy * Wi + ix) * Cs + ch) * (int)sizeof(T)) : OOB;
+            const unsigned dst = sbase + BN * 128 + (wave * (BM / 4) + g * 8) * 128;
+            if (s1) dma16(rs1, off, dst);
+            else    dma16(rs0, off, dst);
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment reads: row (lane&31) of a 32-row block, chunk q = 2s + (lane>>5) -> slot q ^ swz
+    const int fsw = ((lane & 31) >> 1) & 7, fh = lane >> 5;
+    auto compute = [&](int stage) {
+        const unsigned char* Wb = smem + stage * STAGE + (wn * WN + (lane & 31)) * 128;
+        const unsigned char* Pb = smem + stage * STAGE + BN * 128 + (wm * WM + (lane & 31)) * 128;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int so = ((2 * s + fh) ^ fsw) << 4;
+            uint4 af[TN], bf[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) af[i] = *(const uint4*)(Wb + i * 32 * 128 + so);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) bf[j] = *(const uint4*)(Pb + j * 32 * 128 + so);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) GMma<T>::run(af[i], bf[j], acc[i][j]);
+        }
+    };
+
+    int tapN = 0, ccN = 0;
+    auto advance = [&]() { if (++ccN == nchunks) { ccN = 0; ++tapN; } };
+    if constexpr (Cfg::NSTAGE == 2) {
+        issue(tapN, ccN, 0); advance();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int it = 0; it < nit; ++it) {
+            if (it + 1 < nit) { issue(tapN, ccN, (it + 1) & 1); advance(); }
+            compute(it & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        // Three stages, counted waits: tile t+2 is in flight across the barrier of iteration t.
+        // A wave's DMA is ordered for the other waves by its own vmcnt wait followed by the barrier.
+        constexpr int NLD = GW + GP;                   // DMA instructions per tile and wave
+        issue(tapN, ccN, 0); advance();
+        if (nit > 1) { issue(tapN, ccN, 1); advance(); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int st = 0;                                    // stage of tile `it`
+        for (int it = 0; it < nit; ++it) {
+            const int st2 = st >= 1 ? st - 1 : 2;      // (it + 2) % 3
+            if (it + 2 < nit) { issue(tapN, ccN, st2); advance(); }
+            compute(st);
+            if (it + 2 < nit) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            st = st == 2 ? 0 : st + 1;
+        }
+    }
+
+    // epilogue (same as conv_igemm_kernel): bias -> LDS, tile -> LDS, coalesced 16-byte row stores
+    constexpr int OROW = Cfg::OROW;
+    float* sbias = (float*)(smem + BM * OROW);
+    if (tid < BN) sbias[tid] = (a.bias && n0 + tid < a.Cout) ? a.bias[n0 + tid] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int ml = wm * WM + j * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = wn * WN + i * 32 + 8 * q + 4 * (lane >> 5);
+                const float4 bq = *(const float4*)(sbias + nl);
+                float v[4] = {acc[i][j][4 * q] + bq.x, acc[i][j][4 * q + 1] + bq.y,
+                              acc[i][j][4 * q + 2] + bq.z, acc[i][j][4 * q + 3] + bq.w};
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                unsigned char* dst = smem + ml * OROW + nl * (int)sizeof(T);
+                if (sizeof(T) == 2) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *(uint2*)dst = pk;
+                } else {
+                    *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int CPRO = BN * (int)sizeof(T) / 16;
+        T* out = (T*)a.out; const T* mask = (const T*)a.mask;
+        for (int idx = tid; idx < BM * CPRO; idx += 256) {
+            const int row = idx / CPRO, c = idx % CPRO;
+            const long m = m0 + row;
+            const int n = n0 + c * EPC;
+            if (m >= M || n >= a.Cout) continue;
+            uint4 val = *(const uint4*)(smem + row * OROW + c * 16);
+            const long o = m * a.Cout + n;
+            if (mask) {
+                const uint4 mk = *(const uint4*)(mask + o);
+                if (sizeof(T) == 2) {
+                    auto keep = [](uint32_t mw, uint32_t vw) {
+                        const uint32_t lo = ((mw & 0x8000u) == 0 && (mw & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
+                        const uint32_t hi = ((mw & 0x80000000u) == 0 && (mw & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+                        return vw & (lo | hi);
+                    };
+                    val.x = keep(mk.x, val.x); val.y = keep(mk.y, val.y);
+                    val.z = keep(mk.z, val.z); val.w = keep(mk.w, val.w);
+                } else {
+                    if (!(__uint_as_float(mk.x) > 0.f)) val.x = 0;
+                    if (!(__uint_as_float(mk.y) > 0.f)) val.y = 0;
+                    if (!(__uint_as_float(mk.z) > 0.f)) val.z = 0;
+                    if (!(__uint_as_float(mk.w) > 0.f)) val.w = 0;
+                }
+            }
+            *(uint4*)(out + o) = val;
+        }
+    }
+}
+
+template <typename T, int MODE, int BN, int BM, int WN, int WM>
+static int launch_glds_cfg(const ConvArgs& a_in, hipStream_t st) {
+    using Cfg = GldsCfg<T, BN, BM>;
+    auto kern = conv_glds_kernel<T, MODE, BN, BM, WN, WM>;
+    ConvArgs a = a_in;
+    constexpr int NT = GModeTraits<MODE>::NTAPS;
+    if (a.w_elems <= 0) a.w_elems = (NT - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        attr_set = true;
+    }
+    const long M = (long)a.B * a.Ho * a.Wo;
+    const long tiles = (long)cdiv(a.Cout, BN) * cdiv(M, BM);
+    {
+        const long hi = MODE == UPCONV2 ? a.Ho / 2 : (MODE == CONV3S2 ? a.Ho * 2 : a.Ho);
+        const long wi = MODE == UPCONV2 ? a.Wo / 2 : (MODE == CONV3S2 ? a.Wo * 2 : a.Wo);
+        const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
+        if ((long)a.B * hi * wi * cmax * (long)sizeof(T) >= (1L << 31) || a.w_elems * (long)sizeof(T) >= (1L << 31))
+            return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
+    }
+    if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * NT * (a.C0 + a.C1), st);
+    kern<<<dim3((unsigned)tiles), dim3(256), Cfg::SMEM, st>>>(a);
+    if (prof_on()) prof_end(st);
+    return launch_ok();
+}
+
+template <typename T, int MODE>
+static int launch_glds_mode(const ConvArgs& a, hipStream_t st) {
+    const long M = (long)a.B * a.Ho * a.Wo;
+    const long t128 = (long)cdiv(a.Cout, 128) * cdiv(M, 128);
+    const long t64x128 = (long)cdiv(a.Cout, 64) * cdiv(M, 128);
+    if (a.Cout > 64 && t128 >= 384) return launch_glds_cfg<T, MODE, 128, 128, 64, 64>(a, st);
+    if (t64x128 >= 384 || a.Cout <= 64) {
+        if (M >= 128 * 64) return launch_glds_cfg<T, MODE, 64, 128, 64, 32>(a, st);
+    }
+    return launch_glds_cfg<T, MODE, 64, 64, 32, 32>(a, st);
+}
+
+int launch_conv_glds(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
+#define MPU_GCASE(TT)                                                              \
+    switch (mode) {                                                                \
+        case CONV3: return launch_glds_mode<TT, CONV3>(a, st);                     \
+        case UPCONV2: return launch_glds_mode<TT, UPCONV2>(a, st);                 \
+        case CONV3S2: return launch_glds_mode<TT, CONV3S2>(a, st);                 \
+        case CONV1: return launch_glds_mode<TT, CONV1>(a, st);                     \
+        default: return fail(MPU_EINVAL, "%s", "conv: bad mode");                  \
+    }
+    if (dtype == MPU_BF16) { MPU_GCASE(bf16_t) }
+    if (dtype == MPU_F32) { MPU_GCASE(float) }
+#undef MPU_GCASE
+    return fail(MPU_EINVAL, "%s", "conv: bad dtype");
+}
+
+
+// ------------------------------------------------------------------------- //
+// wgrad_glds_kernel: dW[tap][ci][co] = sum_m X[m@tap][ci] * dZ[m][co] with LDS-DMA staging.
+// Both operands are pixel-major (K-major): per K step of 32 pixels the stage holds
+// X[32][BCI] and dZ[32][BCO] as unpadded rows; fragments are read with the LDS transpose read
+// ds_read_b64_tr_b16 (bf16) or plain ds_read_b32 (f32). The four k-rows a transpose read touches
+// are spread over four 64-byte bank groups by XOR-ing the 64-byte granule index of the row
+// (256-byte rows: granule ^= row&3; 128-byte rows: granule ^= (row>>1)&1) on the DMA source side.
+// ------------------------------------------------------------------------- //
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <int ROWB> __device__ __forceinline__ int wg_swz16(int row) {   // XOR mask on the 16-byte slot index
+    return ROWB == 256 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2);
+}
+
+template <typename T, int MODE, int BCI, int BCO>
+__global__ __launch_bounds__(256, 2) void wgrad_glds_kernel(WgradArgs a) {
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int KP = 32;
+    constexpr int RX = BCI * sizeof(T), RZ = BCO * sizeof(T);            // row bytes: 128 or 256
+    static_assert((RX == 128 || RX == 256) && (RZ == 128 || RZ == 256), "row bytes");
+    constexpr int STAGE = KP * (RX + RZ);
+    constexpr int NSTAGE = 3;
+    constexpr int PX = KP * RX / 1024, PZ = KP * RZ / 1024;              // 1-KiB pieces per image
+    constexpr int NPX = PX / 4, NPZ = PZ / 4;                            // pieces per wave
+    static_assert(NPX >= 1 && NPZ >= 1, "tile too small");
+    constexpr int WCI = BCI / 2, WCO = BCO / 2, TI = WCI / 32, TJ = WCO / 32;
+    constexpr int KW = GModeTraits<MODE>::KW;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave & 1, wj = wave >> 1;
+    const int Cin = a.C0 + a.C1;
+    const int tiles_co = (a.Cout + BCO - 1) / BCO;
+    const int ci0 = (blockIdx.x / tiles_co) * BCI, co0 = (blockIdx.x % tiles_co) * BCO;
+    const int tap = blockIdx.y, ky = tap / KW, kx = tap % KW;
+    const long M = (long)a.B * a.Ho * a.Wo;
+    const long mbeg = (long)blockIdx.z * a.mchunk;
+    const long mend = (mbeg + a.mchunk < M) ? mbeg + a.mchunk : M;
+    const int Hi = g_in_h<MODE>(a.Ho), Wi = g_in_h<MODE>(a.Wo);
+    constexpr unsigned OOB = 0xfffffff0u;
+    const long npix = (long)a.B * Hi * Wi;
+    // the ci tile lies entirely in one concat source (host guarantees C0 % BCI == 0 when C1 > 0)
+    const bool s1 = ci0 >= a.C0 && a.C1 > 0;
+    const int Cs = s1 ? a.C1 : a.C0, cs0 = s1 ? ci0 - a.C0 : ci0;
+    const i32x4 rsx = make_rsrc(s1 ? a.x1 : a.x0, npix * Cs * (long)sizeof(T));
+    const i32x4 rsz = make_rsrc(a.dz, M * a.Cout * (long)sizeof(T));
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+
+    // per-lane DMA roles
+    constexpr int SPRX = RX / 16, SPRZ = RZ / 16;                        // 16-byte slots per row
+    int xrow[NPX], xch[NPX], zrow[NPZ], zch[NPZ];
+#pragma unroll
+    for (int g = 0; g < NPX; ++g) {
+        const int piece = wave * NPX + g;
+        xrow[g] = piece * (64 / SPRX) + lane / SPRX;
+        xch[g] = ((lane % SPRX) ^ wg_swz16<RX>(xrow[g])) * EPC;
+    }
+#pragma unroll
+    for (int g = 0; g < NPZ; ++g) {
+        const int piece = wave * NPZ + g;
+        zrow[g] = piece * (64 / SPRZ) + lane / SPRZ;
+        zch[g] = ((lane % SPRZ) ^ wg_swz16<RZ>(zrow[g])) * EPC;
+    }
+    auto issue = [&](long mb, int stage) {
+        const unsigned sb = lds0 + stage * STAGE;
+#pragma unroll
+        for (int g = 0; g < NPX; ++g) {
+            const long m = mb + xrow[g];
+            unsigned off = OOB;
+            if (m < mend && cs0 + xch[g] < Cs) {
+                const int ox = (int)(m % a.Wo); const long t = m / a.Wo;
+                const int oy = (int)(t % a.Ho); const int b = (int)(t / a.Ho);
+                int iy, ix;
+                if (g_tap_src<MODE>(oy, ox, ky, kx, a.Ho, a.Wo, iy, ix))
+                    off = (unsigned)((((long)b * Hi + iy) * Wi + ix) * Cs + cs0 + xch[g]) * (unsigned)sizeof(T);
+            }
+            dma16(rsx, off, sb + (wave * NPX + g) * 1024);
+        }
+#pragma unroll
+        for (int g = 0; g < NPZ; ++g) {
+            const long m = mb + zrow[g];
+            const unsigned off = (m < mend && co0 + zch[g] < a.Cout)
+                                     ? (unsigned)(m * a.Cout + co0 + zch[g]) * (unsigned)sizeof(T) : OOB;
+            dma16(rsz, off, sb + KP * RX + (wave * NPZ + g) * 1024);
+        }
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int stage) {
+        const unsigned char* xb = smem + stage * STAGE;
+        const unsigned char* zb = xb + KP * RX;
+        if constexpr (sizeof(T) == 2) {
+            const int krow = 8 * (lane >> 5) + ((lane & 15) >> 2);        // + s*16 (+4 for the upper half)
+            const int ccol = 16 * ((lane >> 4) & 1) + (lane & 3) * 4;     // element column inside a 32-block
+            // byte offset of (block col + ccol) in a row, swizzled; row&3 and (row>>1)&1 are lane constants
+            auto xoff = [&](int blk) { const int byte = (blk + ccol) * 2;
+                return (((byte >> 4) ^ wg_swz16<RX>(krow)) << 4) + (byte & 15); };
+            auto zoff = [&](int blk) { const int byte = (blk + ccol) * 2;
+                return (((byte >> 4) ^ wg_swz16<RZ>(krow)) << 4) + (byte & 15); };
+#pragma unroll
+            for (int s = 0; s < KP / 16; ++s) {
+                s16x8 af[TI], bf[TJ];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const unsigned char* p = xb + (s * 16 + krow) * RX + xoff(wi * WCI + i * 32);
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * RX));
+                    af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const unsigned char* p = zb + (s * 16 + krow) * RZ + zoff(wj * WCO + j * 32);
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * RZ));
+                    bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll 4
+            for (int k = 0; k < KP; k += 2) {
+                float af[TI], bf[TJ];
+                const int row = k + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const int byte = (wi * WCI + i * 32 + (lane & 31)) * 4;
+                    af[i] = *(const float*)(xb + row * RX + (((byte >> 4) ^ wg_swz16<RX>(row)) << 4) + (byte & 15));
+                }
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const int byte = (wj * WCO + j * 32 + (lane & 31)) * 4;
+                    bf[j] = *(const float*)(zb + row * RZ + (((byte >> 4) ^ wg_swz16<RZ>(row)) << 4) + (byte & 15));
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nit = (int)((mend - mbeg + KP - 1) / KP);
+    constexpr int NLD = NPX + NPZ;
+    if (nit > 0) {
+        issue(mbeg, 0);
+        if (nit > 1) { issue(mbeg + KP, 1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int st = 0;
+        for (int it = 0; it < nit; ++it) {
+            const int st2 = st >= 1 ? st - 1 : 2;
+            if (it + 2 < nit) issue(mbeg + (long)(it + 2) * KP, st2);
+            compute(st);
+            if (it + 2 < nit) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            st = st == 2 ? 0 : st + 1;
+        }
+    }
+    float* P = a.partial + ((long)blockIdx.z * gridDim.y + tap) * (long)Cin * a.Cout;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int co = co0 + wj * WCO + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + wi * WCI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (ci < Cin && co < a.Cout) P[(long)ci * a.Cout + co] = acc[i][j][r];
+            }
+        }
+}
+
+// returns 1 if launched, 0 if this shape must use the register-staged kernel, <0 on error
+template <typename T, int MODE>
+static int try_wgrad_glds_mode(const WgradArgs& a, hipStream_t st) {
+    const int Cin = a.C0 + a.C1;
+    constexpr int ntaps = GModeTraits<MODE>::NTAPS;
+    const long M = (long)a.B * a.Ho * a.Wo;
+    const long hi = MODE == UPCONV2 ? a.Ho / 2 : a.Ho, wi = MODE == UPCONV2 ? a.Wo / 2 : a.Wo;
+    const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
+    if ((long)a.B * hi * wi * cmax * (long)sizeof(T) >= (1L << 31) || M * a.Cout * (long)sizeof(T) >= (1L << 31)) return 0;
+    bool big = false;
+    if constexpr (sizeof(T) == 2) big = Cin >= 128 && a.Cout >= 128 && (a.C1 == 0 || a.C0 % 128 == 0);
+    if (!big && a.C1 > 0 && a.C0 % 64 != 0) return 0;
+    if (big) {
+        if constexpr (sizeof(T) == 2) {
+            dim3 g((unsigned)(cdiv(Cin, 128) * cdiv(a.Cout, 128)), ntaps, a.ksplit);
+            wgrad_glds_kernel<T, MODE, 128, 128><<<g, dim3(256), 0, st>>>(a);
+        }
+    } else {
+        dim3 g((unsigned)(cdiv(Cin, 64) * cdiv(a.Cout, 64)), ntaps, a.ksplit);
+        wgrad_glds_kernel<T, MODE, 64, 64><<<g, dim3(256), 0, st>>>(a);
+    }
+    int rc = launch_ok();
+    return rc ? rc : 1;
+}
+
+int try_wgrad_glds(int dtype, int mode, const WgradArgs& a, hipStream_t st) {
+#define MPU_WGG(TT)                                                               \
+    switch (mode) {                                                               \
+        case CONV3: return try_wgrad_glds_mode<TT, CONV3>(a, st);                 \
+        case UPCONV2: return try_wgrad_glds_mode<TT, UPCONV2>(a, st);             \
+        case CONV1: return try_wgrad_glds_mode<TT, CONV1>(a, st);                 \
+        default: return 0;                                                        \
+    }
+    if (dtype == MPU_BF16) { MPU_WGG(bf16_t) }
+    if (dtype == MPU_F32) { MPU_WGG(float) }
+#undef MPU_WGG
+    return 0;
+}
+
+}  // namespace mpu

@@ -19,6 +19,7 @@
 // under the MFMAs. bf16: v_mfma_f32_32x32x16_bf16; f32: v_mfma_f32_32x32x2_f32
 // (exact f32). The k-order inside a row is permuted identically for both
 // operands, which leaves the dot product unchanged.
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace mpu {
@@ -78,7 +79,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 
 template <typename T, int MODE, int BN, int BM, int WN, int WM>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int EPC = 16 / sizeof(T);          // elements per 16-B chunk
     constexpr int BKE = 128 / sizeof(T);         // elements per K row
     constexpr int LROW = 144;
@@ -97,11 +98,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int n0 = (logical % tiles_n) * BN;
     const long m0 = (long)(logical / tiles_n) * BM;
     const int Cin = a.C0 + a.C1;
-    const int nchunks = (Cin + BKE - 1) / BKE;
+    // K steps: for every tap, the 128-byte channel rows of source 0, then those of source 1
+    // (a row never straddles the two concat sources, so the source is wave-uniform)
+    const int nch0 = (a.C0 + BKE - 1) / BKE, nch1 = (a.C1 + BKE - 1) / BKE;
+    const int nchunks = nch0 + nch1;
     const int nit = NTAPS * nchunks;
     const int Hi = in_h<MODE>(a.Ho), Wi = in_h<MODE>(a.Wo);
     const long M = (long)a.B * a.Ho * a.Wo;
-    const T* in0 = (const T*)a.in0; const T* in1 = (const T*)a.in1; const T* wp = (const T*)a.w;
+    constexpr unsigned OOB = 0xfffffff0u;           // buffer loads beyond num_records return 0
+    const long npix = (long)a.B * Hi * Wi;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.in0, 0, (int)(npix * a.C0 * (long)sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.in1 ? a.in1 : a.in0), 0, (int)(a.in1 ? npix * a.C1 * (long)sizeof(T) : 0), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.w, 0, (int)(a.w_elems * (long)sizeof(T)), 0x00020000);
 
     const int ck = tid & 7, r0 = tid >> 3;
     int pb[NP_ROWS], py[NP_ROWS], px[NP_ROWS];
@@ -114,36 +125,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             pb[i] = b * Hi * Wi; py[i] = oy; px[i] = ox;
         } else { pb[i] = -1; py[i] = 0; px[i] = 0; }
     }
+    unsigned wrow[NW_ROWS];                          // byte offset of this thread's weight rows
+#pragma unroll
+    for (int i = 0; i < NW_ROWS; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        wrow[i] = n < a.Cout ? (unsigned)((long)n * a.w_row_stride * (long)sizeof(T)) : OOB;
+    }
 
-    uint4 wreg[NW_ROWS], preg[NP_ROWS];
-    auto gload = [&](int tap, int cc) {
-        const int ch = cc * BKE + ck * EPC;
-        const bool chv = ch < Cin;
+    auto gload = [&](uint4 (&wr)[NW_ROWS], uint4 (&pr)[NP_ROWS], int tap, int cc) {
+        const bool s1 = cc >= nch0;
+        const int cbase = (s1 ? cc - nch0 : cc) * BKE;
+        const int Cs = s1 ? a.C1 : a.C0;
+        const int ch = cbase + ck * EPC;
+        const bool chv = ch < Cs;
+        const unsigned wk = (unsigned)(((long)tap * a.w_tap_stride + (s1 ? a.C0 : 0) + ch) * (long)sizeof(T));
 #pragma unroll
         for (int i = 0; i < NW_ROWS; ++i) {
-            const int n = n0 + r0 + 32 * i;
-            wreg[i] = make_uint4(0, 0, 0, 0);
-            if (chv && n < a.Cout)
-                wreg[i] = *(const uint4*)(wp + (long)tap * a.w_tap_stride + (long)n * a.w_row_stride + ch);
+            const unsigned off = (chv && wrow[i] != OOB) ? wrow[i] + wk : OOB;
+            wr[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0));
         }
-        const T* src; int cs, Cs;
-        if (ch < a.C0) { src = in0; cs = ch; Cs = a.C0; } else { src = in1; cs = ch - a.C0; Cs = a.C1; }
         const int ky = tap / KW, kx = tap % KW;
 #pragma unroll
         for (int i = 0; i < NP_ROWS; ++i) {
             int iy, ix;
-            const bool v = tap_src<MODE>(py[i], px[i], ky, kx, a.Ho, a.Wo, iy, ix);
-            preg[i] = make_uint4(0, 0, 0, 0);
-            if (v && chv && pb[i] >= 0)
-                preg[i] = *(const uint4*)(src + ((long)pb[i] + (long)iy * Wi + ix) * Cs + cs);
+            const bool v = tap_src<MODE>(py[i], px[i], ky, kx, a.Ho, a.Wo, iy, ix) && chv && pb[i] >= 0;
+            const unsigned off = v ? (unsigned)(((pb[i] + iy * Wi + ix) * Cs + ch) * (int)sizeof(T)) : OOB;
+            pr[i] = s1 ? __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0))
+                       : __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const uint4 (&wr)[NW_ROWS], const uint4 (&pr)[NP_ROWS], int buf) {
         unsigned char* base = smem + buf * STAGE + r0 * LROW + ck * 16;
 #pragma unroll
-        for (int i = 0; i < NW_ROWS; ++i) *(uint4*)(base + i * 32 * LROW) = wreg[i];
+        for (int i = 0; i < NW_ROWS; ++i) *(uint4*)(base + i * 32 * LROW) = wr[i];
 #pragma unroll
-        for (int i = 0; i < NP_ROWS; ++i) *(uint4*)(base + BN * LROW + i * 32 * LROW) = preg[i];
+        for (int i = 0; i < NP_ROWS; ++i) *(uint4*)(base + BN * LROW + i * 32 * LROW) = pr[i];
     };
 
     f32x16 acc[TN][TM];
@@ -171,65 +187,92 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
     };
 
-    int tap = 0, cc = 0;
-    gload(0, 0);
-    lstore(0);
+    // Software pipeline, prefetch distance 2: tile t is consumed from LDS[t&1] while tile t+1
+    // waits in one register set and the loads of tile t+2 are issued into the other.
+    uint4 wA[NW_ROWS], pA[NP_ROWS], wB[NW_ROWS], pB[NP_ROWS];
+    int tapN = 0, ccN = 0;
+    auto advance = [&]() { if (++ccN == nchunks) { ccN = 0; ++tapN; } };
+    gload(wA, pA, tapN, ccN); advance();
+    if (nit > 1) { gload(wB, pB, tapN, ccN); advance(); }
+    lstore(wA, pA, 0);
     __syncthreads();
-    for (int it = 0; it < nit; ++it) {
-        const int buf = it & 1;
-        const bool more = it + 1 < nit;
-        if (more) {
-            if (++cc == nchunks) { cc = 0; ++tap; }
-            gload(tap, cc);
-        }
-        compute(buf);
-        if (more) lstore(buf ^ 1);
+    for (int it = 0; it < nit; it += 2) {
+        if (it + 2 < nit) { gload(wA, pA, tapN, ccN); advance(); }
+        compute(0);
+        if (it + 1 < nit) lstore(wB, pB, 1);
+        __syncthreads();
+        if (it + 1 >= nit) break;
+        if (it + 3 < nit) { gload(wB, pB, tapN, ccN); advance(); }
+        compute(1);
+        if (it + 2 < nit) lstore(wA, pA, 0);
         __syncthreads();
     }
 
-    // epilogue: lane holds pixel m = col, 4 consecutive channels per register quad
-    T* out = (T*)a.out; const T* mask = (const T*)a.mask;
+    // epilogue. The last loop iteration ended with a barrier, so the staging LDS is free:
+    //   1. bias of this tile -> LDS; 2. +bias, ReLU, convert, write the [BM][BN] tile to LDS
+    //   (row = pixel); 3. 16-byte coalesced row stores (+ coalesced ReLU-mask loads).
+    constexpr int OROW = BN * (int)sizeof(T) + 16;          // padded output row
+    static_assert(BM * OROW + BN * 4 <= 2 * STAGE, "epilogue tile must fit the staging LDS");
+    float* sbias = (float*)(smem + BM * OROW);
+    if (tid < BN) sbias[tid] = (a.bias && n0 + tid < a.Cout) ? a.bias[n0 + tid] : 0.f;
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        const long m = m0 + wm * WM + j * 32 + (lane & 31);
-        if (m >= M) continue;
+        const int ml = wm * WM + j * 32 + (lane & 31);
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * WN + i * 32 + 8 * q + 4 * (lane >> 5);
-                if (n >= a.Cout) continue;
-                float v[4];
+                const int nl = wn * WN + i * 32 + 8 * q + 4 * (lane >> 5);
+                const float4 bq = *(const float4*)(sbias + nl);
+                float v[4] = {acc[i][j][4 * q] + bq.x, acc[i][j][4 * q + 1] + bq.y,
+                              acc[i][j][4 * q + 2] + bq.z, acc[i][j][4 * q + 3] + bq.w};
+                if (a.relu) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[i][j][4 * q + e];
-                    if (a.bias) v[e] += a.bias[n + e];
-                    if (a.relu) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                const long o = m * a.Cout + n;
+                unsigned char* dst = smem + ml * OROW + nl * (int)sizeof(T);
                 if (sizeof(T) == 2) {
-                    if (mask) {
-                        const uint2 mk = *(const uint2*)((const bf16_t*)mask + o);
-                        const bf16_t mm[4] = {(bf16_t)(mk.x & 0xffff), (bf16_t)(mk.x >> 16),
-                                              (bf16_t)(mk.y & 0xffff), (bf16_t)(mk.y >> 16)};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (!(bf16_to_f32(mm[e]) > 0.f)) v[e] = 0.f;
-                    }
                     uint2 pk;
                     pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
                     pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                    *(uint2*)((bf16_t*)out + o) = pk;
+                    *(uint2*)dst = pk;
                 } else {
-                    if (mask) {
-                        const float4 mk = *(const float4*)((const float*)mask + o);
-                        if (!(mk.x > 0.f)) v[0] = 0.f;
-                        if (!(mk.y > 0.f)) v[1] = 0.f;
-                        if (!(mk.z > 0.f)) v[2] = 0.f;
-                        if (!(mk.w > 0.f)) v[3] = 0.f;
-                    }
-                    *(float4*)((float*)out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int CPRO = BN * (int)sizeof(T) / 16;       // 16-byte chunks per output row
+        T* out = (T*)a.out; const T* mask = (const T*)a.mask;
+        for (int idx = tid; idx < BM * CPRO; idx += 256) {
+            const int row = idx / CPRO, c = idx % CPRO;
+            const long m = m0 + row;
+            const int n = n0 + c * EPC;
+            if (m >= M || n >= a.Cout) continue;
+            uint4 val = *(const uint4*)(smem + row * OROW + c * 16);
+            const long o = m * a.Cout + n;
+            if (mask) {
+                const uint4 mk = *(const uint4*)(mask + o);
+                if (sizeof(T) == 2) {
+                    // bf16 > 0  <=>  sign bit clear and magnitude non-zero
+                    auto keep = [](uint32_t mw, uint32_t vw) {
+                        const uint32_t lo = ((mw & 0x8000u) == 0 && (mw & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
+                        const uint32_t hi = ((mw & 0x80000000u) == 0 && (mw & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+                        return vw & (lo | hi);
+                    };
+                    val.x = keep(mk.x, val.x); val.y = keep(mk.y, val.y);
+                    val.z = keep(mk.z, val.z); val.w = keep(mk.w, val.w);
+                } else {
+                    if (!(__uint_as_float(mk.x) > 0.f)) val.x = 0;
+                    if (!(__uint_as_float(mk.y) > 0.f)) val.y = 0;
+                    if (!(__uint_as_float(mk.z) > 0.f)) val.z = 0;
+                    if (!(__uint_as_float(mk.w) > 0.f)) val.w = 0;
+                }
+            }
+            *(uint4*)(out + o) = val;
         }
     }
 }
@@ -403,13 +446,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// MPU_CONV_IMPL=regs selects the register-staged kernel of this file; default is the LDS-DMA
+// kernel of conv_glds.hip (same tiling, same results).
+static int conv_impl() {
+    static int impl = -1;
+    if (impl < 0) {
+        const char* e = getenv("MPU_CONV_IMPL");
+        impl = (e && strcmp(e, "regs") == 0) ? 0 : 1;
+    }
+    return impl;
+}
+
 // ------------------------------------------------------------------------- //
 // host-side launchers (internal C++ API used by unet.hip and the op-level ABI)
 // ------------------------------------------------------------------------- //
 template <typename T, int MODE, int BN, int BM, int WN, int WM>
-static int launch_conv_cfg(const ConvArgs& a, hipStream_t st) {
+static int launch_conv_cfg(const ConvArgs& a_in, hipStream_t st) {
     constexpr int SMEM = 2 * (BN + BM) * 144;
     auto kern = conv_igemm_kernel<T, MODE, BN, BM, WN, WM>;
+    ConvArgs a = a_in;
+    if (a.w_elems <= 0) a.w_elems = (ModeTraits<MODE>::NTAPS - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
     static bool attr_set = false;
     if (!attr_set) {
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -417,6 +473,15 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t st) {
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const long tiles = (long)cdiv(a.Cout, BN) * cdiv(M, BM);
+    {   // 32-bit buffer offsets: every operand must stay below 2 GiB
+        constexpr int NT = ModeTraits<MODE>::NTAPS;
+        const long hi = MODE == UPCONV2 ? a.Ho / 2 : (MODE == CONV3S2 ? a.Ho * 2 : a.Ho);
+        const long wi = MODE == UPCONV2 ? a.Wo / 2 : (MODE == CONV3S2 ? a.Wo * 2 : a.Wo);
+        const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
+        if ((long)a.B * hi * wi * cmax * (long)sizeof(T) >= (1L << 31) ||
+            ((NT - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride) * (long)sizeof(T) >= (1L << 31))
+            return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
+    }
     if (prof_on()) {
         const int taps = MODE == UPCONV2 ? 4 : (MODE == CONV1 ? 1 : 9);
         prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * taps * (a.C0 + a.C1), st);
@@ -439,6 +504,7 @@ static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
 }
 
 int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
+    if (conv_impl() == 1) return launch_conv_glds(dtype, mode, a, st);
 #define MPU_CONV_CASE(TT)                                                          \
     switch (mode) {                                                                \
         case CONV3: return launch_conv_mode<TT, CONV3>(a, st);                     \
@@ -458,8 +524,8 @@ long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, i
     const int ntaps = mode == UPCONV2 ? 4 : (mode == CONV1 ? 1 : 9);
     const int bc = (Cin >= 128 && Cout >= 128) ? 128 : 64;
     const long tiles = (long)cdiv(Cin, bc) * cdiv(Cout, bc) * ntaps;
-    long ks = (1024 + tiles - 1) / tiles;                 // aim at ~1024 workgroups
-    const long maxks = (M + 255) / 256;                   // at least 256 pixels per split
+    long ks = (768 + tiles - 1) / tiles;                  // aim at ~768 workgroups (3 per CU)
+    const long maxks = (M + 511) / 512;                   // at least 512 pixels per split
     if (ks > maxks) ks = maxks;
     if (ks < 1) ks = 1;
     long mchunk = ((M + ks - 1) / ks + 31) / 32 * 32;
@@ -477,6 +543,11 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
     if (prof_on())
         prof_begin(PROF_WGRAD, a.flops > 0 ? a.flops : 2.0 * a.B * a.Ho * a.Wo * (double)n, st);
     bool big = false;
+    const int dt_ = sizeof(T) == 2 ? MPU_BF16 : MPU_F32;
+    const int g_ = conv_impl() == 1 ? try_wgrad_glds(dt_, MODE, a, st) : 0;
+    if (g_ < 0) return g_;
+    if (g_ == 1) big = true;                      // launched by the LDS-DMA kernel
+    else
     if constexpr (sizeof(T) == 2) {
         if (Cin >= 128 && a.Cout >= 128) {
             big = true;

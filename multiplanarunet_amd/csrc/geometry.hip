@@ -24,29 +24,58 @@ __device__ __forceinline__ void mat3_apply(const Mat3& M, double x, double y, do
     oz = fma(M.m[8], z, fma(M.m[7], y, M.m[6] * x));
 }
 
+// A coordinate axis: device array + (optionally) a closed form the host has verified to
+// reproduce that array bit for bit (mpu_axis), so values can be computed in registers.
+struct AxisDev { const double* g; int n, kind; double start, step, last, inv_h; };
+
+__device__ __forceinline__ double axis_at(const AxisDev& a, int i) {
+    if (a.kind == 1) return (i == a.n - 1) ? a.last : (double)i * a.step + a.start;   // np.linspace
+    if (a.kind == 2) return ((double)i - a.start) * a.step;                            // voxel axis
+    return a.g[i];
+}
+
 // RegularGridInterpolator._find_indices for one axis: i = searchsorted_left(g,x)-1
-// clipped to [0,n-2]; y = (x-g[i])/(g[i+1]-g[i]); oob = x<g[0] || x>g[n-1].
-__device__ __forceinline__ void find_cell(const double* __restrict__ g, int n, double x,
-                                          int& i, double& y, bool& oob) {
-    const double g0 = g[0], gl = g[n - 1];
+// clipped to [0,n-2]; oob = x<g[0] || x>g[n-1]. The cell is found from a reciprocal-spacing
+// guess and then fixed up against the ACTUAL axis values, so it is exactly NumPy's cell.
+__device__ __forceinline__ int find_cell_index(const AxisDev& a, double x, bool& oob, double& gc, double& gc1) {
+    const int n = a.n;
+    const double g0 = axis_at(a, 0), gl = axis_at(a, n - 1);
     oob = (x < g0) || (x > gl);
     int c;
     if (!(x > g0)) c = 0;
     else if (x > gl) c = n - 2;
     else {
-        c = (int)ceil((x - g0) / (g[1] - g0)) - 1;
+        c = (int)ceil((x - g0) * a.inv_h) - 1;
         c = c < 0 ? 0 : (c > n - 2 ? n - 2 : c);
-        while (c < n - 2 && g[c + 1] < x) ++c;     // need x <= g[c+1]
-        while (c > 0 && g[c] >= x) --c;            // need g[c] <  x
     }
+    gc = axis_at(a, c); gc1 = axis_at(a, c + 1);
+    if (!oob) {
+        while (c < n - 2 && gc1 < x) { ++c; gc = gc1; gc1 = axis_at(a, c + 1); }     // need x <= g[c+1]
+        while (c > 0 && gc >= x) { --c; gc1 = gc; gc = axis_at(a, c); }              // need g[c] <  x
+    }
+    return c;
+}
+// linear: also the normalised distance y = (x-g[i])/(g[i+1]-g[i]) (IEEE division as NumPy)
+__device__ __forceinline__ void find_cell(const AxisDev& a, double x, int& i, double& y, bool& oob) {
+    double gc, gc1;
+    const int c = find_cell_index(a, x, oob, gc, gc1);
     i = c;
-    y = (x - g[c]) / (g[c + 1] - g[c]);
+    y = (x - gc) / (gc1 - gc);
+}
+// nearest: index of np.where(y <= .5, i, i+1). With num = fl(x-g[i]), den = fl(g[i+1]-g[i]) > 0 and a
+// correctly rounded quotient, fl(num/den) <= 0.5  <=>  2*num <= den (0.5 is a double, the next
+// double above den is den+ulp > den*(1+2^-53)), so no division is needed.
+__device__ __forceinline__ int find_nearest(const AxisDev& a, double x, bool& oob) {
+    double gc, gc1;
+    const int c = find_cell_index(a, x, oob, gc, gc1);
+    const double num = x - gc, den = gc1 - gc;
+    return (2.0 * num <= den) ? c : c + 1;
 }
 
 struct SampleArgs {
     const float* vol; const uint8_t* labels;
     int X, Y, Z, C;
-    const double *ax, *ay, *az, *offsets;
+    AxisDev ax, ay, az; const double* offsets;
     Mat3 basis, rot; int has_rot;
     int dim, P; double g_start, g_step;
     const float* bg; uint8_t bg_class;
@@ -54,13 +83,16 @@ struct SampleArgs {
     float* out; uint8_t* out_lab;
 };
 
+// one workgroup = one 16x16 patch of one plane (compact footprint in the volume for any view)
 __global__ __launch_bounds__(256) void sample_view_planes_kernel(SampleArgs a) {
-    const long total = (long)a.P * a.dim * a.dim;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-         t += (long)gridDim.x * blockDim.x) {
-        const int j = (int)(t % a.dim);
-        const int i = (int)((t / a.dim) % a.dim);
-        const int p = (int)(t / ((long)a.dim * a.dim));
+    const int tpd = (a.dim + 15) / 16;
+    const long nblk = (long)a.P * tpd * tpd;
+    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int p = (int)(blk / (tpd * tpd));
+        const int ti = (int)((blk / tpd) % tpd), tj = (int)(blk % tpd);
+        const int i = ti * 16 + (threadIdx.x >> 4), j = tj * 16 + (threadIdx.x & 15);
+        if (i >= a.dim || j >= a.dim) continue;
+        const long t = ((long)p * a.dim + i) * a.dim + j;
         const double gx = (double)i * a.g_step + a.g_start;
         const double gy = (double)j * a.g_step + a.g_start;
         const double off = a.offsets[p];
@@ -72,9 +104,9 @@ __global__ __launch_bounds__(256) void sample_view_planes_kernel(SampleArgs a) {
             rx = qx; ry = qy; rz = qz;
         }
         int i0, i1, i2; double y0, y1, y2; bool o0, o1, o2;
-        find_cell(a.ax, a.X, rx, i0, y0, o0);
-        find_cell(a.ay, a.Y, ry, i1, y1, o1);
-        find_cell(a.az, a.Z, rz, i2, y2, o2);
+        find_cell(a.ax, rx, i0, y0, o0);
+        find_cell(a.ay, ry, i1, y1, o1);
+        find_cell(a.az, rz, i2, y2, o2);
         const bool oob = o0 || o1 || o2;
         // itertools.product order of the 8 corners, weight = ((1*wx)*wy)*wz
         const double wx[2] = {1.0 - y0, y0}, wy[2] = {1.0 - y1, y1}, wz[2] = {1.0 - y2, y2};
@@ -115,7 +147,7 @@ __global__ __launch_bounds__(256) void sample_view_planes_kernel(SampleArgs a) {
 
 // ------------------------------------------------------------------------- //
 struct ViewDev {
-    Mat3 invb; const float* pred; const double* g; const double* offs; int dim, P;
+    Mat3 invb; const float* pred; AxisDev g, offs; int dim, P;
 };
 struct GridDev { Mat3 A; double c[3]; int X, Y, Z; };
 
@@ -125,24 +157,34 @@ __device__ __forceinline__ long view_lookup(const ViewDev& v, double rx, double 
                                             int K, int& pl) {
     double qx, qy, qz;
     mat3_apply(v.invb, rx, ry, rz, qx, qy, qz);
-    int i0, i1, i2; double y0, y1, y2; bool o0, o1, o2;
-    find_cell(v.g, v.dim, qx, i0, y0, o0);
-    find_cell(v.g, v.dim, qy, i1, y1, o1);
-    find_cell(v.offs, v.P, qz, i2, y2, o2);
+    bool o0, o1, o2;
+    const int n0 = find_nearest(v.g, qx, o0);
+    const int n1 = find_nearest(v.g, qy, o1);
+    const int n2 = find_nearest(v.offs, qz, o2);
     if (o0 || o1 || o2) { pl = -1; return -1; }
-    const int n0 = (y0 <= .5) ? i0 : i0 + 1;
-    const int n1 = (y1 <= .5) ? i1 : i1 + 1;
-    const int n2 = (y2 <= .5) ? i2 : i2 + 1;
     pl = n2;
     return (((long)n2 * v.dim + n0) * v.dim + n1) * K;
 }
 
-__device__ __forceinline__ void voxel_real(const GridDev& g, long t, double& rx, double& ry, double& rz) {
-    const int z = (int)(t % g.Z);
-    const int y = (int)((t / g.Z) % g.Y);
-    const int x = (int)(t / ((long)g.Z * g.Y));
+__device__ __forceinline__ void voxel_real(const GridDev& g, int x, int y, int z, double& rx, double& ry, double& rz) {
     mat3_apply(g.A, (double)x, (double)y, (double)z, rx, ry, rz);
     rx = rx - g.c[0]; ry = ry - g.c[1]; rz = rz - g.c[2];
+}
+
+// one workgroup = one 4x4x16 (x,y,z) brick of voxels: compact footprint in every view's
+// prediction volume, 16 consecutive z per row of the brick for the stores.
+constexpr int BRX = 4, BRY = 4, BRZ = 16;
+__device__ __forceinline__ long brick_count(const GridDev& g) {
+    return (long)((g.X + BRX - 1) / BRX) * ((g.Y + BRY - 1) / BRY) * ((g.Z + BRZ - 1) / BRZ);
+}
+__device__ __forceinline__ bool brick_voxel(const GridDev& g, long blk, int& x, int& y, int& z, long& t) {
+    const int nz = (g.Z + BRZ - 1) / BRZ, ny = (g.Y + BRY - 1) / BRY;
+    const int bz = (int)(blk % nz), by = (int)((blk / nz) % ny), bx = (int)(blk / ((long)nz * ny));
+    z = bz * BRZ + (threadIdx.x & 15);
+    y = by * BRY + ((threadIdx.x >> 4) & 3);
+    x = bx * BRX + (threadIdx.x >> 6);
+    t = ((long)x * g.Y + y) * g.Z + z;
+    return x < g.X && y < g.Y && z < g.Z;
 }
 
 template <int K>
@@ -177,30 +219,57 @@ struct FuseArgs {
     float* probs; uint8_t* labels;
 };
 
+// Fused kernel: one workgroup = one 4x4x64 (x,y,z) brick; a thread owns 4 voxels (z, z+16, z+32,
+// z+48) so that every view's parameters are fetched once per 4 voxels and the 4 gathers of a
+// view are independent (ILP). Stores are rows of 16 consecutive z.
+constexpr int FZ = 4;
 template <int K>
 __global__ __launch_bounds__(256) void map_fuse_kernel(FuseArgs a) {
-    const long total = (long)a.grid.X * a.grid.Y * a.grid.Z;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-         t += (long)gridDim.x * blockDim.x) {
-        double rx, ry, rz;
-        voxel_real(a.grid, t, rx, ry, rz);
-        float z[K];
+    const GridDev& g = a.grid;
+    const int nz = (g.Z + BRZ * FZ - 1) / (BRZ * FZ), ny = (g.Y + BRY - 1) / BRY;
+    const long blk = blockIdx.x;
+    const int bz = (int)(blk % nz), by = (int)((blk / nz) % ny), bx = (int)(blk / ((long)nz * ny));
+    const int vx = bx * BRX + (threadIdx.x >> 6);
+    const int vy = by * BRY + ((threadIdx.x >> 4) & 3);
+    const int vz0 = bz * BRZ * FZ + (threadIdx.x & 15);
+    if (vx >= g.X || vy >= g.Y) return;
+    double rx[FZ], ry[FZ], rz[FZ];
+    float z[FZ][K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) z[k] = 0.f;
-        for (int v = 0; v < a.V; ++v) {
-            int pl;
-            const long off = view_lookup(a.views[v], rx, ry, rz, K, pl);
+    for (int u = 0; u < FZ; ++u) {
+        voxel_real(g, vx, vy, vz0 + 16 * u, rx[u], ry[u], rz[u]);
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const float x = (off >= 0) ? a.views[v].pred[off + k] : (k == 0 ? 1.f : 0.f);
-                z[k] = a.sum_fusion ? (z[k] + x) : (z[k] + a.W[v * K + k] * x);
+        for (int k = 0; k < K; ++k) z[u][k] = 0.f;
+    }
+    for (int v = 0; v < a.V; ++v) {
+        const ViewDev& vw = a.views[v];
+        long off[FZ];
+#pragma unroll
+        for (int u = 0; u < FZ; ++u) { int pl; off[u] = view_lookup(vw, rx[u], ry[u], rz[u], K, pl); }
+        float w[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) w[k] = a.sum_fusion ? 1.f : a.W[v * K + k];
+#pragma unroll
+        for (int u = 0; u < FZ; ++u) {
+            float x[K];                                   // one K-wide gather per voxel and view
+            if (off[u] >= 0) __builtin_memcpy(x, vw.pred + off[u], K * sizeof(float));
+            else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) x[k] = k == 0 ? 1.f : 0.f;
             }
+#pragma unroll
+            for (int k = 0; k < K; ++k) z[u][k] = a.sum_fusion ? (z[u][k] + x[k]) : (z[u][k] + w[k] * x[k]);
         }
+    }
+#pragma unroll
+    for (int u = 0; u < FZ; ++u) {
+        const int vz = vz0 + 16 * u;
+        if (vz >= g.Z) continue;
         if (!a.sum_fusion) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) z[k] = z[k] + a.b[k];
+            for (int k = 0; k < K; ++k) z[u][k] = z[u][k] + a.b[k];
         }
-        softmax_argmax_store<K>(z, !a.sum_fusion, t, a.probs, a.labels);
+        softmax_argmax_store<K>(z[u], !a.sum_fusion, ((long)vx * g.Y + vy) * g.Z + vz, a.probs, a.labels);
     }
 }
 
@@ -212,11 +281,12 @@ struct MapArgs {
 // restricted to planes [p_lo,p_hi) (pred points at plane p_lo).
 template <int K, bool ACCUM>
 __global__ __launch_bounds__(256) void map_view_kernel(MapArgs a) {
-    const long total = (long)a.grid.X * a.grid.Y * a.grid.Z;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-         t += (long)gridDim.x * blockDim.x) {
+    const long nblk = brick_count(a.grid);
+    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        int vx, vy, vz; long t;
+        if (!brick_voxel(a.grid, blk, vx, vy, vz, t)) continue;
         double rx, ry, rz;
-        voxel_real(a.grid, t, rx, ry, rz);
+        voxel_real(a.grid, vx, vy, vz, rx, ry, rz);
         int pl;
         const long off = view_lookup(a.view, rx, ry, rz, K, pl);
         if (!ACCUM) {
@@ -267,14 +337,31 @@ __global__ __launch_bounds__(256) void fusion_finalize_kernel(const float* __res
 }
 
 static void to_mat3(const double* s, Mat3& m) { memcpy(m.m, s, sizeof(m.m)); }
+static AxisDev to_axis(const double* d_arr, int n, const mpu_axis& m) {
+    AxisDev a;
+    a.g = d_arr; a.n = n;
+    a.kind = (m.kind == 1 || m.kind == 2) && m.n == n ? m.kind : 0;
+    a.start = m.start; a.step = m.step; a.last = m.last;
+    a.inv_h = m.step > 0 ? 1.0 / m.step : 1.0;
+    return a;
+}
 static void to_view(const mpu_view_pred& v, ViewDev& d) {
     to_mat3(v.inv_basis, d.invb);
-    d.pred = v.d_pred; d.g = v.d_g; d.offs = v.d_offsets; d.dim = v.dim; d.P = v.n_planes;
+    d.pred = v.d_pred; d.dim = v.dim; d.P = v.n_planes;
+    d.g = to_axis(v.d_g, v.dim, v.g_axis);
+    d.offs = to_axis(v.d_offsets, v.n_planes, v.o_axis);
 }
 static void to_grid(const mpu_voxel_grid& g, GridDev& d) {
     to_mat3(g.A, d.A);
     for (int i = 0; i < 3; ++i) d.c[i] = g.center[i];
     d.X = g.shape[0]; d.Y = g.shape[1]; d.Z = g.shape[2];
+}
+static int brick_grid(const GridDev& g) {
+    long b = (long)((g.X + 3) / 4) * ((g.Y + 3) / 4) * ((g.Z + 15) / 16);
+    return (int)(b < 1 ? 1 : (b > (1L << 20) ? (1L << 20) : b));
+}
+static unsigned fuse_grid(const GridDev& g) {
+    return (unsigned)((long)((g.X + 3) / 4) * ((g.Y + 3) / 4) * ((g.Z + 63) / 64));
 }
 static int grid_for(long total) {
     long b = (total + 255) / 256;
@@ -328,13 +415,18 @@ int mpu_sample_view_planes(const float* d_vol, const uint8_t* d_labels, const in
     SampleArgs a;
     a.vol = d_vol; a.labels = d_labels;
     a.X = vol_shape[0]; a.Y = vol_shape[1]; a.Z = vol_shape[2]; a.C = vol_shape[3];
-    a.ax = d_ax; a.ay = d_ay; a.az = d_az; a.offsets = d_offsets;
+    a.ax = to_axis(d_ax, a.X, geom->vol_axis[0]);
+    a.ay = to_axis(d_ay, a.Y, geom->vol_axis[1]);
+    a.az = to_axis(d_az, a.Z, geom->vol_axis[2]);
+    a.offsets = d_offsets;
     to_mat3(geom->basis, a.basis); to_mat3(geom->rot, a.rot); a.has_rot = geom->has_rot;
     a.dim = geom->dim; a.P = geom->n_planes; a.g_start = geom->g_start; a.g_step = geom->g_step;
     a.bg = d_bg; a.bg_class = bg_class; a.center = d_center; a.scale = d_scale;
     a.out = d_out; a.out_lab = d_out_lab;
-    const long total = (long)a.P * a.dim * a.dim;
-    sample_view_planes_kernel<<<dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream>>>(a);
+    const long tpd = (a.dim + 15) / 16;
+    long nblk = (long)a.P * tpd * tpd;
+    if (nblk > (1L << 20)) nblk = 1L << 20;
+    sample_view_planes_kernel<<<dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream>>>(a);
     return launch_ok();
 }
 
@@ -346,7 +438,7 @@ int mpu_map_view_nearest(const mpu_voxel_grid* grid, const mpu_view_pred* view, 
     MapArgs a; to_grid(*grid, a.grid); to_view(*view, a.view);
     a.Wv = nullptr; a.p_lo = 0; a.p_hi = view->n_planes; a.owns_oob = 1; a.out = d_mapped;
     const long total = (long)a.grid.X * a.grid.Y * a.grid.Z;
-    MPU_DISPATCH_K(n_classes, (map_view_kernel<KK, false><<<dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream>>>(a)));
+    MPU_DISPATCH_K(n_classes, (map_view_kernel<KK, false><<<dim3(brick_grid(a.grid)), dim3(256), 0, (hipStream_t)stream>>>(a)));
     return launch_ok();
 }
 
@@ -359,7 +451,7 @@ int mpu_map_accumulate_view(const mpu_voxel_grid* grid, const mpu_view_pred* vie
     MapArgs a; to_grid(*grid, a.grid); to_view(*view, a.view);
     a.Wv = d_Wv; a.p_lo = p_lo; a.p_hi = p_hi; a.owns_oob = owns_oob; a.out = d_z;
     const long total = (long)a.grid.X * a.grid.Y * a.grid.Z;
-    MPU_DISPATCH_K(n_classes, (map_view_kernel<KK, true><<<dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream>>>(a)));
+    MPU_DISPATCH_K(n_classes, (map_view_kernel<KK, true><<<dim3(brick_grid(a.grid)), dim3(256), 0, (hipStream_t)stream>>>(a)));
     return launch_ok();
 }
 
@@ -378,7 +470,7 @@ int mpu_map_fuse_views(const mpu_voxel_grid* grid, const mpu_view_pred* views, i
     }
     a.V = n_views; a.W = d_W; a.b = d_b; a.sum_fusion = sum_fusion; a.probs = d_probs; a.labels = d_labels;
     const long total = (long)a.grid.X * a.grid.Y * a.grid.Z;
-    MPU_DISPATCH_K(n_classes, (map_fuse_kernel<KK><<<dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream>>>(a)));
+    MPU_DISPATCH_K(n_classes, (map_fuse_kernel<KK><<<dim3(fuse_grid(a.grid)), dim3(256), 0, (hipStream_t)stream>>>(a)));
     return launch_ok();
 }
 

@@ -12,6 +12,7 @@ struct ConvArgs {
     const float* bias; const void* mask; void* out;
     int B, Ho, Wo, Cout, relu;
     double flops;                // algorithmic FLOPs of this launch (profiling only; 0 = derive)
+    long w_elems;                // elements addressable from `w` (0 = derive from strides)
 };
 struct WgradArgs {
     const void* x0; const void* x1; int C0, C1;
@@ -27,9 +28,11 @@ bool prof_on();
 void prof_begin(int kind, double flops, hipStream_t st);
 void prof_end(hipStream_t st);
 
-int  launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st);
+int  launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // dispatches on MPU_CONV_IMPL
+int  launch_conv_glds(int dtype, int mode, const ConvArgs& a, hipStream_t st);  // LDS-DMA variant (conv_glds.hip)
 long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out);
 int  launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st);
+int  try_wgrad_glds(int dtype, int mode, const WgradArgs& a, hipStream_t st);   // 1 launched, 0 unsupported shape
 
 // ---- unet_ops.hip ---------------------------------------------------------
 constexpr int RED_MAX_BLOCKS = 256;

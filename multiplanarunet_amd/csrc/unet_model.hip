@@ -170,7 +170,7 @@ double conv_flops(const Run& r, const Conv& c, int lvl, int n_cnt_logical = -1) 
 
 int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* in1, int C1, void* out, int lvl) {
     ConvArgs a;
-    a.flops = conv_flops(r, c, lvl);
+    a.flops = conv_flops(r, c, lvl); a.w_elems = 0;
     a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1;
     a.w = r.wf(c); a.w_tap_stride = (long)c.Cin * c.Cout; a.w_row_stride = c.Cin;
     a.bias = r.params + c.b; a.mask = nullptr; a.out = out;
@@ -182,7 +182,7 @@ int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* i
 int conv_dgrad(const Run& r, const Conv& c, const void* dz, const void* mask, void* out, int out_lvl,
                int n_off, int n_cnt) {
     ConvArgs a;
-    a.in0 = dz; a.in1 = nullptr; a.C0 = c.Cout; a.C1 = 0;
+    a.in0 = dz; a.in1 = nullptr; a.C0 = c.Cout; a.C1 = 0; a.w_elems = 0;
     a.w = (const unsigned char*)r.wd(c) + (long)n_off * c.Cout * r.esz;
     a.w_tap_stride = (long)c.Cin * c.Cout; a.w_row_stride = c.Cout;
     a.bias = nullptr; a.mask = mask; a.out = out;
@@ -455,7 +455,7 @@ int mpu_conv2d_igemm(int32_t dtype, int32_t mode, const void* d_in0, int32_t C0,
     ConvArgs a;
     a.in0 = d_in0; a.in1 = d_in1; a.C0 = C0; a.C1 = C1; a.w = d_w_packed; a.w_tap_stride = w_tap_stride;
     a.w_row_stride = w_row_stride; a.bias = d_bias; a.mask = d_mask; a.out = d_out;
-    a.B = B; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.relu = relu; a.flops = 0;
+    a.B = B; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.relu = relu; a.flops = 0; a.w_elems = 0;
     return launch_conv(dtype, mode, a, (hipStream_t)stream);
 }
 

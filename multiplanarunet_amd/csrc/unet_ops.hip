@@ -48,27 +48,45 @@ static inline int ew_grid(long work) {
 // ------------------------------------------------------------------------- //
 // weight packing: fp32 master (Keras HWIO = [tap][ci][co]) -> MFMA operands
 // ------------------------------------------------------------------------- //
+// forward operand [tap][co][ci]: 32x32 tiles transposed through LDS (coalesced reads along co,
+// coalesced writes along ci)
 template <typename T>
-__global__ void pack_weights_kernel(int mode, const float* __restrict__ W, int Cin, int Cout,
-                                    T* __restrict__ wf, T* __restrict__ wd) {
-    const int ntaps = mode == UPCONV2 ? 4 : (mode == CONV1 ? 1 : 9);
-    const long per_tap = (long)Cin * Cout;
-    // forward operand [tap][co][ci]
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < ntaps * per_tap;
-         e += (long)gridDim.x * blockDim.x) {
-        const int tap = (int)(e / per_tap); const long r = e % per_tap;
-        const int co = (int)(r / Cin), ci = (int)(r % Cin);
-        wf[e] = from_f32<T>(W[(long)tap * per_tap + (long)ci * Cout + co]);
+__global__ __launch_bounds__(256) void pack_fwd_kernel(int ntaps, const float* __restrict__ W, int Cin, int Cout,
+                                                       T* __restrict__ wf) {
+    __shared__ float tile[32][33];
+    const int tci = (Cin + 31) / 32, tco = (Cout + 31) / 32;
+    const long ntiles = (long)ntaps * tci * tco;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tap = (int)(t / (tci * tco)); const int r = (int)(t % (tci * tco));
+        const int ci0 = (r / tco) * 32, co0 = (r % tco) * 32;
+        const float* src = W + (long)tap * Cin * Cout;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ci = ci0 + ty + 8 * k, co = co0 + tx;
+            tile[ty + 8 * k][tx] = (ci < Cin && co < Cout) ? src[(long)ci * Cout + co] : 0.f;
+        }
+        __syncthreads();
+        T* dst = wf + (long)tap * Cin * Cout;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int co = co0 + ty + 8 * k, ci = ci0 + tx;
+            if (ci < Cin && co < Cout) dst[(long)co * Cin + ci] = from_f32<T>(tile[tx][ty + 8 * k]);
+        }
+        __syncthreads();
     }
-    if (!wd) return;
-    // data-gradient operand [tap'][ci][co]
-    const int dtaps = 9;
+}
+
+// data-gradient operand [tap'][ci][co] (same element order as the Keras kernel: coalesced)
+template <typename T>
+__global__ void pack_dgrad_kernel(int mode, const float* __restrict__ W, int Cin, int Cout, T* __restrict__ wd) {
+    const long per_tap = (long)Cin * Cout;
     if (mode == CONV1) {
         for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < per_tap; e += (long)gridDim.x * blockDim.x)
             wd[e] = from_f32<T>(W[e]);
         return;
     }
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < dtaps * per_tap;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < 9 * per_tap;
          e += (long)gridDim.x * blockDim.x) {
         const int tp = (int)(e / per_tap); const long r = e % per_tap;
         float v;
@@ -90,9 +108,17 @@ __global__ void pack_weights_kernel(int mode, const float* __restrict__ W, int C
 }
 
 int launch_pack_weights(int dtype, int mode, const float* W, int Cin, int Cout, void* wf, void* wd, hipStream_t st) {
+    const int ntaps = mode == UPCONV2 ? 4 : (mode == CONV1 ? 1 : 9);
+    long tiles = (long)ntaps * cdiv(Cin, 32) * cdiv(Cout, 32);
+    if (tiles > 4096) tiles = 4096;
     const long n = 9L * Cin * Cout;
-    if (dtype == MPU_BF16) pack_weights_kernel<bf16_t><<<ew_grid(n), 256, 0, st>>>(mode, W, Cin, Cout, (bf16_t*)wf, (bf16_t*)wd);
-    else pack_weights_kernel<float><<<ew_grid(n), 256, 0, st>>>(mode, W, Cin, Cout, (float*)wf, (float*)wd);
+    if (dtype == MPU_BF16) {
+        pack_fwd_kernel<bf16_t><<<(unsigned)tiles, 256, 0, st>>>(ntaps, W, Cin, Cout, (bf16_t*)wf);
+        if (wd) pack_dgrad_kernel<bf16_t><<<ew_grid(n), 256, 0, st>>>(mode, W, Cin, Cout, (bf16_t*)wd);
+    } else {
+        pack_fwd_kernel<float><<<(unsigned)tiles, 256, 0, st>>>(ntaps, W, Cin, Cout, (float*)wf);
+        if (wd) pack_dgrad_kernel<float><<<ew_grid(n), 256, 0, st>>>(mode, W, Cin, Cout, (float*)wd);
+    }
     return launch_ok();
 }
 
@@ -198,19 +224,29 @@ static int launch_colreduce(int dtype, const void* a, const void* b, long M, int
 }
 
 
-// Second stage of the two-stage reductions: block = 32 columns x 8 k-lanes; returns (to the
+// Second stage of the two-stage reductions: block = 8 columns x 32 k-lanes; returns (to the
 // k-lane-0 thread of each column) sum_k partial[k*stride + col] in double, fixed order.
+constexpr int FIN_COLS = 8, FIN_KL = 32;
 __device__ __forceinline__ double partial_sum(const float* __restrict__ partial, int nblk, long stride, int col,
                                               bool valid, double* red /*[256]*/) {
-    const int kl = threadIdx.x >> 5;             // 0..7
+    const int kl = threadIdx.x / FIN_COLS;       // 0..31
     double s = 0.0;
-    if (valid)
-        for (int k = kl; k < nblk; k += 8) s += (double)partial[(long)k * stride + col];
+    if (valid) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {            // up to 256 partial blocks: 8 independent loads per thread
+            const int k = kl + u * FIN_KL;
+            v[u] = k < nblk ? partial[(long)k * stride + col] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
+        for (int k = kl + 8 * FIN_KL; k < nblk; k += FIN_KL) s += (double)partial[(long)k * stride + col];
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     double t = 0.0;
     if (kl == 0)
-        for (int j = 0; j < 8; ++j) t += red[j * 32 + (threadIdx.x & 31)];
+        for (int j = 0; j < FIN_KL; ++j) t += red[j * FIN_COLS + (threadIdx.x % FIN_COLS)];
     __syncthreads();
     return t;
 }
@@ -219,10 +255,10 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
                                          const float* gamma, const float* beta, float* mmean, float* mvar,
                                          float* mean, float* invstd, float* scale, float* shift, float eps, float mom) {
     __shared__ double red[256];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int c = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
     const double s = partial_sum(partial, nblk, 2L * C, c, c < C, red);
     const double ss = partial_sum(partial + C, nblk, 2L * C, c, c < C, red);
-    if (c >= C || threadIdx.x >= 32) return;
+    if (c >= C || threadIdx.x >= FIN_COLS) return;
     const double mu = s / (double)M;
     double var = ss / (double)M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -240,7 +276,7 @@ int launch_bn_stats(int dtype, const void* x, long M, int C, float* partial, con
     int nblk;
     int rc = launch_colreduce<0>(dtype, x, nullptr, M, C, nullptr, nullptr, partial, &nblk, st);
     if (rc) return rc;
-    bn_stats_finalize_kernel<<<cdiv(C, 32), 256, 0, st>>>(partial, nblk, C, M, gamma, beta, mmean, mvar, mean,
+    bn_stats_finalize_kernel<<<cdiv(C, FIN_COLS), 256, 0, st>>>(partial, nblk, C, M, gamma, beta, mmean, mvar, mean,
                                                            invstd, scale, shift, eps, momentum);
     return launch_ok();
 }
@@ -322,10 +358,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                        const float* gamma, const float* mean, const float* invstd,
                                        float* dgamma, float* dbeta, float* coeffs) {
     __shared__ double red[256];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int c = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
     const double s = partial_sum(partial, nblk, 2L * C, c, c < C, red);
     const double sx = partial_sum(partial + C, nblk, 2L * C, c, c < C, red);
-    if (c >= C || threadIdx.x >= 32) return;
+    if (c >= C || threadIdx.x >= FIN_COLS) return;
     dgamma[c] = (float)sx; dbeta[c] = (float)s;
     const double sc = (double)gamma[c] * (double)invstd[c];
     const double mdn = s / (double)M, mdx = sx / (double)M;
@@ -361,7 +397,7 @@ int launch_bn_backward(int dtype, const void* dn, const void* x, long M, int C, 
     int nblk;
     int rc = launch_colreduce<1>(dtype, dn, x, M, C, mean, invstd, partial, &nblk, st);
     if (rc) return rc;
-    bn_bwd_finalize_kernel<<<cdiv(C, 32), 256, 0, st>>>(partial, nblk, C, M, gamma, mean, invstd, dgamma, dbeta, coeffs);
+    bn_bwd_finalize_kernel<<<cdiv(C, FIN_COLS), 256, 0, st>>>(partial, nblk, C, M, gamma, mean, invstd, dgamma, dbeta, coeffs);
     rc = launch_ok();
     if (rc) return rc;
     const long work = M * C / 8;
@@ -423,15 +459,15 @@ int launch_maxpool_bwd_add(int dtype, const void* n, const void* dskip, const vo
 
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* out) {
     __shared__ double red[256];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int c = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
     const double s = partial_sum(partial, nblk, C, c, c < C, red);
-    if (c < C && threadIdx.x < 32) out[c] = (float)s;
+    if (c < C && threadIdx.x < FIN_COLS) out[c] = (float)s;
 }
 int launch_colsum(int dtype, const void* dz, long M, int C, float* partial, float* out, hipStream_t st) {
     int nblk;
     int rc = launch_colreduce<2>(dtype, dz, nullptr, M, C, nullptr, nullptr, partial, &nblk, st);
     if (rc) return rc;
-    colsum_finalize_kernel<<<cdiv(C, 32), 256, 0, st>>>(partial, nblk, C, out);
+    colsum_finalize_kernel<<<cdiv(C, FIN_COLS), 256, 0, st>>>(partial, nblk, C, out);
     return launch_ok();
 }
 
@@ -608,10 +644,10 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const T* __restrict_
 __global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int K, int ldw,
                                          float* dWh, float* dbh) {
     __shared__ double red[256];
-    const int i = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int i = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
     const int tot = C * K + K;
     const double s = partial_sum(partial, nblk, tot, i, i < tot, red);
-    if (i >= tot || threadIdx.x >= 32) return;
+    if (i >= tot || threadIdx.x >= FIN_COLS) return;
     if (i < C * K) dWh[(i / K) * ldw + (i % K)] = (float)s; else dbh[i - C * K] = (float)s;
 }
 
@@ -632,7 +668,7 @@ int launch_head_backward(int dtype, const void* n, const float* probs, const uin
     }
     int rc = launch_ok();
     if (rc) return rc;
-    head_bwd_finalize_kernel<<<cdiv(C * K + K, 32), 256, 0, st>>>(partial, (int)blocks, C, K, ldw, dWh, dbh);
+    head_bwd_finalize_kernel<<<cdiv(C * K + K, FIN_COLS), 256, 0, st>>>(partial, (int)blocks, C, K, ldw, dWh, dbh);
     return launch_ok();
 }
 

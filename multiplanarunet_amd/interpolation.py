@@ -88,8 +88,11 @@ class ViewGeometry:
         self.offsets = np.linspace(-bounds, bounds, P)
         self.n_planes = P
 
-    def struct(self, rot_mat):
+    def struct(self, rot_mat, axes=None):
         g = _lib.ViewGeom()
+        if axes is not None:
+            for k in range(3):
+                g.vol_axis[k] = _lib.make_axis(axes[k])
         g.basis[:] = self.basis.ravel().tolist()
         rot = np.eye(3) if rot_mat is None else rot_mat
         g.rot[:] = np.asarray(rot, np.float64).ravel().tolist()
@@ -198,7 +201,7 @@ def sample_view(volume, geom, want_labels=True, out=None):
         y = torch.empty((P, d, d), dtype=torch.uint8, device=dev)
     offs = torch.tensor(geom.offsets, device=dev)
     shape = (C.c_int32 * 4)(*[int(v) for v in volume.image.shape])
-    gs = geom.struct(volume.rot_mat)
+    gs = geom.struct(volume.rot_mat, volume.axes)
     _lib.call("mpu_sample_view_planes", _lib.ptr(volume.image),
               _lib.ptr(volume.labels if y is not None else None), shape,
               _lib.ptr(volume._axes_dev[0]), _lib.ptr(volume._axes_dev[1]),
@@ -256,6 +259,8 @@ class _ViewPredHolder:
         s.d_offsets = self.offs.data_ptr()
         s.dim = int(self.g.shape[0])
         s.n_planes = int(self.offs.shape[0])
+        s.g_axis = _lib.make_axis(np.asarray(grid[0], np.float64))
+        s.o_axis = _lib.make_axis(np.asarray(grid[2], np.float64))
         self.struct = s
 
 

@@ -74,6 +74,38 @@ def test_capi_library_exports_every_declared_symbol():
     for name in declared:
         assert getattr(lib, name) is not None
     assert lib.mpu_abi_version() >= 1
-    assert ctypes.sizeof(_lib.ViewGeom) == 9 * 8 * 2 + 4 * 4 + 16
-    assert ctypes.sizeof(_lib.ViewPred) == 72 + 24 + 8
+    assert ctypes.sizeof(_lib.Axis) == 32
+    assert ctypes.sizeof(_lib.ViewGeom) == 9 * 8 * 2 + 4 * 4 + 16 + 3 * 32
+    assert ctypes.sizeof(_lib.ViewPred) == 72 + 24 + 8 + 2 * 32
     assert ctypes.sizeof(_lib.VoxelGrid) == 72 + 24 + 16
+
+
+def test_axis_closed_forms_reproduce_the_arrays_bitwise(golden):
+    """make_axis only claims a closed form when it reproduces the reference's axis array exactly."""
+    def rebuild(a):
+        i = np.arange(a.n, dtype=np.float64)
+        if a.kind == 1:
+            v = i * a.step + a.start
+            v[-1] = a.last
+            return v
+        if a.kind == 2:
+            return (i - a.start) * a.step
+        return None
+    n_closed = 0
+    for an in ("ident", "aniso", "rot"):
+        vol = I.Volume(golden["g3_vol"], None, golden["aff_" + an], bg_value=[0.0], device="cpu")
+        for ax in vol.axes:
+            a = _lib.make_axis(ax)
+            assert a.kind in (1, 2)
+            np.testing.assert_array_equal(rebuild(a), ax)
+            n_closed += 1
+    for dim, span in ((16, 30.0), (32, 33.0), (256, 256.0), (512, 512.0), (128, 101.3)):
+        g = I.ViewGeometry([0.3, 0.5, 0.8], dim, span, "same+20")
+        for arr in (g.real_axis, g.offsets):
+            a = _lib.make_axis(arr)
+            if a.kind:
+                np.testing.assert_array_equal(rebuild(a), arr)
+                n_closed += 1
+    assert n_closed >= 15
+    odd = np.array([0.0, 1.0, 2.5, 7.0])                 # non-uniform axis: no closed form claimed
+    assert _lib.make_axis(odd).kind == 0
