@@ -28,12 +28,17 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
     if use_cuda:
+        # MPU_SHARE_GPU=1 (testing aid): every rank uses GPU 0, e.g. with MPU_DIST_BACKEND=gloo on a 1-GPU box
+        if os.environ.get("MPU_SHARE_GPU") == "1":
+            local = 0
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
     device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
+        backend = backend or os.environ.get("MPU_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device
 
 
