@@ -1,0 +1,139 @@
+"""
+`mp predict` on MI355X: flags / project layout of mpunet/bin/predict.py:19-78,433-470; the 6-view
+loop, back-mapping and fusion run in multiplanarunet_amd.predict (distributed: plane-sharded).
+Outputs <out_dir>/nii_files/<id>_PRED.npz (labels + affine; NIfTI writing needs nibabel).
+"""
+import os
+from argparse import ArgumentParser
+import numpy as np
+import torch
+
+from .common import validate_project_dir, load_hparams, load_dataset
+
+
+def get_argparser():
+    p = ArgumentParser(description="Predict using a mpunet model (MI355X hot path).")
+    p.add_argument("--project_dir", type=str, default="./")
+    p.add_argument("-f", help="Predict on a single file (.npz)")
+    p.add_argument("-l", help="Optional single label file (.npz) to use with -f")
+    p.add_argument("--dataset", type=str, default="test")
+    p.add_argument("--out_dir", type=str, default="predictions")
+    p.add_argument("--num_GPUs", type=int, default=1)
+    p.add_argument("--sum_fusion", action="store_true")
+    p.add_argument("--overwrite", action="store_true")
+    p.add_argument("--no_eval", action="store_true")
+    p.add_argument("--eval_prob", type=float, default=1.0)
+    p.add_argument("--force_GPU", type=str, default="")
+    p.add_argument("--save_input_files", action="store_true")
+    p.add_argument("--no_argmax", action="store_true")
+    p.add_argument("--on_val", action="store_true")
+    p.add_argument("--wait_for", type=str, default="")
+    p.add_argument("--continue", action="store_true", dest="continue_")
+    p.add_argument("--synthetic", type=int, default=0)
+    p.add_argument("--dtype", default="bf16", choices=("bf16", "f32"))
+    return p
+
+
+def best_model_path(model_dir):
+    """get_best_model (mpunet/utils/utils.py:88-110): highest val_dice checkpoint, else the final weights."""
+    best, score = None, -1.0
+    for f in os.listdir(model_dir):
+        if f.startswith("@epoch") and "val_dice_" in f:
+            s = float(f.split("val_dice_")[1].rsplit(".", 1)[0])
+            if s > score:
+                best, score = f, s
+    best = best or "model_weights.npz"
+    return os.path.join(model_dir, best)
+
+
+def run(args):
+    from .. import distributed as D
+    from ..unet import UNet
+    from ..fusion_model import FusionModel
+    from ..predict import multi_view_predict
+    from ..interpolation import dice_all
+    from ..data import load_volume_file, as_volume
+    project_dir = os.path.abspath(args.project_dir)
+    validate_project_dir(project_dir)
+    for req in ("views.npz", "model"):
+        if not os.path.exists(os.path.join(project_dir, req)):
+            raise RuntimeError("Invalid project folder: needs train_hparams.yaml, views.npz and model/ (missing %s)" % req)
+    if args.force_GPU:
+        os.environ["HIP_VISIBLE_DEVICES"] = args.force_GPU
+    rank, world, device = D.init_from_env()
+    log = (lambda *a, **k: print(*a, flush=True)) if rank == 0 else (lambda *a, **k: None)
+    hp = load_hparams(project_dir)
+    fit, build = hp["fit"], hp["build"]
+    if args.f:
+        img, lab, aff = load_volume_file(args.f)
+        if args.l:
+            with np.load(args.l) as z:
+                lab = z["labels"] if "labels" in z.files else z[z.files[0]]
+        vols = [as_volume(img, lab, aff, fit.get("bg_value"), fit.get("scaler"), device,
+                          os.path.splitext(os.path.basename(args.f))[0])]
+    else:
+        key = "val_data" if args.on_val else args.dataset.replace("_data", "") + "_data"
+        vols = load_dataset(hp[key], project_dir, hp, device, args.synthetic, seed=5000, need_labels=False)
+    if not vols:
+        raise OSError("no volumes to predict on")
+    if not build.get("dim") or not fit.get("real_space_span") or not build.get("n_classes"):
+        from .common import fill_build_from_data
+        fill_build_from_data(hp, vols)
+    views = np.load(os.path.join(project_dir, "views.npz"))["arr_0"]
+    bkw = {k: v for k, v in build.items() if k != "model_class_name"}
+    model = UNet(logger=log, dtype=args.dtype, device=device, **bkw)
+    wpath = best_model_path(os.path.join(project_dir, "model"))
+    model.load_weights(wpath, by_name=True)
+    log("Loaded weights:", wpath)
+    fm = None
+    if not args.sum_fusion:
+        fm = FusionModel(len(views), build["n_classes"], verbose=False, device=device)
+        fdir = os.path.join(project_dir, "model", "fusion_weights")
+        cands = sorted(os.listdir(fdir)) if os.path.isdir(fdir) else []
+        if cands:
+            fm.load_weights(os.path.join(fdir, cands[0]))
+        else:
+            log("[OBS] no fusion weights found: using the FusionLayer initialisation (W=1, b=0)")
+    out_dir = os.path.join(project_dir, args.out_dir) if not os.path.isabs(args.out_dir) else args.out_dir
+    nii = os.path.join(out_dir, "nii_files")
+    if rank == 0:
+        os.makedirs(nii, exist_ok=True)
+    results = {}
+    for v in vols:
+        dst = os.path.join(nii, "%s_PRED.npz" % v.identifier)
+        if os.path.exists(dst) and args.continue_:
+            continue
+        if os.path.exists(dst) and not args.overwrite:
+            raise OSError("%s exists (use --overwrite or --continue)" % dst)
+        if world > 1:
+            labels = D.multi_view_predict_sharded(model, v, views, build["dim"], fit["real_space_span"], fm,
+                                                  sum_fusion=args.sum_fusion, batch_size=int(fit["batch_size"]))
+            probs = None
+        else:
+            probs, labels = multi_view_predict(model, v, views, build["dim"], fit["real_space_span"], fm,
+                                               sum_fusion=args.sum_fusion, batch_size=int(fit["batch_size"]),
+                                               want_probs=args.no_argmax)
+        if rank == 0:
+            out = {"labels": labels.cpu().numpy(), "affine": v.affine}
+            if args.no_argmax and probs is not None:
+                out["probs"] = probs.cpu().numpy()
+            np.savez_compressed(dst, **out)
+            if v.labels is not None and not args.no_eval:
+                d = dice_all(v.labels, labels, build["n_classes"], ignore_zero=True)
+                results[v.identifier] = d
+                log("%s: dices %s mean %.4f" % (v.identifier, np.round(d, 4), float(np.nanmean(d))))
+    if rank == 0 and results:
+        os.makedirs(os.path.join(out_dir, "csv"), exist_ok=True)
+        with open(os.path.join(out_dir, "csv", "results.csv"), "w") as f:
+            f.write("image,mean_dice," + ",".join("class_%d" % (c + 1) for c in range(build["n_classes"] - 1)) + "\n")
+            for k, d in results.items():
+                f.write("%s,%.5f,%s\n" % (k, float(np.nanmean(d)), ",".join("%.5f" % x for x in d)))
+    return results
+
+
+def entry_func(args=None):
+    run(get_argparser().parse_args(args))
+
+
+if __name__ == "__main__":
+    entry_func()

@@ -1,0 +1,172 @@
+"""
+`mp train` on MI355X: the flags and project layout of mpunet/bin/train.py:18-107,320-376, with the
+training step, the plane sampler and the validation forward on the GPU. One process per GPU under
+torchrun replaces MirroredStrategy (gradient SUM all-reduce over RCCL).
+"""
+import os
+import shutil
+from argparse import ArgumentParser
+import numpy as np
+import torch
+
+from .common import (validate_project_dir, load_hparams, load_dataset, load_or_create_views,
+                     fill_build_from_data)
+
+
+def get_argparser():
+    p = ArgumentParser(description="Fit a mpunet model defined in a project folder (MI355X hot path).")
+    p.add_argument("--project_dir", type=str, default="./")
+    p.add_argument("--num_GPUs", type=int, default=1, help="(one process per GPU: launch with torchrun for >1)")
+    p.add_argument("--force_GPU", type=str, default="", help="sets HIP_VISIBLE_DEVICES")
+    p.add_argument("--continue_training", action="store_true")
+    p.add_argument("--overwrite", action="store_true")
+    p.add_argument("--just_one", action="store_true")
+    p.add_argument("--no_val", action="store_true")
+    p.add_argument("--no_images", action="store_true")
+    p.add_argument("--debug", action="store_true")
+    p.add_argument("--wait_for", type=str, default="")
+    p.add_argument("--train_images_per_epoch", type=int, default=2500)
+    p.add_argument("--val_images_per_epoch", type=int, default=3500)
+    p.add_argument("--max_loaded_images", type=int, default=None)
+    p.add_argument("--epochs", type=int, default=None)
+    p.add_argument("--num_access", type=int, default=50)
+    p.add_argument("--cpu", action="store_true", help="alias of --num_GPUs=0 (rejected: there is no CPU path)")
+    p.add_argument("--synthetic", type=int, default=0, help="train on N generated toy volumes (no files needed)")
+    p.add_argument("--dtype", default="bf16", choices=("bf16", "f32"))
+    return p
+
+
+def validate_args(args):
+    if args.continue_training and args.overwrite:
+        raise ValueError("Cannot both continue training and overwrite the previous training session.")
+    if args.train_images_per_epoch <= 0:
+        raise ValueError("train_images_per_epoch must be a positive integer")
+    if args.val_images_per_epoch <= 0:
+        raise ValueError("val_images_per_epoch must be a positive integer. Use --no_val instead.")
+    if args.force_GPU and args.num_GPUs != 1:
+        raise ValueError("Should not specify both --force_GPU and --num_GPUs")
+    if args.num_GPUs < 0:
+        raise ValueError("num_GPUs must be a positive integer")
+    if args.num_GPUs == 0 or args.cpu:
+        raise NotImplementedError("this build has no CPU execution path (reference: 'Using CPU based "
+                                  "computations only!', mpunet/utils/system.py:80-81)")
+
+
+def validation_dice(model, sampler, steps, n_classes):
+    """Per-class dice over sampled validation batches (callbacks/validation.py:59-230, smooth-free counts)."""
+    tp = np.zeros(n_classes); rel = np.zeros(n_classes); sel = np.zeros(n_classes)
+    for _ in range(steps):
+        x, y, _ = sampler()
+        pred = model.predict_on_batch(x).reshape(y.shape[0], -1, n_classes).argmax(-1).reshape(-1)
+        t = y.reshape(-1).long()
+        for c in range(n_classes):
+            pc, tc = pred == c, t == c
+            tp[c] += int((pc & tc).sum()); rel[c] += int(tc.sum()); sel[c] += int(pc.sum())
+    with np.errstate(invalid="ignore", divide="ignore"):
+        d = 2 * tp / (rel + sel)
+    return float(np.nanmean(d[1:])) if n_classes > 1 else float(d[0])
+
+
+def run(args):
+    from .. import distributed as D
+    from ..unet import UNet
+    from ..data import TrainSampler
+    project_dir = os.path.abspath(args.project_dir)
+    validate_project_dir(project_dir)
+    if args.force_GPU:
+        os.environ["HIP_VISIBLE_DEVICES"] = args.force_GPU
+    rank, world, device = D.init_from_env()
+    log = (lambda *a, **k: print(*a, flush=True)) if rank == 0 else (lambda *a, **k: None)
+    model_dir = os.path.join(project_dir, "model")
+    if rank == 0:
+        if os.path.exists(model_dir) and os.listdir(model_dir) and not (args.overwrite or args.continue_training):
+            raise OSError("There seems to be existing files in the project 'model' folder. "
+                          "Use --overwrite or --continue_training.")
+        if args.overwrite and os.path.exists(model_dir):
+            shutil.rmtree(model_dir)
+        os.makedirs(model_dir, exist_ok=True)
+        os.makedirs(os.path.join(project_dir, "logs"), exist_ok=True)
+    hp = load_hparams(project_dir)
+    train = load_dataset(hp["train_data"], project_dir, hp, device, args.synthetic, seed=0)
+    val = [] if args.no_val else load_dataset(hp["val_data"], project_dir, hp, device,
+                                              max(1, args.synthetic // 4) if args.synthetic else 0, seed=1000)
+    if not train:
+        raise OSError("no training volumes (set train_data.base_dir to a folder with images/*.npz, or --synthetic N)")
+    if args.just_one:
+        train, val = train[:1], val[:1]
+    fill_build_from_data(hp, train)
+    fit, build = hp["fit"], hp["build"]
+    views = load_or_create_views(project_dir, fit["views"], seed=0) if rank == 0 else None
+    if world > 1:
+        torch.distributed.barrier()
+    if views is None:
+        views = np.load(os.path.join(project_dir, "views.npz"))["arr_0"]
+    bkw = {k: v for k, v in build.items() if k != "model_class_name"}
+    model = UNet(logger=log, flatten_output=True, dtype=args.dtype, device=device, **bkw)
+    last = os.path.join(model_dir, "model_weights.npz")
+    if args.continue_training and os.path.exists(last):
+        model.load_weights(last, by_name=True)
+    model.compile(fit["optimizer"], fit["loss"], fit.get("metrics"), optimizer_kwargs=fit.get("optimizer_kwargs"))
+    if world > 1:
+        D.DataParallelTrainer(model)
+    B = int(fit["batch_size"])
+    per_rank = max(1, B // world)
+    mk = lambda vols, noise, seed: TrainSampler(vols, views, build["dim"], fit["real_space_span"], per_rank,
+                                                build["n_classes"], noise_sd=noise,
+                                                fg_batch_fraction=fit["fg_batch_fraction"], seed=seed)
+    tr = mk(train, fit["noise_sd"], 17 + rank)
+    va = mk(val, 0.0, 99) if val else None
+    epochs = args.epochs or int(fit["n_epochs"])
+    steps = max(1, int(np.ceil(args.train_images_per_epoch / B)))
+    vsteps = max(1, int(np.ceil(args.val_images_per_epoch / B)))
+    best, best_path, since_best, lr_wait = -1.0, None, 0, 0
+    csv = os.path.join(project_dir, "logs", "training.csv")
+    try:
+        for ep in range(1, epochs + 1):
+            tot = 0.0
+            for _ in range(steps):
+                x, y, w = tr()
+                tot += float(model.train_step(x, y, w).mean().item())
+            msg = "Epoch %d/%d - loss %.5f" % (ep, epochs, tot / steps)
+            vd = None
+            if va is not None:
+                vd = validation_dice(model, va, vsteps, build["n_classes"])
+                msg += " - val_dice %.5f" % vd
+            log(msg)
+            if rank == 0:
+                with open(csv, "a") as f:
+                    if ep == 1 and f.tell() == 0:
+                        f.write("epoch,loss,val_dice,lr\n")
+                    f.write("%d,%.6f,%s,%g\n" % (ep - 1, tot / steps, "" if vd is None else "%.6f" % vd,
+                                                 model.optimizer_kwargs["lr"]))
+                if vd is not None and vd > best:      # ModelCheckPointClean: keep only the best file
+                    if best_path and os.path.exists(best_path):
+                        os.remove(best_path)
+                    best_path = os.path.join(model_dir, "@epoch_%02d_val_dice_%.5f.npz" % (ep, vd))
+                    model.save_weights(best_path)
+            if vd is not None:
+                if vd > best:
+                    best, since_best, lr_wait = vd, 0, 0
+                else:
+                    since_best += 1; lr_wait += 1
+                    if lr_wait > 2:                   # ReduceLROnPlateau(patience=2, factor=0.90)
+                        model.optimizer_kwargs["lr"] *= 0.9; lr_wait = 0
+                    if since_best >= 15:              # EarlyStopping(patience=15)
+                        log("Early stopping"); break
+    except KeyboardInterrupt:
+        log("Interrupted: saving weights")
+    finally:
+        if rank == 0:
+            model.save_weights(last)
+            log("Saved", last)
+    return model
+
+
+def entry_func(args=None):
+    args = get_argparser().parse_args(args)
+    validate_args(args)
+    run(args)
+
+
+if __name__ == "__main__":
+    entry_func()

@@ -1,0 +1,55 @@
+"""CLI shims: argument surface and validation rules of mp train / mp predict (no GPU)."""
+import os
+import numpy as np
+import pytest
+from multiplanarunet_amd.cli import train as T, predict as P, common as C, mp as MP
+
+
+def test_train_flags_and_validation(tmp_path):
+    a = T.get_argparser().parse_args([])
+    assert a.train_images_per_epoch == 2500 and a.val_images_per_epoch == 3500 and a.num_GPUs == 1
+    for flag in ("--continue_training", "--overwrite", "--just_one", "--no_val", "--no_images", "--debug"):
+        assert getattr(T.get_argparser().parse_args([flag]), flag[2:])
+    with pytest.raises(ValueError):
+        T.validate_args(T.get_argparser().parse_args(["--continue_training", "--overwrite"]))
+    with pytest.raises(ValueError):
+        T.validate_args(T.get_argparser().parse_args(["--train_images_per_epoch", "0"]))
+    with pytest.raises(ValueError):
+        T.validate_args(T.get_argparser().parse_args(["--force_GPU", "0", "--num_GPUs", "2"]))
+    with pytest.raises(NotImplementedError):
+        T.validate_args(T.get_argparser().parse_args(["--num_GPUs", "0"]))     # reference: CPU mode
+    with pytest.raises(RuntimeError):
+        C.validate_project_dir(str(tmp_path))
+
+
+def test_predict_flags():
+    a = P.get_argparser().parse_args(["--sum_fusion", "--no_eval", "--continue", "--on_val", "-f", "x.npz"])
+    assert a.sum_fusion and a.no_eval and a.continue_ and a.on_val and a.f == "x.npz" and a.out_dir == "predictions"
+
+
+def test_hparams_defaults_and_yaml_anchors(tmp_path):
+    (tmp_path / "train_hparams.yaml").write_text(
+        "__CB_x: &X\n  nickname: x\nbuild: &BUILD\n  n_classes: 3\n  dim: 64\n  complexity_factor: 1\n"
+        "fit:\n  batch_size: 8\n  callbacks: [*X]\n__VERSION__: Null\n")
+    hp = C.load_hparams(str(tmp_path))
+    assert hp["build"]["n_classes"] == 3 and hp["build"]["depth"] == 4 and hp["build"]["model_class_name"] == "UNet"
+    assert hp["fit"]["batch_size"] == 8 and hp["fit"]["optimizer_kwargs"]["lr"] == 5e-5
+    assert hp["fit"]["views"] == 6 and hp["fit"]["scaler"] == "RobustScaler" and hp["fit"]["bg_value"] == "1pct"
+
+
+def test_views_file_and_best_model(tmp_path):
+    v = C.load_or_create_views(str(tmp_path), 6, seed=1)
+    assert v.shape == (6, 3) and np.allclose(np.linalg.norm(v, axis=1), 1) and (v[:, 2] >= 0).all()
+    ang = np.rad2deg(np.arccos(np.clip(v @ v.T, -1, 1)))[np.triu_indices(6, 1)]
+    assert ang.min() > 15
+    np.testing.assert_array_equal(np.load(tmp_path / "views.npz")["arr_0"], v)
+    m = tmp_path / "model"; m.mkdir()
+    for n in ("@epoch_03_val_dice_0.71234.npz", "@epoch_07_val_dice_0.80011.npz", "model_weights.npz"):
+        (m / n).write_bytes(b"")
+    assert P.best_model_path(str(m)).endswith("@epoch_07_val_dice_0.80011.npz")
+
+
+def test_mp_dispatch_rejects_out_of_scope_scripts():
+    with pytest.raises(SystemExit):
+        MP.entry_func(["cv_split"])
+    assert MP.entry_func(["--help"]) == 0
