@@ -517,6 +517,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_glds_kernel(WgradArgs a) {
         }
     };
 
+    // bias gradient (a.fuse_db): every workgroup sums the dZ tile of its K steps it % nshare == share
+    // (share = tap * tiles_ci + ci tile), so the extra LDS reads are spread evenly over all workgroups.
+    // thread -> 16-byte channel chunk (tid % CPZ) of rows (tid / CPZ) + k * (256 / CPZ)
+    constexpr int CPZ = RZ / 16;
+    const int tiles_ci = (Cin + BCI - 1) / BCI;
+    const int nshare = (int)gridDim.y * tiles_ci, share = tap * tiles_ci + (int)(blockIdx.x / tiles_co);
+    float dbacc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) dbacc[e] = 0.f;
+    auto colsum_stage = [&](int stage) {
+        const unsigned char* zb = smem + stage * STAGE + KP * RX;
+        const int c = tid % CPZ;
+        for (int r = tid / CPZ; r < KP; r += 256 / CPZ) {
+            const uint4 v = *(const uint4*)(zb + r * RZ + ((c ^ wg_swz16<RZ>(r)) << 4));
+            if (sizeof(T) == 2) {
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dbacc[2 * e] += __uint_as_float(w[e] << 16);
+                    dbacc[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+                }
+            } else {
+                dbacc[0] += __uint_as_float(v.x); dbacc[1] += __uint_as_float(v.y);
+                dbacc[2 % EPC] += __uint_as_float(v.z); dbacc[3 % EPC] += __uint_as_float(v.w);
+            }
+        }
+    };
+
     const int nit = (int)((mend - mbeg + KP - 1) / KP);
     constexpr int NLD = NPX + NPZ;
     if (nit > 0) {
@@ -529,6 +557,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_glds_kernel(WgradArgs a) {
             const int st2 = st >= 1 ? st - 1 : 2;
             if (it + 2 < nit) issue(mbeg + (long)(it + 2) * KP, st2);
             compute(st);
+            if (a.fuse_db && (it % nshare) == share) colsum_stage(st);
             if (it + 2 < nit) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -548,6 +577,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_glds_kernel(WgradArgs a) {
                 if (ci < Cin && co < a.Cout) P[(long)ci * a.Cout + co] = acc[i][j][r];
             }
         }
+    if (a.fuse_db) {        // reduce the 256/CPZ row-groups per chunk through LDS (staging area is free now)
+        float* red = (float*)smem;                 // [256][EPC]
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) red[tid * EPC + e] = dbacc[e];
+        __syncthreads();
+        if (tid < BCO) {
+            const int c = tid / EPC, e = tid % EPC;
+            float s = 0.f;
+            for (int k = 0; k < 256 / CPZ; ++k) s += red[(c + k * CPZ) * EPC + e];
+            if (co0 + tid < a.Cout)
+                a.db_partial[((long)blockIdx.z * nshare + share) * a.Cout + co0 + tid] = s;
+        }
+    }
+}
+
+bool wgrad_glds_supported(int dtype, int mode, const WgradArgs& a) {
+    const int esz = dtype == MPU_BF16 ? 2 : 4;
+    if (mode != CONV3 && mode != UPCONV2 && mode != CONV1) return false;
+    const long M = (long)a.B * a.Ho * a.Wo;
+    const long hi = mode == UPCONV2 ? a.Ho / 2 : a.Ho, wi = mode == UPCONV2 ? a.Wo / 2 : a.Wo;
+    const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
+    if ((long)a.B * hi * wi * cmax * esz >= (1L << 31) || M * a.Cout * esz >= (1L << 31)) return false;
+    const int Cin = a.C0 + a.C1;
+    const bool big = esz == 2 && Cin >= 128 && a.Cout >= 128 && (a.C1 == 0 || a.C0 % 128 == 0);
+    if (!big && a.C1 > 0 && a.C0 % 64 != 0) return false;
+    return true;
 }
 
 // returns 1 if launched, 0 if this shape must use the register-staged kernel, <0 on error
@@ -555,13 +610,9 @@ template <typename T, int MODE>
 static int try_wgrad_glds_mode(const WgradArgs& a, hipStream_t st) {
     const int Cin = a.C0 + a.C1;
     constexpr int ntaps = GModeTraits<MODE>::NTAPS;
-    const long M = (long)a.B * a.Ho * a.Wo;
-    const long hi = MODE == UPCONV2 ? a.Ho / 2 : a.Ho, wi = MODE == UPCONV2 ? a.Wo / 2 : a.Wo;
-    const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
-    if ((long)a.B * hi * wi * cmax * (long)sizeof(T) >= (1L << 31) || M * a.Cout * (long)sizeof(T) >= (1L << 31)) return 0;
+    if (!wgrad_glds_supported(sizeof(T) == 2 ? MPU_BF16 : MPU_F32, MODE, a)) return 0;
     bool big = false;
     if constexpr (sizeof(T) == 2) big = Cin >= 128 && a.Cout >= 128 && (a.C1 == 0 || a.C0 % 128 == 0);
-    if (!big && a.C1 > 0 && a.C0 % 64 != 0) return 0;
     if (big) {
         if constexpr (sizeof(T) == 2) {
             dim3 g((unsigned)(cdiv(Cin, 128) * cdiv(a.Cout, 128)), ntaps, a.ksplit);

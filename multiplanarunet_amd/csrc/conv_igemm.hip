@@ -437,8 +437,8 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradArgs a) {
 }
 
 // second stage: dW[e] = sum_s partial[s][e]  (fixed order: deterministic)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int ksplit,
-                                                           long n, float* __restrict__ dW) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int ksplit, long n,
+                                                           float* __restrict__ dW) {
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
         float s = 0.f;
         for (int k = 0; k < ksplit; ++k) s += partial[(long)k * n + e];
@@ -524,7 +524,8 @@ long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, i
     const int ntaps = mode == UPCONV2 ? 4 : (mode == CONV1 ? 1 : 9);
     const int bc = (Cin >= 128 && Cout >= 128) ? 128 : 64;
     const long tiles = (long)cdiv(Cin, bc) * cdiv(Cout, bc) * ntaps;
-    long ks = (768 + tiles - 1) / tiles;                  // aim at ~768 workgroups (3 per CU)
+    long ks = tiles >= 384 ? 1 : (768 + tiles - 1) / tiles;   // aim at ~768 workgroups (3 per CU);
+                                                          // no split (and no reduce pass) once the tile grid fills the chip
     const long maxks = (M + 511) / 512;                   // at least 512 pixels per split
     if (ks > maxks) ks = maxks;
     if (ks < 1) ks = 1;
@@ -532,18 +533,28 @@ long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, i
     ks = (M + mchunk - 1) / mchunk;
     if (ksplit_out) *ksplit_out = (int)ks;
     if (mchunk_out) *mchunk_out = (int)mchunk;
-    return ks * ntaps * (long)Cin * Cout;
+    // + fused bias-gradient partials: [ks][ntaps * ci-tiles][Cout]
+    return ks * (ntaps * (long)Cin * Cout + (long)ntaps * cdiv(Cin, 64) * Cout);
 }
 
 template <typename T, int MODE>
 static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
     const int Cin = a.C0 + a.C1;
+    const int dt_ = sizeof(T) == 2 ? MPU_BF16 : MPU_F32;
+    // the LDS-DMA kernel also sums dz over the pixels (bias gradient) when it handles the shape
+    a.fuse_db = (a.db && conv_impl() == 1 && wgrad_glds_supported(dt_, MODE, a)) ? 1 : 0;
+    if (a.db && !a.fuse_db) {
+        int rc0 = launch_colsum(dt_, a.dz, (long)a.B * a.Ho * a.Wo, a.Cout, a.colsum_scratch, a.db, st);
+        if (rc0) return rc0;
+    }
+    const long n_ = (long)ModeTraits<MODE>::NTAPS * Cin * a.Cout;
+    a.db_partial = a.partial + (long)a.ksplit * n_;   // tail of the workspace
+    if (a.ksplit == 1) a.partial = dW;            // single split: the kernel's output IS the weight gradient
     const int ntaps = ModeTraits<MODE>::NTAPS;
     const long n = (long)ntaps * Cin * a.Cout;
     if (prof_on())
         prof_begin(PROF_WGRAD, a.flops > 0 ? a.flops : 2.0 * a.B * a.Ho * a.Wo * (double)n, st);
     bool big = false;
-    const int dt_ = sizeof(T) == 2 ? MPU_BF16 : MPU_F32;
     const int g_ = conv_impl() == 1 ? try_wgrad_glds(dt_, MODE, a, st) : 0;
     if (g_ < 0) return g_;
     if (g_ == 1) big = true;                      // launched by the LDS-DMA kernel
@@ -562,6 +573,13 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
     if (prof_on()) prof_end(st);
     int rc = launch_ok();
     if (rc) return rc;
+    if (a.fuse_db) {         // bias gradient: sum the [ksplit * taps * ci-tiles][Cout] partials of the LDS-DMA kernel
+        const bool big128 = sizeof(T) == 2 && Cin >= 128 && a.Cout >= 128 && (a.C1 == 0 || a.C0 % 128 == 0);
+        const int nshare_total = a.ksplit * ntaps * cdiv(Cin, big128 ? 128 : 64);
+        rc = launch_colsum_finalize(a.db_partial, nshare_total, a.Cout, a.db, st);
+        if (rc) return rc;
+    }
+    if (a.ksplit == 1) return MPU_OK;
     long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
     wgrad_reduce_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(a.partial, a.ksplit, n, dW);
     return launch_ok();

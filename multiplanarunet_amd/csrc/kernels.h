@@ -17,9 +17,13 @@ struct ConvArgs {
 struct WgradArgs {
     const void* x0; const void* x1; int C0, C1;
     const void* dz; int Cout;
-    float* partial;
+    float* partial;              // [ksplit][ntaps*Cin*Cout]
+    float* db_partial;           // [ksplit][Cout] (fused bias-gradient partials; set by the launcher)
     int B, Ho, Wo, ksplit, mchunk;
     double flops;
+    float* db;                   // bias gradient sum_m dz[m][co] (NULL = not wanted)
+    float* colsum_scratch;       // [RED_MAX_BLOCKS][Cout] scratch for the unfused bias-gradient path
+    int fuse_db;                 // set by the launcher: the wgrad kernel also produces the db partials
 };
 
 // ---- profile.hip: optional per-launch HIP-event timing of the MFMA kernels ----
@@ -33,6 +37,7 @@ int  launch_conv_glds(int dtype, int mode, const ConvArgs& a, hipStream_t st);  
 long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out);
 int  launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st);
 int  try_wgrad_glds(int dtype, int mode, const WgradArgs& a, hipStream_t st);   // 1 launched, 0 unsupported shape
+bool wgrad_glds_supported(int dtype, int mode, const WgradArgs& a);
 
 // ---- unet_ops.hip ---------------------------------------------------------
 constexpr int RED_MAX_BLOCKS = 256;
@@ -65,6 +70,8 @@ int launch_maxpool_bwd_add(int dtype, const void* n, const void* dskip, const vo
                            int B, int H, int W, int C, void* dn, hipStream_t st);
 // db[c] = sum_m dz[m][c]
 int launch_colsum(int dtype, const void* dz, long M, int C, float* partial, float* out, hipStream_t st);
+// out[c] = sum_k partial[k*C + c], k < nblk (second stage only)
+int launch_colsum_finalize(const float* partial, int nblk, int C, float* out, hipStream_t st);
 
 // 1x1 head: logits = n @ Wh + bh ; probs = softmax (or linear)
 int launch_head_forward(int dtype, const void* n, long M, int C, int K, const float* Wh, int ldw,

@@ -200,9 +200,8 @@ int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* 
     a.flops = conv_flops(r, c, lvl);
     const long M = (long)a.B * a.Ho * a.Wo;
     wgrad_partial_elems(c.mode, c.Cin, c.Cout, M, &a.ksplit, &a.mchunk);
-    int rc = launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st);
-    if (rc) return rc;
-    return launch_colsum(r.m->cfg.dtype, dz, M, c.Cout, (float*)r.at(r.P.partial), r.grads + c.b, r.st);
+    a.db = r.grads + c.b; a.db_partial = nullptr; a.colsum_scratch = (float*)r.at(r.P.partial); a.fuse_db = 0;
+    return launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st);
 }
 
 int bn_fwd(const Run& r, const BN& b, const void* x, int lvl, int training, void* y, void* pooled) {
@@ -470,7 +469,7 @@ int mpu_conv2d_wgrad(int32_t dtype, int32_t mode, const void* d_x0, int32_t C0, 
     MPU_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && Cout % 8 == 0, "mpu_conv2d_wgrad: channels must be multiples of 8");
     WgradArgs a;
     a.x0 = d_x0; a.x1 = d_x1; a.C0 = C0; a.C1 = C1; a.dz = d_dz; a.Cout = Cout; a.partial = d_workspace;
-    a.B = B; a.Ho = Ho; a.Wo = Wo; a.flops = 0;
+    a.B = B; a.Ho = Ho; a.Wo = Wo; a.flops = 0; a.db = nullptr; a.db_partial = nullptr; a.colsum_scratch = nullptr; a.fuse_db = 0;
     wgrad_partial_elems(mode, C0 + C1, Cout, (long)B * Ho * Wo, &a.ksplit, &a.mchunk);
     return launch_wgrad(dtype, mode, a, d_dW, (hipStream_t)stream);
 }

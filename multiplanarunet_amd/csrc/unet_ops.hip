@@ -463,6 +463,10 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     const double s = partial_sum(partial, nblk, C, c, c < C, red);
     if (c < C && threadIdx.x < FIN_COLS) out[c] = (float)s;
 }
+int launch_colsum_finalize(const float* partial, int nblk, int C, float* out, hipStream_t st) {
+    colsum_finalize_kernel<<<cdiv(C, FIN_COLS), 256, 0, st>>>(partial, nblk, C, out);
+    return launch_ok();
+}
 int launch_colsum(int dtype, const void* dz, long M, int C, float* partial, float* out, hipStream_t st) {
     int nblk;
     int rc = launch_colreduce<2>(dtype, dz, nullptr, M, C, nullptr, nullptr, partial, &nblk, st);

@@ -39,7 +39,7 @@ def conv2d(mode, x0, w_packed, cout, out_hw, bias=None, x1=None, mask=None, relu
         w_tap_stride = cout * (C0 + C1)
     _lib.call("mpu_conv2d_igemm", _dt(x0.dtype), mode, _lib.ptr(x0), C0, _lib.ptr(x1), C1,
               _lib.ptr(w_packed), w_tap_stride, w_row_stride, _lib.ptr(bias), _lib.ptr(mask),
-              _lib.ptr(out), B, Ho, Wo, cout, 1 if relu else 0, _lib.stream_ptr())
+              _lib.ptr(out), B, Ho, Wo, cout, int(relu), _lib.stream_ptr())
     return out
 
 
