@@ -121,7 +121,11 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
     const long m0 = (long)(logical / tiles_n) * BM;
     const int nch0 = (a.C0 + BKE - 1) / BKE, nch1 = (a.C1 + BKE - 1) / BKE;
     const int nchunks = nch0 + nch1;
-    const int nit = NTAPS * nchunks;
+    const int nit_all = NTAPS * nchunks;
+    // split-K (deep layers with few output tiles): blockIdx.y owns K steps [it0, it0 + nit)
+    const int ks = a.ksplit > 1 ? a.ksplit : 1;
+    const int it0 = (int)((long)blockIdx.y * nit_all / ks);
+    const int nit = (int)((long)(blockIdx.y + 1) * nit_all / ks) - it0;
     const int Hi = g_in_h<MODE>(a.Ho), Wi = g_in_h<MODE>(a.Wo);
     const long M = (long)a.B * a.Ho * a.Wo;
     constexpr unsigned OOB = 0xfffffff0u;
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
         }
     };
 
-    int tapN = 0, ccN = 0;
+    int tapN = it0 / nchunks, ccN = it0 % nchunks;
     auto advance = [&]() { if (++ccN == nchunks) { ccN = 0; ++tapN; } };
     if constexpr (Cfg::NSTAGE == 2) {
         issue(tapN, ccN, 0); advance();
@@ -243,6 +247,24 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
         }
     }
 
+    if (ks > 1) {        // split-K: raw f32 partial sums; bias / ReLU / mask / convert happen in splitk_finish
+        float* P = a.partial + (long)blockIdx.y * M * a.Cout;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const long m = m0 + wm * WM + j * 32 + (lane & 31);
+            if (m >= M) continue;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * WN + i * 32 + 8 * q + 4 * (lane >> 5);
+                    if (n < a.Cout)
+                        *(float4*)(P + m * a.Cout + n) = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1],
+                                                                     acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                }
+        }
+        return;
+    }
     // epilogue (same as conv_igemm_kernel): bias -> LDS, tile -> LDS, coalesced 16-byte row stores
     constexpr int OROW = Cfg::OROW;
     float* sbias = (float*)(smem + BM * OROW);
@@ -308,6 +330,34 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
     }
 }
 
+// out = act(sum_z partial[z] + bias) (* ReLU mask), 16 bytes of output per thread
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ partial, int ks, long M, int Cout,
+                                                            const float* __restrict__ bias, const T* __restrict__ mask,
+                                                            int relu, T* __restrict__ out) {
+    constexpr int EPC = 16 / sizeof(T);
+    const long total = M * Cout / EPC, stride = M * Cout;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int n = (int)((e * EPC) % Cout);
+        float v[EPC];
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) v[k] = bias ? bias[n + k] : 0.f;
+        for (int z = 0; z < ks; ++z) {
+#pragma unroll
+            for (int k = 0; k < EPC; k += 4) {
+                const float4 p = *(const float4*)(partial + z * stride + e * EPC + k);
+                v[k] += p.x; v[k + 1] += p.y; v[k + 2] += p.z; v[k + 3] += p.w;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) {
+            if (relu) v[k] = fmaxf(v[k], 0.f);
+            if (mask && !(to_f32<T>(mask[e * EPC + k]) > 0.f)) v[k] = 0.f;
+            out[e * EPC + k] = from_f32<T>(v[k]);
+        }
+    }
+}
+
 template <typename T, int MODE, int BN, int BM, int WN, int WM>
 static int launch_glds_cfg(const ConvArgs& a_in, hipStream_t st) {
     using Cfg = GldsCfg<T, BN, BM>;
@@ -330,17 +380,39 @@ static int launch_glds_cfg(const ConvArgs& a_in, hipStream_t st) {
             return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
     }
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * NT * (a.C0 + a.C1), st);
-    kern<<<dim3((unsigned)tiles), dim3(256), Cfg::SMEM, st>>>(a);
+    const int ks = a.ksplit > 1 ? a.ksplit : 1;
+    a.ksplit = ks;
+    kern<<<dim3((unsigned)tiles, ks), dim3(256), Cfg::SMEM, st>>>(a);
+    int rc = launch_ok();
+    if (!rc && ks > 1) {
+        long work = M * a.Cout / (16 / (long)sizeof(T));
+        long blocks = (work + 255) / 256; if (blocks > 4096) blocks = 4096;
+        splitk_finish_kernel<T><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
+                                                                  a.relu, (T*)a.out);
+        rc = launch_ok();
+    }
     if (prof_on()) prof_end(st);
-    return launch_ok();
+    return rc;
 }
 
 template <typename T, int MODE>
-static int launch_glds_mode(const ConvArgs& a, hipStream_t st) {
+static int launch_glds_mode(const ConvArgs& a_in, hipStream_t st) {
+    ConvArgs a = a_in;
+    a.ksplit = 1;
     const long M = (long)a.B * a.Ho * a.Wo;
     const long t128 = (long)cdiv(a.Cout, 128) * cdiv(M, 128);
     const long t64x128 = (long)cdiv(a.Cout, 64) * cdiv(M, 128);
     if (a.Cout > 64 && t128 >= 384) return launch_glds_cfg<T, MODE, 128, 128, 64, 64>(a, st);
+    // few output tiles but a long reduction (deep U-Net levels): 128x128 tiles, K split over workgroups
+    if (a.Cout >= 128 && a.partial && t128 < 256) {
+        constexpr int BKE = 128 / sizeof(T);
+        const int nit = GModeTraits<MODE>::NTAPS * (cdiv(a.C0, BKE) + cdiv(a.C1, BKE));
+        long ks = 512 / (t128 > 0 ? t128 : 1);
+        if (ks > 8) ks = 8;
+        if (ks > nit / 8) ks = nit / 8;
+        while (ks > 1 && ks * M * a.Cout > a.partial_cap) --ks;
+        if (ks > 1) { a.ksplit = (int)ks; return launch_glds_cfg<T, MODE, 128, 128, 64, 64>(a, st); }
+    }
     if (t64x128 >= 384 || a.Cout <= 64) {
         if (M >= 128 * 64) return launch_glds_cfg<T, MODE, 64, 128, 64, 32>(a, st);
     }

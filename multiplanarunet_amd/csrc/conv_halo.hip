@@ -1,0 +1,320 @@
+// conv_halo_kernel: 3x3 SAME convolution (forward, and data gradient with rotated weights) whose
+// input patch stays resident in LDS across the nine taps.
+//
+// The L2 -> LDS fill rate (~57 GB/s per CU measured) bounds the plain implicit GEMM of
+// conv_glds.hip at ~35-40 % of the MFMA peak for 128x128 tiles: every K step re-fetches a
+// 128-pixel operand tile although consecutive taps read the same pixels shifted by one. Here a
+// workgroup owns TH x 32 output pixels x BN channels and, per 64-channel chunk, DMAs the
+// (TH+2) x 34 pixel halo patch ONCE; the nine taps then read their B fragments from the patch at
+// shifted rows (row = (py+ky)*34 + px+kx). Only the [BN][64ch] weight tile changes per tap
+// (3-stage LDS ring, counted vmcnt). Fill bytes per chunk drop from 9*(BN+BM)*128 to
+// PATCH*128 + 9*BN*128 (BN=BM=128: 288 KB -> 170 KB; BN=64: 216 KB -> 98 KB).
+// The XOR swizzle (slot ^= (row>>1)&7) is applied on patch-row indices; 32 consecutive patch rows
+// starting at ANY row are conflict-free for ds_read_b128 (checked for even and odd starts).
+#include <stdlib.h>
+#include "kernels.h"
+
+namespace mpu {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+namespace {
+
+__device__ __forceinline__ i32x4 h_make_rsrc(const void* p, long bytes) {
+    const unsigned long long pa = (unsigned long long)p;
+    i32x4 r;
+    r.x = (int)(unsigned)pa; r.y = (int)((unsigned)(pa >> 32) & 0xffffu); r.z = (int)bytes; r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void h_dma16(const i32x4& rsrc, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
+                 :: "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
+}
+template <typename T> struct HMma;
+template <> struct HMma<bf16_t> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct HMma<float> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+template <typename T, int BN, int TH, int NWS_>
+struct HaloCfg {
+    static constexpr int TW = 32, PW = TW + 2, PH = TH + 2;
+    static constexpr int PROWS = (PH * PW + 7) / 8 * 8;          // patch rows, padded to whole DMA pieces
+    static constexpr int PATCH = PROWS * 128;
+    static constexpr int WSTAGE = BN * 128, NWS = NWS_;
+    static constexpr int BM = TH * TW;
+    static constexpr int OROW = BN * (int)sizeof(T) + 16;
+    static constexpr int EPI = BM * OROW + BN * 4;
+    static constexpr int MAIN = PATCH + NWS * WSTAGE;
+    static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
+};
+
+template <typename T, int BN, int TH, int NWS>
+__global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
+    using Cfg = HaloCfg<T, BN, TH, NWS>;
+    constexpr int EPC = 16 / sizeof(T), BKE = 128 / sizeof(T);
+    constexpr int TW = Cfg::TW, PW = Cfg::PW, PROWS = Cfg::PROWS;
+    constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N;
+    constexpr int TN = 2, TM = TH / WAVES_M;
+    static_assert(TM >= 1 && TM * WAVES_M == TH, "tile split");
+    constexpr int NPP = PROWS / 8;                               // patch DMA pieces
+    constexpr int NPW = (NPP + 3) / 4;                           // ... per wave
+    constexpr int GW = BN / 32;                                  // weight DMA pieces per wave
+    constexpr int BM = Cfg::BM;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WAVES_N, wm = wave / WAVES_N;
+    const int H = a.Ho, W = a.Wo;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int tiles_n = (a.Cout + BN - 1) / BN;
+    // n-tile fastest: the n-tiles of one pixel tile are neighbours in time (shared patch in L2)
+    int t = blockIdx.x;
+    const int n0 = (t % tiles_n) * BN; t /= tiles_n;
+    const int x0 = (t % tiles_x) * TW; t /= tiles_x;
+    const int y0 = (t % tiles_y) * TH; const int b = t / tiles_y;
+    const int nch0 = (a.C0 + BKE - 1) / BKE, nch1 = (a.C1 + BKE - 1) / BKE;
+    const int nchunks = nch0 + nch1;
+    const int nsteps = nchunks * 9;
+    constexpr unsigned OOB = 0xfffffff0u;
+    const long npix = (long)a.B * H * W;
+    const i32x4 rs0 = h_make_rsrc(a.in0, npix * a.C0 * (long)sizeof(T));
+    const i32x4 rs1 = h_make_rsrc(a.in1 ? a.in1 : a.in0, a.in1 ? npix * a.C1 * (long)sizeof(T) : 0);
+    const i32x4 rsw = h_make_rsrc(a.w, a.w_elems * (long)sizeof(T));
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    const unsigned ldsW = lds0 + Cfg::PATCH;
+
+    // --- per-lane DMA roles -------------------------------------------------------------
+    const int lrow = lane >> 3, slot = lane & 7;
+    int ppix[NPW], pchunk[NPW];                                 // patch: input pixel index (or -1), source chunk
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+        const int piece = wave + 4 * k;
+        const int pr = piece * 8 + lrow;                         // patch row
+        const int py = pr / PW, px = pr % PW;
+        const int iy = y0 + py - 1, ix = x0 + px - 1;
+        const bool v = piece < NPP && pr < Cfg::PH * PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        ppix[k] = v ? (b * H + iy) * W + ix : -1;
+        pchunk[k] = slot ^ ((pr >> 1) & 7);
+    }
+    unsigned wrow[GW]; int wchunk[GW];
+#pragma unroll
+    for (int g = 0; g < GW; ++g) {
+        const int rl = wave * (BN / 4) + g * 8 + lrow;
+        const int n = n0 + rl;
+        wrow[g] = n < a.Cout ? (unsigned)((long)n * a.w_row_stride * (long)sizeof(T)) : OOB;
+        wchunk[g] = slot ^ ((rl >> 1) & 7);
+    }
+    auto chunk_src = [&](int cc, bool& s1, int& cbase, int& Cs) {
+        s1 = cc >= nch0; cbase = (s1 ? cc - nch0 : cc) * BKE; Cs = s1 ? a.C1 : a.C0;
+    };
+    auto issue_patch = [&](int cc) {
+        bool s1; int cbase, Cs; chunk_src(cc, s1, cbase, Cs);
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            const int piece = wave + 4 * k;
+            if (piece < NPP) {                                   // wave-uniform
+                const int ch = cbase + pchunk[k] * EPC;
+                const unsigned off = (ppix[k] >= 0 && ch < Cs) ? (unsigned)((ppix[k] * Cs + ch) * (int)sizeof(T)) : OOB;
+                if (s1) h_dma16(rs1, off, lds0 + piece * 1024);
+                else    h_dma16(rs0, off, lds0 + piece * 1024);
+            }
+        }
+    };
+    auto issue_w = [&](int step, int stage) {                    // step = chunk * 9 + tap
+        const int cc = step / 9, tap = step - cc * 9;
+        bool s1; int cbase, Cs; chunk_src(cc, s1, cbase, Cs);
+        const long wkbase = (long)tap * a.w_tap_stride + (s1 ? a.C0 : 0) + cbase;
+#pragma unroll
+        for (int g = 0; g < GW; ++g) {
+            const int ch = wchunk[g] * EPC;
+            const unsigned off = (cbase + ch < Cs && wrow[g] != OOB)
+                                     ? wrow[g] + (unsigned)((wkbase + ch) * (long)sizeof(T)) : OOB;
+            h_dma16(rsw, off, ldsW + stage * Cfg::WSTAGE + (wave * (BN / 4) + g * 8) * 128);
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fsw = ((lane & 31) >> 1) & 7, fh = lane >> 5;
+    auto compute = [&](int tap, int stage) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const unsigned char* Wb = smem + Cfg::PATCH + stage * Cfg::WSTAGE + (wn * 64 + (lane & 31)) * 128;
+        int prow[TM], psw[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            prow[j] = (wm * TM + j + ky) * PW + kx + (lane & 31);         // patch row of this lane's pixel
+            psw[j] = (prow[j] >> 1) & 7;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int q = 2 * s + fh;
+            uint4 af[TN], bf[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) af[i] = *(const uint4*)(Wb + i * 32 * 128 + ((q ^ fsw) << 4));
+#pragma unroll
+            for (int j = 0; j < TM; ++j) bf[j] = *(const uint4*)(smem + prow[j] * 128 + ((q ^ psw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) HMma<T>::run(af[i], bf[j], acc[i][j]);
+        }
+    };
+
+    // --- pipeline: patch once per chunk (single buffer), weights through an NWS-stage ring ---
+    issue_patch(0);
+    issue_w(0, 0);
+    if (NWS == 3 && nsteps > 1) { issue_w(1, 1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int st = 0, tap = 0, cc = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        constexpr int AHEAD = NWS - 1;                           // prefetch distance
+        const int stn = (st + AHEAD) % NWS;
+        const bool more = step + AHEAD < nsteps;
+        if (more) issue_w(step + AHEAD, stn);
+        compute(tap, st);
+        const bool reload = (tap == 8) && (cc + 1 < nchunks);
+        if (reload) {
+            // every wave has finished reading the patch before it is overwritten
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue_patch(cc + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (NWS == 3 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        st = (st + 1) % NWS;
+        if (++tap == 9) { tap = 0; ++cc; }
+    }
+
+    // --- epilogue: bias -> LDS, tile -> LDS, coalesced 16-byte row stores ------------------
+    constexpr int OROW = Cfg::OROW;
+    float* sbias = (float*)(smem + BM * OROW);
+    if (tid < BN) sbias[tid] = (a.bias && n0 + tid < a.Cout) ? a.bias[n0 + tid] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int ml = (wm * TM + j) * TW + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = wn * 64 + i * 32 + 8 * q + 4 * (lane >> 5);
+                const float4 bq = *(const float4*)(sbias + nl);
+                float v[4] = {acc[i][j][4 * q] + bq.x, acc[i][j][4 * q + 1] + bq.y,
+                              acc[i][j][4 * q + 2] + bq.z, acc[i][j][4 * q + 3] + bq.w};
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                unsigned char* dst = smem + ml * OROW + nl * (int)sizeof(T);
+                if (sizeof(T) == 2) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *(uint2*)dst = pk;
+                } else {
+                    *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int CPRO = BN * (int)sizeof(T) / 16;
+        T* out = (T*)a.out; const T* mask = (const T*)a.mask;
+        for (int idx = tid; idx < BM * CPRO; idx += 256) {
+            const int row = idx / CPRO, c = idx % CPRO;
+            const int y = y0 + row / TW, x = x0 + row % TW;
+            const int n = n0 + c * EPC;
+            if (y >= H || x >= W || n >= a.Cout) continue;
+            uint4 val = *(const uint4*)(smem + row * OROW + c * 16);
+            const long o = ((long)(b * H + y) * W + x) * a.Cout + n;
+            if (mask) {
+                const uint4 mk = *(const uint4*)(mask + o);
+                if (sizeof(T) == 2) {
+                    auto keep = [](uint32_t mw, uint32_t vw) {
+                        const uint32_t lo = ((mw & 0x8000u) == 0 && (mw & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
+                        const uint32_t hi = ((mw & 0x80000000u) == 0 && (mw & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+                        return vw & (lo | hi);
+                    };
+                    val.x = keep(mk.x, val.x); val.y = keep(mk.y, val.y);
+                    val.z = keep(mk.z, val.z); val.w = keep(mk.w, val.w);
+                } else {
+                    if (!(__uint_as_float(mk.x) > 0.f)) val.x = 0;
+                    if (!(__uint_as_float(mk.y) > 0.f)) val.y = 0;
+                    if (!(__uint_as_float(mk.z) > 0.f)) val.z = 0;
+                    if (!(__uint_as_float(mk.w) > 0.f)) val.w = 0;
+                }
+            }
+            *(uint4*)(out + o) = val;
+        }
+    }
+}
+
+template <typename T, int BN, int TH, int NWS>
+int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
+    using Cfg = HaloCfg<T, BN, TH, NWS>;
+    auto kern = conv_halo_kernel<T, BN, TH, NWS>;
+    ConvArgs a = a_in;
+    if (a.w_elems <= 0) a.w_elems = 8 * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        attr_set = true;
+    }
+    const long M = (long)a.B * a.Ho * a.Wo;
+    const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
+    if (M * cmax * (long)sizeof(T) >= (1L << 31) || a.w_elems * (long)sizeof(T) >= (1L << 31))
+        return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
+    const long tiles = (long)a.B * cdiv(a.Ho, TH) * cdiv(a.Wo, Cfg::TW) * cdiv(a.Cout, BN);
+    if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * 9 * (a.C0 + a.C1), st);
+    kern<<<dim3((unsigned)tiles), dim3(256), Cfg::SMEM, st>>>(a);
+    if (prof_on()) prof_end(st);
+    return launch_ok();
+}
+
+}  // namespace
+
+// 1 = launched, 0 = shape not suited (caller falls back to the plain implicit GEMM), < 0 = error
+int try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
+    if (mode != CONV3 || a.Wo < 32 || a.Ho < 4) return 0;
+    int rc;
+    static int variant = -1;                      // MPU_HALO_VARIANT: tuning aid
+    if (variant < 0) { const char* e = getenv("MPU_HALO_VARIANT"); variant = e ? atoi(e) : 0; }
+    const long tiles8 = (long)a.B * cdiv(a.Ho, 8) * cdiv(a.Wo, 32);
+    const bool tall = a.Ho % 8 == 0 && tiles8 * cdiv(a.Cout, 64) >= 512 && variant != 1;
+    if (dtype == MPU_BF16) {
+        if (a.Cout > 64) rc = (tall && variant == 2) ? launch_halo_cfg<bf16_t, 128, 8, 2>(a, st)
+                                                      : launch_halo_cfg<bf16_t, 128, 4, 3>(a, st);
+        else rc = tall ? launch_halo_cfg<bf16_t, 64, 8, 3>(a, st) : launch_halo_cfg<bf16_t, 64, 4, 3>(a, st);
+    } else if (dtype == MPU_F32) {
+        if (a.Cout > 64) rc = launch_halo_cfg<float, 128, 4, 3>(a, st);
+        else rc = launch_halo_cfg<float, 64, 4, 3>(a, st);
+    } else return 0;
+    return rc ? rc : 1;
+}
+
+}  // namespace mpu

@@ -503,8 +503,20 @@ static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
     return launch_conv_cfg<T, MODE, 64, 64, 32, 32>(a, st);
 }
 
+static int halo_on() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MPU_CONV_HALO"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on;
+}
+
 int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
-    if (conv_impl() == 1) return launch_conv_glds(dtype, mode, a, st);
+    if (conv_impl() == 1) {
+        if (halo_on()) {
+            const int h = try_conv_halo(dtype, mode, a, st);
+            if (h != 0) return h < 0 ? h : MPU_OK;
+        }
+        return launch_conv_glds(dtype, mode, a, st);
+    }
 #define MPU_CONV_CASE(TT)                                                          \
     switch (mode) {                                                                \
         case CONV3: return launch_conv_mode<TT, CONV3>(a, st);                     \

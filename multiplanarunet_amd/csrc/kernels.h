@@ -13,6 +13,9 @@ struct ConvArgs {
     int B, Ho, Wo, Cout, relu;
     double flops;                // algorithmic FLOPs of this launch (profiling only; 0 = derive)
     long w_elems;                // elements addressable from `w` (0 = derive from strides)
+    float* partial;              // split-K scratch [ksplit][M][Cout] f32 (NULL = never split)
+    long partial_cap;            // floats available at `partial`
+    int ksplit;                  // set by the launcher
 };
 struct WgradArgs {
     const void* x0; const void* x1; int C0, C1;
@@ -34,6 +37,7 @@ void prof_end(hipStream_t st);
 
 int  launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // dispatches on MPU_CONV_IMPL
 int  launch_conv_glds(int dtype, int mode, const ConvArgs& a, hipStream_t st);  // LDS-DMA variant (conv_glds.hip)
+int  try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st);     // LDS-resident patch variant (conv_halo.hip)
 long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out);
 int  launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st);
 int  try_wgrad_glds(int dtype, int mode, const WgradArgs& a, hipStream_t st);   // 1 launched, 0 unsupported shape

@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 #include <cmath>
+#include <stdlib.h>
 #include "kernels.h"
 
 using namespace mpu;
@@ -39,6 +40,9 @@ struct mpu_unet {
     long n_params = 0, n_state = 0, n_packed = 0, n_stats = 0, n_logical = 0;
     int head_C = 0; long head_w = 0, head_b = 0;
     int cmax = 0;
+    // backward-pass concurrency: weight gradients run on a side stream next to the data gradients
+    mutable hipStream_t side = nullptr;
+    mutable hipEvent_t ev_ready = nullptr, ev_done = nullptr;
 
     // indices into conv / bn
     int enc_c1(int i) const { return 2 * i; }
@@ -100,7 +104,7 @@ struct Plan {
     std::vector<long> c1, c2, n, p, dskip;          // encoder levels
     long c1b, c2b, nb;
     std::vector<long> u1, n1, c2u, c3u, n2;         // up levels
-    long probs, gA, gB, gC, partial, wpartial, coeffs, stats, total;
+    long probs, gA, gB, gC, partial, partial2, wpartial, wpartial_floats, coeffs, stats, total;
 };
 
 Plan make_plan(const mpu_unet* m, int B) {
@@ -132,6 +136,7 @@ Plan make_plan(const mpu_unet* m, int B) {
     const long he = (long)RED_MAX_BLOCKS * (m->head_C * m->cfg.n_classes + m->cfg.n_classes);
     if (he > pe) pe = he;
     P.partial = take(pe * 4);
+    P.partial2 = take((long)RED_MAX_BLOCKS * m->cmax * 4);
     long we = 0;
     for (size_t i = 0; i < m->conv.size(); ++i) {
         const Conv& c = m->conv[i];
@@ -143,7 +148,14 @@ Plan make_plan(const mpu_unet* m, int B) {
             if (e > we) we = e;
         }
     }
+    {   // the same scratch serves split-K forward / data-gradient convs: [ks<=8][M][Cout] at the deep levels
+        for (int l = 0; l <= D; ++l) {
+            const long M = (long)B * (m->cfg.H >> l) * (m->cfg.W >> l);
+            if ((long)cdiv(M, 128) * cdiv(m->F[l], 128) < 256) { const long e = 8 * M * m->F[l]; if (e > we) we = e; }
+        }
+    }
     P.wpartial = take(we * 4);
+    P.wpartial_floats = we;
     P.coeffs = take(3L * m->cmax * 4);
     P.stats = take(m->n_stats * 4);
     P.total = off;
@@ -152,6 +164,8 @@ Plan make_plan(const mpu_unet* m, int B) {
 
 struct Run {
     const mpu_unet* m; int B; hipStream_t st; unsigned char* ws; Plan P;
+    bool overlap = false;          // weight gradients on the model's side stream
+    mutable bool pending = false;  // a weight gradient is in flight on the side stream
     const float* params; const unsigned char* packed; float* state; float* grads;
     int esz;
     void* at(long off) const { return ws + off; }
@@ -171,6 +185,7 @@ double conv_flops(const Run& r, const Conv& c, int lvl, int n_cnt_logical = -1) 
 int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* in1, int C1, void* out, int lvl) {
     ConvArgs a;
     a.flops = conv_flops(r, c, lvl); a.w_elems = 0;
+    a.partial = r.overlap ? nullptr : (float*)r.at(r.P.wpartial); a.partial_cap = r.P.wpartial_floats; a.ksplit = 1;
     a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1;
     a.w = r.wf(c); a.w_tap_stride = (long)c.Cin * c.Cout; a.w_row_stride = c.Cin;
     a.bias = r.params + c.b; a.mask = nullptr; a.out = out;
@@ -183,6 +198,7 @@ int conv_dgrad(const Run& r, const Conv& c, const void* dz, const void* mask, vo
                int n_off, int n_cnt) {
     ConvArgs a;
     a.in0 = dz; a.in1 = nullptr; a.C0 = c.Cout; a.C1 = 0; a.w_elems = 0;
+    a.partial = r.overlap ? nullptr : (float*)r.at(r.P.wpartial); a.partial_cap = r.P.wpartial_floats; a.ksplit = 1;
     a.w = (const unsigned char*)r.wd(c) + (long)n_off * c.Cout * r.esz;
     a.w_tap_stride = (long)c.Cin * c.Cout; a.w_row_stride = c.Cout;
     a.bias = nullptr; a.mask = mask; a.out = out;
@@ -200,8 +216,31 @@ int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* 
     a.flops = conv_flops(r, c, lvl);
     const long M = (long)a.B * a.Ho * a.Wo;
     wgrad_partial_elems(c.mode, c.Cin, c.Cout, M, &a.ksplit, &a.mchunk);
-    a.db = r.grads + c.b; a.db_partial = nullptr; a.colsum_scratch = (float*)r.at(r.P.partial); a.fuse_db = 0;
-    return launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st);
+    a.db = r.grads + c.b; a.db_partial = nullptr; a.colsum_scratch = (float*)r.at(r.P.partial2); a.fuse_db = 0;
+    if (!r.overlap) return launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st);
+    // fork: the side stream waits until dz (and everything before it) is produced on the main stream
+    MPU_CHECK_HIP(hipEventRecord(r.m->ev_ready, r.st));
+    MPU_CHECK_HIP(hipStreamWaitEvent(r.m->side, r.m->ev_ready, 0));
+    int rc = launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.m->side);
+    if (rc) return rc;
+    MPU_CHECK_HIP(hipEventRecord(r.m->ev_done, r.m->side));
+    r.pending = true;
+    return MPU_OK;
+}
+
+int wgrad_join(const Run& r);
+int conv_wgrad_after_join(const Run& r, const Conv& c, const void* x0, int C0, const void* x1, int C1, const void* dz, int lvl) {
+    int rc = wgrad_join(r);      // one weight gradient in flight at a time (they share the split-K scratch)
+    return rc ? rc : conv_wgrad(r, c, x0, C0, x1, C1, dz, lvl);
+}
+
+// join: the main stream may not overwrite a buffer the in-flight weight gradient still reads
+int wgrad_join(const Run& r) {
+    if (r.pending) {
+        MPU_CHECK_HIP(hipStreamWaitEvent(r.st, r.m->ev_done, 0));
+        r.pending = false;
+    }
+    return MPU_OK;
 }
 
 int bn_fwd(const Run& r, const BN& b, const void* x, int lvl, int training, void* y, void* pooled) {
@@ -268,45 +307,51 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
     RC(launch_head_backward(dt, last, (const float*)r.at(P.probs), d_y, d_sw, M0, (long)m->cfg.H * m->cfg.W,
                             m->head_C, m->cfg.n_classes, r.params + m->head_w, m->cfg.n_classes,
                             (float*)r.at(P.partial), gA, r.grads + m->head_w, r.grads + m->head_b, d_loss, r.st));
+    // Each weight gradient (side stream) runs next to the data gradient of the same layer (main stream);
+    // wgrad_join() precedes the first main-stream kernel that overwrites the dz buffer it reads.
     for (int j = D - 1; j >= 0; --j) {
         const int lvl = D - 1 - j, f = m->F[lvl];
         const Conv& cu = m->conv[m->up_c(j, 0)]; const Conv& c2 = m->conv[m->up_c(j, 1)];
         const Conv& c3 = m->conv[m->up_c(j, 2)];
         const void* prev = j > 0 ? r.at(P.n2[j - 1]) : r.at(P.nb);
         const int Cprev = j > 0 ? m->F[lvl + 1] : m->F[D];
-        RC(bn_bwd(r, m->bn[m->up_bn(j, 1)], gA, r.at(P.c3u[j]), lvl, gB));                 // dz3
-        RC(conv_wgrad(r, c3, r.at(P.c2u[j]), f, nullptr, 0, gB, lvl));
-        RC(conv_dgrad(r, c3, gB, r.at(P.c2u[j]), gA, lvl, 0, f));                          // dz2
-        RC(conv_wgrad(r, c2, r.at(P.n[lvl]), f, r.at(P.n1[j]), f, gA, lvl));
+        RC(wgrad_join(r));                                                                 // gB is about to be written
+        RC(bn_bwd(r, m->bn[m->up_bn(j, 1)], gA, r.at(P.c3u[j]), lvl, gB));                 // dz3 -> gB
+        RC(conv_wgrad(r, c3, r.at(P.c2u[j]), f, nullptr, 0, gB, lvl));                     //   reads gB
+        RC(conv_dgrad(r, c3, gB, r.at(P.c2u[j]), gA, lvl, 0, f));                          // dz2 -> gA
+        RC(wgrad_join(r));
+        RC(conv_wgrad(r, c2, r.at(P.n[lvl]), f, r.at(P.n1[j]), f, gA, lvl));               //   reads gA
         RC(conv_dgrad(r, c2, gA, nullptr, r.at(P.dskip[lvl]), lvl, 0, f));                 // d skip
-        RC(conv_dgrad(r, c2, gA, nullptr, gB, lvl, f, f));                                 // d n1
-        RC(bn_bwd(r, m->bn[m->up_bn(j, 0)], gB, r.at(P.u1[j]), lvl, gC));                  // dz up-conv
-        RC(conv_wgrad(r, cu, prev, Cprev, nullptr, 0, gC, lvl));
-        RC(conv_dgrad(r, cu, gC, nullptr, gA, lvl + 1, 0, Cprev));                         // d prev
+        RC(conv_dgrad(r, c2, gA, nullptr, gB, lvl, f, f));                                 // d n1 -> gB
+        RC(bn_bwd(r, m->bn[m->up_bn(j, 0)], gB, r.at(P.u1[j]), lvl, gC));                  // dz up-conv -> gC
+        RC(wgrad_join(r));                                                                 // gA is about to be written
+        RC(conv_wgrad(r, cu, prev, Cprev, nullptr, 0, gC, lvl));                           //   reads gC
+        RC(conv_dgrad(r, cu, gC, nullptr, gA, lvl + 1, 0, Cprev));                         // d prev -> gA
     }
     {   // bottom
         const Conv& c1 = m->conv[m->bot_c1()]; const Conv& c2 = m->conv[m->bot_c2()];
         const void* xin = D > 0 ? r.at(P.p[D - 1]) : r.at(P.xin);
         const int Cx = D > 0 ? m->F[D - 1] : m->cin_pad;
-        RC(bn_bwd(r, m->bn[m->bot_bn()], gA, r.at(P.c2b), D, gB));
-        RC(conv_wgrad(r, c2, r.at(P.c1b), m->F[D], nullptr, 0, gB, D));
+        RC(bn_bwd(r, m->bn[m->bot_bn()], gA, r.at(P.c2b), D, gB));                         // gC reader may still run: gB is free
+        RC(conv_wgrad_after_join(r, c2, r.at(P.c1b), m->F[D], nullptr, 0, gB, D));
         RC(conv_dgrad(r, c2, gB, r.at(P.c1b), gA, D, 0, m->F[D]));
-        RC(conv_wgrad(r, c1, xin, Cx, nullptr, 0, gA, D));
-        if (D > 0) RC(conv_dgrad(r, c1, gA, nullptr, gB, D, 0, Cx));                       // d pooled
+        RC(conv_wgrad_after_join(r, c1, xin, Cx, nullptr, 0, gA, D));
+        if (D > 0) RC(conv_dgrad(r, c1, gA, nullptr, gB, D, 0, Cx));                       // d pooled -> gB (gB reader joined above)
     }
     for (int i = D - 1; i >= 0; --i) {
         const Conv& c1 = m->conv[m->enc_c1(i)]; const Conv& c2 = m->conv[m->enc_c2(i)];
         const int H = m->cfg.H >> i, W = m->cfg.W >> i;
+        RC(wgrad_join(r));                                                                 // gA is about to be written
         RC(launch_maxpool_bwd_add(dt, r.at(P.n[i]), r.at(P.dskip[i]), gB, r.B, H, W, m->F[i], gA, r.st));
         RC(bn_bwd(r, m->bn[m->enc_bn(i)], gA, r.at(P.c2[i]), i, gB));
         RC(conv_wgrad(r, c2, r.at(P.c1[i]), m->F[i], nullptr, 0, gB, i));
         RC(conv_dgrad(r, c2, gB, r.at(P.c1[i]), gA, i, 0, m->F[i]));
         const void* xin = i > 0 ? r.at(P.p[i - 1]) : r.at(P.xin);
         const int Cx = i > 0 ? m->F[i - 1] : m->cin_pad;
-        RC(conv_wgrad(r, c1, xin, Cx, nullptr, 0, gA, i));
+        RC(conv_wgrad_after_join(r, c1, xin, Cx, nullptr, 0, gA, i));
         if (i > 0) RC(conv_dgrad(r, c1, gA, nullptr, gB, i, 0, Cx));
     }
-    return MPU_OK;
+    return wgrad_join(r);            // the gradient buffer is complete when the main stream continues
 }
 
 int make_run(Run& r, const mpu_unet* m, int batch, const float* params, const void* packed, float* state,
@@ -316,6 +361,13 @@ int make_run(Run& r, const mpu_unet* m, int batch, const float* params, const vo
     r.m = m; r.B = batch; r.st = (hipStream_t)stream; r.ws = (unsigned char*)ws; r.P = make_plan(m, batch);
     r.params = params; r.packed = (const unsigned char*)packed; r.state = state; r.grads = grads;
     r.esz = m->cfg.dtype == MPU_BF16 ? 2 : 4;
+    const char* ov = getenv("MPU_WGRAD_OVERLAP");
+    r.overlap = grads != nullptr && ov && ov[0] == '1';    // measured: no gain on MI355X (both kernels fill the chip); off by default
+    if (r.overlap && !m->side) {
+        MPU_CHECK_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+        MPU_CHECK_HIP(hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming));
+        MPU_CHECK_HIP(hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming));
+    }
     return MPU_OK;
 }
 
@@ -373,7 +425,11 @@ mpu_unet* mpu_unet_create(const mpu_unet_config* cfg) {
     return m;
 }
 
-void mpu_unet_destroy(mpu_unet* m) { delete m; }
+void mpu_unet_destroy(mpu_unet* m) {
+    if (!m) return;
+    if (m->side) { (void)hipStreamDestroy(m->side); (void)hipEventDestroy(m->ev_ready); (void)hipEventDestroy(m->ev_done); }
+    delete m;
+}
 
 int64_t mpu_unet_param_floats(const mpu_unet* m) { return m ? m->n_params : 0; }
 int64_t mpu_unet_bn_state_floats(const mpu_unet* m) { return m ? m->n_state : 0; }
@@ -454,7 +510,7 @@ int mpu_conv2d_igemm(int32_t dtype, int32_t mode, const void* d_in0, int32_t C0,
     ConvArgs a;
     a.in0 = d_in0; a.in1 = d_in1; a.C0 = C0; a.C1 = C1; a.w = d_w_packed; a.w_tap_stride = w_tap_stride;
     a.w_row_stride = w_row_stride; a.bias = d_bias; a.mask = d_mask; a.out = d_out;
-    a.B = B; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.relu = relu; a.flops = 0; a.w_elems = 0;
+    a.B = B; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.relu = relu; a.flops = 0; a.w_elems = 0; a.partial = nullptr; a.partial_cap = 0; a.ksplit = 1;
     return launch_conv(dtype, mode, a, (hipStream_t)stream);
 }
 

@@ -44,7 +44,10 @@ CASES = [
     (CONV3,   2, 16, 16, 64, 0, 64),
     (CONV3,   1, 12, 20, 8, 0, 72),        # ragged M / N, tiny Cin
     (CONV3,   2, 8, 8, 64, 64, 128),       # concat of two sources
-    (CONV3,   3, 32, 32, 128, 0, 136),     # 128-wide tiles with ragged N
+    (CONV3,   3, 32, 32, 128, 0, 136),     # 128-wide tiles with ragged N (LDS-resident patch kernel)
+    (CONV3,   2, 36, 40, 64, 64, 64),      # patch kernel: ragged H and W tiles, concat, 64-channel tile
+    (CONV3,   1, 64, 96, 72, 0, 40),       # patch kernel: channel tail (72 = 64 + 8), ragged N
+    (CONV3,   2, 8, 64, 192, 0, 128),      # patch kernel: three channel chunks (patch reloaded twice)
     (UPCONV2, 2, 16, 16, 128, 0, 64),
     (UPCONV2, 1, 8, 12, 72, 0, 40),
     (CONV1,   2, 16, 16, 64, 0, 8),
