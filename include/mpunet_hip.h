@@ -199,6 +199,12 @@ int     mpu_unet_tensor_info(const mpu_unet* m, int32_t idx, char* name, int32_t
  * Call after every change of d_params (set_weights, load_weights, Adam). */
 int mpu_unet_pack_weights(const mpu_unet* m, const float* d_params, void* d_packed, void* stream);
 
+/* Inference-mode BatchNormalization is folded into the producing convolutions: this computes the
+ * per-channel scale/shift (gamma, beta, moving statistics, epsilon 1e-3) into the tail of d_packed.
+ * Call after every change of d_params / d_bn_state and before mpu_unet_forward(training = 0). */
+int mpu_unet_prepare_inference(const mpu_unet* m, const float* d_params, const float* d_bn_state,
+                               void* d_packed, void* stream);
+
 /* model.predict_on_batch / the forward half of a Model.fit step
  * (mpunet/utils/fusion/fuse_and_predict.py:88, mpunet/train/trainer.py:246).
  *   d_x   f32 [B,H,W,n_channels] ; d_out f32 [B,H,W,n_classes] (probabilities or

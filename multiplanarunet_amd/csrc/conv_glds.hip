@@ -91,7 +91,7 @@ template <typename T, int BN, int BM>
 struct GldsCfg {
     static constexpr int STAGE = (BN + BM) * 128;
     static constexpr int OROW = BN * (int)sizeof(T) + 16;
-    static constexpr int EPI = BM * OROW + BN * 4;
+    static constexpr int EPI = BM * OROW + 3 * BN * 4;
     // three stages (prefetch distance 2) only where three workgroups still fit one CU's 160 KiB:
     // measured, workgroups per CU matter more than prefetch depth (64x128: 2 stages/3 WGs 42.9 us
     // vs 3 stages/2 WGs 52.1 us on the 64-filter full-resolution layer)
@@ -268,7 +268,12 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
     // epilogue (same as conv_igemm_kernel): bias -> LDS, tile -> LDS, coalesced 16-byte row stores
     constexpr int OROW = Cfg::OROW;
     float* sbias = (float*)(smem + BM * OROW);
-    if (tid < BN) sbias[tid] = (a.bias && n0 + tid < a.Cout) ? a.bias[n0 + tid] : 0.f;
+    if (tid < BN) {
+        const bool nv = n0 + tid < a.Cout;
+        sbias[tid] = (a.bias && nv) ? a.bias[n0 + tid] : 0.f;
+        sbias[BN + tid] = (a.post_scale && nv) ? a.post_scale[n0 + tid] : 1.f;
+        sbias[2 * BN + tid] = (a.post_scale && nv) ? a.post_shift[n0 + tid] : 0.f;
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -284,6 +289,11 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
                 if (a.relu) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (a.post_scale) {
+                    const float4 sq = *(const float4*)(sbias + BN + nl), hq = *(const float4*)(sbias + 2 * BN + nl);
+                    v[0] = v[0] * sq.x + hq.x; v[1] = v[1] * sq.y + hq.y;
+                    v[2] = v[2] * sq.z + hq.z; v[3] = v[3] * sq.w + hq.w;
                 }
                 unsigned char* dst = smem + ml * OROW + nl * (int)sizeof(T);
                 if (sizeof(T) == 2) {
@@ -334,7 +344,8 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ partial, int ks, long M, int Cout,
                                                             const float* __restrict__ bias, const T* __restrict__ mask,
-                                                            int relu, T* __restrict__ out) {
+                                                            int relu, const float* __restrict__ ps,
+                                                            const float* __restrict__ ph, T* __restrict__ out) {
     constexpr int EPC = 16 / sizeof(T);
     const long total = M * Cout / EPC, stride = M * Cout;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -352,6 +363,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < EPC; ++k) {
             if (relu) v[k] = fmaxf(v[k], 0.f);
+            if (ps) v[k] = v[k] * ps[n + k] + ph[n + k];
             if (mask && !(to_f32<T>(mask[e * EPC + k]) > 0.f)) v[k] = 0.f;
             out[e * EPC + k] = from_f32<T>(v[k]);
         }
@@ -388,7 +400,7 @@ static int launch_glds_cfg(const ConvArgs& a_in, hipStream_t st) {
         long work = M * a.Cout / (16 / (long)sizeof(T));
         long blocks = (work + 255) / 256; if (blocks > 4096) blocks = 4096;
         splitk_finish_kernel<T><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
-                                                                  a.relu, (T*)a.out);
+                                                                  a.relu, a.post_scale, a.post_shift, (T*)a.out);
         rc = launch_ok();
     }
     if (prof_on()) prof_end(st);

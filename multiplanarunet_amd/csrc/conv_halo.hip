@@ -55,7 +55,7 @@ struct HaloCfg {
     static constexpr int WSTAGE = BN * 128, NWS = NWS_;
     static constexpr int BM = TH * TW;
     static constexpr int OROW = BN * (int)sizeof(T) + 16;
-    static constexpr int EPI = BM * OROW + BN * 4;
+    static constexpr int EPI = BM * OROW + 3 * BN * 4;
     static constexpr int MAIN = PATCH + NWS * WSTAGE;
     static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
 };
@@ -212,7 +212,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
     // --- epilogue: bias -> LDS, tile -> LDS, coalesced 16-byte row stores ------------------
     constexpr int OROW = Cfg::OROW;
     float* sbias = (float*)(smem + BM * OROW);
-    if (tid < BN) sbias[tid] = (a.bias && n0 + tid < a.Cout) ? a.bias[n0 + tid] : 0.f;
+    if (tid < BN) {
+        const bool nv = n0 + tid < a.Cout;
+        sbias[tid] = (a.bias && nv) ? a.bias[n0 + tid] : 0.f;
+        sbias[BN + tid] = (a.post_scale && nv) ? a.post_scale[n0 + tid] : 1.f;
+        sbias[2 * BN + tid] = (a.post_scale && nv) ? a.post_shift[n0 + tid] : 0.f;
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -228,6 +233,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
                 if (a.relu) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (a.post_scale) {
+                    const float4 sq = *(const float4*)(sbias + BN + nl), hq = *(const float4*)(sbias + 2 * BN + nl);
+                    v[0] = v[0] * sq.x + hq.x; v[1] = v[1] * sq.y + hq.y;
+                    v[2] = v[2] * sq.z + hq.z; v[3] = v[3] * sq.w + hq.w;
                 }
                 unsigned char* dst = smem + ml * OROW + nl * (int)sizeof(T);
                 if (sizeof(T) == 2) {

@@ -13,6 +13,8 @@ struct ConvArgs {
     int B, Ho, Wo, Cout, relu;
     double flops;                // algorithmic FLOPs of this launch (profiling only; 0 = derive)
     long w_elems;                // elements addressable from `w` (0 = derive from strides)
+    const float* post_scale;     // optional per-channel affine applied AFTER bias/ReLU (inference-mode
+    const float* post_shift;     //   BatchNormalization folded into the producing conv); NULL = none
     float* partial;              // split-K scratch [ksplit][M][Cout] f32 (NULL = never split)
     long partial_cap;            // floats available at `partial`
     int ksplit;                  // set by the launcher
@@ -63,6 +65,8 @@ int launch_bn_stats(int dtype, const void* x, long M, int C, float* partial,
 int launch_bn_infer_coeffs(const float* gamma, const float* beta, const float* moving_mean,
                            const float* moving_var, int C, float eps, float* scale, float* shift, hipStream_t st);
 // y = x*scale + shift (and optionally 2x2 max-pool of y)
+// 2x2/stride-2 max pooling (inference path; training pools inside bn_apply)
+int launch_maxpool(int dtype, const void* x, int B, int H, int W, int C, void* pooled, hipStream_t st);
 int launch_bn_apply(int dtype, const void* x, int B, int H, int W, int C, const float* scale,
                     const float* shift, void* y, void* pooled, hipStream_t st);
 // BN backward: dgamma, dbeta and dz = (x>0) * d(x) where x is the post-ReLU BN input

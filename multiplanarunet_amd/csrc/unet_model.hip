@@ -38,6 +38,7 @@ struct mpu_unet {
     std::vector<BN> bn;
     std::vector<Tensor> tensors;
     long n_params = 0, n_state = 0, n_packed = 0, n_stats = 0, n_logical = 0;
+    long infer_off = 0;                      // byte offset of the inference BN coefficients inside the packed buffer
     int head_C = 0; long head_w = 0, head_b = 0;
     int cmax = 0;
     // backward-pass concurrency: weight gradients run on a side stream next to the data gradients
@@ -182,10 +183,12 @@ double conv_flops(const Run& r, const Conv& c, int lvl, int n_cnt_logical = -1) 
     return 2.0 * M * taps * c.lCin * c.lCout;
 }
 
-int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* in1, int C1, void* out, int lvl) {
+int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* in1, int C1, void* out, int lvl,
+             const float* post_scale = nullptr, const float* post_shift = nullptr) {
     ConvArgs a;
     a.flops = conv_flops(r, c, lvl); a.w_elems = 0;
     a.partial = r.overlap ? nullptr : (float*)r.at(r.P.wpartial); a.partial_cap = r.P.wpartial_floats; a.ksplit = 1;
+    a.post_scale = post_scale; a.post_shift = post_shift;
     a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1;
     a.w = r.wf(c); a.w_tap_stride = (long)c.Cin * c.Cout; a.w_row_stride = c.Cin;
     a.bias = r.params + c.b; a.mask = nullptr; a.out = out;
@@ -199,6 +202,7 @@ int conv_dgrad(const Run& r, const Conv& c, const void* dz, const void* mask, vo
     ConvArgs a;
     a.in0 = dz; a.in1 = nullptr; a.C0 = c.Cout; a.C1 = 0; a.w_elems = 0;
     a.partial = r.overlap ? nullptr : (float*)r.at(r.P.wpartial); a.partial_cap = r.P.wpartial_floats; a.ksplit = 1;
+    a.post_scale = nullptr; a.post_shift = nullptr;
     a.w = (const unsigned char*)r.wd(c) + (long)n_off * c.Cout * r.esz;
     a.w_tap_stride = (long)c.Cin * c.Cout; a.w_row_stride = c.Cout;
     a.bias = nullptr; a.mask = mask; a.out = out;
@@ -266,7 +270,45 @@ int bn_bwd(const Run& r, const BN& b, const void* dn, const void* x, int lvl, vo
 
 #define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
+// inference: BatchNormalization (moving statistics) is a per-channel affine after the ReLU; it is applied in
+// the epilogue of the producing conv (coefficients from mpu_unet_prepare_inference), so no BN kernel runs.
+int run_forward_infer(const Run& r, const float* d_x, float* d_out) {
+    const mpu_unet* m = r.m; const int D = m->cfg.depth; const Plan& P = r.P;
+    const int dt = m->cfg.dtype;
+    const long M0 = (long)r.B * m->cfg.H * m->cfg.W;
+    const float* co = (const float*)(r.packed + m->infer_off);
+    auto sc = [&](const BN& b) { return co + b.st + 2L * b.C; };
+    auto sh = [&](const BN& b) { return co + b.st + 3L * b.C; };
+    RC(launch_cast_pad(dt, d_x, M0, m->cfg.n_channels, m->cin_pad, r.at(P.xin), r.st));
+    const void* cur = r.at(P.xin); int Ccur = m->cin_pad;
+    for (int i = 0; i < D; ++i) {
+        const BN& b = m->bn[m->enc_bn(i)];
+        RC(conv_fwd(r, m->conv[m->enc_c1(i)], cur, Ccur, nullptr, 0, r.at(P.c1[i]), i));
+        RC(conv_fwd(r, m->conv[m->enc_c2(i)], r.at(P.c1[i]), m->F[i], nullptr, 0, r.at(P.n[i]), i, sc(b), sh(b)));
+        RC(launch_maxpool(dt, r.at(P.n[i]), r.B, m->cfg.H >> i, m->cfg.W >> i, m->F[i], r.at(P.p[i]), r.st));
+        cur = r.at(P.p[i]); Ccur = m->F[i];
+    }
+    {
+        const BN& b = m->bn[m->bot_bn()];
+        RC(conv_fwd(r, m->conv[m->bot_c1()], cur, Ccur, nullptr, 0, r.at(P.c1b), D));
+        RC(conv_fwd(r, m->conv[m->bot_c2()], r.at(P.c1b), m->F[D], nullptr, 0, r.at(P.nb), D, sc(b), sh(b)));
+    }
+    const void* prev = r.at(P.nb); int Cprev = m->F[D];
+    for (int j = 0; j < D; ++j) {
+        const int lvl = D - 1 - j, f = m->F[lvl];
+        const BN& b1 = m->bn[m->up_bn(j, 0)]; const BN& b2 = m->bn[m->up_bn(j, 1)];
+        RC(conv_fwd(r, m->conv[m->up_c(j, 0)], prev, Cprev, nullptr, 0, r.at(P.n1[j]), lvl, sc(b1), sh(b1)));
+        RC(conv_fwd(r, m->conv[m->up_c(j, 1)], r.at(P.n[lvl]), f, r.at(P.n1[j]), f, r.at(P.c2u[j]), lvl));
+        RC(conv_fwd(r, m->conv[m->up_c(j, 2)], r.at(P.c2u[j]), f, nullptr, 0, r.at(P.n2[j]), lvl, sc(b2), sh(b2)));
+        prev = r.at(P.n2[j]); Cprev = f;
+    }
+    float* out = d_out ? d_out : (float*)r.at(P.probs);
+    return launch_head_forward(dt, prev, M0, m->head_C, m->cfg.n_classes, r.params + m->head_w, m->cfg.n_classes,
+                               r.params + m->head_b, m->cfg.softmax, out, r.st);
+}
+
 int run_forward(const Run& r, const float* d_x, int training, float* d_out) {
+    if (!training) return run_forward_infer(r, d_x, d_out);
     const mpu_unet* m = r.m; const int D = m->cfg.depth; const Plan& P = r.P;
     const long M0 = (long)r.B * m->cfg.H * m->cfg.W;
     RC(launch_cast_pad(m->cfg.dtype, d_x, M0, m->cfg.n_channels, m->cin_pad, r.at(P.xin), r.st));
@@ -422,6 +464,7 @@ mpu_unet* mpu_unet_create(const mpu_unet_config* cfg) {
         snprintf(buf, sizeof(buf), "upsample_L%d_BN1", j); add_bn(m, buf, m->F[lvl], m->Fl[lvl]);
         snprintf(buf, sizeof(buf), "upsample_L%d_BN2", j); add_bn(m, buf, m->F[lvl], m->Fl[lvl]);
     }
+    m->infer_off = (m->n_packed * (cfg->dtype == MPU_BF16 ? 2 : 4) + 255) / 256 * 256;
     return m;
 }
 
@@ -433,7 +476,10 @@ void mpu_unet_destroy(mpu_unet* m) {
 
 int64_t mpu_unet_param_floats(const mpu_unet* m) { return m ? m->n_params : 0; }
 int64_t mpu_unet_bn_state_floats(const mpu_unet* m) { return m ? m->n_state : 0; }
-int64_t mpu_unet_packed_bytes(const mpu_unet* m) { return m ? m->n_packed * (m->cfg.dtype == MPU_BF16 ? 2 : 4) : 0; }
+int64_t mpu_unet_packed_bytes(const mpu_unet* m) {
+    if (!m) return 0;
+    return m->infer_off + m->n_stats * 4;      // MFMA operands, then scale/shift of every BN for inference
+}
 int64_t mpu_unet_logical_param_count(const mpu_unet* m) { return m ? m->n_logical : 0; }
 int32_t mpu_unet_num_tensors(const mpu_unet* m) { return m ? (int32_t)m->tensors.size() : 0; }
 
@@ -462,6 +508,16 @@ int mpu_unet_pack_weights(const mpu_unet* m, const float* d_params, void* d_pack
                                (unsigned char*)d_packed + c.wf * esz, (unsigned char*)d_packed + c.wd * esz,
                                (hipStream_t)stream));
     }
+    return MPU_OK;
+}
+
+int mpu_unet_prepare_inference(const mpu_unet* m, const float* d_params, const float* d_bn_state, void* d_packed,
+                                void* stream) {
+    MPU_REQUIRE(m && d_params && d_bn_state && d_packed, "mpu_unet_prepare_inference: null argument");
+    float* co = (float*)((unsigned char*)d_packed + m->infer_off);
+    for (const BN& b : m->bn)
+        RC(launch_bn_infer_coeffs(d_params + b.g, d_params + b.b, d_bn_state + b.mm, d_bn_state + b.mv, b.C, BN_EPS,
+                                  co + b.st + 2L * b.C, co + b.st + 3L * b.C, (hipStream_t)stream));
     return MPU_OK;
 }
 
@@ -511,6 +567,7 @@ int mpu_conv2d_igemm(int32_t dtype, int32_t mode, const void* d_in0, int32_t C0,
     a.in0 = d_in0; a.in1 = d_in1; a.C0 = C0; a.C1 = C1; a.w = d_w_packed; a.w_tap_stride = w_tap_stride;
     a.w_row_stride = w_row_stride; a.bias = d_bias; a.mask = d_mask; a.out = d_out;
     a.B = B; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.relu = relu; a.flops = 0; a.w_elems = 0; a.partial = nullptr; a.partial_cap = 0; a.ksplit = 1;
+    a.post_scale = nullptr; a.post_shift = nullptr;
     return launch_conv(dtype, mode, a, (hipStream_t)stream);
 }
 

@@ -341,6 +341,33 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, int B, int H, int W, int C, T* __restrict__ pooled) {
+    constexpr int N = Vec<T>::N;
+    const int cpr = C / N, Hp = H / 2, Wp = W / 2;
+    const long total = (long)B * Hp * Wp * cpr;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % cpr); long t = e / cpr;
+        const int px = (int)(t % Wp); t /= Wp;
+        const int py = (int)(t % Hp); const int b = (int)(t / Hp);
+        float mx[N];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float v[N];
+            Vec<T>::load(x + ((((long)b * H + 2 * py + (d >> 1)) * W + 2 * px + (d & 1)) * cpr + c) * N, v);
+#pragma unroll
+            for (int i = 0; i < N; ++i) mx[i] = d == 0 ? v[i] : fmaxf(mx[i], v[i]);
+        }
+        Vec<T>::store(pooled + e * N, mx);
+    }
+}
+int launch_maxpool(int dtype, const void* x, int B, int H, int W, int C, void* pooled, hipStream_t st) {
+    const long work = (long)B * (H / 2) * (W / 2) * C / 8;
+    if (dtype == MPU_BF16) maxpool_kernel<bf16_t><<<ew_grid(work), 256, 0, st>>>((const bf16_t*)x, B, H, W, C, (bf16_t*)pooled);
+    else maxpool_kernel<float><<<ew_grid(work), 256, 0, st>>>((const float*)x, B, H, W, C, (float*)pooled);
+    return launch_ok();
+}
+
 int launch_bn_apply(int dtype, const void* x, int B, int H, int W, int C, const float* scale, const float* shift,
                     void* y, void* pooled, hipStream_t st) {
     const long work = (long)B * H * W * C / 8 / (pooled ? 4 : 1);

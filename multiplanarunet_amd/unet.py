@@ -263,6 +263,7 @@ class UNet:
         return int(sum(int(np.prod(ls)) for (_, _, _, ls) in self._tensors.values()))
 
     def _repack(self):
+        self._infer_dirty = True
         if self.device.type != "cuda":
             return          # host-only introspection (layout, weight I/O); nothing can run without a GPU
         _lib.call("mpu_unet_pack_weights", self._h, _lib.ptr(self.params), _lib.ptr(self.packed),
@@ -290,6 +291,12 @@ class UNet:
         B = X.shape[0]
         # the workspace layout depends on the batch it was planned for
         ws = self._workspace_exact(B)
+        if training:
+            self._infer_dirty = True               # the moving statistics are about to change
+        elif getattr(self, "_infer_dirty", True):
+            _lib.call("mpu_unet_prepare_inference", self._h, _lib.ptr(self.params), _lib.ptr(self.bn_state),
+                      _lib.ptr(self.packed), _lib.stream_ptr())
+            self._infer_dirty = False
         if out is None:
             out = torch.empty((B, self.img_shape[0], self.img_shape[1], self.n_classes),
                               dtype=torch.float32, device=self.device)

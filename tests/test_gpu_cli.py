@@ -12,7 +12,7 @@ def test_mp_train_then_predict_synthetic(tmp_path):
     proj.mkdir()
     (proj / "train_hparams.yaml").write_text(
         "build:\n  model_class_name: UNet\n  n_classes: 3\n  n_channels: 1\n  dim: 64\n  depth: 3\n"
-        "  complexity_factor: 0.0625\n  out_activation: softmax\n"
+        "  complexity_factor: 0.0625\n  out_activation: softmax\n  seed: 0\n"
         "fit:\n  views: 3\n  noise_sd: 0.1\n  real_space_span: 64.0\n  batch_size: 8\n  n_epochs: 2\n"
         "  optimizer: Adam\n  optimizer_kwargs: {lr: 1.0e-3, decay: 0.0, beta_1: 0.9, beta_2: 0.999, epsilon: 1.0e-8}\n"
         "  loss: SparseCategoricalCrossentropy\n  fg_batch_fraction: 0.5\n  bg_value: 1pct\n  scaler: RobustScaler\n")
