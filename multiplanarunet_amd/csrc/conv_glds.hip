@@ -481,10 +481,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_glds_kernel(WgradArgs a) {
     const int wi = wave & 1, wj = wave >> 1;
     const int Cin = a.C0 + a.C1;
     const int tiles_co = (a.Cout + BCO - 1) / BCO;
-    const int ci0 = (blockIdx.x / tiles_co) * BCI, co0 = (blockIdx.x % tiles_co) * BCO;
-    const int tap = blockIdx.y, ky = tap / KW, kx = tap % KW;
+    // XCD-aware decode of the 1-D grid: all taps (and tiles) of one pixel chunk z run on ONE XCD
+    // (workgroup g is dispatched to XCD g % 8), back to back, so x and dZ of the chunk are fetched
+    // from HBM once and re-read from that XCD's L2 by the other taps (PMC: 9x less FETCH_SIZE).
+    constexpr int NTAPS_ = GModeTraits<MODE>::NTAPS;
+    const int ntile = tiles_co * ((Cin + BCI - 1) / BCI);
+    // locality unit = (pixel chunk z, output tile): its taps sit on one XCD, units are dealt round-robin
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tap = slot % NTAPS_, unit = (slot / NTAPS_) * 8 + xcd;
+    if (unit >= a.ksplit * ntile) return;
+    const int tile = unit % ntile, zsplit = unit / ntile;
+    const int ci0 = (tile / tiles_co) * BCI, co0 = (tile % tiles_co) * BCO;
+    const int ky = tap / KW, kx = tap % KW;
     const long M = (long)a.B * a.Ho * a.Wo;
-    const long mbeg = (long)blockIdx.z * a.mchunk;
+    const long mbeg = (long)zsplit * a.mchunk;
     const long mend = (mbeg + a.mchunk < M) ? mbeg + a.mchunk : M;
     const int Hi = g_in_h<MODE>(a.Ho), Wi = g_in_h<MODE>(a.Wo);
     constexpr unsigned OOB = 0xfffffff0u;
@@ -606,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_glds_kernel(WgradArgs a) {
     // thread -> 16-byte channel chunk (tid % CPZ) of rows (tid / CPZ) + k * (256 / CPZ)
     constexpr int CPZ = RZ / 16;
     const int tiles_ci = (Cin + BCI - 1) / BCI;
-    const int nshare = (int)gridDim.y * tiles_ci, share = tap * tiles_ci + (int)(blockIdx.x / tiles_co);
+    const int nshare = NTAPS_ * tiles_ci, share = tap * tiles_ci + (tile / tiles_co);
     float dbacc[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) dbacc[e] = 0.f;
@@ -649,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_glds_kernel(WgradArgs a) {
             st = st == 2 ? 0 : st + 1;
         }
     }
-    float* P = a.partial + ((long)blockIdx.z * gridDim.y + tap) * (long)Cin * a.Cout;
+    float* P = a.partial + ((long)zsplit * NTAPS_ + tap) * (long)Cin * a.Cout;
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -671,7 +681,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_glds_kernel(WgradArgs a) {
             float s = 0.f;
             for (int k = 0; k < 256 / CPZ; ++k) s += red[(c + k * CPZ) * EPC + e];
             if (co0 + tid < a.Cout)
-                a.db_partial[((long)blockIdx.z * nshare + share) * a.Cout + co0 + tid] = s;
+                a.db_partial[((long)zsplit * nshare + share) * a.Cout + co0 + tid] = s;
         }
     }
 }
@@ -699,12 +709,14 @@ static int try_wgrad_glds_mode(const WgradArgs& a, hipStream_t st) {
     if constexpr (sizeof(T) == 2) big = Cin >= 128 && a.Cout >= 128 && (a.C1 == 0 || a.C0 % 128 == 0);
     if (big) {
         if constexpr (sizeof(T) == 2) {
-            dim3 g((unsigned)(cdiv(Cin, 128) * cdiv(a.Cout, 128)), ntaps, a.ksplit);
-            wgrad_glds_kernel<T, MODE, 128, 128><<<g, dim3(256), 0, st>>>(a);
+            const long units = (long)a.ksplit * cdiv(Cin, 128) * cdiv(a.Cout, 128);
+            const long g = 8 * ((units + 7) / 8) * ntaps;
+            wgrad_glds_kernel<T, MODE, 128, 128><<<dim3((unsigned)g), dim3(256), 0, st>>>(a);
         }
     } else {
-        dim3 g((unsigned)(cdiv(Cin, 64) * cdiv(a.Cout, 64)), ntaps, a.ksplit);
-        wgrad_glds_kernel<T, MODE, 64, 64><<<g, dim3(256), 0, st>>>(a);
+        const long units = (long)a.ksplit * cdiv(Cin, 64) * cdiv(a.Cout, 64);
+        const long g = 8 * ((units + 7) / 8) * ntaps;
+        wgrad_glds_kernel<T, MODE, 64, 64><<<dim3((unsigned)g), dim3(256), 0, st>>>(a);
     }
     int rc = launch_ok();
     return rc ? rc : 1;

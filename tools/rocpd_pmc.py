@@ -19,7 +19,7 @@ by = defaultdict(dict)
 for n, c, v, k, t in rows:
     by[re.sub(r"\(.*", "", n).replace("_ZN3mpu", "")][c] = (v, k, t)
 for n, d in sorted(by.items(), key=lambda kv: -max(x[2] for x in kv[1].values())):
-    if "igemm" not in n and len(sys.argv) < 3: continue
+    if not any(k in n for k in ("igemm", "conv_", "wgrad_")) and len(sys.argv) < 3: continue
     k = max(x[1] for x in d.values()); t = max(x[2] for x in d.values())
     print("%s  (%d dispatches, %.1f us avg)" % (n[:100], k, t / k / 1e3))
     print("    " + "  ".join("%s=%.4g" % (c, v[0] / k) for c, v in sorted(d.items())))
