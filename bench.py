@@ -142,12 +142,21 @@ def main():
                        "algorithmic_gflop_per_slice": round(gf_slice, 2)},
             "step_tflops_algorithmic": round(gf_slice * B * world / 1e3 / (ms_step / 1e3), 1),
         }
+        traffic = {}
+        try:   # HBM bytes per launch from the rocprofv3 PMC passes of this round (profiles/, see its note)
+            tfile = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic_pmc.json"))[-1]
+            with open(os.path.join(ROOT, "profiles", tfile)) as f:
+                traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["classes"].items()}
+            out["config"]["traffic_source"] = "profiles/" + tfile
+        except Exception:
+            pass
         if events:
             def leg(name):
                 ms, fl, n = roof[name]
                 ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
                 return {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                        "traffic": round(traffic[name]) if name in traffic else None,
                         "launches_per_step": n // max(args.steps, 1),
                         "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
                         "kernel_ms_per_step": round(ms / args.steps, 4),
