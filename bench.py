@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--predict-only", action="store_true", help="only the 6-view predict+fuse leg (profiling aid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a HIP graph")
     args = ap.parse_args()
 
     from multiplanarunet_amd import distributed as D
@@ -104,14 +105,31 @@ def main():
         step()
     lib = _lib.load()
     events = not args.no_kernel_events
-    barrier()
-    if events:
-        lib.mpu_profile_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    # N=1: the whole step (fwd + bwd + Adam + repack, ~260 launches) is replayed from one HIP graph; the
+    # per-launch HIP events of the roofline leg need eager launches, so they are taken over a second region
+    # of the same K steps right after (same kernels, same arguments). N>1 keeps eager launches (RCCL between).
+    graphed = world == 1 and not args.no_graph
+    dt_eager = None
+    if graphed:
+        replay = model.make_graphed_train_step(x, y, sw)
+        replay()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            replay()
+        barrier()
+        dt = time.perf_counter() - t0
+    if events or not graphed:
+        barrier()
+        if events:
+            lib.mpu_profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt_eager = time.perf_counter() - t0
+        if not graphed:
+            dt = dt_eager
     roof = {}
     if events:
         import ctypes as C
@@ -139,9 +157,12 @@ def main():
                                    "%d slices of %dx%dx1 per GPU, 3 classes, Adam + sparse CE (BASELINE.json configs[1])"
                                    % (B, dim, dim),
                        "slices_per_gpu": B, "parallelism": "dp%d" % world,
+                       "launch": "hip-graph replay" if graphed else "eager",
                        "algorithmic_gflop_per_slice": round(gf_slice, 2)},
             "step_tflops_algorithmic": round(gf_slice * B * world / 1e3 / (ms_step / 1e3), 1),
         }
+        if graphed and dt_eager is not None:
+            out["ms_per_step_eager_with_events"] = round(dt_eager / args.steps * 1e3, 4)
         traffic = {}
         try:   # HBM bytes per launch from the rocprofv3 PMC passes of this round (profiles/, see its note)
             tfile = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic_pmc.json"))[-1]

@@ -232,6 +232,12 @@ int mpu_unet_backward(const mpu_unet* m, int32_t batch, const uint8_t* d_y,
 int mpu_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n,
                   int64_t t, double lr, double beta1, double beta2, double eps, void* stream);
 
+/* Same update with the step count t-1 held in device memory (*d_step, incremented by the call): the form a
+ * captured HIP graph can replay, since every replay must see a new bias-correction factor. */
+int mpu_adam_step_device_counter(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n,
+                                 int64_t* d_step, double lr, double beta1, double beta2, double eps,
+                                 void* stream);
+
 /* Single-layer entry points (unit tests / layer-wise integration). Channels
  * must be multiples of 8. d_w is the fp32 Keras HWIO kernel; d_w_dgrad may be
  * NULL; sizes: fwd taps*Cin*Cout elements, dgrad 9*Cin*Cout elements.

@@ -91,6 +91,8 @@ int launch_head_backward(int dtype, const void* n, const float* probs, const uin
                          const float* Wh, int ldw, float* partial, void* dn, float* dWh, float* dbh,
                          float* loss, hipStream_t st);
 
+int launch_adam_dev(float* p, const float* g, float* m, float* v, long n, long long* step, double lr, double b1,
+                    double b2, float eps, hipStream_t st);
 int launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha, float b1, float b2,
                 float eps, hipStream_t st);
 

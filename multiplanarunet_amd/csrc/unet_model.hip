@@ -547,6 +547,12 @@ int mpu_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v,
                        (hipStream_t)stream);
 }
 
+int mpu_adam_step_device_counter(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n,
+                                 int64_t* d_step, double lr, double beta1, double beta2, double eps, void* stream) {
+    MPU_REQUIRE(d_params && d_grads && d_m && d_v && d_step && n >= 0, "mpu_adam_step_device_counter: bad argument");
+    return launch_adam_dev(d_params, d_grads, d_m, d_v, n, (long long*)d_step, lr, beta1, beta2, (float)eps, (hipStream_t)stream);
+}
+
 // ---- op-level entry points (unit tests, integration of single layers) ------
 int mpu_conv2d_pack_weights(int32_t dtype, int32_t mode, const float* d_w, int32_t Cin, int32_t Cout,
                             void* d_w_fwd, void* d_w_dgrad, void* stream) {

@@ -714,6 +714,30 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         p[e] = p[e] - (mm * alpha) / (sqrtf(vv) + eps);
     }
 }
+// graph-replayable variant: the 1-based step count lives in device memory (a captured launch cannot take a
+// new host-computed step size on every replay)
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, long n, const long long* __restrict__ step, double lr,
+                                double b1d, double b2d, float eps) {
+    const double t = (double)(*step + 1);
+    const float alpha = (float)(lr * sqrt(1.0 - pow(b2d, t)) / (1.0 - pow(b1d, t)));
+    const float b1 = (float)b1d, b2 = (float)b2d;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const float gg = g[e];
+        const float mm = m[e] + (gg - m[e]) * (1.f - b1);
+        const float vv = v[e] + (gg * gg - v[e]) * (1.f - b2);
+        m[e] = mm; v[e] = vv;
+        p[e] = p[e] - (mm * alpha) / (sqrtf(vv) + eps);
+    }
+}
+__global__ void incr_step_kernel(long long* step) { *step += 1; }
+int launch_adam_dev(float* p, const float* g, float* m, float* v, long n, long long* step, double lr, double b1,
+                    double b2, float eps, hipStream_t st) {
+    adam_dev_kernel<<<ew_grid(n), 256, 0, st>>>(p, g, m, v, n, step, lr, b1, b2, eps);
+    incr_step_kernel<<<1, 1, 0, st>>>(step);
+    return launch_ok();
+}
+
 int launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha, float b1, float b2, float eps,
                 hipStream_t st) {
     adam_kernel<<<ew_grid(n), 256, 0, st>>>(p, g, m, v, n, alpha, b1, b2, eps);

@@ -388,6 +388,47 @@ class UNet:
                   float(k["beta_1"]), float(k["beta_2"]), float(k["epsilon"]), _lib.stream_ptr())
         self._repack()
 
+    # ---- HIP-graph replay of the whole step (launch-bound regime) ---------------------------------
+    def make_graphed_train_step(self, x, y, sample_weight=None):
+        """
+        Capture forward + backward + Adam + repack (~260 kernel launches) into one HIP graph that reads the
+        given DEVICE tensors x, y, sample_weight in place; returns replay() which runs one train step per
+        call. Single-GPU only (the RCCL all-reduce stays eager). The Adam step count lives on the device.
+        """
+        if self._grad_hook is not None:
+            raise NotImplementedError("graphed train step is single-GPU (gradient all-reduce is eager)")
+        for t in (x, y):
+            if not torch.is_tensor(t) or t.device.type != "cuda":
+                raise ValueError("graphed train step needs device tensors")
+        self._ensure_adam()
+        step_dev = torch.tensor([self.iterations], dtype=torch.int64, device=self.device)
+        k = self.optimizer_kwargs
+
+        def body():
+            self.forward_backward(x, y, sample_weight, want_loss=False)
+            _lib.call("mpu_adam_step_device_counter", _lib.ptr(self.params), _lib.ptr(self.grads),
+                      _lib.ptr(self._adam_m), _lib.ptr(self._adam_v), self.params.numel(), _lib.ptr(step_dev),
+                      float(k["lr"]), float(k["beta_1"]), float(k["beta_2"]), float(k["epsilon"]), _lib.stream_ptr())
+            self._repack()
+
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                   # warm-up outside capture (lazy inits, allocations)
+            body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body()
+        self.iterations += 1                            # the warm-up step
+
+        def replay():
+            graph.replay()
+            self.iterations += 1
+            self._infer_dirty = True
+        replay.graph = graph
+        return replay
+
     def train_step(self, x, y, sample_weight=None, want_loss=True):
         """One Model.fit inner step. Returns the per-pixel loss [B,H*W] (device) or None."""
         _, loss = self.forward_backward(x, y, sample_weight, want_loss)

@@ -180,3 +180,24 @@ def test_training_reduces_loss_bf16():
     for _ in range(30):
         last = m.train_on_batch(x, y.reshape(B, -1, 1))
     assert last < 0.6 * first, (first, last)
+
+
+def test_graphed_train_step_matches_eager():
+    """HIP-graph replay of the step (device-side Adam step counter) == the eager step, bit for bit."""
+    from multiplanarunet_amd.unet import UNet
+    rng = np.random.RandomState(3)
+    B, H = 4, 32
+    x = torch.tensor(rng.randn(B, H, H, 1).astype(np.float32), device="cuda")
+    y = torch.tensor(rng.randint(0, 3, (B, H * H, 1)).astype(np.uint8), device="cuda")
+    sw = torch.ones(B, device="cuda")
+    a = UNet(n_classes=3, dim=H, depth=2, complexity_factor=0.25, dtype="bf16", logger=quiet, seed=0)
+    b = UNet(n_classes=3, dim=H, depth=2, complexity_factor=0.25, dtype="bf16", logger=quiet, seed=0)
+    for _ in range(4):
+        a.train_step(x, y, sw, want_loss=False)
+    replay = b.make_graphed_train_step(x, y, sw)       # performs step 1 while warming up
+    for _ in range(3):
+        replay()
+    torch.cuda.synchronize()
+    assert b.iterations == a.iterations == 4
+    assert torch.equal(a.params, b.params) and torch.equal(a.bn_state, b.bn_state)
+    assert torch.equal(a.predict_on_batch(x), b.predict_on_batch(x))
