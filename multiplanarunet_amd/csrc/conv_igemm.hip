@@ -21,6 +21,7 @@
 // operands, which leaves the dot product unchanged.
 #include <stdlib.h>
 #include "kernels.h"
+#include "reduce.h"
 
 namespace mpu {
 
@@ -446,13 +447,71 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradArgs a) {
         }
 }
 
-// second stage: dW[e] = sum_s partial[s][e]  (fixed order: deterministic)
+// second stage: dW[e] = sum_s partial[s][e]  (fixed order: deterministic); 16-B loads, 4 splits in flight
+// Blocks past `main_blocks` finish the fused bias gradient (db = sum of the wgrad kernel's column-sum partials).
+struct DbFin { const float* partial; float* db; int nshare, C, main_blocks; };
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int ksplit, long n,
-                                                           float* __restrict__ dW) {
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < ksplit; ++k) s += partial[(long)k * n + e];
-        dW[e] = s;
+                                                           float* __restrict__ dW, DbFin f) {
+    if ((int)blockIdx.x >= f.main_blocks) {
+        __shared__ double dred[256];
+        colsum_finalize_block((int)blockIdx.x - f.main_blocks, f.partial, f.nshare, f.C, f.db, dred);
+        return;
+    }
+    const long n4 = n >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(partial);
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)f.main_blocks * 256) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = 0;
+        for (; k + 4 <= ksplit; k += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = p4[(long)(k + u) * n4 + e];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; k < ksplit; ++k) {
+            const float4 v = p4[(long)k * n4 + e];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(dW)[e] = s;
+    }
+}
+
+// many splits of a small weight tensor (full-resolution layers): 4 k-lanes per 16-B column, fixed-order LDS combine
+__global__ __launch_bounds__(256) void wgrad_reduce_kl4_kernel(const float* __restrict__ partial, int ksplit, long n,
+                                                               float* __restrict__ dW, DbFin f) {
+    if ((int)blockIdx.x >= f.main_blocks) {
+        __shared__ double dred[256];
+        colsum_finalize_block((int)blockIdx.x - f.main_blocks, f.partial, f.nshare, f.C, f.db, dred);
+        return;
+    }
+    __shared__ float4 red[256];
+    const long n4 = n >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(partial);
+    const int col = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + col;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < n4) {
+        int k = kl;
+        for (; k + 12 < ksplit; k += 16) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = p4[(long)(k + 4 * u) * n4 + e];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; k < ksplit; k += 4) {
+            const float4 v = p4[(long)k * n4 + e];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (kl == 0 && e < n4) {
+#pragma unroll
+        for (int j = 1; j < 4; ++j) { const float4 v = red[j * 64 + col]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        reinterpret_cast<float4*>(dW)[e] = s;
     }
 }
 
@@ -595,15 +654,25 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
     if (prof_on()) prof_end(st);
     int rc = launch_ok();
     if (rc) return rc;
+    DbFin f; f.partial = nullptr; f.db = nullptr; f.nshare = 0; f.C = 0; f.main_blocks = 0;
+    int db_blocks = 0;
     if (a.fuse_db) {         // bias gradient: sum the [ksplit * taps * ci-tiles][Cout] partials of the LDS-DMA kernel
         const bool big128 = sizeof(T) == 2 && Cin >= 128 && a.Cout >= 128 && (a.C1 == 0 || a.C0 % 128 == 0);
-        const int nshare_total = a.ksplit * ntaps * cdiv(Cin, big128 ? 128 : 64);
-        rc = launch_colsum_finalize(a.db_partial, nshare_total, a.Cout, a.db, st);
-        if (rc) return rc;
+        f.partial = a.db_partial; f.db = a.db; f.C = a.Cout;
+        f.nshare = a.ksplit * ntaps * cdiv(Cin, big128 ? 128 : 64);
+        db_blocks = cdiv(a.Cout, FIN_COLS);
+        if (a.ksplit == 1) return launch_colsum_finalize(a.db_partial, f.nshare, a.Cout, a.db, st);
     }
     if (a.ksplit == 1) return MPU_OK;
-    long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
-    wgrad_reduce_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(a.partial, a.ksplit, n, dW);
+    const long n4 = n / 4;
+    if (a.ksplit >= 8 && n4 <= 64L * 8192) {
+        f.main_blocks = (int)((n4 + 63) / 64);
+        wgrad_reduce_kl4_kernel<<<dim3((unsigned)(f.main_blocks + db_blocks)), dim3(256), 0, st>>>(a.partial, a.ksplit, n, dW, f);
+    } else {
+        long blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096;
+        f.main_blocks = (int)blocks;
+        wgrad_reduce_kernel<<<dim3((unsigned)(f.main_blocks + db_blocks)), dim3(256), 0, st>>>(a.partial, a.ksplit, n, dW, f);
+    }
     return launch_ok();
 }
 

@@ -46,9 +46,14 @@ int  try_wgrad_glds(int dtype, int mode, const WgradArgs& a, hipStream_t st);   
 bool wgrad_glds_supported(int dtype, int mode, const WgradArgs& a);
 
 // ---- unet_ops.hip ---------------------------------------------------------
-constexpr int RED_MAX_BLOCKS = 256;
+constexpr int RED_MAX_BLOCKS = 1024;
 
 // fp32 master [taps][Cin][Cout] -> packed operands in T
+// one launch for every 3x3 / up-conv layer of a model (offsets in ELEMENTS of params / the packed buffer)
+struct PackJob { int mode, Cin, Cout, unit_begin, fwd_units, _pad; long w, wf, wd; };
+constexpr int PACK_MAX_JOBS = 40;
+struct PackTable { int njobs, _pad; PackJob job[PACK_MAX_JOBS]; };
+int launch_pack_all(int dtype, PackTable& tab, const float* params, void* packed, hipStream_t st);
 int launch_pack_weights(int dtype, int mode, const float* W, int Cin, int Cout,
                         void* w_fwd, void* w_dgrad, hipStream_t st);
 int launch_cast_pad(int dtype, const float* x, long M, int Cin, int Cpad, void* out, hipStream_t st);

@@ -501,14 +501,15 @@ int64_t mpu_unet_workspace_bytes(const mpu_unet* m, int32_t batch) {
 
 int mpu_unet_pack_weights(const mpu_unet* m, const float* d_params, void* d_packed, void* stream) {
     MPU_REQUIRE(m && d_params && d_packed, "mpu_unet_pack_weights: null argument");
-    const int esz = m->cfg.dtype == MPU_BF16 ? 2 : 4;
+    PackTable tab; tab.njobs = 0; tab._pad = 0;
     for (const Conv& c : m->conv) {
         if (c.mode == CONV1) continue;
-        RC(launch_pack_weights(m->cfg.dtype, c.mode, d_params + c.w, c.Cin, c.Cout,
-                               (unsigned char*)d_packed + c.wf * esz, (unsigned char*)d_packed + c.wd * esz,
-                               (hipStream_t)stream));
+        MPU_REQUIRE(tab.njobs < PACK_MAX_JOBS, "mpu_unet_pack_weights: too many layers");
+        PackJob& j = tab.job[tab.njobs++];
+        j.mode = c.mode; j.Cin = c.Cin; j.Cout = c.Cout; j.unit_begin = j.fwd_units = j._pad = 0;
+        j.w = c.w; j.wf = c.wf; j.wd = c.wd;
     }
-    return MPU_OK;
+    return launch_pack_all(m->cfg.dtype, tab, d_params, d_packed, (hipStream_t)stream);
 }
 
 int mpu_unet_prepare_inference(const mpu_unet* m, const float* d_params, const float* d_bn_state, void* d_packed,

@@ -7,6 +7,7 @@
 // Reference semantics: mpunet/models/unet.py:114-216 (layer order), Keras
 // defaults restated in SURVEY.md section 8a rows a6/a7, oracle/unet_ref.py.
 #include "kernels.h"
+#include "reduce.h"
 
 namespace mpu {
 
@@ -39,6 +40,25 @@ template <> struct Vec<bf16_t> {
         *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
+
+constexpr int COEF_LDS_C = 1024;      // per-channel coefficient tables up to this many channels are staged in LDS
+template <int NTAB>
+__device__ __forceinline__ const float* stage_coeffs(const float* __restrict__ k, int C, float* lds) {
+    if (C > COEF_LDS_C) return nullptr;
+    for (int i = threadIdx.x; i < NTAB * C; i += 256) lds[i] = k[i];
+    __syncthreads();
+    return lds;
+}
+template <int N>
+__device__ __forceinline__ void coef_load(const float* lds, const float* __restrict__ glob, int off, float* out) {
+    if (lds) {
+#pragma unroll
+        for (int i = 0; i < N; i += 4) *reinterpret_cast<float4*>(out + i) = *reinterpret_cast<const float4*>(lds + off + i);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i += 4) *reinterpret_cast<float4*>(out + i) = *reinterpret_cast<const float4*>(glob + off + i);
+    }
+}
 
 static inline int ew_grid(long work) {
     long b = (work + 255) / 256;
@@ -107,6 +127,84 @@ __global__ void pack_dgrad_kernel(int mode, const float* __restrict__ W, int Cin
     }
 }
 
+// ---- all layers of a model in ONE launch ------------------------------------------------------
+// unit = one 32x32 forward tile, or one 1024-element chunk of the data-gradient operand; the job
+// table travels in the kernel arguments (no device-side table to keep in sync).
+template <typename T>
+__device__ __forceinline__ void pack_fwd_tile(const PackJob& j, int t, const float* __restrict__ params, T* packed,
+                                              float (*tile)[33]) {
+    const int Cin = j.Cin, Cout = j.Cout;
+    const int tci = (Cin + 31) / 32, tco = (Cout + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tap = t / (tci * tco); const int r = t % (tci * tco);
+    const int ci0 = (r / tco) * 32, co0 = (r % tco) * 32;
+    const float* src = params + j.w + (long)tap * Cin * Cout;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ci = ci0 + ty + 8 * k, co = co0 + tx;
+        tile[ty + 8 * k][tx] = (ci < Cin && co < Cout) ? src[(long)ci * Cout + co] : 0.f;
+    }
+    __syncthreads();
+    T* dst = packed + j.wf + (long)tap * Cin * Cout;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int co = co0 + ty + 8 * k, ci = ci0 + tx;
+        if (ci < Cin && co < Cout) dst[(long)co * Cin + ci] = from_f32<T>(tile[tx][ty + 8 * k]);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void pack_dgrad_chunk(const PackJob& j, int chunk, const float* __restrict__ params, T* packed) {
+    const long per_tap = (long)j.Cin * j.Cout;                 // multiple of 64: a float4 never straddles taps
+    const long e = (long)chunk * 1024 + threadIdx.x * 4;
+    if (e >= 9 * per_tap) return;
+    const int tp = (int)(e / per_tap); const long r = e % per_tap;
+    const float* W = params + j.w;
+    float4 v;
+    if (j.mode == CONV3) {
+        v = *reinterpret_cast<const float4*>(W + (long)(8 - tp) * per_tap + r);
+    } else {
+        const int dy = tp / 3 - 1, dx = tp % 3 - 1;
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ky = 0; ky < 2; ++ky) {
+            if ((dy == -1 && ky != 1) || (dy == 1 && ky != 0)) continue;
+            for (int kx = 0; kx < 2; ++kx) {
+                if ((dx == -1 && kx != 1) || (dx == 1 && kx != 0)) continue;
+                const float4 u = *reinterpret_cast<const float4*>(W + (long)(ky * 2 + kx) * per_tap + r);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+        }
+    }
+    T* dst = packed + j.wd + e;
+    dst[0] = from_f32<T>(v.x); dst[1] = from_f32<T>(v.y); dst[2] = from_f32<T>(v.z); dst[3] = from_f32<T>(v.w);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_all_kernel(PackTable tab, const float* __restrict__ params, T* packed) {
+    __shared__ float tile[32][33];
+    int ji = 0;
+    while (ji + 1 < tab.njobs && (int)blockIdx.x >= tab.job[ji + 1].unit_begin) ++ji;
+    const PackJob& j = tab.job[ji];
+    const int u = (int)blockIdx.x - j.unit_begin;
+    if (u < j.fwd_units) pack_fwd_tile<T>(j, u, params, packed, tile);
+    else pack_dgrad_chunk<T>(j, u - j.fwd_units, params, packed);
+}
+
+int launch_pack_all(int dtype, PackTable& tab, const float* params, void* packed, hipStream_t st) {
+    int units = 0;
+    for (int i = 0; i < tab.njobs; ++i) {
+        PackJob& j = tab.job[i];
+        const int ntaps = j.mode == UPCONV2 ? 4 : 9;
+        j.unit_begin = units;
+        j.fwd_units = ntaps * cdiv(j.Cin, 32) * cdiv(j.Cout, 32);
+        units += j.fwd_units + (int)cdiv(9L * j.Cin * j.Cout, 1024L);
+    }
+    if (units == 0) return MPU_OK;
+    if (dtype == MPU_BF16) pack_all_kernel<bf16_t><<<units, 256, 0, st>>>(tab, params, (bf16_t*)packed);
+    else pack_all_kernel<float><<<units, 256, 0, st>>>(tab, params, (float*)packed);
+    return launch_ok();
+}
+
 int launch_pack_weights(int dtype, int mode, const float* W, int Cin, int Cout, void* wf, void* wd, hipStream_t st) {
     const int ntaps = mode == UPCONV2 ? 4 : (mode == CONV1 ? 1 : 9);
     long tiles = (long)ntaps * cdiv(Cin, 32) * cdiv(Cout, 32);
@@ -167,21 +265,34 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
 #pragma unroll
                 for (int i = 0; i < N; ++i) { mu[i] = mean[c * N + i]; is[i] = invstd[c * N + i]; }
             }
-            for (long r = r_beg + ty; r < r_end; r += TY) {
-                float va[N];
-                Vec<T>::load(a + r * C + (long)c * N, va);
+            auto accum = [&](const float* va, const float* vb) {
                 if (OP == 0) {
 #pragma unroll
                     for (int i = 0; i < N; ++i) { s0[i] += va[i]; s1[i] += va[i] * va[i]; }
                 } else if (OP == 1) {
-                    float vb[N];
-                    Vec<T>::load(b + r * C + (long)c * N, vb);
 #pragma unroll
                     for (int i = 0; i < N; ++i) { s0[i] += va[i]; s1[i] += va[i] * ((vb[i] - mu[i]) * is[i]); }
                 } else {
 #pragma unroll
                     for (int i = 0; i < N; ++i) s0[i] += va[i];
                 }
+            };
+            long r = r_beg + ty;
+            for (; r + 3L * TY < r_end; r += 4L * TY) {       // 4 (8) independent 16-B loads in flight per thread
+                float va[4][N], vb[4][N];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    Vec<T>::load(a + (r + (long)u * TY) * C + (long)c * N, va[u]);
+                    if (OP == 1) Vec<T>::load(b + (r + (long)u * TY) * C + (long)c * N, vb[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) accum(va[u], vb[u]);
+            }
+            for (; r < r_end; r += TY) {
+                float va[N], vb[N];
+                Vec<T>::load(a + r * C + (long)c * N, va);
+                if (OP == 1) Vec<T>::load(b + r * C + (long)c * N, vb);
+                accum(va, vb);
             }
         }
         // reduce over ty through LDS
@@ -204,9 +315,11 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
     }
 }
 
-static int red_blocks(long M, int* rows_per_blk) {
+static int red_blocks(long M, int C, int* rows_per_blk) {
     long rpb = (M + RED_MAX_BLOCKS - 1) / RED_MAX_BLOCKS;
-    if (rpb < 64) rpb = 64;
+    int TX = 1; while (TX < C / 8 && TX < 256) TX <<= 1;      // as in the kernel (f32: C/4, only more rows per thread)
+    const long min_rows = 4L * (256 / TX);                    // >= 4 rows per thread
+    if (rpb < min_rows) rpb = min_rows;
     *rows_per_blk = (int)rpb;
     return (int)((M + rpb - 1) / rpb);
 }
@@ -214,7 +327,7 @@ static int red_blocks(long M, int* rows_per_blk) {
 template <int OP>
 static int launch_colreduce(int dtype, const void* a, const void* b, long M, int C, const float* mean,
                             const float* invstd, float* partial, int* nblk_out, hipStream_t st) {
-    int rpb; const int nblk = red_blocks(M, &rpb);
+    int rpb; const int nblk = red_blocks(M, C, &rpb);
     *nblk_out = nblk;
     if (dtype == MPU_BF16)
         colreduce_kernel<bf16_t, OP><<<nblk, 256, 0, st>>>((const bf16_t*)a, (const bf16_t*)b, M, C, mean, invstd, rpb, partial);
@@ -224,41 +337,15 @@ static int launch_colreduce(int dtype, const void* a, const void* b, long M, int
 }
 
 
-// Second stage of the two-stage reductions: block = 8 columns x 32 k-lanes; returns (to the
-// k-lane-0 thread of each column) sum_k partial[k*stride + col] in double, fixed order.
-constexpr int FIN_COLS = 8, FIN_KL = 32;
-__device__ __forceinline__ double partial_sum(const float* __restrict__ partial, int nblk, long stride, int col,
-                                              bool valid, double* red /*[256]*/) {
-    const int kl = threadIdx.x / FIN_COLS;       // 0..31
-    double s = 0.0;
-    if (valid) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {            // up to 256 partial blocks: 8 independent loads per thread
-            const int k = kl + u * FIN_KL;
-            v[u] = k < nblk ? partial[(long)k * stride + col] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += (double)v[u];
-        for (int k = kl + 8 * FIN_KL; k < nblk; k += FIN_KL) s += (double)partial[(long)k * stride + col];
-    }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    double t = 0.0;
-    if (kl == 0)
-        for (int j = 0; j < FIN_KL; ++j) t += red[j * FIN_COLS + (threadIdx.x % FIN_COLS)];
-    __syncthreads();
-    return t;
-}
-
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
                                          const float* gamma, const float* beta, float* mmean, float* mvar,
                                          float* mean, float* invstd, float* scale, float* shift, float eps, float mom) {
     __shared__ double red[256];
     const int c = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
-    const double s = partial_sum(partial, nblk, 2L * C, c, c < C, red);
-    const double ss = partial_sum(partial + C, nblk, 2L * C, c, c < C, red);
+    double st[2];
+    partial_sums<2>(partial, nblk, 2L * C, C, c, c < C, red, st);
     if (c >= C || threadIdx.x >= FIN_COLS) return;
+    const double s = st[0], ss = st[1];
     const double mu = s / (double)M;
     double var = ss / (double)M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -300,17 +387,33 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        T* __restrict__ y, T* __restrict__ pooled) {
     constexpr int N = Vec<T>::N;
+    __shared__ __attribute__((aligned(16))) float kc[2 * COEF_LDS_C];
+    const float* lds = nullptr;                              // scale -> kc[0..C), shift -> kc[C..2C)
+    if (C <= COEF_LDS_C) {
+        for (int i = threadIdx.x; i < C; i += 256) { kc[i] = scale[i]; kc[C + i] = shift[i]; }
+        __syncthreads();
+        lds = kc;
+    }
     const int cpr = C / N;
     if (!POOL) {
         const long total = (long)B * H * W * cpr;
-        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long stride = (long)gridDim.x * 256;
+        auto one = [&](long e, float (&v)[N]) {
             const int c = (int)(e % cpr);
-            float v[N];
-            Vec<T>::load(x + e * N, v);
+            float sc[N], sh[N];
+            coef_load<N>(lds, scale, c * N, sc);
+            if (lds) coef_load<N>(lds, scale, C + c * N, sh); else coef_load<N>(nullptr, shift, c * N, sh);
 #pragma unroll
-            for (int i = 0; i < N; ++i) v[i] = v[i] * scale[c * N + i] + shift[c * N + i];
+            for (int i = 0; i < N; ++i) v[i] = v[i] * sc[i] + sh[i];
             Vec<T>::store(y + e * N, v);
+        };
+        long e = (long)blockIdx.x * 256 + threadIdx.x;
+        for (; e + stride < total; e += 2 * stride) {
+            float v0[N], v1[N];
+            Vec<T>::load(x + e * N, v0); Vec<T>::load(x + (e + stride) * N, v1);
+            one(e, v0); one(e + stride, v1);
         }
+        if (e < total) { float v0[N]; Vec<T>::load(x + e * N, v0); one(e, v0); }
     } else {
         const int Hp = H / 2, Wp = W / 2;
         const long total = (long)B * Hp * Wp * cpr;
@@ -318,21 +421,24 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
             const int c = (int)(e % cpr); long t = e / cpr;
             const int px = (int)(t % Wp); t /= Wp;
             const int py = (int)(t % Hp); const int b = (int)(t / Hp);
-            float sc[N], sh[N], mx[N];
-#pragma unroll
-            for (int i = 0; i < N; ++i) { sc[i] = scale[c * N + i]; sh[i] = shift[c * N + i]; }
+            float sc[N], sh[N], mx[N], v[4][N];
+            long o[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const long o = ((((long)b * H + 2 * py + (d >> 1)) * W + 2 * px + (d & 1)) * cpr + c) * N;
-                float v[N];
-                Vec<T>::load(x + o, v);
+                o[d] = ((((long)b * H + 2 * py + (d >> 1)) * W + 2 * px + (d & 1)) * cpr + c) * N;
+                Vec<T>::load(x + o[d], v[d]);
+            }
+            coef_load<N>(lds, scale, c * N, sc);
+            if (lds) coef_load<N>(lds, scale, C + c * N, sh); else coef_load<N>(nullptr, shift, c * N, sh);
 #pragma unroll
-                for (int i = 0; i < N; ++i) v[i] = v[i] * sc[i] + sh[i];
-                Vec<T>::store(y + o, v);
+            for (int d = 0; d < 4; ++d) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) v[d][i] = v[d][i] * sc[i] + sh[i];
+                Vec<T>::store(y + o[d], v[d]);
                 // the pooled value is the max of the STORED (rounded) values
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
-                    const float r = to_f32<T>(from_f32<T>(v[i]));
+                    const float r = to_f32<T>(from_f32<T>(v[d][i]));
                     mx[i] = d == 0 ? r : fmaxf(mx[i], r);
                 }
             }
@@ -386,9 +492,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                        float* dgamma, float* dbeta, float* coeffs) {
     __shared__ double red[256];
     const int c = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
-    const double s = partial_sum(partial, nblk, 2L * C, c, c < C, red);
-    const double sx = partial_sum(partial + C, nblk, 2L * C, c, c < C, red);
+    double st[2];
+    partial_sums<2>(partial, nblk, 2L * C, C, c, c < C, red, st);
     if (c >= C || threadIdx.x >= FIN_COLS) return;
+    const double s = st[0], sx = st[1];
     dgamma[c] = (float)sx; dbeta[c] = (float)s;
     const double sc = (double)gamma[c] * (double)invstd[c];
     const double mdn = s / (double)M, mdx = sx / (double)M;
@@ -402,19 +509,30 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dn, const T* __restrict__ x, long M, int C,
                                                            const float* __restrict__ k, T* __restrict__ dz) {
     constexpr int N = Vec<T>::N;
+    __shared__ __attribute__((aligned(16))) float kc[3 * COEF_LDS_C];
+    const float* lds = stage_coeffs<3>(k, C, kc);
     const int cpr = C / N;
     const long total = M * cpr;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long stride = (long)gridDim.x * 256;
+    auto one = [&](long e, const float* g, const float* v) {
         const int c = (int)(e % cpr);
-        float g[N], v[N], o[N];
-        Vec<T>::load(dn + e * N, g);
-        Vec<T>::load(x + e * N, v);
+        float k1[N], k2[N], k3[N], o[N];
+        coef_load<N>(lds, k, c * N, k1); coef_load<N>(lds, k, C + c * N, k2); coef_load<N>(lds, k, 2 * C + c * N, k3);
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int ch = c * N + i;
-            o[i] = v[i] > 0.f ? (k[ch] * g[i] + k[C + ch] * v[i] + k[2 * C + ch]) : 0.f;
-        }
+        for (int i = 0; i < N; ++i) o[i] = v[i] > 0.f ? (k1[i] * g[i] + k2[i] * v[i] + k3[i]) : 0.f;
         Vec<T>::store(dz + e * N, o);
+    };
+    long e = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; e + stride < total; e += 2 * stride) {
+        float g0[N], v0[N], g1[N], v1[N];
+        Vec<T>::load(dn + e * N, g0); Vec<T>::load(x + e * N, v0);
+        Vec<T>::load(dn + (e + stride) * N, g1); Vec<T>::load(x + (e + stride) * N, v1);
+        one(e, g0, v0); one(e + stride, g1, v1);
+    }
+    if (e < total) {
+        float g0[N], v0[N];
+        Vec<T>::load(dn + e * N, g0); Vec<T>::load(x + e * N, v0);
+        one(e, g0, v0);
     }
 }
 
@@ -427,7 +545,7 @@ int launch_bn_backward(int dtype, const void* dn, const void* x, long M, int C, 
     bn_bwd_finalize_kernel<<<cdiv(C, FIN_COLS), 256, 0, st>>>(partial, nblk, C, M, gamma, mean, invstd, dgamma, dbeta, coeffs);
     rc = launch_ok();
     if (rc) return rc;
-    const long work = M * C / 8;
+    const long work = M * C / 8 / 2;
     if (dtype == MPU_BF16)
         bn_bwd_apply_kernel<bf16_t><<<ew_grid(work), 256, 0, st>>>((const bf16_t*)dn, (const bf16_t*)x, M, C, coeffs, (bf16_t*)dz);
     else
@@ -486,9 +604,7 @@ int launch_maxpool_bwd_add(int dtype, const void* n, const void* dskip, const vo
 
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* out) {
     __shared__ double red[256];
-    const int c = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
-    const double s = partial_sum(partial, nblk, C, c, c < C, red);
-    if (c < C && threadIdx.x < FIN_COLS) out[c] = (float)s;
+    colsum_finalize_block(blockIdx.x, partial, nblk, C, out, red);
 }
 int launch_colsum_finalize(const float* partial, int nblk, int C, float* out, hipStream_t st) {
     colsum_finalize_kernel<<<cdiv(C, FIN_COLS), 256, 0, st>>>(partial, nblk, C, out);
@@ -677,7 +793,8 @@ __global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __r
     __shared__ double red[256];
     const int i = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
     const int tot = C * K + K;
-    const double s = partial_sum(partial, nblk, tot, i, i < tot, red);
+    double s;
+    partial_sums<1>(partial, nblk, tot, 0, i, i < tot, red, &s);
     if (i >= tot || threadIdx.x >= FIN_COLS) return;
     if (i < C * K) dWh[(i / K) * ldw + (i % K)] = (float)s; else dbh[i - C * K] = (float)s;
 }
