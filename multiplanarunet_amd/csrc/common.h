@@ -34,12 +34,14 @@ inline int launch_ok() {
 // bf16 <-> f32 (round-to-nearest-even, as torch.bfloat16)
 typedef uint16_t bf16_t;
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {      // branch-free RNE; NaN stays NaN
-    const uint32_t u = __float_as_uint(f);
-    const uint32_t r = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-    const uint32_t nan = (u >> 16) | 0x40u;
-    return (bf16_t)(((u & 0x7fffffffu) > 0x7f800000u) ? nan : r);
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even, NaN stays NaN)
+typedef __bf16 mpu_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float mpu_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {
+    const mpu_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mpu_bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(f32x2_to_bf16x2(f, 0.f) & 0xffffu); }
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }

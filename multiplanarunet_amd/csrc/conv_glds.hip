@@ -298,8 +298,8 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
                 unsigned char* dst = smem + ml * OROW + nl * (int)sizeof(T);
                 if (sizeof(T) == 2) {
                     uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    pk.x = f32x2_to_bf16x2(v[0], v[1]);
+                    pk.y = f32x2_to_bf16x2(v[2], v[3]);
                     *(uint2*)dst = pk;
                 } else {
                     *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);

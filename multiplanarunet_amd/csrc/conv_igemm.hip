@@ -245,8 +245,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                 unsigned char* dst = smem + ml * OROW + nl * (int)sizeof(T);
                 if (sizeof(T) == 2) {
                     uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    pk.x = f32x2_to_bf16x2(v[0], v[1]);
+                    pk.y = f32x2_to_bf16x2(v[2], v[3]);
                     *(uint2*)dst = pk;
                 } else {
                     *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
@@ -581,6 +581,8 @@ static int halo_on() {
 int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
     if (conv_impl() == 1) {
         if (halo_on()) {
+            const int w = try_conv_ws(dtype, mode, a, st);
+            if (w != 0) return w < 0 ? w : MPU_OK;
             const int h = try_conv_halo(dtype, mode, a, st);
             if (h != 0) return h < 0 ? h : MPU_OK;
         }

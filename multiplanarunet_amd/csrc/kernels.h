@@ -39,6 +39,7 @@ void prof_end(hipStream_t st);
 
 int  launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // dispatches on MPU_CONV_IMPL
 int  launch_conv_glds(int dtype, int mode, const ConvArgs& a, hipStream_t st);  // LDS-DMA variant (conv_glds.hip)
+int  try_conv_ws(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // register-stationary weights, persistent (conv_ws.hip)
 int  try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st);     // LDS-resident patch variant (conv_halo.hip)
 long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out);
 int  launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st);

@@ -48,6 +48,8 @@ CASES = [
     (CONV3,   2, 36, 40, 64, 64, 64),      # patch kernel: ragged H and W tiles, concat, 64-channel tile
     (CONV3,   1, 64, 96, 72, 0, 40),       # patch kernel: channel tail (72 = 64 + 8), ragged N
     (CONV3,   2, 8, 64, 192, 0, 128),      # patch kernel: three channel chunks (patch reloaded twice)
+    (CONV3,   4, 130, 250, 8, 0, 24),      # register-stationary-weights kernel (>= 1024 tiles): ragged H, W, N; tiny Cin
+    (CONV3,   2, 256, 256, 64, 0, 64),     # ... full 64 -> 64 layer, 4 tiles per persistent workgroup
     (UPCONV2, 2, 16, 16, 128, 0, 64),
     (UPCONV2, 1, 8, 12, 72, 0, 40),
     (CONV1,   2, 16, 16, 64, 0, 8),

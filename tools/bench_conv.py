@@ -1,7 +1,7 @@
 """Micro-benchmark of the conv kernels on the cfg2 layer shapes (dev tool). usage: bench_conv.py [fwd|wgrad] [reps]"""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multiplanarunet_amd import ops
 CONV3, UPCONV2, CONV3S2, CONV1 = 0, 1, 2, 3
 B = 16
@@ -40,12 +40,20 @@ for name, mode, H, C0, C1, Cout in LAYERS:
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    import ctypes as C
+    from multiplanarunet_amd import _lib
+    lib = _lib.load()
+    lib.mpu_profile_enable(1)          # per-launch HIP events: pure kernel time (the python loop is launch-bound)
     e0.record()
     for _ in range(reps): run()
     e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
+    ms, fl_, n_ = C.c_double(), C.c_double(), C.c_int64()
+    lib.mpu_profile_summary(0 if what == "fwd" else 1, C.byref(ms), C.byref(fl_), C.byref(n_))
+    lib.mpu_profile_enable(0)
+    wall = e0.elapsed_time(e1) * 1e3 / reps
+    us = ms.value * 1e3 / max(n_.value, 1) * (n_.value / reps)
     taps = {0: 9, 1: 4, 2: 9, 3: 1}[mode]
     fl = 2.0 * B * H * H * Cout * taps * Cin
     tot_t += us; tot_f += fl
-    print("%-8s M=%7d N=%5d K=%6d  %8.1f us  %7.1f TF/s" % (name, B * H * H, Cout, taps * Cin, us, fl / us / 1e6), flush=True)
+    print("%-8s M=%7d N=%5d K=%6d  %8.1f us  %7.1f TF/s   (loop wall %.1f us)" % (name, B * H * H, Cout, taps * Cin, us, fl / us / 1e6, wall), flush=True)
 print("total %.1f us  %.1f TF/s" % (tot_t, tot_f / tot_t / 1e6))
