@@ -617,15 +617,24 @@ long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, i
     if (ksplit_out) *ksplit_out = (int)ks;
     if (mchunk_out) *mchunk_out = (int)mchunk;
     // + fused bias-gradient partials: [ks][ntaps * ci-tiles][Cout]
-    return ks * (ntaps * (long)Cin * Cout + (long)ntaps * cdiv(Cin, 64) * Cout);
+    long elems = ks * (ntaps * (long)Cin * Cout + (long)ntaps * cdiv(Cin, 64) * Cout);
+    // the all-taps kernel (wgrad_taps.hip) keeps one partial copy per pixel strip
+    if (mode == CONV3 && (long)Cin * Cout <= TAPS_MAX_CICO) {
+        const long te = (long)(TAPS_MAX_WGS / (cdiv(Cin, 64) * cdiv(Cout, 64))) * (9L * Cin * Cout + Cout);
+        if (te > elems) elems = te;
+    }
+    return elems;
 }
 
 template <typename T, int MODE>
 static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
     const int Cin = a.C0 + a.C1;
     const int dt_ = sizeof(T) == 2 ? MPU_BF16 : MPU_F32;
-    // the LDS-DMA kernel also sums dz over the pixels (bias gradient) when it handles the shape
-    a.fuse_db = (a.db && conv_impl() == 1 && wgrad_glds_supported(dt_, MODE, a)) ? 1 : 0;
+    TapsPlan taps; taps.use = 0;
+    if (conv_impl() == 1) taps = wgrad_taps_plan(dt_, MODE, a.B, a.Ho, a.Wo, a.C0, a.C1, a.Cout);
+    if (taps.use) a.ksplit = taps.nstrips;        // one partial copy per pixel strip
+    // the LDS-DMA kernels also sum dz over the pixels (bias gradient) when they handle the shape
+    a.fuse_db = (a.db && conv_impl() == 1 && (taps.use || wgrad_glds_supported(dt_, MODE, a))) ? 1 : 0;
     if (a.db && !a.fuse_db) {
         int rc0 = launch_colsum(dt_, a.dz, (long)a.B * a.Ho * a.Wo, a.Cout, a.colsum_scratch, a.db, st);
         if (rc0) return rc0;
@@ -638,9 +647,11 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
     if (prof_on())
         prof_begin(PROF_WGRAD, a.flops > 0 ? a.flops : 2.0 * a.B * a.Ho * a.Wo * (double)n, st);
     bool big = false;
-    const int g_ = conv_impl() == 1 ? try_wgrad_glds(dt_, MODE, a, st) : 0;
+    int g_ = 0;
+    if (taps.use) { g_ = launch_wgrad_taps(a, taps, st); if (g_) return g_; g_ = 1; }
+    else if (conv_impl() == 1) g_ = try_wgrad_glds(dt_, MODE, a, st);
     if (g_ < 0) return g_;
-    if (g_ == 1) big = true;                      // launched by the LDS-DMA kernel
+    if (g_ == 1) big = true;                      // launched by an LDS-DMA kernel
     else
     if constexpr (sizeof(T) == 2) {
         if (Cin >= 128 && a.Cout >= 128) {
@@ -661,7 +672,7 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
     if (a.fuse_db) {         // bias gradient: sum the [ksplit * taps * ci-tiles][Cout] partials of the LDS-DMA kernel
         const bool big128 = sizeof(T) == 2 && Cin >= 128 && a.Cout >= 128 && (a.C1 == 0 || a.C0 % 128 == 0);
         f.partial = a.db_partial; f.db = a.db; f.C = a.Cout;
-        f.nshare = a.ksplit * ntaps * cdiv(Cin, big128 ? 128 : 64);
+        f.nshare = taps.use ? taps.nstrips : a.ksplit * ntaps * cdiv(Cin, big128 ? 128 : 64);
         db_blocks = cdiv(a.Cout, FIN_COLS);
         if (a.ksplit == 1) return launch_colsum_finalize(a.db_partial, f.nshare, a.Cout, a.db, st);
     }

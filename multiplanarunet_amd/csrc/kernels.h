@@ -42,6 +42,13 @@ int  launch_conv_glds(int dtype, int mode, const ConvArgs& a, hipStream_t st);  
 int  try_conv_ws(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // register-stationary weights, persistent (conv_ws.hip)
 int  try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st);     // LDS-resident patch variant (conv_halo.hip)
 long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out);
+// all-taps weight gradient for the high-resolution 3x3 layers (wgrad_taps.hip)
+struct TapsPlan { int use, RH, sx, sy, nstrips; };
+constexpr long TAPS_MAX_CICO = 512L * 512;     // eligible layers: Cin * Cout up to this
+constexpr int TAPS_MAX_WGS = 1024;             // strips * 64x64 tiles; bounds the fp32 partial workspace (one copy of
+                                               // dW per strip): <= 1024 * 9 * 4096 floats = 151 MB for any layer
+TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout);
+int  launch_wgrad_taps(const WgradArgs& a, const TapsPlan& p, hipStream_t st);
 int  launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st);
 int  try_wgrad_glds(int dtype, int mode, const WgradArgs& a, hipStream_t st);   // 1 launched, 0 unsupported shape
 bool wgrad_glds_supported(int dtype, int mode, const WgradArgs& a);

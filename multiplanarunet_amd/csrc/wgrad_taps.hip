@@ -1,0 +1,247 @@
+// wgrad_taps_kernel: weight gradient of a 3x3 SAME convolution with ALL NINE TAPS accumulated by
+// one workgroup (bf16, the high-resolution layers: few channels, very many pixels).
+//
+//   dW[tap][ci][co] = sum_m X[m @ tap][ci] * dZ[m][co]
+//
+// The per-tap kernel (wgrad_glds_kernel) streams an X tile and a dZ tile per 32-pixel K step for
+// ONE tap: at 64x64 channels that is 8 KB of L2->LDS traffic per 0.26 MFLOP (32 flop/B) and the
+// nine taps re-read the same pixels nine times. Here a workgroup walks a 32-pixel-wide column
+// strip of one image, one output row per K step: it keeps a rolling window of three X rows (34
+// pixels each, halo included) plus the dZ row in LDS, so a step fetches ONE new X row and ONE dZ
+// row (8.25 KB) for all nine taps: 2.36 MFLOP, 286 flop/B. The L2->LDS fill and the HBM re-reads
+// drop 9x; the kernel is MFMA-bound.
+//
+// MFMA shape: v_mfma_f32_16x16x32_bf16 (K = 32 pixels = one step). Wave w owns input channels
+// [16w, 16w+16) of the 64-channel tile, all 64 output channels, all nine taps: 36 accumulators of
+// 4 VGPRs. Per step a wave reads the four dZ fragments once (shared by the nine taps) and one X
+// fragment per tap (the tap's shifted pixels): 26 LDS transpose reads for 36 MFMAs.
+// Both operands are pixel-major in memory (K-major): fragments come from ds_read_b64_tr_b16.
+// Bias gradient: one extra MFMA per wave and step against an all-ones A fragment sums dZ over
+// the pixels (wave w: output channels [16w, 16w+16)).
+// Output: fp32 partials [strip][tap][ci][co] (+ bias partials [strip][co]) reduced in fixed order
+// by wgrad_reduce*_kernel: deterministic, no atomics.
+#include <stdlib.h>
+#include "kernels.h"
+
+namespace mpu {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+namespace {
+
+constexpr int XPX = 40;                  // pixels per staged X row (34 used: 32 + halo; 5 DMA pieces of 8)
+constexpr int XROWB = XPX * 128;         // bytes per staged X row (64 channels bf16 per pixel)
+constexpr int NXR = 5;                   // X row ring: rows t..t+2 in use, t+3 landed, t+4 in flight
+constexpr int ZROWB = 32 * 128;          // bytes per staged dZ row
+constexpr int NZR = 3;
+
+__device__ __forceinline__ i32x4 t_make_rsrc(const void* p, long bytes) {
+    const unsigned long long pa = (unsigned long long)p;
+    i32x4 r;
+    r.x = (int)(unsigned)pa; r.y = (int)((unsigned)(pa >> 32) & 0xffffu); r.z = (int)bytes; r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void t_dma16(const i32x4& rsrc, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
+                 :: "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ s16x8 t_frag(const unsigned char* p_lo, const unsigned char* p_hi) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p_lo));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p_hi));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(WgradArgs a, TapsPlan p) {
+    __shared__ __attribute__((aligned(128))) unsigned char smem[NXR * XROWB + NZR * ZROWB];
+    constexpr unsigned OOB = 0xfffffff0u;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.Ho, W = a.Wo;
+    const int Cin = a.C0 + a.C1;
+    const int tiles_co = (a.Cout + 63) / 64;
+    const int ntile = tiles_co * ((Cin + 63) / 64);
+    // XCD-aware decode: the tiles of one strip run on one XCD (shared X / dZ in its L2)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = slot % ntile, strip = (slot / ntile) * 8 + xcd;
+    if (strip >= p.nstrips) return;
+    const int xs = strip % p.sx; int t_ = strip / p.sx;
+    const int ys = t_ % p.sy; const int b = t_ / p.sy;
+    const int x0 = xs * 32, y0 = ys * p.RH;
+    const int nsteps = (y0 + p.RH < H ? y0 + p.RH : H) - y0;
+    const int ci0 = (tile / tiles_co) * 64, co0 = (tile % tiles_co) * 64;
+    const bool s1 = ci0 >= a.C0 && a.C1 > 0;             // the ci tile lies in one concat source (C0 % 64 == 0 then)
+    const int Cs = s1 ? a.C1 : a.C0, cs0 = s1 ? ci0 - a.C0 : ci0;
+    const long npix = (long)a.B * H * W;
+    const i32x4 rsx = t_make_rsrc(s1 ? a.x1 : a.x0, npix * Cs * 2L);
+    const i32x4 rsz = t_make_rsrc(a.dz, npix * a.Cout * 2L);
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    const unsigned ldsZ = lds0 + NXR * XROWB;
+
+    // ---- DMA: piece q of a step's group: q < 5: 8 pixels of the new X row; q >= 5: 8 pixels of the dZ row.
+    // 128-byte pixel rows; the 64-byte granule of a row is XOR-ed with (pixel>>1)&1 so that the four k-rows
+    // of a transpose read fall in four different bank groups.
+    const int dpx = lane >> 3, dsl = lane & 7;
+    auto issue_x = [&](int r) {                                  // X row r of this strip = image row y0 - 1 + r
+        const int iy = y0 - 1 + r;
+        const unsigned base = lds0 + (r % NXR) * XROWB;
+        const bool rowok = (unsigned)iy < (unsigned)H;
+        for (int q = wave; q < 5; q += 4) {
+            const int c = q * 8 + dpx, ix = x0 - 1 + c;
+            const int ch = (dsl ^ (((c >> 1) & 1) << 2)) * 8;
+            const bool v = rowok && c < 34 && (unsigned)ix < (unsigned)W && cs0 + ch < Cs;
+            const unsigned off = v ? (unsigned)((((b * H + iy) * W + ix) * Cs + cs0 + ch) * 2) : OOB;
+            t_dma16(rsx, off, base + q * 1024);
+        }
+    };
+    auto issue_z = [&](int t) {                                  // dZ row of step t = image row y0 + t
+        const int y = y0 + t;
+        const unsigned base = ldsZ + (t % NZR) * ZROWB;
+        const int c = wave * 8 + dpx, x = x0 + c;
+        const int ch = (dsl ^ (((c >> 1) & 1) << 2)) * 8;
+        const bool v = y < H && x < W && co0 + ch < a.Cout;
+        const unsigned off = v ? (unsigned)((((b * H + y) * W + x) * a.Cout + co0 + ch) * 2) : OOB;
+        t_dma16(rsz, off, base + wave * 1024);
+    };
+    // DMAs per wave in one step group (X row + dZ row): waves 0 gets X pieces 0 and 4
+    const int ngrp = (wave == 0 ? 2 : 1) + 1;
+
+    // ---- fragment addressing (16x16x32: lane group g = lane>>4 holds k = 8g..8g+7; i = lane&15 the row/col) ----
+    const int g = lane >> 4, i = lane & 15;
+    // a transpose read covers 4 k-rows x 16 columns; lane i addresses k-row (i>>2), columns (i&3)*4
+    int offA[3][2];                                              // X: per kx shift and low/high half, inside a row slot
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = kx + 8 * g + (i >> 2) + 4 * h;         // staged pixel column
+            const int slot16 = (wave * 2 + ((i & 3) >> 1)) ^ (((c >> 1) & 1) << 2);
+            offA[kx][h] = c * 128 + (slot16 << 4) + (i & 1) * 8;
+        }
+    int offB[4][2];                                              // dZ: per 16-channel block and half
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = 8 * g + (i >> 2) + 4 * h;
+            const int slot16 = (cb * 2 + ((i & 3) >> 1)) ^ (((c >> 1) & 1) << 2);
+            offB[cb][h] = c * 128 + (slot16 << 4) + (i & 1) * 8;
+        }
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[tp][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 accdb = {0.f, 0.f, 0.f, 0.f};
+    const s16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+
+    // ---- pipeline: step t uses X rows t, t+1, t+2 and dZ row t; issues X row t+4 and dZ row t+2 -----------
+    issue_x(0); issue_x(1); issue_x(2); issue_z(0);
+    issue_x(3); issue_z(1);
+    // wait for the first group (rows 0..2 + dZ 0); the second (ngrp DMAs) may still be in flight
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    (void)ngrp;
+    for (int t = 0; t < nsteps; ++t) {
+        if (t + 2 < nsteps) { issue_x(t + 4); issue_z(t + 2); }
+        const unsigned char* zb = smem + NXR * XROWB + (t % NZR) * ZROWB;
+        s16x8 bz[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) bz[cb] = t_frag(zb + offB[cb][0], zb + offB[cb][1]);
+        const unsigned char* xr[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) xr[ky] = smem + ((t + ky) % NXR) * XROWB;
+        s16x8 af = t_frag(xr[0] + offA[0][0], xr[0] + offA[0][1]);
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            s16x8 an = af;
+            if (tp + 1 < 9) {
+                const int ky = (tp + 1) / 3, kx = (tp + 1) % 3;
+                an = t_frag(xr[ky] + offA[kx][0], xr[ky] + offA[kx][1]);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+                acc[tp][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bz[cb], acc[tp][cb], 0, 0, 0);
+            af = an;
+        }
+        if (a.fuse_db) {
+            s16x8 bw = bz[0];
+            if (wave == 1) bw = bz[1]; else if (wave == 2) bw = bz[2]; else if (wave == 3) bw = bz[3];
+            accdb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bw, accdb, 0, 0, 0);
+        }
+        // group t+1 has landed (group t+2, just issued, may be in flight); all waves are done with step t's rows
+        if (t + 2 < nsteps) {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- partial sums: [strip][tap][ci][co] -------------------------------------------------------------
+    float* P = a.partial + (long)strip * 9 * Cin * a.Cout;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int co = co0 + cb * 16 + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + wave * 16 + 4 * g + r;
+                if (ci < Cin && co < a.Cout) P[((long)tp * Cin + ci) * a.Cout + co] = acc[tp][cb][r];
+            }
+        }
+    if (a.fuse_db && ci0 == 0 && g == 0) {                      // every row of accdb holds the column sums: take row 0
+        const int co = co0 + wave * 16 + i;
+        if (co < a.Cout) a.db_partial[(long)strip * a.Cout + co] = accdb[0];
+    }
+}
+
+}  // namespace
+
+// Strip decomposition: 32-pixel-wide column strips of RH rows; aims at ~2 workgroups per CU while keeping
+// the number of fp32 partial copies (one per strip) small: their write + re-read is the kernel's HBM traffic.
+TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout) {
+    TapsPlan p; p.use = 0; p.RH = 0; p.sx = 0; p.sy = 0; p.nstrips = 0;
+    static int on = -1, target = 0; static long max_cico = 0;
+    if (on < 0) {
+        const char* e = getenv("MPU_WGRAD_TAPS"); on = (e && e[0] == '0') ? 0 : 1;
+        const char* t = getenv("MPU_WGRAD_TAPS_WGS"); target = t ? atoi(t) : 512;
+        const char* c = getenv("MPU_WGRAD_TAPS_CICO"); max_cico = c ? atol(c) : TAPS_MAX_CICO;
+        if (max_cico > TAPS_MAX_CICO) max_cico = TAPS_MAX_CICO;
+    }
+    const int Cin = C0 + C1;
+    if (!on || dtype != MPU_BF16 || mode != CONV3 || W < 32 || H < 8) return p;
+    if (C1 > 0 && C0 % 64 != 0) return p;
+    if ((long)Cin * Cout > max_cico) return p;
+    const long M = (long)B * H * W;
+    if (M * (C0 > C1 ? C0 : C1) * 2L >= (1L << 31) || M * Cout * 2L >= (1L << 31)) return p;
+    const int ntile = cdiv(Cin, 64) * cdiv(Cout, 64);
+    const int sx = cdiv(W, 32);
+    int best = 0; long bestd = 1L << 60;
+    for (int rh = 8; rh <= 256; rh *= 2) {
+        const long ns = (long)B * sx * cdiv(H, rh);
+        if (ns * ntile > TAPS_MAX_WGS) continue;
+        const long wgs = ns * ntile;
+        const long d = wgs > target ? wgs - target : target - wgs;
+        if (d < bestd) { bestd = d; best = rh; }
+        if (rh >= H) break;
+    }
+    if (!best) return p;
+    p.RH = best; p.sx = sx; p.sy = cdiv(H, best); p.nstrips = B * sx * p.sy;
+    if ((long)p.nstrips * ntile < 128) return p;                 // too little parallelism: the per-tap kernel splits finer
+    p.use = 1;
+    return p;
+}
+
+int launch_wgrad_taps(const WgradArgs& a, const TapsPlan& p, hipStream_t st) {
+    const int Cin = a.C0 + a.C1;
+    const int ntile = cdiv(Cin, 64) * cdiv(a.Cout, 64);
+    const int grid = cdiv(p.nstrips, 8) * 8 * ntile;
+    wgrad_taps_kernel<<<dim3((unsigned)grid), dim3(256), 0, st>>>(a, p);
+    return launch_ok();
+}
+
+}  // namespace mpu
