@@ -54,7 +54,7 @@ int  try_wgrad_glds(int dtype, int mode, const WgradArgs& a, hipStream_t st);   
 bool wgrad_glds_supported(int dtype, int mode, const WgradArgs& a);
 
 // ---- unet_ops.hip ---------------------------------------------------------
-constexpr int RED_MAX_BLOCKS = 1024;
+constexpr int RED_MAX_BLOCKS = 256;
 
 // fp32 master [taps][Cin][Cout] -> packed operands in T
 // one launch for every 3x3 / up-conv layer of a model (offsets in ELEMENTS of params / the packed buffer)

@@ -241,16 +241,18 @@ int launch_cast_pad(int dtype, const float* x, long M, int Cin, int Cpad, void* 
 //   OP 2: (sum x)                               bias gradient
 // partial layout [nblk][NS][C]
 // ------------------------------------------------------------------------- //
+constexpr int CR_THREADS = 512;      // column-reduction block size
 template <typename T, int OP>
-__global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a, const T* __restrict__ b, long M, int C,
+__global__ __launch_bounds__(CR_THREADS) void colreduce_kernel(const T* __restrict__ a, const T* __restrict__ b, long M, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         int rows_per_blk, float* __restrict__ partial) {
     constexpr int N = Vec<T>::N;
     constexpr int NS = OP == 2 ? 1 : 2;
-    __shared__ float red[256 * N * NS];
+    __shared__ float red[CR_THREADS * N * NS];
+    __shared__ float red2[(256 * N * NS > CR_THREADS) ? 256 * N * NS : CR_THREADS];   // [Q][V], Q*V <= max(CR_THREADS, V)
     const int cpr = C / N;
     int TX = 1; while (TX < cpr && TX < 256) TX <<= 1;
-    const int TY = 256 / TX;
+    const int TY = CR_THREADS / TX;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const long r_beg = (long)blockIdx.x * rows_per_blk;
     long r_end = r_beg + rows_per_blk; if (r_end > M) r_end = M;
@@ -302,14 +304,26 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
             if (NS == 2) red[(threadIdx.x * NS + 1) * N + i] = s1[i];
         }
         __syncthreads();
-        if (ty == 0 && c < cpr) {
-            for (int s = 0; s < NS; ++s)
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    float acc = 0.f;
-                    for (int y = 0; y < TY; ++y) acc += red[((y * TX + tx) * NS + s) * N + i];
-                    partial[((long)blockIdx.x * NS + s) * C + c * N + i] = acc;
-                }
+        {   // two-level block reduction over the TY row-lanes: V = TX*NS*N values per row-lane; every thread sums a
+            // slice of the row-lanes of one value, then one thread per value combines the Q slices (fixed order)
+            const int V = TX * NS * N;
+            const int Q = CR_THREADS / V > 0 ? CR_THREADS / V : 1;
+            const int per = (TY + Q - 1) / Q;
+            for (int idx = threadIdx.x; idx < V * Q; idx += CR_THREADS) {
+                const int v = idx % V, q = idx / V;
+                double acc = 0.0;
+                for (int y = q * per; y < (q + 1) * per && y < TY; ++y) acc += (double)red[y * V + v];
+                red2[q * V + v] = (float)acc;
+            }
+            __syncthreads();
+            for (int v = threadIdx.x; v < V; v += CR_THREADS) {
+                double accd = 0.0;
+                for (int q = 0; q < Q; ++q) accd += (double)red2[q * V + v];
+                const float acc = (float)accd;
+                const int tx2 = v / (NS * N), s = (v / N) % NS, i = v % N;
+                const int c2 = cg + tx2;
+                if (c2 < cpr) partial[((long)blockIdx.x * NS + s) * C + c2 * N + i] = acc;
+            }
         }
         __syncthreads();
     }
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a,
 static int red_blocks(long M, int C, int* rows_per_blk) {
     long rpb = (M + RED_MAX_BLOCKS - 1) / RED_MAX_BLOCKS;
     int TX = 1; while (TX < C / 8 && TX < 256) TX <<= 1;      // as in the kernel (f32: C/4, only more rows per thread)
-    const long min_rows = 4L * (256 / TX);                    // >= 4 rows per thread
+    const long min_rows = 4L * (CR_THREADS / TX);             // >= 4 rows per thread
     if (rpb < min_rows) rpb = min_rows;
     *rows_per_blk = (int)rpb;
     return (int)((M + rpb - 1) / rpb);
@@ -330,9 +344,9 @@ static int launch_colreduce(int dtype, const void* a, const void* b, long M, int
     int rpb; const int nblk = red_blocks(M, C, &rpb);
     *nblk_out = nblk;
     if (dtype == MPU_BF16)
-        colreduce_kernel<bf16_t, OP><<<nblk, 256, 0, st>>>((const bf16_t*)a, (const bf16_t*)b, M, C, mean, invstd, rpb, partial);
+        colreduce_kernel<bf16_t, OP><<<nblk, CR_THREADS, 0, st>>>((const bf16_t*)a, (const bf16_t*)b, M, C, mean, invstd, rpb, partial);
     else
-        colreduce_kernel<float, OP><<<nblk, 256, 0, st>>>((const float*)a, (const float*)b, M, C, mean, invstd, rpb, partial);
+        colreduce_kernel<float, OP><<<nblk, CR_THREADS, 0, st>>>((const float*)a, (const float*)b, M, C, mean, invstd, rpb, partial);
     return launch_ok();
 }
 
