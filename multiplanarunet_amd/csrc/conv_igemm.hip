@@ -632,7 +632,7 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
     const int dt_ = sizeof(T) == 2 ? MPU_BF16 : MPU_F32;
     TapsPlan taps; taps.use = 0;
     if (conv_impl() == 1) taps = wgrad_taps_plan(dt_, MODE, a.B, a.Ho, a.Wo, a.C0, a.C1, a.Cout);
-    if (taps.use) a.ksplit = taps.nstrips;        // one partial copy per pixel strip
+    if (taps.use) a.ksplit = (taps.nstrips + 1) / 2;   // one partial copy per pair of pixel strips
     // the LDS-DMA kernels also sum dz over the pixels (bias gradient) when they handle the shape
     a.fuse_db = (a.db && conv_impl() == 1 && (taps.use || wgrad_glds_supported(dt_, MODE, a))) ? 1 : 0;
     if (a.db && !a.fuse_db) {
@@ -672,7 +672,7 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
     if (a.fuse_db) {         // bias gradient: sum the [ksplit * taps * ci-tiles][Cout] partials of the LDS-DMA kernel
         const bool big128 = sizeof(T) == 2 && Cin >= 128 && a.Cout >= 128 && (a.C1 == 0 || a.C0 % 128 == 0);
         f.partial = a.db_partial; f.db = a.db; f.C = a.Cout;
-        f.nshare = taps.use ? taps.nstrips : a.ksplit * ntaps * cdiv(Cin, big128 ? 128 : 64);
+        f.nshare = taps.use ? a.ksplit : a.ksplit * ntaps * cdiv(Cin, big128 ? 128 : 64);
         db_blocks = cdiv(a.Cout, FIN_COLS);
         if (a.ksplit == 1) return launch_colsum_finalize(a.db_partial, f.nshare, a.Cout, a.db, st);
     }

@@ -18,7 +18,11 @@
 // Both operands are pixel-major in memory (K-major): fragments come from ds_read_b64_tr_b16.
 // Bias gradient: one extra MFMA per wave and step against an all-ones A fragment sums dZ over
 // the pixels (wave w: output channels [16w, 16w+16)).
-// Output: fp32 partials [strip][tap][ci][co] (+ bias partials [strip][co]) reduced in fixed order
+// A workgroup is TWO such 4-wave groups working on neighbouring strips with their own LDS rings; at
+// the end they add their accumulators through LDS (taps 0-4 end up in group 0, taps 5-8 in group 1)
+// so only one fp32 partial copy per PAIR of strips goes to HBM: the partial write + re-read is
+// this kernel's dominant HBM traffic.
+// Output: fp32 partials [pair][tap][ci][co] (+ bias partials [pair][co]) reduced in fixed order
 // by wgrad_reduce*_kernel: deterministic, no atomics.
 #include <stdlib.h>
 #include "kernels.h"
@@ -54,23 +58,40 @@ __device__ __forceinline__ s16x8 t_frag(const unsigned char* p_lo, const unsigne
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(WgradArgs a, TapsPlan p) {
-    __shared__ __attribute__((aligned(128))) unsigned char smem[NXR * XROWB + NZR * ZROWB];
+constexpr int GROUP_LDS = NXR * XROWB + NZR * ZROWB;            // rings of one 4-wave group
+constexpr int XCH_A = 4 * 84 * 256, XCH_B = 4 * 64 * 256;       // accumulator exchange: taps 0-4 (+bias) / taps 5-8
+constexpr int TAPS_SMEM = XCH_A + XCH_B > 2 * GROUP_LDS ? XCH_A + XCH_B : 2 * GROUP_LDS;
+
+__global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPlan p) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem_all[];
     constexpr unsigned OOB = 0xfffffff0u;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave8 >> 2, wave = wave8 & 3;
+    unsigned char* smem = smem_all + grp * GROUP_LDS;
     const int H = a.Ho, W = a.Wo;
     const int Cin = a.C0 + a.C1;
     const int tiles_co = (a.Cout + 63) / 64;
     const int ntile = tiles_co * ((Cin + 63) / 64);
     // XCD-aware decode: the tiles of one strip run on one XCD (shared X / dZ in its L2)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int tile = slot % ntile, strip = (slot / ntile) * 8 + xcd;
-    if (strip >= p.nstrips) return;
+    const int npairs = (p.nstrips + 1) / 2;
+    const int tile = slot % ntile, pair = (slot / ntile) * 8 + xcd;
+    if (pair >= npairs) return;
+    const int strip = pair * 2 + grp;
+    const bool valid = strip < p.nstrips;
     const int xs = strip % p.sx; int t_ = strip / p.sx;
     const int ys = t_ % p.sy; const int b = t_ / p.sy;
     const int x0 = xs * 32, y0 = ys * p.RH;
-    const int nsteps = (y0 + p.RH < H ? y0 + p.RH : H) - y0;
+    const int nsteps = valid ? (y0 + p.RH < H ? y0 + p.RH : H) - y0 : 0;
+    int nsteps_wg;                                               // both groups run the same number of barriers
+    {
+        const int s0 = pair * 2, s1 = pair * 2 + 1;
+        const int ya = ((s0 / p.sx) % p.sy) * p.RH, yb = ((s1 / p.sx) % p.sy) * p.RH;
+        const int n0 = (ya + p.RH < H ? ya + p.RH : H) - ya;
+        const int n1 = s1 < p.nstrips ? (yb + p.RH < H ? yb + p.RH : H) - yb : 0;
+        nsteps_wg = n0 > n1 ? n0 : n1;
+    }
     const int ci0 = (tile / tiles_co) * 64, co0 = (tile % tiles_co) * 64;
     const bool s1 = ci0 >= a.C0 && a.C1 > 0;             // the ci tile lies in one concat source (C0 % 64 == 0 then)
     const int Cs = s1 ? a.C1 : a.C0, cs0 = s1 ? ci0 - a.C0 : ci0;
@@ -139,13 +160,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(WgradArgs a, TapsPla
     const s16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
 
     // ---- pipeline: step t uses X rows t, t+1, t+2 and dZ row t; issues X row t+4 and dZ row t+2 -----------
-    issue_x(0); issue_x(1); issue_x(2); issue_z(0);
-    issue_x(3); issue_z(1);
+    if (valid) {
+        issue_x(0); issue_x(1); issue_x(2); issue_z(0);
+        issue_x(3); issue_z(1);
+    }
     // wait for the first group (rows 0..2 + dZ 0); the second (ngrp DMAs) may still be in flight
     if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     (void)ngrp;
-    for (int t = 0; t < nsteps; ++t) {
+    for (int t = 0; t < nsteps_wg; ++t) {
+        if (t >= nsteps) {                                       // the other group still has rows to do
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            continue;
+        }
         if (t + 2 < nsteps) { issue_x(t + 4); issue_z(t + 2); }
         const unsigned char* zb = smem + NXR * XROWB + (t % NZR) * ZROWB;
         s16x8 bz[4];
@@ -180,10 +208,51 @@ __global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(WgradArgs a, TapsPla
         __builtin_amdgcn_s_barrier();
     }
 
-    // ---- partial sums: [strip][tap][ci][co] -------------------------------------------------------------
-    float* P = a.partial + (long)strip * 9 * Cin * a.Cout;
+    // ---- combine the two groups through LDS (the rings are free now): group 0 ends up with taps 0-4 and the
+    // bias sums, group 1 with taps 5-8; each stores its share of the pair's partial copy -----------------
+    {
+        float* xa = reinterpret_cast<float*>(smem_all) + (wave * 84) * 64 + lane;            // [wave][84][lane]
+        float* xb = reinterpret_cast<float*>(smem_all + XCH_A) + (wave * 64) * 64 + lane;    // [wave][64][lane]
+        if (grp == 1) {
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
+            for (int tp = 0; tp < 5; ++tp)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xa[((tp * 4 + cb) * 4 + r) * 64] = acc[tp][cb][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xa[(80 + r) * 64] = accdb[r];
+        } else {
+#pragma unroll
+            for (int tp = 5; tp < 9; ++tp)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xb[(((tp - 5) * 4 + cb) * 4 + r) * 64] = acc[tp][cb][r];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int tp = 0; tp < 5; ++tp)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[tp][cb][r] += xa[((tp * 4 + cb) * 4 + r) * 64];
+            accdb[0] += xa[80 * 64];
+        } else {
+#pragma unroll
+            for (int tp = 5; tp < 9; ++tp)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[tp][cb][r] += xb[(((tp - 5) * 4 + cb) * 4 + r) * 64];
+        }
+    }
+    // ---- partial sums: [pair][tap][ci][co] ---------------------------------------------------------------
+    float* P = a.partial + (long)pair * 9 * Cin * a.Cout;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        if ((tp < 5) != (grp == 0)) continue;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
             const int co = co0 + cb * 16 + i;
@@ -193,9 +262,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(WgradArgs a, TapsPla
                 if (ci < Cin && co < a.Cout) P[((long)tp * Cin + ci) * a.Cout + co] = acc[tp][cb][r];
             }
         }
-    if (a.fuse_db && ci0 == 0 && g == 0) {                      // every row of accdb holds the column sums: take row 0
+    }
+    if (a.fuse_db && grp == 0 && ci0 == 0 && g == 0) {          // every row of accdb holds the column sums: take row 0
         const int co = co0 + wave * 16 + i;
-        if (co < a.Cout) a.db_partial[(long)strip * a.Cout + co] = accdb[0];
+        if (co < a.Cout) a.db_partial[(long)pair * a.Cout + co] = accdb[0];
     }
 }
 
@@ -239,8 +309,14 @@ TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C
 int launch_wgrad_taps(const WgradArgs& a, const TapsPlan& p, hipStream_t st) {
     const int Cin = a.C0 + a.C1;
     const int ntile = cdiv(Cin, 64) * cdiv(a.Cout, 64);
-    const int grid = cdiv(p.nstrips, 8) * 8 * ntile;
-    wgrad_taps_kernel<<<dim3((unsigned)grid), dim3(256), 0, st>>>(a, p);
+    const int npairs = (p.nstrips + 1) / 2;
+    const int grid = cdiv(npairs, 8) * 8 * ntile;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
+        attr_set = true;
+    }
+    wgrad_taps_kernel<<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(a, p);
     return launch_ok();
 }
 
