@@ -132,56 +132,83 @@ __global__ void pack_dgrad_kernel(int mode, const float* __restrict__ W, int Cin
 // table travels in the kernel arguments (no device-side table to keep in sync).
 template <typename T>
 __device__ __forceinline__ void pack_fwd_tile(const PackJob& j, int t, const float* __restrict__ params, T* packed,
-                                              float (*tile)[33]) {
+                                              float (*tile)[65]) {
+    // 64x64 tile: 16-byte reads along co, transpose through LDS, 16-byte writes along ci
+    constexpr int N = Vec<T>::N;
     const int Cin = j.Cin, Cout = j.Cout;
-    const int tci = (Cin + 31) / 32, tco = (Cout + 31) / 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tci = (Cin + 63) / 64, tco = (Cout + 63) / 64;
     const int tap = t / (tci * tco); const int r = t % (tci * tco);
-    const int ci0 = (r / tco) * 32, co0 = (r % tco) * 32;
+    const int ci0 = (r / tco) * 64, co0 = (r % tco) * 64;
     const float* src = params + j.w + (long)tap * Cin * Cout;
+    {
+        const int ty = threadIdx.x >> 4, tx4 = (threadIdx.x & 15) * 4;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int ci = ci0 + ty + 8 * k, co = co0 + tx;
-        tile[ty + 8 * k][tx] = (ci < Cin && co < Cout) ? src[(long)ci * Cout + co] : 0.f;
+        for (int k = 0; k < 4; ++k) {
+            const int cil = ty + 16 * k, ci = ci0 + cil, co = co0 + tx4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci < Cin && co < Cout) v = *reinterpret_cast<const float4*>(src + (long)ci * Cout + co);   // Cout % 8 == 0
+            tile[cil][tx4] = v.x; tile[cil][tx4 + 1] = v.y; tile[cil][tx4 + 2] = v.z; tile[cil][tx4 + 3] = v.w;
+        }
     }
     __syncthreads();
     T* dst = packed + j.wf + (long)tap * Cin * Cout;
+    constexpr int GPR = 64 / N, RPP = 256 / GPR;                  // 16-byte groups per co row, co rows per pass
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int co = co0 + ty + 8 * k, ci = ci0 + tx;
-        if (ci < Cin && co < Cout) dst[(long)co * Cin + ci] = from_f32<T>(tile[tx][ty + 8 * k]);
+    for (int pass = 0; pass < 64 / RPP; ++pass) {
+        const int col = threadIdx.x / GPR + pass * RPP, cil = (threadIdx.x % GPR) * N;
+        const int co = co0 + col, ci = ci0 + cil;
+        if (ci < Cin && co < Cout) {                              // Cin % 8 == 0: the whole vector is in range
+            float v[N];
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = tile[cil + e][col];
+            Vec<T>::store(dst + (long)co * Cin + ci, v);
+        }
     }
 }
 
 template <typename T>
 __device__ __forceinline__ void pack_dgrad_chunk(const PackJob& j, int chunk, const float* __restrict__ params, T* packed) {
-    const long per_tap = (long)j.Cin * j.Cout;                 // multiple of 64: a float4 never straddles taps
-    const long e = (long)chunk * 1024 + threadIdx.x * 4;
+    const long per_tap = (long)j.Cin * j.Cout;                 // multiple of 64: 8 consecutive elements never straddle taps
+    const long e = (long)chunk * 2048 + threadIdx.x * 8;
     if (e >= 9 * per_tap) return;
     const int tp = (int)(e / per_tap); const long r = e % per_tap;
     const float* W = params + j.w;
-    float4 v;
+    float v[8];
+    auto load8 = [&](const float* p, float* o) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    };
     if (j.mode == CONV3) {
-        v = *reinterpret_cast<const float4*>(W + (long)(8 - tp) * per_tap + r);
-    } else {
-        const int dy = tp / 3 - 1, dx = tp % 3 - 1;
-        v = make_float4(0.f, 0.f, 0.f, 0.f);
+        load8(W + (long)(8 - tp) * per_tap + r, v);            // 180-degree rotated taps
+    } else {                                                    // UPCONV2 -> 3x3 stride-2 combined taps
+        const int dy = tp / 3 - 1, dx = tp % 3 - 1;             // S(-1)={1}, S(0)={0,1}, S(1)={0}
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
         for (int ky = 0; ky < 2; ++ky) {
             if ((dy == -1 && ky != 1) || (dy == 1 && ky != 0)) continue;
             for (int kx = 0; kx < 2; ++kx) {
                 if ((dx == -1 && kx != 1) || (dx == 1 && kx != 0)) continue;
-                const float4 u = *reinterpret_cast<const float4*>(W + (long)(ky * 2 + kx) * per_tap + r);
-                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                float u[8];
+                load8(W + (long)(ky * 2 + kx) * per_tap + r, u);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += u[i];
             }
         }
     }
     T* dst = packed + j.wd + e;
-    dst[0] = from_f32<T>(v.x); dst[1] = from_f32<T>(v.y); dst[2] = from_f32<T>(v.z); dst[3] = from_f32<T>(v.w);
+    constexpr int N = Vec<T>::N;
+#pragma unroll
+    for (int h = 0; h < 8 / N; ++h) {
+        float w[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) w[i] = v[h * N + i];
+        Vec<T>::store(dst + h * N, w);
+    }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void pack_all_kernel(PackTable tab, const float* __restrict__ params, T* packed) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[64][65];
     int ji = 0;
     while (ji + 1 < tab.njobs && (int)blockIdx.x >= tab.job[ji + 1].unit_begin) ++ji;
     const PackJob& j = tab.job[ji];
@@ -196,8 +223,8 @@ int launch_pack_all(int dtype, PackTable& tab, const float* params, void* packed
         PackJob& j = tab.job[i];
         const int ntaps = j.mode == UPCONV2 ? 4 : 9;
         j.unit_begin = units;
-        j.fwd_units = ntaps * cdiv(j.Cin, 32) * cdiv(j.Cout, 32);
-        units += j.fwd_units + (int)cdiv(9L * j.Cin * j.Cout, 1024L);
+        j.fwd_units = ntaps * cdiv(j.Cin, 64) * cdiv(j.Cout, 64);
+        units += j.fwd_units + (int)cdiv(9L * j.Cin * j.Cout, 2048L);
     }
     if (units == 0) return MPU_OK;
     if (dtype == MPU_BF16) pack_all_kernel<bf16_t><<<units, 256, 0, st>>>(tab, params, (bf16_t*)packed);
