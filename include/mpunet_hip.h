@@ -226,6 +226,18 @@ int mpu_unet_backward(const mpu_unet* m, int32_t batch, const uint8_t* d_y,
                       float* d_bn_state, void* d_workspace, float* d_grads, float* d_loss,
                       void* stream);
 
+/* Data-parallel training: the backward pass finishes the flat gradient buffer from its END towards its start
+ * (head, up blocks, bottom, encoder levels). mpu_unet_grad_ready_points returns the number of ready points and
+ * writes their float offsets (descending): after point k every gradient at offset >= offsets[k] is final.
+ * mpu_unet_backward_events is mpu_unet_backward that also records ready_events[k] (hipEvent_t, NULL = skip) on
+ * `stream` at point k, so the caller can start the all-reduce of a bucket (tf.distribute.MirroredStrategy's
+ * gradient aggregation, mpunet/bin/train.py:349) while the rest of the backward pass is still running. */
+int32_t mpu_unet_grad_ready_points(const mpu_unet* m, int64_t* offsets, int32_t cap);
+int mpu_unet_backward_events(const mpu_unet* m, int32_t batch, const uint8_t* d_y,
+                             const float* d_sample_weight, const float* d_params, const void* d_packed,
+                             float* d_bn_state, void* d_workspace, float* d_grads, float* d_loss,
+                             void* const* ready_events, int32_t n_events, void* stream);
+
 /* Keras Adam (TF ApplyAdam form), t = 1-based step; YAML defaults
  * lr 5e-5, beta_1 .9, beta_2 .999, epsilon 1e-8
  * (mpunet/bin/defaults/MultiPlanar/train_hparams.yaml:126). */

@@ -168,6 +168,7 @@ struct Run {
     bool overlap = false;          // weight gradients on the model's side stream
     mutable bool pending = false;  // a weight gradient is in flight on the side stream
     const float* params; const unsigned char* packed; float* state; float* grads;
+    void* const* ready_events = nullptr; int n_ready = 0;        // gradient-ready points (mpu_unet_backward_events)
     int esz;
     void* at(long off) const { return ws + off; }
     const void* wf(const Conv& c) const { return packed + c.wf * esz; }
@@ -340,6 +341,18 @@ int run_forward(const Run& r, const float* d_x, int training, float* d_out) {
     return MPU_OK;
 }
 
+int wgrad_join(const Run& r);
+
+// gradient-ready point k (see mpu_unet_grad_ready_points): everything the backward pass will write at or
+// above that offset of the flat gradient buffer has been enqueued; record the caller's event there
+int mark_ready(const Run& r, int k) {
+    if (!r.ready_events || k >= r.n_ready || !r.ready_events[k]) return MPU_OK;
+    int rc = wgrad_join(r);
+    if (rc) return rc;
+    MPU_CHECK_HIP(hipEventRecord((hipEvent_t)r.ready_events[k], r.st));
+    return MPU_OK;
+}
+
 int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_loss) {
     const mpu_unet* m = r.m; const int D = m->cfg.depth; const Plan& P = r.P;
     const int dt = m->cfg.dtype;
@@ -349,6 +362,8 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
     RC(launch_head_backward(dt, last, (const float*)r.at(P.probs), d_y, d_sw, M0, (long)m->cfg.H * m->cfg.W,
                             m->head_C, m->cfg.n_classes, r.params + m->head_w, m->cfg.n_classes,
                             (float*)r.at(P.partial), gA, r.grads + m->head_w, r.grads + m->head_b, d_loss, r.st));
+    int point = 0;
+    RC(mark_ready(r, point++));                                                            // head
     // Each weight gradient (side stream) runs next to the data gradient of the same layer (main stream);
     // wgrad_join() precedes the first main-stream kernel that overwrites the dz buffer it reads.
     for (int j = D - 1; j >= 0; --j) {
@@ -369,6 +384,7 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
         RC(wgrad_join(r));                                                                 // gA is about to be written
         RC(conv_wgrad(r, cu, prev, Cprev, nullptr, 0, gC, lvl));                           //   reads gC
         RC(conv_dgrad(r, cu, gC, nullptr, gA, lvl + 1, 0, Cprev));                         // d prev -> gA
+        RC(mark_ready(r, point++));                                                        // up block j
     }
     {   // bottom
         const Conv& c1 = m->conv[m->bot_c1()]; const Conv& c2 = m->conv[m->bot_c2()];
@@ -379,6 +395,7 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
         RC(conv_dgrad(r, c2, gB, r.at(P.c1b), gA, D, 0, m->F[D]));
         RC(conv_wgrad_after_join(r, c1, xin, Cx, nullptr, 0, gA, D));
         if (D > 0) RC(conv_dgrad(r, c1, gA, nullptr, gB, D, 0, Cx));                       // d pooled -> gB (gB reader joined above)
+        RC(mark_ready(r, point++));                                                        // bottom
     }
     for (int i = D - 1; i >= 0; --i) {
         const Conv& c1 = m->conv[m->enc_c1(i)]; const Conv& c2 = m->conv[m->enc_c2(i)];
@@ -392,6 +409,7 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
         const int Cx = i > 0 ? m->F[i - 1] : m->cin_pad;
         RC(conv_wgrad_after_join(r, c1, xin, Cx, nullptr, 0, gA, i));
         if (i > 0) RC(conv_dgrad(r, c1, gA, nullptr, gB, i, 0, Cx));
+        RC(mark_ready(r, point++));                                                        // encoder level i
     }
     return wgrad_join(r);            // the gradient buffer is complete when the main stream continues
 }
@@ -537,6 +555,30 @@ int mpu_unet_backward(const mpu_unet* m, int32_t batch, const uint8_t* d_y, cons
     MPU_REQUIRE(m && m->cfg.softmax, "mpu_unet_backward: training needs out_activation='softmax'");
     Run r;
     RC(make_run(r, m, batch, d_params, d_packed, d_bn_state, d_grads, d_workspace, stream));
+    return run_backward(r, d_y, d_sample_weight, d_loss);
+}
+
+int32_t mpu_unet_grad_ready_points(const mpu_unet* m, int64_t* offsets, int32_t cap) {
+    if (!m) return 0;
+    const int D = m->cfg.depth;
+    std::vector<long> pts;
+    pts.push_back(m->head_w < m->head_b ? m->head_w : m->head_b);
+    for (int j = D - 1; j >= 0; --j) pts.push_back(m->conv[m->up_c(j, 0)].w);
+    pts.push_back(m->conv[m->bot_c1()].w);
+    for (int i = D - 1; i >= 0; --i) pts.push_back(m->conv[m->enc_c1(i)].w);
+    for (size_t k = 0; k < pts.size() && (int)k < cap; ++k) offsets[k] = pts[k];
+    return (int32_t)pts.size();
+}
+
+int mpu_unet_backward_events(const mpu_unet* m, int32_t batch, const uint8_t* d_y, const float* d_sample_weight,
+                             const float* d_params, const void* d_packed, float* d_bn_state, void* d_workspace,
+                             float* d_grads, float* d_loss, void* const* ready_events, int32_t n_events,
+                             void* stream) {
+    MPU_REQUIRE(d_y && d_sample_weight && d_grads, "mpu_unet_backward_events: null argument");
+    MPU_REQUIRE(m && m->cfg.softmax, "mpu_unet_backward_events: training needs out_activation='softmax'");
+    Run r;
+    RC(make_run(r, m, batch, d_params, d_packed, d_bn_state, d_grads, d_workspace, stream));
+    r.ready_events = ready_events; r.n_ready = ready_events ? n_events : 0;
     return run_backward(r, d_y, d_sample_weight, d_loss);
 }
 

@@ -64,19 +64,62 @@ def allreduce_sum_(flat, bucket_bytes=64 << 20):
 
 
 class DataParallelTrainer:
-    """Wires the gradient all-reduce into UNet.train_step (model._grad_hook)."""
+    """
+    Wires the gradient all-reduce into UNet.train_step (model._grad_hook).
 
-    def __init__(self, model, bucket_bytes=64 << 20, broadcast_weights=True):
+    overlap=True (default on GPUs): the backward pass finishes the flat gradient buffer from its end towards its
+    start and records an event per gradient-ready point (mpu_unet_backward_events); buckets of >= bucket_bytes are
+    all-reduced on a communication stream as soon as their event fires, while the remaining data/weight
+    gradients are still being computed. Adam waits for all buckets. Same result as one all-reduce after the
+    backward pass (SUM is element-wise).
+    """
+
+    def __init__(self, model, bucket_bytes=32 << 20, broadcast_weights=True, overlap=None):
         self.model = model
         self.bucket_bytes = bucket_bytes
-        model._grad_hook = self._hook
+        dev = getattr(model, "device", None)
+        can = dev is not None and dev.type == "cuda" and hasattr(model, "grad_ready_points")
+        self.overlap = can if overlap is None else (bool(overlap) and can)
+        self.ready_events = None
+        self.buckets = []                          # (point index, lo, hi) in the order the backward pass completes them
+        if self.overlap:
+            pts = model.grad_ready_points()
+            n = model.grads.numel()
+            hi = n
+            self.ready_events = [None] * len(pts)
+            step = max(1, bucket_bytes // 4)
+            for k, off in enumerate(pts):
+                last = k == len(pts) - 1
+                if hi - off >= step or (last and hi > off) or (last and not self.buckets):
+                    ev = torch.cuda.Event()
+                    ev.record()                    # forces the underlying hipEvent_t into existence
+                    self.ready_events[k] = ev
+                    self.buckets.append((k, off if not last else 0, hi))
+                    hi = off if not last else 0
+            if hi > 0:                             # ready points always end at offset 0; defensive
+                self.buckets[-1] = (self.buckets[-1][0], 0, self.buckets[-1][2])
+            self.comm = torch.cuda.Stream(device=model.device)
+            torch.cuda.synchronize()
+        model._grad_hook = self
         if broadcast_weights and world_size() > 1:
             dist.broadcast(model.params, src=0)
             dist.broadcast(model.bn_state, src=0)
             model._repack()
 
-    def _hook(self, grads):
-        allreduce_sum_(grads, self.bucket_bytes)
+    def __call__(self, grads):
+        if world_size() == 1:
+            return
+        if not self.overlap:
+            allreduce_sum_(grads, self.bucket_bytes)
+            return
+        works = []
+        with torch.cuda.stream(self.comm):
+            for k, lo, hi in self.buckets:
+                self.comm.wait_event(self.ready_events[k])
+                works.append(dist.all_reduce(grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()                               # the compute stream waits for the collectives
+        torch.cuda.current_stream().wait_stream(self.comm)
 
 
 # --------------------------------------------------------------------------- #

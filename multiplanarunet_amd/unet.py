@@ -357,8 +357,18 @@ class UNet:
             self._adam_m = torch.zeros_like(self.params)
             self._adam_v = torch.zeros_like(self.params)
 
-    def forward_backward(self, x, y, sample_weight=None, want_loss=True):
-        """Train-mode forward + backward; fills self.grads (sum-gradient). Returns (probs, loss[B,H*W] or None)."""
+    def grad_ready_points(self):
+        """Float offsets (descending) of the backward pass's gradient-ready points: after point k every gradient at
+        offset >= offsets[k] of the flat buffer is final (head, up blocks, bottom, encoder levels)."""
+        import ctypes as C
+        buf = (C.c_int64 * 32)()
+        n = _lib.load().mpu_unet_grad_ready_points(self._h, buf, 32)
+        return [int(buf[i]) for i in range(n)]
+
+    def forward_backward(self, x, y, sample_weight=None, want_loss=True, ready_events=None):
+        """Train-mode forward + backward; fills self.grads (sum-gradient). Returns (probs, loss[B,H*W] or None).
+        ready_events: optional list (one entry per grad_ready_points(), None = skip) of torch.cuda.Event recorded
+        on the current stream when that part of the gradient buffer is final (data-parallel overlap)."""
         X = self._as_input(x)
         B = X.shape[0]
         if not torch.is_tensor(y):
@@ -373,9 +383,16 @@ class UNet:
                                  else sample_weight).to(device=self.device, dtype=torch.float32).contiguous()
         probs = self._forward(X, training=True)
         loss = torch.empty((B, y.shape[1]), dtype=torch.float32, device=self.device) if want_loss else None
-        _lib.call("mpu_unet_backward", self._h, B, _lib.ptr(y), _lib.ptr(sw), _lib.ptr(self.params),
-                  _lib.ptr(self.packed), _lib.ptr(self.bn_state), _lib.ptr(self._ws), _lib.ptr(self.grads),
-                  _lib.ptr(loss), _lib.stream_ptr())
+        if ready_events is None:
+            _lib.call("mpu_unet_backward", self._h, B, _lib.ptr(y), _lib.ptr(sw), _lib.ptr(self.params),
+                      _lib.ptr(self.packed), _lib.ptr(self.bn_state), _lib.ptr(self._ws), _lib.ptr(self.grads),
+                      _lib.ptr(loss), _lib.stream_ptr())
+        else:
+            import ctypes as C
+            arr = (C.c_void_p * len(ready_events))(*[None if e is None else e.cuda_event for e in ready_events])
+            _lib.call("mpu_unet_backward_events", self._h, B, _lib.ptr(y), _lib.ptr(sw), _lib.ptr(self.params),
+                      _lib.ptr(self.packed), _lib.ptr(self.bn_state), _lib.ptr(self._ws), _lib.ptr(self.grads),
+                      _lib.ptr(loss), arr, len(ready_events), _lib.stream_ptr())
         return probs, loss
 
     def apply_gradients(self):
@@ -431,9 +448,11 @@ class UNet:
 
     def train_step(self, x, y, sample_weight=None, want_loss=True):
         """One Model.fit inner step. Returns the per-pixel loss [B,H*W] (device) or None."""
-        _, loss = self.forward_backward(x, y, sample_weight, want_loss)
-        if self._grad_hook is not None:
-            self._grad_hook(self.grads)          # data-parallel: SUM of replica gradients
+        hook = self._grad_hook
+        events = getattr(hook, "ready_events", None)
+        _, loss = self.forward_backward(x, y, sample_weight, want_loss, ready_events=events)
+        if hook is not None:
+            hook(self.grads)                     # data-parallel: SUM of replica gradients
         self.apply_gradients()
         return loss
 
