@@ -113,23 +113,23 @@ def main():
     if graphed:
         replay = model.make_graphed_train_step(x, y, sw)
         replay()
+        run = replay
+    else:
+        run = step
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if events:                                   # roofline leg: same K steps again, eager, per-launch HIP events on
         barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            replay()
-        barrier()
-        dt = time.perf_counter() - t0
-    if events or not graphed:
-        barrier()
-        if events:
-            lib.mpu_profile_enable(1)
+        lib.mpu_profile_enable(1)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         barrier()
         dt_eager = time.perf_counter() - t0
-        if not graphed:
-            dt = dt_eager
     roof = {}
     if events:
         import ctypes as C
@@ -161,7 +161,7 @@ def main():
                        "algorithmic_gflop_per_slice": round(gf_slice, 2)},
             "step_tflops_algorithmic": round(gf_slice * B * world / 1e3 / (ms_step / 1e3), 1),
         }
-        if graphed and dt_eager is not None:
+        if dt_eager is not None:
             out["ms_per_step_eager_with_events"] = round(dt_eager / args.steps * 1e3, 4)
         traffic = {}
         try:   # HBM bytes per launch from the rocprofv3 PMC passes of this round (profiles/, see its note)
