@@ -226,6 +226,18 @@ int mpu_unet_backward(const mpu_unet* m, int32_t batch, const uint8_t* d_y,
                       float* d_bn_state, void* d_workspace, float* d_grads, float* d_loss,
                       void* stream);
 
+/* Fusion-model training (mpunet/bin/train_fusion.py:327-362 `fusion_model.fit`): one Adam step of the FusionLayer
+ * (mpunet/models/fusion_model.py:14-39) on a batch of points x[n][V][K] with integer targets y[n] under the
+ * reference's per-point generalized Dice loss (mpunet/evaluate/loss_functions.py:207-246, SUM_OVER_BATCH_SIZE) plus
+ * its 1e-6 * mean(square) regularisers. t >= 1: Keras Adam step t is applied to d_W [V][K] / d_b [K] (moments in
+ * d_adam_m / d_adam_v, V*K+K floats); t == 0: gradients and loss only. d_grads_out (V*K+K floats) and d_loss_out
+ * (1 float, the batch loss BEFORE the update) may be NULL. */
+int64_t mpu_fusion_train_workspace_floats(int32_t n_views, int32_t n_classes);
+int mpu_fusion_train_step(const float* d_x, const uint8_t* d_y, int64_t n, int32_t n_views,
+                          int32_t n_classes, float* d_W, float* d_b, float* d_adam_m, float* d_adam_v,
+                          int64_t t, double lr, double beta1, double beta2, double eps,
+                          float* d_workspace, float* d_grads_out, float* d_loss_out, void* stream);
+
 /* Data-parallel training: the backward pass finishes the flat gradient buffer from its END towards its start
  * (head, up blocks, bottom, encoder levels). mpu_unet_grad_ready_points returns the number of ready points and
  * writes their float offsets (descending): after point k every gradient at offset >= offsets[k] is final.

@@ -2,7 +2,7 @@
 import sys
 import importlib
 
-SCRIPTS = ("train", "predict")
+SCRIPTS = ("train", "train_fusion", "predict")
 
 
 def entry_func(argv=None):

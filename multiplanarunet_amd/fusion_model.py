@@ -3,6 +3,8 @@ mpunet.models.FusionModel on MI355X (mpunet/models/fusion_model.py:14-75):
 softmax_k(sum_v W[v,k] x[n,v,k] + b[0,k]); W (V,K) init 1.0, b (1,K) init 0.0.
 predict() accepts the reference's explicit [N,V,K] layout; the predict pipeline
 uses the fused map+fuse kernel instead (multiplanarunet_amd.interpolation.map_and_fuse).
+Training (mpunet/bin/train_fusion.py:327-362): compile() + fit()/train_on_batch() run the per-point
+generalized Dice loss, its gradient and Keras Adam(1e-3) in mpu_fusion_train_step (csrc/fusion_train.hip).
 """
 import numpy as np
 import torch
@@ -31,6 +33,12 @@ class FusionModel:
         self.W = torch.ones((n_inputs, n_classes), dtype=torch.float32, device=self.device)
         self.b = torch.zeros((1, n_classes), dtype=torch.float32, device=self.device)
         self.layers = [_FusionLayerShim(self)]
+        self.weight = weight                       # GDL class-weight type: Simple | Square | Uniform (identical per point)
+        if str(weight).lower() not in ("simple", "square", "uniform"):
+            raise ValueError('The variable type_weight "%s" is not defined.' % weight)
+        self.optimizer_kwargs = None
+        self.iterations = 0
+        self.stop_training = False
         if verbose:
             self._log()
 
@@ -62,6 +70,112 @@ class FusionModel:
     def load_weights(self, path, by_name=False):
         with np.load(path) as z:
             self.set_weights([z["W"], z["b"]])
+
+    # ---- training ---------------------------------------------------------------------------------
+    def compile(self, optimizer="Adam", loss=None, metrics=None, optimizer_kwargs=None, **kwargs):
+        """train_fusion.py:343-345: Adam(lr=1e-3) (Keras defaults b1 .9, b2 .999, eps 1e-7), loss = the model's GDL."""
+        if optimizer not in ("Adam", "adam"):
+            raise NotImplementedError("FusionModel training supports the reference's optimizer (Adam) only")
+        kw = dict(lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7)
+        kw.update(optimizer_kwargs or {})
+        if "learning_rate" in kw:
+            kw["lr"] = kw.pop("learning_rate")
+        self.optimizer_kwargs = kw
+        n = self.count_params()
+        self._adam_m = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self._adam_v = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self._ws = torch.empty(int(_lib.load().mpu_fusion_train_workspace_floats(self.n_inputs, self.n_classes)),
+                               dtype=torch.float32, device=self.device)
+        self.iterations = 0
+        return self
+
+    def _check_xy(self, x, y):
+        xd = torch.as_tensor(x).to(device=self.device, dtype=torch.float32).contiguous()
+        if xd.ndim != 3 or xd.shape[1] != self.n_inputs or xd.shape[2] != self.n_classes:
+            raise ValueError("expected input [N,%d,%d]" % (self.n_inputs, self.n_classes))
+        yd = torch.as_tensor(y).to(device=self.device).reshape(-1).to(torch.uint8).contiguous()
+        if yd.shape[0] != xd.shape[0]:
+            raise ValueError("x and y must have the same number of points")
+        return xd, yd
+
+    def _step(self, xd, yd, apply, want_grads=False):
+        if self.optimizer_kwargs is None:
+            self.compile()
+        k = self.optimizer_kwargs
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        grads = torch.empty(self.count_params(), dtype=torch.float32, device=self.device) if want_grads else None
+        t = 0
+        if apply:
+            self.iterations += 1
+            t = self.iterations
+        _lib.call("mpu_fusion_train_step", _lib.ptr(xd), _lib.ptr(yd), xd.shape[0], self.n_inputs, self.n_classes,
+                  _lib.ptr(self.W), _lib.ptr(self.b), _lib.ptr(self._adam_m), _lib.ptr(self._adam_v), t,
+                  float(k["lr"]), float(k["beta_1"]), float(k["beta_2"]), float(k["epsilon"]), _lib.ptr(self._ws),
+                  _lib.ptr(grads), _lib.ptr(loss), _lib.stream_ptr())
+        return loss, grads
+
+    def loss_and_gradients(self, x, y):
+        """Batch loss and d loss / d (W, b) without updating (parity tests)."""
+        xd, yd = self._check_xy(x, y)
+        loss, g = self._step(xd, yd, apply=False, want_grads=True)
+        V, K = self.n_inputs, self.n_classes
+        return float(loss.item()), g[:V * K].reshape(V, K).cpu().numpy(), g[V * K:].reshape(1, K).cpu().numpy()
+
+    def train_on_batch(self, x, y):
+        xd, yd = self._check_xy(x, y)
+        loss, _ = self._step(xd, yd, apply=True)
+        return float(loss.item())
+
+    def fit(self, x, y, batch_size=2 ** 17, epochs=1, shuffle=True, validation_data=None, early_stopping=None,
+            verbose=0, seed=None, callbacks=None, **kwargs):
+        """
+        Keras Model.fit on an in-memory point set (train_fusion.py:205-216): per epoch a fresh shuffle, batches of
+        batch_size points (the last one may be short), epoch loss = point-weighted mean of the batch losses.
+        validation_data=(X_val, y_val): logs val_dice = mean foreground Dice of the argmax (ValDiceScores,
+        callbacks/validation.py:308-354); early_stopping=n: stop after n epochs without a val_dice improvement
+        (EarlyStopping(monitor='val_dice', mode='max', min_delta=0)). Returns {"loss": [...], "val_dice": [...]}.
+        """
+        from .interpolation import dice_all
+        xd, yd = self._check_xy(x, y)
+        N = xd.shape[0]
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(int(seed) if seed is not None else int(np.random.randint(0, 2 ** 31 - 1)))
+        if validation_data is not None:
+            xv, yv = self._check_xy(*validation_data)
+        hist = {"loss": [], "val_dice": []}
+        best, wait = -np.inf, 0
+        self.stop_training = False
+        for ep in range(epochs):
+            if shuffle:
+                perm = torch.randperm(N, generator=gen).to(self.device)
+                xe, ye = xd[perm], yd[perm]
+            else:
+                xe, ye = xd, yd
+            tot = torch.zeros(1, dtype=torch.float64, device=self.device)
+            for s in range(0, N, batch_size):
+                e = min(N, s + batch_size)
+                loss, _ = self._step(xe[s:e], ye[s:e], apply=True)
+                tot += loss.double() * (e - s)
+            hist["loss"].append(float(tot.item()) / N)
+            msg = "Epoch %d/%d - loss: %.6f" % (ep + 1, epochs, hist["loss"][-1])
+            if validation_data is not None:
+                pred = self.predict(xv).argmax(-1)
+                d = dice_all(yv, pred, self.n_classes, ignore_zero=True)
+                vd = float(np.nanmean(d))
+                hist["val_dice"].append(vd)
+                msg += " - val_dice: %.4f (per class %s)" % (vd, np.round(d, 4))
+                if early_stopping is not None:
+                    if vd > best:
+                        best, wait = vd, 0
+                    else:
+                        wait += 1
+                        if wait >= early_stopping:
+                            self.stop_training = True
+            if verbose:
+                self.logger(msg)
+            if self.stop_training:
+                break
+        return hist
 
     def predict(self, x, batch_size=10 ** 4, verbose=0):
         """x [N,V,K] (numpy or device tensor) -> probabilities [N,K]."""

@@ -31,3 +31,16 @@ def test_mp_train_then_predict_synthetic(tmp_path):
     res = (proj / "predictions" / "csv" / "results.csv").read_text().splitlines()
     mean_dice = float(res[1].split(",")[1])
     assert mean_dice > 0.5, res
+    # fusion-model training on the project, then predict with the learned FusionLayer
+    hist = mp.entry_func(["train_fusion", "--project_dir", str(proj), "--synthetic", "2", "--epochs", "4",
+                          "--images_per_round", "2", "--batch_size", "65536", "--seed", "0"])
+    fdir = proj / "model" / "fusion_weights"
+    files = os.listdir(fdir)
+    assert len(files) == 1 and files[0].endswith("_fusion_weights.npz")
+    z = np.load(fdir / files[0])
+    assert z["W"].shape == (3, 3) and z["b"].shape == (1, 3) and not np.allclose(z["W"], 1.0)
+    mp.entry_func(["predict", "--project_dir", str(proj), "--synthetic", "1", "--overwrite"])
+    res2 = (proj / "predictions" / "csv" / "results.csv").read_text().splitlines()
+    assert float(res2[1].split(",")[1]) > 0.5, res2
+    with pytest.raises(OSError):
+        mp.entry_func(["train_fusion", "--project_dir", str(proj), "--synthetic", "1"])       # exists, no --overwrite
