@@ -52,21 +52,6 @@ def validate_args(args):
                                   "computations only!', mpunet/utils/system.py:80-81)")
 
 
-def validation_dice(model, sampler, steps, n_classes):
-    """Per-class dice over sampled validation batches (callbacks/validation.py:59-230, smooth-free counts)."""
-    tp = np.zeros(n_classes); rel = np.zeros(n_classes); sel = np.zeros(n_classes)
-    for _ in range(steps):
-        x, y, _ = sampler()
-        pred = model.predict_on_batch(x).reshape(y.shape[0], -1, n_classes).argmax(-1).reshape(-1)
-        t = y.reshape(-1).long()
-        for c in range(n_classes):
-            pc, tc = pred == c, t == c
-            tp[c] += int((pc & tc).sum()); rel[c] += int(tc.sum()); sel[c] += int(pc.sum())
-    with np.errstate(invalid="ignore", divide="ignore"):
-        d = 2 * tp / (rel + sel)
-    return float(np.nanmean(d[1:])) if n_classes > 1 else float(d[0])
-
-
 def run(args):
     from .. import distributed as D
     from ..unet import UNet
@@ -119,40 +104,38 @@ def run(args):
     epochs = args.epochs or int(fit["n_epochs"])
     steps = max(1, int(np.ceil(args.train_images_per_epoch / B)))
     vsteps = max(1, int(np.ceil(args.val_images_per_epoch / B)))
-    best, best_path, since_best, lr_wait = -1.0, None, 0, 0
+    from ..validation import Validation, ReduceLROnPlateau, EarlyStopping, ModelCheckPointClean
+    validation = Validation(va, vsteps, build["n_classes"], logger=log, verbose=rank == 0) if va is not None else None
+    # the YAML's callback list (bin/defaults/MultiPlanar/train_hparams.yaml:7-45): rlop, mcp_clean, es, csv
+    rlop = ReduceLROnPlateau(patience=2, factor=0.90, monitor="val_dice", mode="max", logger=log)
+    es = EarlyStopping(monitor="val_dice", min_delta=0, patience=15, mode="max", logger=log)
+    mcp = ModelCheckPointClean(os.path.join(model_dir, "@epoch_{epoch:02d}_val_dice_{val_dice:.5f}.npz"),
+                               monitor="val_dice", mode="max", logger=log, verbose=1)
     csv = os.path.join(project_dir, "logs", "training.csv")
     try:
-        for ep in range(1, epochs + 1):
+        for ep in range(epochs):
             tot = 0.0
             for _ in range(steps):
                 x, y, w = tr()
                 tot += float(model.train_step(x, y, w).mean().item())
-            msg = "Epoch %d/%d - loss %.5f" % (ep, epochs, tot / steps)
-            vd = None
-            if va is not None:
-                vd = validation_dice(model, va, vsteps, build["n_classes"])
-                msg += " - val_dice %.5f" % vd
-            log(msg)
+            logs = {"loss": tot / steps}
+            if validation is not None:
+                validation.on_epoch_end(model, ep, logs)
+            log("Epoch %d/%d - " % (ep + 1, epochs) + " - ".join("%s: %.5f" % kv for kv in logs.items()))
+            if validation is not None:
+                rlop.on_epoch_end(model, ep, logs)
+                if rank == 0:
+                    mcp.on_epoch_end(model, ep, logs)
+                es.on_epoch_end(model, ep, logs)
             if rank == 0:
                 with open(csv, "a") as f:
-                    if ep == 1 and f.tell() == 0:
-                        f.write("epoch,loss,val_dice,lr\n")
-                    f.write("%d,%.6f,%s,%g\n" % (ep - 1, tot / steps, "" if vd is None else "%.6f" % vd,
-                                                 model.optimizer_kwargs["lr"]))
-                if vd is not None and vd > best:      # ModelCheckPointClean: keep only the best file
-                    if best_path and os.path.exists(best_path):
-                        os.remove(best_path)
-                    best_path = os.path.join(model_dir, "@epoch_%02d_val_dice_%.5f.npz" % (ep, vd))
-                    model.save_weights(best_path)
-            if vd is not None:
-                if vd > best:
-                    best, since_best, lr_wait = vd, 0, 0
-                else:
-                    since_best += 1; lr_wait += 1
-                    if lr_wait > 2:                   # ReduceLROnPlateau(patience=2, factor=0.90)
-                        model.optimizer_kwargs["lr"] *= 0.9; lr_wait = 0
-                    if since_best >= 15:              # EarlyStopping(patience=15)
-                        log("Early stopping"); break
+                    if f.tell() == 0:
+                        f.write("epoch,loss,val_dice,val_precision,val_recall,lr\n")
+                    f.write("%d,%.6f,%s,%s,%s,%g\n" % (ep, logs["loss"], *["" if logs.get(k) is None else "%.6f" % logs[k]
+                                                                         for k in ("val_dice", "val_precision", "val_recall")],
+                                                      model.optimizer_kwargs["lr"]))
+            if model.stop_training:
+                break
     except KeyboardInterrupt:
         log("Interrupted: saving weights")
     finally:

@@ -1,0 +1,179 @@
+"""
+Epoch-end validation and the Keras callbacks that consume it.
+
+  Validation ............ mpunet/callbacks/validation.py:59-306: predict `steps` validation batches, count
+                          TP / relevant / selected per class (bincounts), per-class precision, recall, Dice,
+                          logs val_dice / val_precision / val_recall = nanmean over classes (background NaN).
+                          The counting runs on the GPU (torch.bincount on the label tensors); under data
+                          parallelism the int64 counts are SUM all-reduced.
+                          NOTE the reference passes sel=relevant, rel=selected into _compute_dice
+                          (validation.py:211-213), so its "precision" is TP/relevant and its "recall"
+                          TP/selected; Dice is symmetric. The logs here carry the same (swapped) meaning.
+  ReduceLROnPlateau ..... tf.keras semantics with the YAML's kwargs {patience 2, factor .9, monitor val_dice, max}
+                          (min_delta 1e-4, cooldown 0, min_lr 0: Keras defaults)
+  EarlyStopping ......... {monitor val_dice, min_delta 0, patience 15, mode max}
+  ModelCheckPointClean .. mpunet/callbacks/mcp_clean.py:25-59: save_best_only checkpoints named
+                          @epoch_{epoch:02d}_val_dice_{val_dice:.5f}, older ones removed.
+"""
+import os
+import numpy as np
+import torch
+
+
+def count_cm_elements(pred_labels, true_labels, n_classes):
+    """TP, relevant, selected per class as int64 tensors (validation.py:115-125)."""
+    p = pred_labels.reshape(-1).long()
+    y = true_labels.reshape(-1).long()
+    tps = torch.bincount(torch.where(y == p, y, torch.full_like(y, n_classes)), minlength=n_classes + 1)[:n_classes]
+    rel = torch.bincount(y, minlength=n_classes)[:n_classes]
+    sel = torch.bincount(p, minlength=n_classes)[:n_classes]
+    return tps, rel, sel
+
+
+def compute_dice(tp, rel, sel):
+    """validation.py:59-89 (_compute_dice): zeros where a denominator is zero. numpy float32 out."""
+    tp, rel, sel = (np.asarray(a, dtype=np.float64) for a in (tp, rel, sel))
+    precisions = np.zeros(tp.shape, np.float32)
+    recalls = np.zeros_like(precisions)
+    dices = np.zeros_like(precisions)
+    sm, rm = sel > 0, rel > 0
+    precisions[sm] = tp[sm] / sel[sm]
+    recalls[rm] = tp[rm] / rel[rm]
+    intrs, union = 2 * precisions * recalls, precisions + recalls
+    dm = union > 0
+    dices[dm] = intrs[dm] / union[dm]
+    return precisions, recalls, dices
+
+
+class Validation:
+    def __init__(self, sampler, steps, n_classes, ignore_class_zero=True, logger=None, verbose=True):
+        self.sampler, self.steps, self.n_classes = sampler, int(steps), int(n_classes)
+        self.ignore_bg = ignore_class_zero
+        self.logger = logger or print
+        self.verbose = verbose
+
+    def evaluate(self, model):
+        K = self.n_classes
+        dev = model.device
+        TP = torch.zeros(K, dtype=torch.int64, device=dev)
+        REL = torch.zeros_like(TP); SEL = torch.zeros_like(TP)
+        for _ in range(self.steps):
+            x, y, _w = self.sampler()
+            pred = model.predict_on_batch(x)
+            lab = pred.reshape(-1, K).argmax(-1)
+            tps, rel, sel = count_cm_elements(lab, y.to(dev), K)
+            TP += tps; REL += rel; SEL += sel
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            cnt = torch.stack([TP, REL, SEL])
+            torch.distributed.all_reduce(cnt)
+            TP, REL, SEL = cnt[0], cnt[1], cnt[2]
+        # as the reference: sel=relevant, rel=selected
+        precisions, recalls, dices = compute_dice(TP.cpu().numpy(), rel=SEL.cpu().numpy(), sel=REL.cpu().numpy())
+        if self.ignore_bg:
+            precisions[0] = recalls[0] = dices[0] = np.nan
+        return {"dice": dices, "recall": recalls, "precision": precisions}
+
+    def on_epoch_end(self, model, epoch, logs):
+        cw = self.evaluate(model)
+        with np.errstate(all="ignore"):
+            for name, values in cw.items():
+                logs["val_" + name] = float(np.nanmean(values)) if np.any(~np.isnan(values)) else float("nan")
+        if self.verbose:
+            rows = ["Validation Results for epoch %d" % epoch,
+                    "        " + "  ".join("%9s" % c for c in ["mean"] + ["cls %d" % i for i in range(self.n_classes)])]
+            for name, values in cw.items():
+                vals = [logs["val_" + name]] + list(values)
+                rows.append("%-9s" % name + "  ".join("%9s" % ("-" if np.isnan(v) else "%.4f" % v) for v in vals))
+            self.logger("\n".join(rows))
+        return cw
+
+
+class ReduceLROnPlateau:
+    def __init__(self, monitor="val_dice", factor=0.9, patience=2, mode="max", min_delta=1e-4, cooldown=0, min_lr=0.0,
+                 verbose=1, logger=None):
+        if factor >= 1.0:
+            raise ValueError("ReduceLROnPlateau does not support a factor >= 1.0.")
+        self.monitor, self.factor, self.patience, self.mode = monitor, factor, patience, mode
+        self.min_delta, self.cooldown, self.min_lr = min_delta, cooldown, min_lr
+        self.logger = logger or print
+        self.verbose = verbose
+        self.best = -np.inf if mode == "max" else np.inf
+        self.wait = 0
+        self.cooldown_counter = 0
+
+    def _better(self, a, b):
+        return a > b + self.min_delta if self.mode == "max" else a < b - self.min_delta
+
+    def on_epoch_end(self, model, epoch, logs):
+        cur = logs.get(self.monitor)
+        logs["lr"] = model.optimizer_kwargs["lr"]
+        if cur is None or np.isnan(cur):
+            return
+        if self.cooldown_counter > 0:
+            self.cooldown_counter -= 1
+            self.wait = 0
+        if self._better(cur, self.best):
+            self.best, self.wait = cur, 0
+        elif self.cooldown_counter <= 0:
+            self.wait += 1
+            if self.wait >= self.patience:
+                old = float(model.optimizer_kwargs["lr"])
+                if old > self.min_lr:
+                    new = max(old * self.factor, self.min_lr)
+                    model.optimizer_kwargs["lr"] = new
+                    if self.verbose:
+                        self.logger("Epoch %05d: ReduceLROnPlateau reducing learning rate to %s." % (epoch + 1, new))
+                    self.cooldown_counter = self.cooldown
+                    self.wait = 0
+
+
+class EarlyStopping:
+    def __init__(self, monitor="val_dice", min_delta=0, patience=15, mode="max", verbose=1, logger=None):
+        self.monitor, self.min_delta, self.patience, self.mode = monitor, abs(min_delta), patience, mode
+        self.logger = logger or print
+        self.verbose = verbose
+        self.best = -np.inf if mode == "max" else np.inf
+        self.wait = 0
+        self.stopped_epoch = 0
+
+    def on_epoch_end(self, model, epoch, logs):
+        cur = logs.get(self.monitor)
+        if cur is None:
+            return
+        better = cur - self.min_delta > self.best if self.mode == "max" else cur + self.min_delta < self.best
+        if better:
+            self.best, self.wait = cur, 0
+        else:
+            self.wait += 1
+            if self.wait >= self.patience:
+                self.stopped_epoch = epoch
+                model.stop_training = True
+                if self.verbose:
+                    self.logger("Epoch %05d: early stopping" % (epoch + 1))
+
+
+class ModelCheckPointClean:
+    """save_best_only + save_weights_only; the previously saved file is removed (mcp_clean.py:25-59)."""
+
+    def __init__(self, filepath, monitor="val_dice", mode="max", verbose=1, logger=None):
+        self.filepath, self.monitor, self.mode = filepath, monitor, mode
+        self.logger = logger or print
+        self.verbose = verbose
+        self.best = -np.inf if mode == "max" else np.inf
+        self.last_file = None
+
+    def on_epoch_end(self, model, epoch, logs):
+        cur = logs.get(self.monitor)
+        if cur is None or np.isnan(cur):
+            return
+        if (cur > self.best) if self.mode == "max" else (cur < self.best):
+            path = self.filepath.format(epoch=epoch + 1, **logs)
+            if self.verbose:
+                self.logger("Epoch %05d: %s improved from %.5f to %.5f, saving model to %s"
+                            % (epoch + 1, self.monitor, self.best, cur, path))
+            self.best = cur
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            model.save_weights(path)
+            if self.last_file and self.last_file != path and os.path.exists(self.last_file):
+                os.remove(self.last_file)
+            self.last_file = path
