@@ -226,6 +226,17 @@ int mpu_unet_backward(const mpu_unet* m, int32_t batch, const uint8_t* d_y,
                       float* d_bn_state, void* d_workspace, float* d_grads, float* d_loss,
                       void* stream);
 
+/* Elastic2D augmentation of one training slice (mpunet/augmentation/elastic_deformation.py:6-69, applied by
+ * mpunet/augmentation/augmenters.py:87-107 after scaling): image [H][W][C] f32 bilinear with fill d_bg[c],
+ * labels [H][W] u8 nearest with fill 0 (either pair may be NULL), displaced by alpha * gaussian_filter(2*noise-1)
+ * of the two uniform [0,1) fields d_noise [2][H][W] (f64). d_gauss_w: the 2*radius+1 normalised Gaussian weights
+ * (f64; radius = int(4*sigma + .5)); d_workspace: mpu_elastic_workspace_doubles(H, W) doubles. */
+int64_t mpu_elastic_workspace_doubles(int32_t H, int32_t W);
+int mpu_elastic_transform_2d(const float* d_image, const uint8_t* d_labels, int32_t H, int32_t W, int32_t C,
+                             const double* d_noise, const double* d_gauss_w, int32_t radius, double alpha,
+                             const float* d_bg, double* d_workspace, float* d_out_image,
+                             uint8_t* d_out_labels, void* stream);
+
 /* Fusion-model training (mpunet/bin/train_fusion.py:327-362 `fusion_model.fit`): one Adam step of the FusionLayer
  * (mpunet/models/fusion_model.py:14-39) on a batch of points x[n][V][K] with integer targets y[n] under the
  * reference's per-point generalized Dice loss (mpunet/evaluate/loss_functions.py:207-246, SUM_OVER_BATCH_SIZE) plus

@@ -17,7 +17,7 @@ ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall",
           "-Wno-unused-function", "-Wno-unused-variable"]
 # geometry.hip restates fp64 NumPy arithmetic op by op: no FMA contraction.
-PER_FILE = {"geometry.hip": ["-ffp-contract=off"]}
+PER_FILE = {"geometry.hip": ["-ffp-contract=off"], "augment.hip": ["-ffp-contract=off"]}
 
 
 def sources():

@@ -96,11 +96,16 @@ def run(args):
         D.DataParallelTrainer(model)
     B = int(fit["batch_size"])
     per_rank = max(1, B // world)
-    mk = lambda vols, noise, seed: TrainSampler(vols, views, build["dim"], fit["real_space_span"], per_rank,
-                                                build["n_classes"], noise_sd=noise,
-                                                fg_batch_fraction=fit["fg_batch_fraction"], seed=seed)
-    tr = mk(train, fit["noise_sd"], 17 + rank)
-    va = mk(val, 0.0, 99) if val else None
+    from ..augmentation import build_augmenters
+    mk = lambda vols, noise, seed, augs: TrainSampler(vols, views, build["dim"], fit["real_space_span"], per_rank,
+                                                      build["n_classes"], noise_sd=noise,
+                                                      fg_batch_fraction=fit["fg_batch_fraction"], seed=seed,
+                                                      augmenters=augs)
+    augs = build_augmenters(fit.get("augmenters"), seed=1000 + rank)     # YAML fit.augmenters (Elastic2D)
+    if augs:
+        log("Augmenters:", ", ".join(str(a) for a in augs))
+    tr = mk(train, fit["noise_sd"], 17 + rank, augs)
+    va = mk(val, 0.0, 99, None) if val else None
     epochs = args.epochs or int(fit["n_epochs"])
     steps = max(1, int(np.ceil(args.train_images_per_epoch / B)))
     vsteps = max(1, int(np.ceil(args.val_images_per_epoch / B)))

@@ -105,7 +105,8 @@ class TrainSampler:
     """Random-plane batch sampler (training half of IsotrophicLiveViewSequence2D)."""
 
     def __init__(self, volumes, views, dim, real_space_span, batch_size, n_classes, noise_sd=0.1,
-                 fg_batch_fraction=0.5, force_all_fg="auto", sample_weights=None, seed=None, max_tries=10):
+                 fg_batch_fraction=0.5, force_all_fg="auto", sample_weights=None, seed=None, max_tries=10,
+                 augmenters=None):
         self.volumes = list(volumes)
         self.views = np.asarray(views, float)
         self.dim, self.span = int(dim), real_space_span
@@ -117,6 +118,7 @@ class TrainSampler:
         self.sample_weights = sample_weights or [1.0] * len(self.volumes)
         self.rng = np.random.RandomState(seed)
         self.max_tries = max_tries
+        self.augmenters = list(augmenters or [])      # applied after scaling (isotrophic_live_view_sequence_2d.py:203-208)
 
     def _one_plane(self, vol):
         view = self.views[self.rng.randint(0, len(self.views))]
@@ -130,7 +132,7 @@ class TrainSampler:
         return X[0], y[0]
 
     def __call__(self):
-        xs, ys, ws = [], [], []
+        xs, ys, ws, bgs = [], [], [], []
         has_fg, fg_vec = 0, np.zeros(len(self.fg_classes), bool)
         B = self.batch_size
         for _ in range(B):
@@ -162,11 +164,13 @@ class TrainSampler:
                         has_fg += inc
                         fg_vec = fg_vec_try
                         break
-            xs.append(x); ys.append(y); ws.append(self.sample_weights[vi])
+            xs.append(x); ys.append(y); ws.append(self.sample_weights[vi]); bgs.append(list(vol.bg_value))
         x = torch.stack(xs)
-        y = torch.stack(ys).reshape(B, -1, 1)
+        y = torch.stack(ys)
         w = torch.tensor(ws, dtype=torch.float32, device=x.device)
-        return x, y, w
+        for aug in self.augmenters:
+            x, y, w = aug(x, y, bgs, w)
+        return x, y.reshape(B, -1, 1), w
 
     def __iter__(self):
         while True:

@@ -15,7 +15,8 @@ def test_mp_train_then_predict_synthetic(tmp_path):
         "  complexity_factor: 0.0625\n  out_activation: softmax\n  seed: 0\n"
         "fit:\n  views: 3\n  noise_sd: 0.1\n  real_space_span: 64.0\n  batch_size: 8\n  n_epochs: 2\n"
         "  optimizer: Adam\n  optimizer_kwargs: {lr: 1.0e-3, decay: 0.0, beta_1: 0.9, beta_2: 0.999, epsilon: 1.0e-8}\n"
-        "  loss: SparseCategoricalCrossentropy\n  fg_batch_fraction: 0.5\n  bg_value: 1pct\n  scaler: RobustScaler\n")
+        "  loss: SparseCategoricalCrossentropy\n  fg_batch_fraction: 0.5\n  bg_value: 1pct\n  scaler: RobustScaler\n"
+        "  augmenters: [{cls_name: Elastic2D, kwargs: {alpha: [0, 100], sigma: [6, 9], apply_prob: 0.333}}]\n")
     mp.entry_func(["train", "--project_dir", str(proj), "--synthetic", "4", "--epochs", "6",
                    "--train_images_per_epoch", "160", "--val_images_per_epoch", "32"])
     assert (proj / "model" / "model_weights.npz").exists() and (proj / "views.npz").exists()
