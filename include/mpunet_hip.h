@@ -226,6 +226,12 @@ int mpu_unet_backward(const mpu_unet* m, int32_t batch, const uint8_t* d_y,
                       float* d_bn_state, void* d_workspace, float* d_grads, float* d_loss,
                       void* stream);
 
+/* Accept / reject statistics of one sampled training slice (mpunet/sequences/isotrophic_live_view_sequence.py:91-128:
+ * np.isin(fg_classes, lab), np.any(~np.isclose(im, bg))): d_out2[0] = OR of (1 << label) over the labels (< 32),
+ * d_out2[1] = 1 when some pixel differs from its channel's background value d_bg[c]. Either input may be NULL. */
+int mpu_plane_stats(const uint8_t* d_labels, const float* d_image, int64_t n_pixels, int32_t n_channels,
+                    const float* d_bg, uint32_t* d_out2, void* stream);
+
 /* Elastic2D augmentation of one training slice (mpunet/augmentation/elastic_deformation.py:6-69, applied by
  * mpunet/augmentation/augmenters.py:87-107 after scaling): image [H][W][C] f32 bilinear with fill d_bg[c],
  * labels [H][W] u8 nearest with fill 0 (either pair may be NULL), displaced by alpha * gaussian_filter(2*noise-1)

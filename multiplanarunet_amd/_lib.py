@@ -102,6 +102,7 @@ _SIGS = {
     "mpu_unet_forward": (C.c_int, [c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, c_p, c_p]),
     "mpu_unet_backward": (C.c_int, [c_p, i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "mpu_adam_step": (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, f64, f64, f64, f64, c_p]),
+    "mpu_plane_stats": (C.c_int, [c_p, c_p, i64, C.c_int32, c_p, c_p, c_p]),
     "mpu_elastic_workspace_doubles": (C.c_int64, [C.c_int32, C.c_int32]),
     "mpu_elastic_transform_2d": (C.c_int, [c_p, c_p, C.c_int32, C.c_int32, C.c_int32, c_p, c_p, C.c_int32, f64, c_p, c_p,
                                            c_p, c_p, c_p]),

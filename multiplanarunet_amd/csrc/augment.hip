@@ -88,12 +88,44 @@ __global__ __launch_bounds__(256) void elastic_warp_kernel(const float* __restri
     }
 }
 
+// class-presence mask and "not all background" flag of one sampled slice (the accept / reject test of the
+// train-time sampler: validate_lab / validate_lab_vec / is_valid_im, isotrophic_live_view_sequence.py:91-128)
+__global__ __launch_bounds__(256) void plane_stats_kernel(const uint8_t* __restrict__ y, const float* __restrict__ x, long npix,
+                                                          int C, const float* __restrict__ bg, unsigned* __restrict__ out) {
+    unsigned mask = 0, nonbg = 0;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < npix; t += (long)gridDim.x * 256) {
+        if (y) { const unsigned l = y[t]; if (l < 32) mask |= 1u << l; }
+        if (x)
+            for (int c = 0; c < C; ++c) {
+                const float b = bg[c];
+                const double lhs = (double)fabsf(x[t * C + c] - b), rhs = 1e-8 + 1e-5 * fabs((double)b);   // ~np.isclose
+                if (!(lhs <= rhs)) nonbg = 1;
+            }
+    }
+    for (int o = 32; o > 0; o >>= 1) { mask |= __shfl_xor(mask, o, 64); nonbg |= __shfl_xor(nonbg, o, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (mask) atomicOr(&out[0], mask);
+        if (nonbg) atomicOr(&out[1], nonbg);
+    }
+}
+
 }  // namespace
 }  // namespace mpu
 
 using namespace mpu;
 
 extern "C" {
+
+int mpu_plane_stats(const uint8_t* d_labels, const float* d_image, int64_t n_pixels, int32_t n_channels,
+                    const float* d_bg, uint32_t* d_out2, void* stream) {
+    MPU_REQUIRE((d_labels || d_image) && d_out2 && n_pixels >= 1, "mpu_plane_stats: null argument");
+    MPU_REQUIRE(!d_image || (d_bg && n_channels >= 1), "mpu_plane_stats: image needs its background values");
+    hipStream_t st = (hipStream_t)stream;
+    MPU_CHECK_HIP(hipMemsetAsync(d_out2, 0, 2 * sizeof(uint32_t), st));
+    long blocks = (n_pixels + 255) / 256; if (blocks > 256) blocks = 256;
+    plane_stats_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d_labels, d_image, (long)n_pixels, n_channels, d_bg, d_out2);
+    return launch_ok();
+}
 
 int64_t mpu_elastic_workspace_doubles(int32_t H, int32_t W) { return 4L * H * W; }
 

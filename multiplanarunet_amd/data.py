@@ -101,8 +101,79 @@ def audit_dim_and_span(volumes, min_dim=128, max_dim=512):
     return dim, span
 
 
+def plane_basis_fast(view, noise=None):
+    """
+    [u v n] (row-major 3x3, columns u, v, n) of interpolation.plane_basis in plain Python floats: the same
+    construction (normalise, add noise, normalise, |.| rule for small x/y, u = R(axis, -90 deg) n, v = n x u)
+    without the reference's float32 round trips - agrees to ~1e-7, which is far below the random `noise_sd`
+    the training planes carry anyway. ~10x cheaper than the NumPy version (the sampler's host cost).
+    """
+    import math
+    n0, n1, n2 = float(view[0]), float(view[1]), float(view[2])
+    r = math.sqrt(n0 * n0 + n1 * n1 + n2 * n2)
+    n0, n1, n2 = n0 / r, n1 / r, n2 / r
+    if noise is not None:
+        n0 += float(noise[0]); n1 += float(noise[1]); n2 += float(noise[2])
+        r = math.sqrt(n0 * n0 + n1 * n1 + n2 * n2)
+        n0, n1, n2 = n0 / r, n1 / r, n2 / r
+    if n0 < 0.2 and n1 < 0.2:
+        n0, n1 = abs(n0), abs(n1)
+    if abs(n0) <= 1e-8 and abs(n1) <= 1e-8:
+        u = (1.0, 0.0, 0.0); v = (0.0, 1.0, 0.0)
+    else:
+        s0, s1, s2 = n0, n1, n2 + 1.0
+        r = math.sqrt(s0 * s0 + s1 * s1 + s2 * s2)
+        s0, s1, s2 = s0 / r, s1 / r, s2 / r
+        a0, a1, a2 = n1 * s2 - n2 * s1, n2 * s0 - n0 * s2, n0 * s1 - n1 * s0
+        r = math.sqrt(a0 * a0 + a1 * a1 + a2 * a2)
+        a0, a1, a2 = a0 / r, a1 / r, a2 / r
+        th = math.radians(-90.0)
+        qa = math.cos(th / 2.0); sn = math.sin(th / 2.0)
+        b, c, d = -a0 * sn, -a1 * sn, -a2 * sn
+        aa, bb, cc, dd = qa * qa, b * b, c * c, d * d
+        bc, ad, ac, ab, bd, cd = b * c, qa * d, qa * c, qa * b, b * d, c * d
+        R = ((aa + bb - cc - dd, 2 * (bc + ad), 2 * (bd - ac)),
+             (2 * (bc - ad), aa + cc - bb - dd, 2 * (cd + ab)),
+             (2 * (bd + ac), 2 * (cd - ab), aa + dd - bb - cc))
+        u = tuple(R[i][0] * n0 + R[i][1] * n1 + R[i][2] * n2 for i in range(3))
+        v = (n1 * u[2] - n2 * u[1], n2 * u[0] - n0 * u[2], n0 * u[1] - n1 * u[0])
+    return [u[0], v[0], n0, u[1], v[1], n1, u[2], v[2], n2]
+
+
+class _VolCache:
+    """Per-volume constants of the sampling call (built once): ctypes pieces and device-side background values."""
+
+    def __init__(self, vol, dim, span):
+        import ctypes as C
+        from . import _lib
+        self.shape = (C.c_int32 * 4)(*[int(v) for v in vol.image.shape])
+        g = _lib.ViewGeom()
+        for k in range(3):
+            g.vol_axis[k] = _lib.make_axis(vol.axes[k])
+        rot = np.eye(3) if vol.rot_mat is None else np.asarray(vol.rot_mat, np.float64)
+        g.rot[:] = rot.ravel().tolist()
+        g.has_rot = 0 if vol.rot_mat is None else 1
+        hd = span // 2
+        g.dim, g.n_planes = int(dim), 1
+        g.g_start, g.g_step = float(-hd), float((hd - (-hd)) / float(dim - 1))
+        self.geom = g
+        bg = torch.tensor(vol.bg_value, dtype=torch.float64, device=vol.device)
+        if vol.scaler is not None:                           # planes come out scaled: compare with the scaled value
+            c, s_ = vol.scaler
+            bg = (bg - torch.tensor(np.asarray(c, np.float64), device=vol.device)) / \
+                torch.tensor(np.asarray(s_, np.float64), device=vol.device)
+        self.bg_scaled = bg.float().contiguous()
+        self.ptrs = [_lib.ptr(vol.image), _lib.ptr(vol.labels), _lib.ptr(vol._axes_dev[0]), _lib.ptr(vol._axes_dev[1]),
+                     _lib.ptr(vol._axes_dev[2]), _lib.ptr(vol._bg), _lib.ptr(vol._center), _lib.ptr(vol._scale)]
+
+
 class TrainSampler:
-    """Random-plane batch sampler (training half of IsotrophicLiveViewSequence2D)."""
+    """
+    Random-plane batch sampler (training half of IsotrophicLiveViewSequence2D). Every plane is cut by the HIP
+    sampling kernel straight into the batch tensors; the accept / reject statistics of a candidate (classes
+    present, not-all-background) come back in one 8-byte read (mpu_plane_stats), which is the only host
+    synchronisation per candidate.
+    """
 
     def __init__(self, volumes, views, dim, real_space_span, batch_size, n_classes, noise_sd=0.1,
                  fg_batch_fraction=0.5, force_all_fg="auto", sample_weights=None, seed=None, max_tries=10,
@@ -119,55 +190,78 @@ class TrainSampler:
         self.rng = np.random.RandomState(seed)
         self.max_tries = max_tries
         self.augmenters = list(augmenters or [])      # applied after scaling (isotrophic_live_view_sequence_2d.py:203-208)
+        self._cache = {}
+        self._fg_mask = 0
+        for c in self.fg_classes:
+            self._fg_mask |= 1 << int(c)
+        self._views_l = [tuple(float(a) for a in v) for v in self.views]
 
-    def _one_plane(self, vol):
-        view = self.views[self.rng.randint(0, len(self.views))]
+    def _vc(self, vi):
+        c = self._cache.get(vi)
+        if c is None:
+            c = self._cache[vi] = _VolCache(self.volumes[vi], self.dim, self.span)
+        return c
+
+    def _cut(self, vi, X, Y, slot, off_dev, stats):
+        """One candidate plane of volume vi into X[slot], Y[slot]; returns (class mask, not-all-bg flag)."""
+        import ctypes as C
+        from . import _lib
+        vol, vc = self.volumes[vi], self._vc(vi)
+        view = self._views_l[self.rng.randint(0, len(self._views_l))]
         half = self.span // 2
         off = self.rng.uniform(-half, half)
         noise = self.rng.normal(scale=self.noise_sd, size=3) if self.noise_sd else None
-        g = ViewGeometry(view, self.dim, self.span, "same", noise=noise)
-        g.offsets = np.array([off])
-        g.n_planes = 1
-        X, y = sample_view(vol, g, want_labels=True)
-        return X[0], y[0]
+        g = vc.geom
+        g.basis[:] = plane_basis_fast(view, noise)
+        off_dev.fill_(off)                                    # scalar fill: no host->device copy of a tensor
+        st = _lib.stream_ptr()
+        p = vc.ptrs
+        xs, ys = X[slot], Y[slot]
+        _lib.call("mpu_sample_view_planes", p[0], p[1], vc.shape, p[2], p[3], p[4], C.byref(g), _lib.ptr(off_dev),
+                  p[5], vol.bg_class, p[6], p[7], _lib.ptr(xs), _lib.ptr(ys), st)
+        _lib.call("mpu_plane_stats", _lib.ptr(ys), _lib.ptr(xs), self.dim * self.dim, vol.n_channels,
+                  _lib.ptr(vc.bg_scaled), _lib.ptr(stats), st)
+        m, nb = stats.tolist()                                # the one synchronisation per candidate
+        return m, bool(nb)
 
     def __call__(self):
-        xs, ys, ws, bgs = [], [], [], []
-        has_fg, fg_vec = 0, np.zeros(len(self.fg_classes), bool)
-        B = self.batch_size
-        for _ in range(B):
+        B, d = self.batch_size, self.dim
+        vol0 = self.volumes[0]
+        dev = vol0.device
+        X = torch.empty((B, d, d, vol0.n_channels), dtype=torch.float32, device=dev)
+        Y = torch.empty((B, d, d), dtype=torch.uint8, device=dev)
+        off_dev = torch.empty(1, dtype=torch.float64, device=dev)
+        stats = torch.empty(2, dtype=torch.int32, device=dev)
+        ws, bgs = [], []
+        has_fg, fg_vec = 0, 0                                 # fg_vec: bit mask of the fg classes seen so far
+        nfg = len(self.fg_classes)
+        for slot in range(B):
             vi = self.rng.randint(0, len(self.volumes))
-            vol = self.volumes[vi]
             for t in range(1, self.max_tries + 1):
-                x, y = self._one_plane(vol)
-                present = np.isin(self.fg_classes, torch.unique(y).cpu().numpy())
+                m, nonbg = self._cut(vi, X, Y, slot, off_dev, stats)
+                present = m & self._fg_mask
                 last = t == self.max_tries
                 if self.force_all_fg and not last:
                     new = fg_vec | present
-                    if not (new.all() or (~new).sum() < (B - len(ys))):
+                    missing = nfg - bin(new).count("1")
+                    if not (missing == 0 or missing < (B - slot)):
                         continue
-                    fg_vec_try = new
+                    fg_try = new
                 else:
-                    fg_vec_try = fg_vec
-                if present.any():
+                    fg_try = fg_vec
+                if present:
                     ok, inc = True, 1
-                elif (self.n_fg_slices - has_fg) < (B - len(ys)):
+                elif (self.n_fg_slices - has_fg) < (B - slot):
                     ok, inc = True, 0
                 else:
                     ok, inc = False, 0
-                if ok or last:
-                    bg = torch.tensor(vol.bg_value, device=x.device)
-                    if vol.scaler is not None:           # compare against the scaled background value
-                        c, s = vol.scaler
-                        bg = ((bg.double() - torch.tensor(c, device=x.device)) / torch.tensor(s, device=x.device)).float()
-                    if last or bool((~torch.isclose(x, bg.expand_as(x))).any()):
-                        has_fg += inc
-                        fg_vec = fg_vec_try
-                        break
-            xs.append(x); ys.append(y); ws.append(self.sample_weights[vi]); bgs.append(list(vol.bg_value))
-        x = torch.stack(xs)
-        y = torch.stack(ys)
-        w = torch.tensor(ws, dtype=torch.float32, device=x.device)
+                if (ok or last) and (last or nonbg):
+                    has_fg += inc
+                    fg_vec = fg_try
+                    break
+            ws.append(self.sample_weights[vi]); bgs.append(list(self.volumes[vi].bg_value))
+        x, y = X, Y
+        w = torch.tensor(ws, dtype=torch.float32, device=dev)
         for aug in self.augmenters:
             x, y, w = aug(x, y, bgs, w)
         return x, y.reshape(B, -1, 1), w

@@ -53,3 +53,21 @@ def test_mp_dispatch_rejects_out_of_scope_scripts():
     with pytest.raises(SystemExit):
         MP.entry_func(["cv_split"])
     assert MP.entry_func(["--help"]) == 0
+
+
+def test_plane_basis_fast_agrees_with_reference_construction():
+    """The sampler's pure-Python basis equals interpolation.plane_basis up to the reference's float32 round trips."""
+    from multiplanarunet_amd.interpolation import plane_basis
+    from multiplanarunet_amd.data import plane_basis_fast
+    rng = np.random.RandomState(0)
+    for i in range(500):
+        v = rng.randn(3)
+        if i % 7 == 0:
+            v[:2] *= 1e-3
+        if i % 50 == 0:
+            v = np.array([0.0, 0.0, 1.0])
+        nz = rng.randn(3) * 0.1 if i % 2 else None
+        a = plane_basis(v, nz)
+        b = np.array(plane_basis_fast(v, nz)).reshape(3, 3)
+        assert np.abs(a - b).max() < 1e-6
+        assert np.abs(b.T @ b - np.eye(3)).max() < 1e-6          # orthonormal
