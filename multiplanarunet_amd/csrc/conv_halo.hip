@@ -316,9 +316,14 @@ int try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
     if (variant < 0) { const char* e = getenv("MPU_HALO_VARIANT"); variant = e ? atoi(e) : 0; }
     const long tiles8 = (long)a.B * cdiv(a.Ho, 8) * cdiv(a.Wo, 32);
     const bool tall = a.Ho % 8 == 0 && tiles8 * cdiv(a.Cout, 64) >= 512 && variant != 1;
+    // 128-channel tiles: 8-row pixel tiles halve the weight re-streaming per pixel (the L2->LDS fill bounds this
+    // kernel) but need >= ~4 workgroups per CU to keep the chip busy: large batches / images only (predict)
+    static long th8_min = -1;
+    if (th8_min < 0) { const char* e = getenv("MPU_HALO_TH8_MIN"); th8_min = e ? atol(e) : 768; }
+    const bool tall128 = a.Ho % 8 == 0 && variant != 1 && (variant == 2 || tiles8 * cdiv(a.Cout, 128) >= th8_min);
     if (dtype == MPU_BF16) {
-        if (a.Cout > 64) rc = (tall && variant == 2) ? launch_halo_cfg<bf16_t, 128, 8, 2>(a, st)
-                                                      : launch_halo_cfg<bf16_t, 128, 4, 3>(a, st);
+        if (a.Cout > 64) rc = tall128 ? launch_halo_cfg<bf16_t, 128, 8, 2>(a, st)
+                                      : launch_halo_cfg<bf16_t, 128, 4, 3>(a, st);
         else rc = tall ? launch_halo_cfg<bf16_t, 64, 8, 3>(a, st) : launch_halo_cfg<bf16_t, 64, 4, 3>(a, st);
     } else if (dtype == MPU_F32) {
         if (a.Cout > 64) rc = launch_halo_cfg<float, 128, 4, 3>(a, st);
