@@ -47,9 +47,12 @@ template <> struct HMma<float> {
     }
 };
 
-template <typename T, int BN, int TH, int NWS_>
+// MODE: CONV3 (3x3 SAME: halo of one pixel) or UPCONV2 (nearest-upsample x2 + 2x2 SAME with TF's 0/1 padding: the
+// patch lives at the LOW resolution, output pixel (oy, ox) and tap (ky, kx) read low-res pixel ((oy+ky)>>1, (ox+kx)>>1))
+template <typename T, int BN, int TH, int NWS_, int MODE = CONV3>
 struct HaloCfg {
-    static constexpr int TW = 32, PW = TW + 2, PH = TH + 2;
+    static constexpr int NT = MODE == UPCONV2 ? 4 : 9, KW = MODE == UPCONV2 ? 2 : 3;
+    static constexpr int TW = 32, PW = MODE == UPCONV2 ? TW / 2 + 2 : TW + 2, PH = MODE == UPCONV2 ? TH / 2 + 1 : TH + 2;
     static constexpr int PROWS = (PH * PW + 7) / 8 * 8;          // patch rows, padded to whole DMA pieces
     static constexpr int PATCH = PROWS * 128;
     static constexpr int WSTAGE = BN * 128, NWS = NWS_;
@@ -60,9 +63,10 @@ struct HaloCfg {
     static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
 };
 
-template <typename T, int BN, int TH, int NWS>
+template <typename T, int BN, int TH, int NWS, int MODE = CONV3>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
-    using Cfg = HaloCfg<T, BN, TH, NWS>;
+    using Cfg = HaloCfg<T, BN, TH, NWS, MODE>;
+    constexpr int NT = Cfg::NT, KW = Cfg::KW;
     constexpr int EPC = 16 / sizeof(T), BKE = 128 / sizeof(T);
     constexpr int TW = Cfg::TW, PW = Cfg::PW, PROWS = Cfg::PROWS;
     constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N;
@@ -87,9 +91,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
     const int y0 = (t % tiles_y) * TH; const int b = t / tiles_y;
     const int nch0 = (a.C0 + BKE - 1) / BKE, nch1 = (a.C1 + BKE - 1) / BKE;
     const int nchunks = nch0 + nch1;
-    const int nsteps = nchunks * 9;
+    const int nsteps = nchunks * NT;
     constexpr unsigned OOB = 0xfffffff0u;
-    const long npix = (long)a.B * H * W;
+    const int Hi = MODE == UPCONV2 ? H / 2 : H, Wi = MODE == UPCONV2 ? W / 2 : W;     // input resolution
+    const long npix = (long)a.B * Hi * Wi;
     const i32x4 rs0 = h_make_rsrc(a.in0, npix * a.C0 * (long)sizeof(T));
     const i32x4 rs1 = h_make_rsrc(a.in1 ? a.in1 : a.in0, a.in1 ? npix * a.C1 * (long)sizeof(T) : 0);
     const i32x4 rsw = h_make_rsrc(a.w, a.w_elems * (long)sizeof(T));
@@ -104,9 +109,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
         const int piece = wave + 4 * k;
         const int pr = piece * 8 + lrow;                         // patch row
         const int py = pr / PW, px = pr % PW;
-        const int iy = y0 + py - 1, ix = x0 + px - 1;
-        const bool v = piece < NPP && pr < Cfg::PH * PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        ppix[k] = v ? (b * H + iy) * W + ix : -1;
+        const int iy = MODE == UPCONV2 ? y0 / 2 + py : y0 + py - 1, ix = MODE == UPCONV2 ? x0 / 2 + px : x0 + px - 1;
+        const bool v = piece < NPP && pr < Cfg::PH * PW && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+        ppix[k] = v ? (b * Hi + iy) * Wi + ix : -1;
         pchunk[k] = slot ^ ((pr >> 1) & 7);
     }
     unsigned wrow[GW]; int wchunk[GW];
@@ -133,8 +138,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
             }
         }
     };
-    auto issue_w = [&](int step, int stage) {                    // step = chunk * 9 + tap
-        const int cc = step / 9, tap = step - cc * 9;
+    auto issue_w = [&](int step, int stage) {                    // step = chunk * NT + tap
+        const int cc = step / NT, tap = step - cc * NT;
         bool s1; int cbase, Cs; chunk_src(cc, s1, cbase, Cs);
         const long wkbase = (long)tap * a.w_tap_stride + (s1 ? a.C0 : 0) + cbase;
 #pragma unroll
@@ -156,12 +161,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
 
     const int fsw = ((lane & 31) >> 1) & 7, fh = lane >> 5;
     auto compute = [&](int tap, int stage) {
-        const int ky = tap / 3, kx = tap - ky * 3;
+        const int ky = tap / KW, kx = tap - ky * KW;
         const unsigned char* Wb = smem + Cfg::PATCH + stage * Cfg::WSTAGE + (wn * 64 + (lane & 31)) * 128;
         int prow[TM], psw[TM];
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-            prow[j] = (wm * TM + j + ky) * PW + kx + (lane & 31);         // patch row of this lane's pixel
+            prow[j] = MODE == UPCONV2 ? ((wm * TM + j + ky) >> 1) * PW + ((kx + (lane & 31)) >> 1)
+                                      : (wm * TM + j + ky) * PW + kx + (lane & 31);   // patch row of this lane's pixel
             psw[j] = (prow[j] >> 1) & 7;
         }
 #pragma unroll
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
         const bool more = step + AHEAD < nsteps;
         if (more) issue_w(step + AHEAD, stn);
         compute(tap, st);
-        const bool reload = (tap == 8) && (cc + 1 < nchunks);
+        const bool reload = (tap == NT - 1) && (cc + 1 < nchunks);
         if (reload) {
             // every wave has finished reading the patch before it is overwritten
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
         }
         __builtin_amdgcn_s_barrier();
         st = (st + 1) % NWS;
-        if (++tap == 9) { tap = 0; ++cc; }
+        if (++tap == NT) { tap = 0; ++cc; }
     }
 
     // --- epilogue: bias -> LDS, tile -> LDS, coalesced 16-byte row stores ------------------
@@ -284,12 +290,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
     }
 }
 
-template <typename T, int BN, int TH, int NWS>
+template <typename T, int BN, int TH, int NWS, int MODE = CONV3>
 int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
-    using Cfg = HaloCfg<T, BN, TH, NWS>;
-    auto kern = conv_halo_kernel<T, BN, TH, NWS>;
+    using Cfg = HaloCfg<T, BN, TH, NWS, MODE>;
+    auto kern = conv_halo_kernel<T, BN, TH, NWS, MODE>;
     ConvArgs a = a_in;
-    if (a.w_elems <= 0) a.w_elems = 8 * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
+    if (a.w_elems <= 0) a.w_elems = (Cfg::NT - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
     static bool attr_set = false;
     if (!attr_set) {
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
@@ -300,7 +306,7 @@ int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
     if (M * cmax * (long)sizeof(T) >= (1L << 31) || a.w_elems * (long)sizeof(T) >= (1L << 31))
         return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
     const long tiles = (long)a.B * cdiv(a.Ho, TH) * cdiv(a.Wo, Cfg::TW) * cdiv(a.Cout, BN);
-    if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * 9 * (a.C0 + a.C1), st);
+    if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);
     kern<<<dim3((unsigned)tiles), dim3(256), Cfg::SMEM, st>>>(a);
     if (prof_on()) prof_end(st);
     return launch_ok();
@@ -310,8 +316,15 @@ int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
 
 // 1 = launched, 0 = shape not suited (caller falls back to the plain implicit GEMM), < 0 = error
 int try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
-    if (mode != CONV3 || a.Wo < 32 || a.Ho < 4) return 0;
+    if ((mode != CONV3 && mode != UPCONV2) || a.Wo < 32 || a.Ho < 4) return 0;
     int rc;
+    if (mode == UPCONV2) {                       // low-resolution patch variant of the up-convolution
+        static int up_on = -1;
+        if (up_on < 0) { const char* e = getenv("MPU_HALO_UPCONV"); up_on = (e && e[0] == '0') ? 0 : 1; }
+        if (!up_on || dtype != MPU_BF16 || (a.Ho & 3) || (a.Wo & 1)) return 0;
+        rc = a.Cout > 64 ? launch_halo_cfg<bf16_t, 128, 4, 3, UPCONV2>(a, st) : launch_halo_cfg<bf16_t, 64, 4, 3, UPCONV2>(a, st);
+        return rc ? rc : 1;
+    }
     static int variant = -1;                      // MPU_HALO_VARIANT: tuning aid
     if (variant < 0) { const char* e = getenv("MPU_HALO_VARIANT"); variant = e ? atoi(e) : 0; }
     const long tiles8 = (long)a.B * cdiv(a.Ho, 8) * cdiv(a.Wo, 32);
