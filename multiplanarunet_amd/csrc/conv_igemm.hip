@@ -619,8 +619,8 @@ long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, i
     // + fused bias-gradient partials: [ks][ntaps * ci-tiles][Cout]
     long elems = ks * (ntaps * (long)Cin * Cout + (long)ntaps * cdiv(Cin, 64) * Cout);
     // the all-taps kernel (wgrad_taps.hip) keeps one partial copy per pixel strip
-    if (mode == CONV3 && (long)Cin * Cout <= TAPS_MAX_CICO) {
-        const long te = (long)(TAPS_MAX_WGS / (cdiv(Cin, 64) * cdiv(Cout, 64))) * (9L * Cin * Cout + Cout);
+    if ((mode == CONV3 || mode == UPCONV2) && (long)Cin * Cout <= TAPS_MAX_CICO) {
+        const long te = (long)(TAPS_MAX_WGS / (cdiv(Cin, 64) * cdiv(Cout, 64))) * ((long)ntaps * Cin * Cout + Cout);
         if (te > elems) elems = te;
     }
     return elems;
@@ -648,7 +648,7 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
         prof_begin(PROF_WGRAD, a.flops > 0 ? a.flops : 2.0 * a.B * a.Ho * a.Wo * (double)n, st);
     bool big = false;
     int g_ = 0;
-    if (taps.use) { g_ = launch_wgrad_taps(a, taps, st); if (g_) return g_; g_ = 1; }
+    if (taps.use) { g_ = launch_wgrad_taps(MODE, a, taps, st); if (g_) return g_; g_ = 1; }
     else if (conv_impl() == 1) g_ = try_wgrad_glds(dt_, MODE, a, st);
     if (g_ < 0) return g_;
     if (g_ == 1) big = true;                      // launched by an LDS-DMA kernel

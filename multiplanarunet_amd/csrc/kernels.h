@@ -48,7 +48,7 @@ constexpr long TAPS_MAX_CICO = 512L * 512;     // eligible layers: Cin * Cout up
 constexpr int TAPS_MAX_WGS = 1024;             // strips * 64x64 tiles; bounds the fp32 partial workspace (one copy of
                                                // dW per strip): <= 1024 * 9 * 4096 floats = 151 MB for any layer
 TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout);
-int  launch_wgrad_taps(const WgradArgs& a, const TapsPlan& p, hipStream_t st);
+int  launch_wgrad_taps(int mode, const WgradArgs& a, const TapsPlan& p, hipStream_t st);
 int  launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st);
 int  try_wgrad_glds(int dtype, int mode, const WgradArgs& a, hipStream_t st);   // 1 launched, 0 unsupported shape
 bool wgrad_glds_supported(int dtype, int mode, const WgradArgs& a);

@@ -62,7 +62,13 @@ constexpr int GROUP_LDS = NXR * XROWB + NZR * ZROWB;            // rings of one 
 constexpr int XCH_A = 4 * 84 * 256, XCH_B = 4 * 64 * 256;       // accumulator exchange: taps 0-4 (+bias) / taps 5-8
 constexpr int TAPS_SMEM = XCH_A + XCH_B > 2 * GROUP_LDS ? XCH_A + XCH_B : 2 * GROUP_LDS;
 
+// MODE CONV3: nine taps, X rows y-1..y+1 at full resolution. MODE UPCONV2 (nearest-upsample x2 + 2x2 conv): four
+// taps; staged "X row r" is the low-resolution row (y0 + r) >> 1 (each low-res row is staged for both upsampled rows
+// it feeds), 17 low-res pixels wide, and tap (ky, kx) reads staged row t + ky at pixel (px + kx) >> 1.
+template <int MODE>
 __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPlan p) {
+    constexpr int NT = MODE == UPCONV2 ? 4 : 9, KW = MODE == UPCONV2 ? 2 : 3;
+    constexpr int NXP = MODE == UPCONV2 ? 3 : 5;                 // DMA pieces (8 pixels) per staged X row
     extern __shared__ __attribute__((aligned(128))) unsigned char smem_all[];
     constexpr unsigned OOB = 0xfffffff0u;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -96,7 +102,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPla
     const bool s1 = ci0 >= a.C0 && a.C1 > 0;             // the ci tile lies in one concat source (C0 % 64 == 0 then)
     const int Cs = s1 ? a.C1 : a.C0, cs0 = s1 ? ci0 - a.C0 : ci0;
     const long npix = (long)a.B * H * W;
-    const i32x4 rsx = t_make_rsrc(s1 ? a.x1 : a.x0, npix * Cs * 2L);
+    const int Hi = MODE == UPCONV2 ? H / 2 : H, Wi = MODE == UPCONV2 ? W / 2 : W;
+    const i32x4 rsx = t_make_rsrc(s1 ? a.x1 : a.x0, (long)a.B * Hi * Wi * Cs * 2L);
     const i32x4 rsz = t_make_rsrc(a.dz, npix * a.Cout * 2L);
     const unsigned lds0 = (unsigned)(uintptr_t)smem;
     const unsigned ldsZ = lds0 + NXR * XROWB;
@@ -105,15 +112,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPla
     // 128-byte pixel rows; the 64-byte granule of a row is XOR-ed with (pixel>>1)&1 so that the four k-rows
     // of a transpose read fall in four different bank groups.
     const int dpx = lane >> 3, dsl = lane & 7;
-    auto issue_x = [&](int r) {                                  // X row r of this strip = image row y0 - 1 + r
-        const int iy = y0 - 1 + r;
+    auto issue_x = [&](int r) {                                  // staged X row r of this strip
+        int iy; bool rowok;
+        if (MODE == UPCONV2) { const int uy = y0 + r; rowok = uy < H; iy = uy >> 1; }
+        else { iy = y0 - 1 + r; rowok = (unsigned)iy < (unsigned)H; }
         const unsigned base = lds0 + (r % NXR) * XROWB;
-        const bool rowok = (unsigned)iy < (unsigned)H;
-        for (int q = wave; q < 5; q += 4) {
-            const int c = q * 8 + dpx, ix = x0 - 1 + c;
+        for (int q = wave; q < NXP; q += 4) {
+            const int c = q * 8 + dpx;
+            const int ix = MODE == UPCONV2 ? x0 / 2 + c : x0 - 1 + c;
             const int ch = (dsl ^ (((c >> 1) & 1) << 2)) * 8;
-            const bool v = rowok && c < 34 && (unsigned)ix < (unsigned)W && cs0 + ch < Cs;
-            const unsigned off = v ? (unsigned)((((b * H + iy) * W + ix) * Cs + cs0 + ch) * 2) : OOB;
+            const bool v = rowok && c < (MODE == UPCONV2 ? 17 : 34) && (unsigned)ix < (unsigned)Wi && cs0 + ch < Cs;
+            const unsigned off = v ? (unsigned)((((b * Hi + iy) * Wi + ix) * Cs + cs0 + ch) * 2) : OOB;
             t_dma16(rsx, off, base + q * 1024);
         }
     };
@@ -126,18 +135,25 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPla
         const unsigned off = v ? (unsigned)((((b * H + y) * W + x) * a.Cout + co0 + ch) * 2) : OOB;
         t_dma16(rsz, off, base + wave * 1024);
     };
-    // DMAs per wave in one step group (X row + dZ row): waves 0 gets X pieces 0 and 4
-    const int ngrp = (wave == 0 ? 2 : 1) + 1;
+    // DMAs per wave in one step group (X row pieces wave, wave+4, ... < NXP, plus one dZ piece): wait until only the
+    // group issued last is outstanding
+    auto wait_keep_one_group = [&]() {
+        const int nx = (NXP - wave + 3) / 4;                     // CONV3: 2,1,1,1   UPCONV2: 1,1,1,0
+        if (nx == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (nx == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    };
 
     // ---- fragment addressing (16x16x32: lane group g = lane>>4 holds k = 8g..8g+7; i = lane&15 the row/col) ----
     const int g = lane >> 4, i = lane & 15;
     // a transpose read covers 4 k-rows x 16 columns; lane i addresses k-row (i>>2), columns (i&3)*4
-    int offA[3][2];                                              // X: per kx shift and low/high half, inside a row slot
+    int offA[KW][2];                                             // X: per kx shift and low/high half, inside a row slot
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
+    for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int c = kx + 8 * g + (i >> 2) + 4 * h;         // staged pixel column
+            const int cu = kx + 8 * g + (i >> 2) + 4 * h;        // (upsampled) pixel column of this k-row
+            const int c = MODE == UPCONV2 ? cu >> 1 : cu;        // staged pixel column
             const int slot16 = (wave * 2 + ((i & 3) >> 1)) ^ (((c >> 1) & 1) << 2);
             offA[kx][h] = c * 128 + (slot16 << 4) + (i & 1) * 8;
         }
@@ -151,9 +167,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPla
             offB[cb][h] = c * 128 + (slot16 << 4) + (i & 1) * 8;
         }
 
-    f32x4 acc[9][4];
+    f32x4 acc[NT][4];
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
+    for (int tp = 0; tp < NT; ++tp)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) acc[tp][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 accdb = {0.f, 0.f, 0.f, 0.f};
@@ -164,10 +180,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPla
         issue_x(0); issue_x(1); issue_x(2); issue_z(0);
         issue_x(3); issue_z(1);
     }
-    // wait for the first group (rows 0..2 + dZ 0); the second (ngrp DMAs) may still be in flight
-    if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    // wait for the first group (rows 0..2 + dZ 0); the second may still be in flight
+    wait_keep_one_group();
     __builtin_amdgcn_s_barrier();
-    (void)ngrp;
     for (int t = 0; t < nsteps_wg; ++t) {
         if (t >= nsteps) {                                       // the other group still has rows to do
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -179,15 +194,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPla
         s16x8 bz[4];
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) bz[cb] = t_frag(zb + offB[cb][0], zb + offB[cb][1]);
-        const unsigned char* xr[3];
+        const unsigned char* xr[KW];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) xr[ky] = smem + ((t + ky) % NXR) * XROWB;
+        for (int ky = 0; ky < KW; ++ky) xr[ky] = smem + ((t + ky) % NXR) * XROWB;
         s16x8 af = t_frag(xr[0] + offA[0][0], xr[0] + offA[0][1]);
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) {
+        for (int tp = 0; tp < NT; ++tp) {
             s16x8 an = af;
-            if (tp + 1 < 9) {
-                const int ky = (tp + 1) / 3, kx = (tp + 1) % 3;
+            if (tp + 1 < NT) {
+                const int ky = (tp + 1) / KW, kx = (tp + 1) % KW;
                 an = t_frag(xr[ky] + offA[kx][0], xr[ky] + offA[kx][1]);
             }
 #pragma unroll
@@ -201,9 +216,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPla
             accdb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bw, accdb, 0, 0, 0);
         }
         // group t+1 has landed (group t+2, just issued, may be in flight); all waves are done with step t's rows
-        if (t + 2 < nsteps) {
-            if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t + 2 < nsteps) wait_keep_one_group();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -211,48 +225,49 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPla
     // ---- combine the two groups through LDS (the rings are free now): group 0 ends up with taps 0-4 and the
     // bias sums, group 1 with taps 5-8; each stores its share of the pair's partial copy -----------------
     {
-        float* xa = reinterpret_cast<float*>(smem_all) + (wave * 84) * 64 + lane;            // [wave][84][lane]
+        constexpr int NA = (NT + 1) / 2;                                                     // taps kept by group 0
+        float* xa = reinterpret_cast<float*>(smem_all) + (wave * 84) * 64 + lane;            // [wave][<= 84][lane]
         float* xb = reinterpret_cast<float*>(smem_all + XCH_A) + (wave * 64) * 64 + lane;    // [wave][64][lane]
         if (grp == 1) {
 #pragma unroll
-            for (int tp = 0; tp < 5; ++tp)
+            for (int tp = 0; tp < NA; ++tp)
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) xa[((tp * 4 + cb) * 4 + r) * 64] = acc[tp][cb][r];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xa[(80 + r) * 64] = accdb[r];
+            for (int r = 0; r < 4; ++r) xa[(NA * 16 + r) * 64] = accdb[r];
         } else {
 #pragma unroll
-            for (int tp = 5; tp < 9; ++tp)
+            for (int tp = NA; tp < NT; ++tp)
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) xb[(((tp - 5) * 4 + cb) * 4 + r) * 64] = acc[tp][cb][r];
+                    for (int r = 0; r < 4; ++r) xb[(((tp - NA) * 4 + cb) * 4 + r) * 64] = acc[tp][cb][r];
         }
         __syncthreads();
         if (grp == 0) {
 #pragma unroll
-            for (int tp = 0; tp < 5; ++tp)
+            for (int tp = 0; tp < NA; ++tp)
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[tp][cb][r] += xa[((tp * 4 + cb) * 4 + r) * 64];
-            accdb[0] += xa[80 * 64];
+            accdb[0] += xa[NA * 16 * 64];
         } else {
 #pragma unroll
-            for (int tp = 5; tp < 9; ++tp)
+            for (int tp = NA; tp < NT; ++tp)
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[tp][cb][r] += xb[(((tp - 5) * 4 + cb) * 4 + r) * 64];
+                    for (int r = 0; r < 4; ++r) acc[tp][cb][r] += xb[(((tp - NA) * 4 + cb) * 4 + r) * 64];
         }
     }
     // ---- partial sums: [pair][tap][ci][co] ---------------------------------------------------------------
-    float* P = a.partial + (long)pair * 9 * Cin * a.Cout;
+    float* P = a.partial + (long)pair * NT * Cin * a.Cout;
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-        if ((tp < 5) != (grp == 0)) continue;
+    for (int tp = 0; tp < NT; ++tp) {
+        if ((tp < (NT + 1) / 2) != (grp == 0)) continue;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
             const int co = co0 + cb * 16 + i;
@@ -283,7 +298,8 @@ TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C
         if (max_cico > TAPS_MAX_CICO) max_cico = TAPS_MAX_CICO;
     }
     const int Cin = C0 + C1;
-    if (!on || dtype != MPU_BF16 || mode != CONV3 || W < 32 || H < 8) return p;
+    if (!on || dtype != MPU_BF16 || (mode != CONV3 && mode != UPCONV2) || W < 32 || H < 8) return p;
+    if (mode == UPCONV2 && ((H | W) & 1)) return p;
     if (C1 > 0 && C0 % 64 != 0) return p;
     if ((long)Cin * Cout > max_cico) return p;
     const long M = (long)B * H * W;
@@ -306,17 +322,19 @@ TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C
     return p;
 }
 
-int launch_wgrad_taps(const WgradArgs& a, const TapsPlan& p, hipStream_t st) {
+int launch_wgrad_taps(int mode, const WgradArgs& a, const TapsPlan& p, hipStream_t st) {
     const int Cin = a.C0 + a.C1;
     const int ntile = cdiv(Cin, 64) * cdiv(a.Cout, 64);
     const int npairs = (p.nstrips + 1) / 2;
     const int grid = cdiv(npairs, 8) * 8 * ntile;
     static bool attr_set = false;
     if (!attr_set) {
-        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
+        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel<CONV3>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
+        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel<UPCONV2>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
         attr_set = true;
     }
-    wgrad_taps_kernel<<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(a, p);
+    if (mode == UPCONV2) wgrad_taps_kernel<UPCONV2><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(a, p);
+    else wgrad_taps_kernel<CONV3><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(a, p);
     return launch_ok();
 }
 

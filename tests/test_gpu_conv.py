@@ -53,6 +53,7 @@ CASES = [
     (CONV3,   6, 128, 128, 16, 0, 256),    # large grid of 128-channel tiles: the 8-row patch variant (768 tiles)
     (UPCONV2, 2, 32, 64, 72, 0, 136),      # low-resolution patch variant of the up-conv: channel tail, ragged N
     (UPCONV2, 2, 36, 40, 64, 0, 64),       # ... ragged W tile, 64-channel tile, far-edge zero padding
+    (UPCONV2, 4, 128, 96, 16, 0, 24),      # all-taps weight gradient of the up-conv (192 strips), ragged channel tiles
     (UPCONV2, 2, 16, 16, 128, 0, 64),
     (UPCONV2, 1, 8, 12, 72, 0, 40),
     (CONV1,   2, 16, 16, 64, 0, 8),
