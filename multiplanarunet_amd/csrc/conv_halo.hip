@@ -334,9 +334,15 @@ int try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
     static long th8_min = -1;
     if (th8_min < 0) { const char* e = getenv("MPU_HALO_TH8_MIN"); th8_min = e ? atol(e) : 768; }
     const bool tall128 = a.Ho % 8 == 0 && variant != 1 && (variant == 2 || tiles8 * cdiv(a.Cout, 128) >= th8_min);
+    // few 128-channel tiles (deep levels at small batch): 64-channel tiles double the workgroup count at nearly the
+    // same L2->LDS bytes per flop (patch + 9 x 8 KB vs patch + 9 x 16 KB per chunk, half the flops)
+    static long bn64_below = -1;
+    if (bn64_below < 0) { const char* e = getenv("MPU_HALO_BN64_BELOW"); bn64_below = e ? atol(e) : 768; }
+    const long tiles4 = (long)a.B * cdiv(a.Ho, 4) * cdiv(a.Wo, 32);
+    const bool narrow = a.Cout > 64 && tiles4 * cdiv(a.Cout, 128) < bn64_below;
     if (dtype == MPU_BF16) {
-        if (a.Cout > 64) rc = tall128 ? launch_halo_cfg<bf16_t, 128, 8, 2>(a, st)
-                                      : launch_halo_cfg<bf16_t, 128, 4, 3>(a, st);
+        if (a.Cout > 64 && !narrow) rc = tall128 ? launch_halo_cfg<bf16_t, 128, 8, 2>(a, st)
+                                                 : launch_halo_cfg<bf16_t, 128, 4, 3>(a, st);
         else rc = tall ? launch_halo_cfg<bf16_t, 64, 8, 3>(a, st) : launch_halo_cfg<bf16_t, 64, 4, 3>(a, st);
     } else if (dtype == MPU_F32) {
         if (a.Cout > 64) rc = launch_halo_cfg<float, 128, 4, 3>(a, st);
