@@ -419,8 +419,13 @@ static int launch_glds_mode(const ConvArgs& a_in, hipStream_t st) {
     if (a.Cout >= 128 && a.partial && t128 < 256) {
         constexpr int BKE = 128 / sizeof(T);
         const int nit = GModeTraits<MODE>::NTAPS * (cdiv(a.C0, BKE) + cdiv(a.C1, BKE));
-        long ks = 512 / (t128 > 0 ? t128 : 1);
-        if (ks > 8) ks = 8;
+        static long sk_target = -1, sk_max = 8;
+        if (sk_target < 0) {
+            const char* e = getenv("MPU_SPLITK_TARGET"); sk_target = e ? atol(e) : 512;
+            const char* m = getenv("MPU_SPLITK_MAX"); sk_max = m ? atol(m) : 8;
+        }
+        long ks = sk_target / (t128 > 0 ? t128 : 1);
+        if (ks > sk_max) ks = sk_max;
         if (ks > nit / 8) ks = nit / 8;
         while (ks > 1 && ks * M * a.Cout > a.partial_cap) --ks;
         if (ks > 1) { a.ksplit = (int)ks; return launch_glds_cfg<T, MODE, 128, 128, 64, 64>(a, st); }
