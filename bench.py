@@ -197,7 +197,7 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def bench_predict(device, quiet, D=256, V=6, K=3, reps=2):
+def bench_predict(device, quiet, D=256, V=6, K=3, reps=2, batch=None):
     """BASELINE.json configs[2]: 6-view predict+fuse on one 256^3x1 synthetic volume."""
     from multiplanarunet_amd.unet import UNet
     from multiplanarunet_amd.fusion_model import FusionModel
@@ -210,13 +210,14 @@ def bench_predict(device, quiet, D=256, V=6, K=3, reps=2):
     model = UNet(n_classes=K, dim=D, n_channels=1, depth=4, complexity_factor=1, dtype="bf16", logger=quiet,
                  seed=0, device=device)
     fm = FusionModel(V, K, verbose=False, device=device)
-    multi_view_predict(model, vol, views, D, float(D), fm, batch_size=24, want_probs=False)      # warm-up
+    batch = batch or (int(os.environ["MPU_BENCH_PREDICT_BATCH"]) if "MPU_BENCH_PREDICT_BATCH" in os.environ else None)
+    multi_view_predict(model, vol, views, D, float(D), fm, batch_size=batch, want_probs=False)      # warm-up
     torch.cuda.synchronize()
     best, tim = None, None
     for _ in range(reps):
         t = {}
         t0 = time.perf_counter()
-        multi_view_predict(model, vol, views, D, float(D), fm, batch_size=24, want_probs=False, timings=t)
+        multi_view_predict(model, vol, views, D, float(D), fm, batch_size=batch, want_probs=False, timings=t)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if best is None or el < best:

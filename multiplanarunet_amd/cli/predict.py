@@ -107,11 +107,11 @@ def run(args):
             raise OSError("%s exists (use --overwrite or --continue)" % dst)
         if world > 1:
             labels = D.multi_view_predict_sharded(model, v, views, build["dim"], fit["real_space_span"], fm,
-                                                  sum_fusion=args.sum_fusion, batch_size=int(fit["batch_size"]))
+                                                  sum_fusion=args.sum_fusion, batch_size=None)
             probs = None
         else:
             probs, labels = multi_view_predict(model, v, views, build["dim"], fit["real_space_span"], fm,
-                                               sum_fusion=args.sum_fusion, batch_size=int(fit["batch_size"]),
+                                               sum_fusion=args.sum_fusion, batch_size=None,
                                                want_probs=args.no_argmax)
         if rank == 0:
             out = {"labels": labels.cpu().numpy(), "affine": v.affine}

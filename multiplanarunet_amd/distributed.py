@@ -188,7 +188,7 @@ def all_gather_slabs(slab, X):
 
 
 def multi_view_predict_sharded(model, volume, views, dim, real_space_span, fusion_model=None,
-                               sum_fusion=False, batch_size=16, n_planes="same+20"):
+                               sum_fusion=False, batch_size=None, n_planes="same+20"):
     """
     multiplanarunet_amd.predict.multi_view_predict over all ranks. Every rank
     holds the full input volume; returns the full uint8 label volume on every rank.

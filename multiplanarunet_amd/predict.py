@@ -11,10 +11,12 @@ from .interpolation import ViewGeometry, sample_view, map_and_fuse
 
 
 def multi_view_predict(model, volume, views, dim, real_space_span, fusion_model=None,
-                       sum_fusion=False, batch_size=16, n_planes="same+20",
+                       sum_fusion=False, batch_size=None, n_planes="same+20",
                        want_probs=True, timings=None):
     """
     Returns (merged f32 [X,Y,Z,K] or None, merged_map u8 [X,Y,Z]).
+    batch_size=None: even chunks of the view's planes as large as the kernels' operand bound allows
+    (UNet.auto_batch; 276 planes of 256x256 -> 3 x 92) - the result does not depend on it.
     fusion_model: object with .W (V,K) and .b (1,K) device tensors (FusionModel) or None with sum_fusion.
     """
     if fusion_model is None and not sum_fusion:

@@ -312,10 +312,29 @@ class UNet:
         out = self._forward(self._as_input(X), training=False)
         return out.reshape(out.shape[0], -1, self.n_classes) if self.flatten_output else out
 
+    def max_batch(self):
+        """Largest batch whose activations stay below the kernels' 2 GiB (32-bit offset) operand bound."""
+        H, W = self.img_shape[:2]
+        f0 = 8 * ((self.filters[0] + 7) // 8)                       # level-0 filters (padded); the conservative up-conv
+        per_image = H * W * 2 * f0 * self.params_esz()              # check prices 2*F0 channels at full resolution
+        return max(1, int((2 ** 31 - 1) // per_image))
+
+    def params_esz(self):
+        return 2 if self.dtype == torch.bfloat16 else 4
+
+    def auto_batch(self, n, cap=128):
+        """Even chunks of n images, as large as the operand bound (and `cap`) allow: big batches fill the chip at the
+        deep levels (276 planes of 256x256 -> 3 x 92)."""
+        bmax = max(1, min(cap, self.max_batch()))
+        chunks = -(-n // bmax)
+        return -(-n // chunks)
+
     def predict(self, X, batch_size=8, verbose=0):
-        """model.predict: inference-mode forward in chunks of batch_size; returns a device tensor."""
+        """model.predict: inference-mode forward in chunks of batch_size (None: auto_batch); returns a device tensor."""
         numpy_in = not torch.is_tensor(X)
         n = X.shape[0]
+        if batch_size is None:
+            batch_size = self.auto_batch(n)
         out = torch.empty((n, self.img_shape[0], self.img_shape[1], self.n_classes),
                           dtype=torch.float32, device=self.device)
         for s in range(0, n, batch_size):
