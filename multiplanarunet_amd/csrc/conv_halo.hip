@@ -303,7 +303,8 @@ int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
-    if (M * cmax * (long)sizeof(T) >= (1L << 31) || a.w_elems * (long)sizeof(T) >= (1L << 31))
+    const long Min = MODE == UPCONV2 ? M / 4 : M;                // input pixels (32-bit DMA offsets); the output is
+    if (Min * cmax * (long)sizeof(T) >= (1L << 31) || a.w_elems * (long)sizeof(T) >= (1L << 31))   // addressed in 64 bits
         return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
     const long tiles = (long)a.B * cdiv(a.Ho, TH) * cdiv(a.Wo, Cfg::TW) * cdiv(a.Cout, BN);
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);

@@ -315,14 +315,14 @@ class UNet:
     def max_batch(self):
         """Largest batch whose activations stay below the kernels' 2 GiB (32-bit offset) operand bound."""
         H, W = self.img_shape[:2]
-        f0 = 8 * ((self.filters[0] + 7) // 8)                       # level-0 filters (padded); the conservative up-conv
-        per_image = H * W * 2 * f0 * self.params_esz()              # check prices 2*F0 channels at full resolution
+        f0 = 8 * ((self.filters[0] + 7) // 8)                       # level-0 filters (padded): the largest activations
+        per_image = H * W * f0 * self.params_esz()
         return max(1, int((2 ** 31 - 1) // per_image))
 
     def params_esz(self):
         return 2 if self.dtype == torch.bfloat16 else 4
 
-    def auto_batch(self, n, cap=128):
+    def auto_batch(self, n, cap=160):
         """Even chunks of n images, as large as the operand bound (and `cap`) allow: big batches fill the chip at the
         deep levels (276 planes of 256x256 -> 3 x 92)."""
         bmax = max(1, min(cap, self.max_batch()))
