@@ -19,6 +19,7 @@ namespace mpu {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 namespace {
 
@@ -138,17 +139,28 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
             }
         }
     };
-    auto issue_w = [&](int step, int stage) {                    // step = chunk * NT + tap
-        const int cc = step / NT, tap = step - cc * NT;
-        bool s1; int cbase, Cs; chunk_src(cc, s1, cbase, Cs);
-        const long wkbase = (long)tap * a.w_tap_stride + (s1 ? a.C0 : 0) + cbase;
+    // Weight tile of the NEXT not-yet-requested step: running (tap, chunk) counters and a per-lane byte offset
+    // computed once, so a request is one add + the DMA (the former per-step index arithmetic cost ~400 cycles of
+    // every ~1800-cycle step).
+    unsigned wlane[GW]; int wch[GW];
+#pragma unroll
+    for (int g = 0; g < GW; ++g) {
+        wch[g] = wchunk[g] * EPC;
+        wlane[g] = wrow[g] == OOB ? OOB : wrow[g] + (unsigned)(wch[g] * (int)sizeof(T));
+    }
+    int w_tap = 0, w_cc = 0;                                     // position of the next request
+    auto issue_w = [&](int /*step*/, int stage) {
+        const bool s1 = w_cc >= nch0;
+        const int cbase = (s1 ? w_cc - nch0 : w_cc) * BKE, Cs = s1 ? a.C1 : a.C0;
+        const unsigned soff = (unsigned)(((long)w_tap * a.w_tap_stride + (s1 ? a.C0 : 0) + cbase) * (long)sizeof(T));
+        const unsigned dst = ldsW + stage * Cfg::WSTAGE + wave * (BN / 4) * 128;
+        const int room = Cs - cbase;                             // channels left in this source: only a tail chunk masks
 #pragma unroll
         for (int g = 0; g < GW; ++g) {
-            const int ch = wchunk[g] * EPC;
-            const unsigned off = (cbase + ch < Cs && wrow[g] != OOB)
-                                     ? wrow[g] + (unsigned)((wkbase + ch) * (long)sizeof(T)) : OOB;
-            h_dma16(rsw, off, ldsW + stage * Cfg::WSTAGE + (wave * (BN / 4) + g * 8) * 128);
+            const unsigned off = (wch[g] < room && wlane[g] != OOB) ? wlane[g] + soff : OOB;
+            h_dma16(rsw, off, dst + g * 8 * 128);
         }
+        if (++w_tap == NT) { w_tap = 0; ++w_cc; }
     };
 
     f32x16 acc[TN][TM];
@@ -170,18 +182,30 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
                                       : (wm * TM + j + ky) * PW + kx + (lane & 31);   // patch row of this lane's pixel
             psw[j] = (prow[j] >> 1) & 7;
         }
+        // All fragments of the tap are requested before the first MFMA (sched_barrier keeps the compiler from sinking
+        // the reads back next to their uses, which serialises LDS latency -> wait -> MFMA and ran the loop at ~1/3
+        // of the matrix pipe's rate); the MFMAs then wait on lgkmcnt progressively.
+        constexpr int SG = (TN + TM > 4) ? 2 : 4;                // k-steps requested together (register budget)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int q = 2 * s + fh;
-            uint4 af[TN], bf[TM];
+        for (int g0 = 0; g0 < 4; g0 += SG) {
+            uint4 af[SG][TN], bf[SG][TM];
 #pragma unroll
-            for (int i = 0; i < TN; ++i) af[i] = *(const uint4*)(Wb + i * 32 * 128 + ((q ^ fsw) << 4));
+            for (int s = 0; s < SG; ++s) {
+                const int q = 2 * (g0 + s) + fh;
 #pragma unroll
-            for (int j = 0; j < TM; ++j) bf[j] = *(const uint4*)(smem + prow[j] * 128 + ((q ^ psw[j]) << 4));
+                for (int i = 0; i < TN; ++i) af[s][i] = *(const uint4*)(Wb + i * 32 * 128 + ((q ^ fsw) << 4));
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+                for (int j = 0; j < TM; ++j) bf[s][j] = *(const uint4*)(smem + prow[j] * 128 + ((q ^ psw[j]) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < TM; ++j) HMma<T>::run(af[i], bf[j], acc[i][j]);
+            for (int s = 0; s < SG; ++s) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) HMma<T>::run(af[s][i], bf[s][j], acc[i][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -225,56 +249,75 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
         sbias[2 * BN + tid] = (a.post_scale && nv) ? a.post_shift[n0 + tid] : 0.f;
     }
     __syncthreads();
+    {   // accumulators -> staging tile: bias, ReLU as a clamp (no branch, no canonicalisation), optional affine, convert
+        const float lo = a.relu ? 0.f : -__builtin_inff();
+        const int nbase = wn * 64 + 4 * (lane >> 5);
+        float4 bq[TN][4];
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int ml = (wm * TM + j) * TW + (lane & 31);
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
+            for (int q = 0; q < 4; ++q) bq[i][q] = *(const float4*)(sbias + nbase + i * 32 + 8 * q);
+        unsigned char* drow = smem + ((wm * TM) * TW + (lane & 31)) * OROW + nbase * (int)sizeof(T);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nl = wn * 64 + i * 32 + 8 * q + 4 * (lane >> 5);
-                const float4 bq = *(const float4*)(sbias + nl);
-                float v[4] = {acc[i][j][4 * q] + bq.x, acc[i][j][4 * q + 1] + bq.y,
-                              acc[i][j][4 * q + 2] + bq.z, acc[i][j][4 * q + 3] + bq.w};
-                if (a.relu) {
+        for (int j = 0; j < TM; ++j) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (a.post_scale) {
-                    const float4 sq = *(const float4*)(sbias + BN + nl), hq = *(const float4*)(sbias + 2 * BN + nl);
-                    v[0] = v[0] * sq.x + hq.x; v[1] = v[1] * sq.y + hq.y;
-                    v[2] = v[2] * sq.z + hq.z; v[3] = v[3] * sq.w + hq.w;
-                }
-                unsigned char* dst = smem + ml * OROW + nl * (int)sizeof(T);
-                if (sizeof(T) == 2) {
-                    uint2 pk;
-                    pk.x = f32x2_to_bf16x2(v[0], v[1]);
-                    pk.y = f32x2_to_bf16x2(v[2], v[3]);
-                    *(uint2*)dst = pk;
-                } else {
-                    *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+            for (int i = 0; i < TN; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4] = {acc[i][j][4 * q] + bq[i][q].x, acc[i][j][4 * q + 1] + bq[i][q].y,
+                                  acc[i][j][4 * q + 2] + bq[i][q].z, acc[i][j][4 * q + 3] + bq[i][q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, __builtin_inff());
+                    if (a.post_scale) {
+                        const int nl = nbase + i * 32 + 8 * q;
+                        const float4 sq = *(const float4*)(sbias + BN + nl), hq = *(const float4*)(sbias + 2 * BN + nl);
+                        v[0] = v[0] * sq.x + hq.x; v[1] = v[1] * sq.y + hq.y;
+                        v[2] = v[2] * sq.z + hq.z; v[3] = v[3] * sq.w + hq.w;
+                    }
+                    unsigned char* dst = drow + j * TW * OROW + (i * 32 + 8 * q) * (int)sizeof(T);
+                    if (sizeof(T) == 2) {
+                        uint2 pk;
+                        pk.x = f32x2_to_bf16x2(v[0], v[1]);
+                        pk.y = f32x2_to_bf16x2(v[2], v[3]);
+                        *(uint2*)dst = pk;
+                    } else {
+                        *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                    }
                 }
             }
         }
     }
     __syncthreads();
-    {
-        constexpr int CPRO = BN * (int)sizeof(T) / 16;
-        T* out = (T*)a.out; const T* mask = (const T*)a.mask;
-        for (int idx = tid; idx < BM * CPRO; idx += 256) {
-            const int row = idx / CPRO, c = idx % CPRO;
-            const int y = y0 + row / TW, x = x0 + row % TW;
-            const int n = n0 + c * EPC;
-            if (y >= H || x >= W || n >= a.Cout) continue;
-            uint4 val = *(const uint4*)(smem + row * OROW + c * 16);
-            const long o = ((long)(b * H + y) * W + x) * a.Cout + n;
-            if (mask) {
-                const uint4 mk = *(const uint4*)(mask + o);
+    {   // staging tile -> global: 16-byte pieces, buffer stores with hardware bounds checks; per thread the channel
+        // piece is fixed and the pixel advances by RPI rows of the tile per iteration (all compile-time strides)
+        constexpr int CPRO = BN * (int)sizeof(T) / 16, RPI = 256 / CPRO, XPI = TW / RPI > 0 ? TW / RPI : 1;
+        static_assert(RPI <= TW && TW % RPI == 0, "a pass covers a fraction of one tile row");
+        const long npo = (long)a.B * H * W;
+        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(npo * a.Cout * (long)sizeof(T)), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask ? a.mask : a.out), 0,
+                                                                              (int)(npo * a.Cout * (long)sizeof(T)), 0x00020000);
+        const int c = tid % CPRO, r0 = tid / CPRO;
+        const int n = n0 + c * EPC;
+        const int pixB = a.Cout * (int)sizeof(T);
+        const int obase = ((b * H + y0) * W + x0) * pixB;                        // scalar part
+        const int lane_off = n * (int)sizeof(T) + r0 * pixB;
+        const unsigned char* srow = smem + r0 * OROW + c * 16;
+        const bool n_ok = n < a.Cout;
+#pragma unroll
+        for (int it = 0; it < BM / RPI; ++it) {
+            const int yy = it / XPI, xx = (it % XPI) * RPI;                       // tile row / column offset of this pass
+            const bool ok = n_ok && (y0 + yy < H) && (x0 + xx + r0 < W);
+            u32x4 val = *(const u32x4*)(srow + it * RPI * OROW);
+            // (no scalar offset operand: it is added after the range check of the vector offset, which would wrap
+            // the out-of-range marker of masked lanes back into the buffer)
+            const unsigned off = ok ? (unsigned)(obase + lane_off + (yy * W + xx) * pixB) : OOB;
+            if (a.mask) {
+                const u32x4 mk = __builtin_amdgcn_raw_buffer_load_b128(rsm, off, 0, 0);
                 if (sizeof(T) == 2) {
                     auto keep = [](uint32_t mw, uint32_t vw) {
-                        const uint32_t lo = ((mw & 0x8000u) == 0 && (mw & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
-                        const uint32_t hi = ((mw & 0x80000000u) == 0 && (mw & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
-                        return vw & (lo | hi);
+                        const uint32_t lo16 = ((mw & 0x8000u) == 0 && (mw & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
+                        const uint32_t hi16 = ((mw & 0x80000000u) == 0 && (mw & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+                        return vw & (lo16 | hi16);
                     };
                     val.x = keep(mk.x, val.x); val.y = keep(mk.y, val.y);
                     val.z = keep(mk.z, val.z); val.w = keep(mk.w, val.w);
@@ -285,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
                     if (!(__uint_as_float(mk.w) > 0.f)) val.w = 0;
                 }
             }
-            *(uint4*)(out + o) = val;
+            __builtin_amdgcn_raw_buffer_store_b128(val, rso, off, 0, 0);
         }
     }
 }
@@ -303,8 +346,9 @@ int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
-    const long Min = MODE == UPCONV2 ? M / 4 : M;                // input pixels (32-bit DMA offsets); the output is
-    if (Min * cmax * (long)sizeof(T) >= (1L << 31) || a.w_elems * (long)sizeof(T) >= (1L << 31))   // addressed in 64 bits
+    const long Min = MODE == UPCONV2 ? M / 4 : M;                // input pixels (32-bit DMA / buffer-store offsets)
+    if (Min * cmax * (long)sizeof(T) >= (1L << 31) || a.w_elems * (long)sizeof(T) >= (1L << 31) ||
+        M * a.Cout * (long)sizeof(T) >= (1L << 31))
         return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
     const long tiles = (long)a.B * cdiv(a.Ho, TH) * cdiv(a.Wo, Cfg::TW) * cdiv(a.Cout, BN);
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);

@@ -235,9 +235,10 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
                 const int j = it >> 1;                               // pixel row of this wave, column (it&1)*16 + lane>>2
                 const bool ok = n_ok && ((it & 1) ? xok1 : xok0) && (y0 + wm * TM + j < H);
                 u32x4 val = *(const u32x4*)(stage_r + it * 16 * OROW);
-                const unsigned off = ok ? (unsigned)(out_l + (j * W + (it & 1) * 16) * a.Cout * 2) : OOB;
+                // (no scalar offset operand: it would be added after the range check and wrap the out-of-range marker)
+                const unsigned off = ok ? (unsigned)(obase + out_l + (j * W + (it & 1) * 16) * a.Cout * 2) : OOB;
                 if (a.mask) {
-                    const u32x4 mk = __builtin_amdgcn_raw_buffer_load_b128(rsm, off, obase, 0);
+                    const u32x4 mk = __builtin_amdgcn_raw_buffer_load_b128(rsm, off, 0, 0);
                     auto keep = [](uint32_t mw, uint32_t vw) {
                         const uint32_t lo = ((mw & 0x8000u) == 0 && (mw & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
                         const uint32_t hi = ((mw & 0x80000000u) == 0 && (mw & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
                     val.x = keep(mk.x, val.x); val.y = keep(mk.y, val.y);
                     val.z = keep(mk.z, val.z); val.w = keep(mk.w, val.w);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(val, rso, off, obase, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(val, rso, off, 0, 0);
             }
         }
     }
