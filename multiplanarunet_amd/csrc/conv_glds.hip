@@ -159,26 +159,43 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
         } else { pb[g] = -1; py[g] = 0; px[g] = 0; }
     }
 
+    // Requests: per-lane byte offsets computed once (weights) or once per tap (pixels: the tap's source pixel and
+    // its validity), so a request is one multiply-add + the DMA instead of ~25 integer instructions.
+    unsigned wlane[GW]; int wch[GW], pch[GP];
+#pragma unroll
+    for (int g = 0; g < GW; ++g) {
+        wch[g] = wchunk[g] * EPC;
+        wlane[g] = wrow[g] == OOB ? OOB : wrow[g] + (unsigned)(wch[g] * (int)sizeof(T));
+    }
+#pragma unroll
+    for (int g = 0; g < GP; ++g) pch[g] = pchunk[g] * EPC;
+    int ptap[GP], cur_tap = -1;                                  // source pixel index of the current tap (or -1)
     auto issue = [&](int tap, int cc, int stage) {
         const bool s1 = cc >= nch0;
         const int cbase = (s1 ? cc - nch0 : cc) * BKE;
         const int Cs = s1 ? a.C1 : a.C0;
-        const long wkbase = (long)tap * a.w_tap_stride + (s1 ? a.C0 : 0) + cbase;
+        const int room = Cs - cbase;                             // only a tail chunk masks channels
+        const unsigned soff = (unsigned)(((long)tap * a.w_tap_stride + (s1 ? a.C0 : 0) + cbase) * (long)sizeof(T));
         const unsigned sbase = lds0 + stage * STAGE;
 #pragma unroll
         for (int g = 0; g < GW; ++g) {
-            const int ch = wchunk[g] * EPC;
-            const unsigned off = (cbase + ch < Cs && wrow[g] != OOB)
-                                     ? wrow[g] + (unsigned)((wkbase + ch) * (long)sizeof(T)) : OOB;
+            const unsigned off = (wch[g] < room && wlane[g] != OOB) ? wlane[g] + soff : OOB;
             dma16(rsw, off, sbase + (wave * (BN / 4) + g * 8) * 128);
         }
-        const int ky = tap / KW, kx = tap % KW;
+        if (tap != cur_tap) {
+            cur_tap = tap;
+            const int ky = tap / KW, kx = tap % KW;
+#pragma unroll
+            for (int g = 0; g < GP; ++g) {
+                int iy, ix;
+                const bool v = g_tap_src<MODE>(py[g], px[g], ky, kx, a.Ho, a.Wo, iy, ix) && pb[g] >= 0;
+                ptap[g] = v ? pb[g] + iy * Wi + ix : -1;
+            }
+        }
 #pragma unroll
         for (int g = 0; g < GP; ++g) {
-            int iy, ix;
-            const int ch = cbase + pchunk[g] * EPC;
-            const bool v = g_tap_src<MODE>(py[g], px[g], ky, kx, a.Ho, a.Wo, iy, ix) && ch < Cs && pb[g] >= 0;
-            const unsigned off = v ? (unsigned)(((pb[g] + iy * Wi + ix) * Cs + ch) * (int)sizeof(T)) : OOB;
+            const unsigned off = (ptap[g] >= 0 && pch[g] < room)
+                                     ? (unsigned)((ptap[g] * Cs + cbase + pch[g]) * (int)sizeof(T)) : OOB;
             const unsigned dst = sbase + BN * 128 + (wave * (BM / 4) + g * 8) * 128;
             if (s1) dma16(rs1, off, dst);
             else    dma16(rs0, off, dst);
@@ -198,18 +215,26 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
     auto compute = [&](int stage) {
         const unsigned char* Wb = smem + stage * STAGE + (wn * WN + (lane & 31)) * 128;
         const unsigned char* Pb = smem + stage * STAGE + BN * 128 + (wm * WM + (lane & 31)) * 128;
+        constexpr int SG = (TN + TM > 4) ? 2 : 4;                // k-steps requested together (register budget)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int so = ((2 * s + fh) ^ fsw) << 4;
-            uint4 af[TN], bf[TM];
+        for (int g0 = 0; g0 < 4; g0 += SG) {
+            uint4 af[SG][TN], bf[SG][TM];
 #pragma unroll
-            for (int i = 0; i < TN; ++i) af[i] = *(const uint4*)(Wb + i * 32 * 128 + so);
+            for (int s = 0; s < SG; ++s) {
+                const int so = ((2 * (g0 + s) + fh) ^ fsw) << 4;
 #pragma unroll
-            for (int j = 0; j < TM; ++j) bf[j] = *(const uint4*)(Pb + j * 32 * 128 + so);
+                for (int i = 0; i < TN; ++i) af[s][i] = *(const uint4*)(Wb + i * 32 * 128 + so);
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+                for (int j = 0; j < TM; ++j) bf[s][j] = *(const uint4*)(Pb + j * 32 * 128 + so);
+            }
+            __builtin_amdgcn_sched_barrier(0);                   // keep the reads ahead of the MFMAs (see conv_halo.hip)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) GMma<T>::run(af[i], bf[j], acc[i][j]);
+            for (int s = 0; s < SG; ++s)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) GMma<T>::run(af[s][i], bf[s][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
