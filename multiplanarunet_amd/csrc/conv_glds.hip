@@ -551,27 +551,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_glds_kernel(WgradArgs a) {
         zrow[g] = piece * (64 / SPRZ) + lane / SPRZ;
         zch[g] = ((lane % SPRZ) ^ wg_swz16<RZ>(zrow[g])) * EPC;
     }
-    auto issue = [&](long mb, int stage) {
+    // Requests advance by KP pixels per step: every lane keeps the (ox, oy, image) of its next X pixel and steps them
+    // incrementally - the former per-request 64-bit divisions cost several hundred instructions per DMA, more than
+    // the step's MFMAs.
+    int xm[NPX], xox[NPX], xoy[NPX], xb[NPX], zm[NPZ];
+#pragma unroll
+    for (int g = 0; g < NPX; ++g) {
+        const long m = mbeg + xrow[g];
+        xm[g] = (int)m;
+        xox[g] = (int)(m % a.Wo); const long t = m / a.Wo;
+        xoy[g] = (int)(t % a.Ho); xb[g] = (int)(t / a.Ho);
+    }
+#pragma unroll
+    for (int g = 0; g < NPZ; ++g) zm[g] = (int)(mbeg + zrow[g]);
+    const int mend_i = (int)mend;
+    auto issue = [&](long /*mb: sequential, KP apart*/, int stage) {
         const unsigned sb = lds0 + stage * STAGE;
 #pragma unroll
         for (int g = 0; g < NPX; ++g) {
-            const long m = mb + xrow[g];
             unsigned off = OOB;
-            if (m < mend && cs0 + xch[g] < Cs) {
-                const int ox = (int)(m % a.Wo); const long t = m / a.Wo;
-                const int oy = (int)(t % a.Ho); const int b = (int)(t / a.Ho);
+            if (xm[g] < mend_i && cs0 + xch[g] < Cs) {
                 int iy, ix;
-                if (g_tap_src<MODE>(oy, ox, ky, kx, a.Ho, a.Wo, iy, ix))
-                    off = (unsigned)((((long)b * Hi + iy) * Wi + ix) * Cs + cs0 + xch[g]) * (unsigned)sizeof(T);
+                if (g_tap_src<MODE>(xoy[g], xox[g], ky, kx, a.Ho, a.Wo, iy, ix))
+                    off = (unsigned)((((xb[g] * Hi + iy) * Wi + ix) * Cs + cs0 + xch[g]) * (int)sizeof(T));
             }
             dma16(rsx, off, sb + (wave * NPX + g) * 1024);
+            xm[g] += KP; xox[g] += KP;
+            while (xox[g] >= a.Wo) { xox[g] -= a.Wo; if (++xoy[g] == a.Ho) { xoy[g] = 0; ++xb[g]; } }
         }
 #pragma unroll
         for (int g = 0; g < NPZ; ++g) {
-            const long m = mb + zrow[g];
-            const unsigned off = (m < mend && co0 + zch[g] < a.Cout)
-                                     ? (unsigned)(m * a.Cout + co0 + zch[g]) * (unsigned)sizeof(T) : OOB;
+            const unsigned off = (zm[g] < mend_i && co0 + zch[g] < a.Cout)
+                                     ? (unsigned)((zm[g] * a.Cout + co0 + zch[g]) * (int)sizeof(T)) : OOB;
             dma16(rsz, off, sb + KP * RX + (wave * NPZ + g) * 1024);
+            zm[g] += KP;
         }
     };
 
