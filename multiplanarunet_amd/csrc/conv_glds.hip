@@ -607,29 +607,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_glds_kernel(WgradArgs a) {
                 return (((byte >> 4) ^ wg_swz16<RX>(krow)) << 4) + (byte & 15); };
             auto zoff = [&](int blk) { const int byte = (blk + ccol) * 2;
                 return (((byte >> 4) ^ wg_swz16<RZ>(krow)) << 4) + (byte & 15); };
+            s16x8 af[KP / 16][TI], bf[KP / 16][TJ];               // all fragments of the step first, then the MFMAs
 #pragma unroll
             for (int s = 0; s < KP / 16; ++s) {
-                s16x8 af[TI], bf[TJ];
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
                     const unsigned char* p = xb + (s * 16 + krow) * RX + xoff(wi * WCI + i * 32);
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * RX));
-                    af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    af[s][i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
                     const unsigned char* p = zb + (s * 16 + krow) * RZ + zoff(wj * WCO + j * 32);
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * RZ));
-                    bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    bf[s][j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < KP / 16; ++s)
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-            }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         } else {
 #pragma unroll 4
             for (int k = 0; k < KP; k += 2) {
