@@ -112,27 +112,43 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPla
     // 128-byte pixel rows; the 64-byte granule of a row is XOR-ed with (pixel>>1)&1 so that the four k-rows
     // of a transpose read fall in four different bank groups.
     const int dpx = lane >> 3, dsl = lane & 7;
+    // per-lane parts of the request offsets are fixed for the whole strip (column, channel chunk, their validity);
+    // a request then costs a scalar row base + one add instead of ~20 integer instructions per piece and step
+    unsigned xlane[2]; unsigned zlane;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int q = wave + 4 * k;
+        const int c = q * 8 + dpx;
+        const int ix = MODE == UPCONV2 ? x0 / 2 + c : x0 - 1 + c;
+        const int ch = (dsl ^ (((c >> 1) & 1) << 2)) * 8;
+        const bool v = q < NXP && c < (MODE == UPCONV2 ? 17 : 34) && (unsigned)ix < (unsigned)Wi && cs0 + ch < Cs;
+        xlane[k] = v ? (unsigned)((ix * Cs + cs0 + ch) * 2) : OOB;
+    }
+    {
+        const int c = wave * 8 + dpx, x = x0 + c;
+        const int ch = (dsl ^ (((c >> 1) & 1) << 2)) * 8;
+        zlane = (x < W && co0 + ch < a.Cout) ? (unsigned)((x * a.Cout + co0 + ch) * 2) : OOB;
+    }
     auto issue_x = [&](int r) {                                  // staged X row r of this strip
         int iy; bool rowok;
         if (MODE == UPCONV2) { const int uy = y0 + r; rowok = uy < H; iy = uy >> 1; }
         else { iy = y0 - 1 + r; rowok = (unsigned)iy < (unsigned)H; }
         const unsigned base = lds0 + (r % NXR) * XROWB;
-        for (int q = wave; q < NXP; q += 4) {
-            const int c = q * 8 + dpx;
-            const int ix = MODE == UPCONV2 ? x0 / 2 + c : x0 - 1 + c;
-            const int ch = (dsl ^ (((c >> 1) & 1) << 2)) * 8;
-            const bool v = rowok && c < (MODE == UPCONV2 ? 17 : 34) && (unsigned)ix < (unsigned)Wi && cs0 + ch < Cs;
-            const unsigned off = v ? (unsigned)((((b * Hi + iy) * Wi + ix) * Cs + cs0 + ch) * 2) : OOB;
-            t_dma16(rsx, off, base + q * 1024);
+        const unsigned rowoff = (unsigned)(((b * Hi + iy) * Wi) * Cs * 2);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int q = wave + 4 * k;
+            if (q < NXP) {                                       // wave-uniform
+                const unsigned off = (rowok && xlane[k] != OOB) ? rowoff + xlane[k] : OOB;
+                t_dma16(rsx, off, base + q * 1024);
+            }
         }
     };
     auto issue_z = [&](int t) {                                  // dZ row of step t = image row y0 + t
         const int y = y0 + t;
         const unsigned base = ldsZ + (t % NZR) * ZROWB;
-        const int c = wave * 8 + dpx, x = x0 + c;
-        const int ch = (dsl ^ (((c >> 1) & 1) << 2)) * 8;
-        const bool v = y < H && x < W && co0 + ch < a.Cout;
-        const unsigned off = v ? (unsigned)((((b * H + y) * W + x) * a.Cout + co0 + ch) * 2) : OOB;
+        const unsigned rowoff = (unsigned)(((b * H + y) * W) * a.Cout * 2);
+        const unsigned off = (y < H && zlane != OOB) ? rowoff + zlane : OOB;
         t_dma16(rsz, off, base + wave * 1024);
     };
     // DMAs per wave in one step group (X row pieces wave, wave+4, ... < NXP, plus one dZ piece): wait until only the
