@@ -98,7 +98,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int n0 = (logical % tiles_n) * BN;
     const long m0 = (long)(logical / tiles_n) * BM;
-    const int Cin = a.C0 + a.C1;
     // K steps: for every tap, the 128-byte channel rows of source 0, then those of source 1
     // (a row never straddles the two concat sources, so the source is wave-uniform)
     const int nch0 = (a.C0 + BKE - 1) / BKE, nch1 = (a.C1 + BKE - 1) / BKE;

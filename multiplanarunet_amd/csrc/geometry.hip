@@ -437,7 +437,6 @@ int mpu_map_view_nearest(const mpu_voxel_grid* grid, const mpu_view_pred* view, 
     MPU_REQUIRE(view->dim >= 2 && view->n_planes >= 2, "mpu_map_view_nearest: view needs dim>=2, planes>=2");
     MapArgs a; to_grid(*grid, a.grid); to_view(*view, a.view);
     a.Wv = nullptr; a.p_lo = 0; a.p_hi = view->n_planes; a.owns_oob = 1; a.out = d_mapped;
-    const long total = (long)a.grid.X * a.grid.Y * a.grid.Z;
     MPU_DISPATCH_K(n_classes, (map_view_kernel<KK, false><<<dim3(brick_grid(a.grid)), dim3(256), 0, (hipStream_t)stream>>>(a)));
     return launch_ok();
 }
@@ -450,7 +449,6 @@ int mpu_map_accumulate_view(const mpu_voxel_grid* grid, const mpu_view_pred* vie
     MPU_REQUIRE(0 <= p_lo && p_lo < p_hi && p_hi <= view->n_planes, "mpu_map_accumulate_view: bad plane range");
     MapArgs a; to_grid(*grid, a.grid); to_view(*view, a.view);
     a.Wv = d_Wv; a.p_lo = p_lo; a.p_hi = p_hi; a.owns_oob = owns_oob; a.out = d_z;
-    const long total = (long)a.grid.X * a.grid.Y * a.grid.Z;
     MPU_DISPATCH_K(n_classes, (map_view_kernel<KK, true><<<dim3(brick_grid(a.grid)), dim3(256), 0, (hipStream_t)stream>>>(a)));
     return launch_ok();
 }
@@ -469,7 +467,6 @@ int mpu_map_fuse_views(const mpu_voxel_grid* grid, const mpu_view_pred* views, i
         to_view(views[v], a.views[v]);
     }
     a.V = n_views; a.W = d_W; a.b = d_b; a.sum_fusion = sum_fusion; a.probs = d_probs; a.labels = d_labels;
-    const long total = (long)a.grid.X * a.grid.Y * a.grid.Z;
     MPU_DISPATCH_K(n_classes, (map_fuse_kernel<KK><<<dim3(fuse_grid(a.grid)), dim3(256), 0, (hipStream_t)stream>>>(a)));
     return launch_ok();
 }
