@@ -79,6 +79,8 @@ class DataParallelTrainer:
         self.bucket_bytes = bucket_bytes
         dev = getattr(model, "device", None)
         can = dev is not None and dev.type == "cuda" and hasattr(model, "grad_ready_points")
+        if overlap is None and os.environ.get("MPU_DP_OVERLAP") == "0":
+            overlap = False                        # A/B switch: one bucketed all-reduce after the backward pass
         self.overlap = can if overlap is None else (bool(overlap) and can)
         self.ready_events = None
         self.buckets = []                          # (point index, lo, hi) in the order the backward pass completes them
