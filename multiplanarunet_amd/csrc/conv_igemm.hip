@@ -606,7 +606,12 @@ long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, i
     const int ntaps = mode == UPCONV2 ? 4 : (mode == CONV1 ? 1 : 9);
     const int bc = (Cin >= 128 && Cout >= 128) ? 128 : 64;
     const long tiles = (long)cdiv(Cin, bc) * cdiv(Cout, bc) * ntaps;
-    long ks = tiles >= 384 ? 1 : (768 + tiles - 1) / tiles;   // aim at ~768 workgroups (3 per CU);
+    static long target = -1, nosplit = 384;
+    if (target < 0) {
+        const char* e = getenv("MPU_WGRAD_SPLIT_TARGET"); target = e ? atol(e) : 512;
+        const char* n = getenv("MPU_WGRAD_NOSPLIT_TILES"); nosplit = n ? atol(n) : 384;
+    }
+    long ks = tiles >= nosplit ? 1 : (target + tiles - 1) / tiles;   // aim at ~512 workgroups (2 per CU: measured best, fewer fp32 partial copies);
                                                           // no split (and no reduce pass) once the tile grid fills the chip
     const long maxks = (M + 511) / 512;                   // at least 512 pixels per split
     if (ks > maxks) ks = maxks;
