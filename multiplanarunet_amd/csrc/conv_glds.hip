@@ -365,19 +365,28 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
     }
 }
 
-// out = act(sum_z partial[z] + bias) (* ReLU mask), 16 bytes of output per thread
-template <typename T>
+// out = act(sum_z partial[z] + bias) (* ReLU mask), 16 bytes of output per thread (one 16-byte load of the mask, one
+// 16-byte store). STATS: also the fused BatchNorm statistics of the stored values - the grid is sized so that a
+// thread keeps its channel group over all its rows; per-block column sums go to stats[blockIdx][2][Cout].
+template <typename T, bool STATS>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ partial, int ks, long M, int Cout,
                                                             const float* __restrict__ bias, const T* __restrict__ mask,
                                                             int relu, const float* __restrict__ ps,
-                                                            const float* __restrict__ ph, T* __restrict__ out) {
+                                                            const float* __restrict__ ph, T* __restrict__ out,
+                                                            float* __restrict__ stats) {
     constexpr int EPC = 16 / sizeof(T);
     const long total = M * Cout / EPC, stride = M * Cout;
+    float ssum[EPC], ssq[EPC];
+#pragma unroll
+    for (int k = 0; k < EPC; ++k) { ssum[k] = 0.f; ssq[k] = 0.f; }
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int n = (int)((e * EPC) % Cout);
         float v[EPC];
 #pragma unroll
-        for (int k = 0; k < EPC; ++k) v[k] = bias ? bias[n + k] : 0.f;
+        for (int k = 0; k < EPC; k += 4) {
+            const float4 b4 = bias ? *(const float4*)(bias + n + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[k] = b4.x; v[k + 1] = b4.y; v[k + 2] = b4.z; v[k + 3] = b4.w;
+        }
         for (int z = 0; z < ks; ++z) {
 #pragma unroll
             for (int k = 0; k < EPC; k += 4) {
@@ -385,13 +394,63 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
                 v[k] += p.x; v[k + 1] += p.y; v[k + 2] += p.z; v[k + 3] += p.w;
             }
         }
+        uint4 mk = make_uint4(0, 0, 0, 0);
+        if (mask) mk = *(const uint4*)(mask + e * EPC);
 #pragma unroll
         for (int k = 0; k < EPC; ++k) {
             if (relu) v[k] = fmaxf(v[k], 0.f);
             if (ps) v[k] = v[k] * ps[n + k] + ph[n + k];
-            if (mask && !(to_f32<T>(mask[e * EPC + k]) > 0.f)) v[k] = 0.f;
-            out[e * EPC + k] = from_f32<T>(v[k]);
         }
+        uint4 o;
+        if (sizeof(T) == 2) {
+            o.x = f32x2_to_bf16x2(v[0], v[1]); o.y = f32x2_to_bf16x2(v[2], v[3]);
+            o.z = f32x2_to_bf16x2(v[4 % EPC], v[5 % EPC]); o.w = f32x2_to_bf16x2(v[6 % EPC], v[7 % EPC]);
+            if (mask) {
+                auto keep = [](uint32_t mw, uint32_t vw) {
+                    const uint32_t lo = ((mw & 0x8000u) == 0 && (mw & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
+                    const uint32_t hi = ((mw & 0x80000000u) == 0 && (mw & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+                    return vw & (lo | hi);
+                };
+                o.x = keep(mk.x, o.x); o.y = keep(mk.y, o.y); o.z = keep(mk.z, o.z); o.w = keep(mk.w, o.w);
+            }
+        } else {
+            o.x = __float_as_uint(v[0]); o.y = __float_as_uint(v[1]); o.z = __float_as_uint(v[2]); o.w = __float_as_uint(v[3]);
+            if (mask) {
+                if (!(__uint_as_float(mk.x) > 0.f)) o.x = 0;
+                if (!(__uint_as_float(mk.y) > 0.f)) o.y = 0;
+                if (!(__uint_as_float(mk.z) > 0.f)) o.z = 0;
+                if (!(__uint_as_float(mk.w) > 0.f)) o.w = 0;
+            }
+        }
+        *(uint4*)(out + e * EPC) = o;
+        if (STATS) {                                  // statistics of the STORED (rounded) values
+            if (sizeof(T) == 2) {
+                const uint32_t wv[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float lo = __uint_as_float(wv[q] << 16), hi = __uint_as_float(wv[q] & 0xffff0000u);
+                    ssum[(2 * q) % EPC] += lo; ssq[(2 * q) % EPC] += lo * lo;
+                    ssum[(2 * q + 1) % EPC] += hi; ssq[(2 * q + 1) % EPC] += hi * hi;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < EPC; ++k) { ssum[k] += v[k]; ssq[k] += v[k] * v[k]; }
+            }
+        }
+    }
+    if (STATS) {      // (gridDim.x * 256) % (Cout / EPC) == 0: the thread's channel group n is the same for all its rows
+        __shared__ float red[256 * EPC * 2];
+        const int cpr = Cout / EPC, cgi = threadIdx.x % cpr, nl = 256 / cpr;       // nl row-lanes per channel group
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) { red[(threadIdx.x * EPC + k) * 2] = ssum[k]; red[(threadIdx.x * EPC + k) * 2 + 1] = ssq[k]; }
+        __syncthreads();
+        for (int vv = threadIdx.x; vv < Cout * 2; vv += 256) {
+            const int col = vv >> 1, st2 = vv & 1, cg2 = col / EPC, k = col % EPC;
+            double acc = 0.0;
+            for (int rl = 0; rl < nl; ++rl) acc += (double)red[(((rl * cpr) + cg2) * EPC + k) * 2 + st2];
+            stats[((long)blockIdx.x * 2 + st2) * Cout + col] = (float)acc;
+        }
+        (void)cgi;
     }
 }
 
@@ -424,8 +483,19 @@ static int launch_glds_cfg(const ConvArgs& a_in, hipStream_t st) {
     if (!rc && ks > 1) {
         long work = M * a.Cout / (16 / (long)sizeof(T));
         long blocks = (work + 255) / 256; if (blocks > 4096) blocks = 4096;
-        splitk_finish_kernel<T><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
-                                                                  a.relu, a.post_scale, a.post_shift, (T*)a.out);
+        const int cpr = a.Cout / (16 / (int)sizeof(T));
+        // fused BN statistics: <= 256 blocks, every thread keeps its channel group (256 % cpr == 0, cpr <= 256)
+        const bool st_ok = a.stats && a.stats_rows && cpr <= 256 && 256 % cpr == 0 && a.Cout % (16 / (int)sizeof(T)) == 0;
+        if (st_ok) {
+            if (blocks > 256) blocks = 256;
+            if (blocks * 2 * a.Cout > a.stats_cap) blocks = a.stats_cap / (2 * a.Cout);
+            *a.stats_rows = (int)blocks;
+            splitk_finish_kernel<T, true><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
+                                                                            a.relu, a.post_scale, a.post_shift, (T*)a.out, a.stats);
+        } else {
+            splitk_finish_kernel<T, false><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
+                                                                             a.relu, a.post_scale, a.post_shift, (T*)a.out, nullptr);
+        }
         rc = launch_ok();
     }
     if (prof_on()) prof_end(st);

@@ -303,11 +303,28 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
         const int lane_off = n * (int)sizeof(T) + r0 * pixB;
         const unsigned char* srow = smem + r0 * OROW + c * 16;
         const bool n_ok = n < a.Cout;
+        float ssum[EPC], ssq[EPC];                                                // fused BN statistics (a.stats)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
 #pragma unroll
         for (int it = 0; it < BM / RPI; ++it) {
             const int yy = it / XPI, xx = (it % XPI) * RPI;                       // tile row / column offset of this pass
             const bool ok = n_ok && (y0 + yy < H) && (x0 + xx + r0 < W);
             u32x4 val = *(const u32x4*)(srow + it * RPI * OROW);
+            if (a.stats && ok) {
+                if (sizeof(T) == 2) {
+                    const uint32_t wv[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = __uint_as_float(wv[e] << 16), hi = __uint_as_float(wv[e] & 0xffff0000u);
+                        ssum[2 * e] += lo; ssq[2 * e] += lo * lo; ssum[2 * e + 1] += hi; ssq[2 * e + 1] += hi * hi;
+                    }
+                } else {
+                    const float fv[4] = {__uint_as_float(val.x), __uint_as_float(val.y), __uint_as_float(val.z), __uint_as_float(val.w)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ssum[e % EPC] += fv[e]; ssq[e % EPC] += fv[e] * fv[e]; }
+                }
+            }
             // (no scalar offset operand: it is added after the range check of the vector offset, which would wrap
             // the out-of-range marker of masked lanes back into the buffer)
             const unsigned off = ok ? (unsigned)(obase + lane_off + (yy * W + xx) * pixB) : OOB;
@@ -330,6 +347,23 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
             }
             __builtin_amdgcn_raw_buffer_store_b128(val, rso, off, 0, 0);
         }
+        if (a.stats) {   // block reduction over the RPI row-lanes of each column (fixed order), one partial row per pixel tile
+            __syncthreads();                                                      // the staging tile has been read
+            float* red = (float*)smem;                                            // [RPI][BN][2]
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                red[(r0 * BN + c * EPC + e) * 2] = ssum[e];
+                red[(r0 * BN + c * EPC + e) * 2 + 1] = ssq[e];
+            }
+            __syncthreads();
+            const int ptile = blockIdx.x / tiles_n;                               // pixel-tile index (n-tile fastest)
+            for (int v = tid; v < BN * 2; v += 256) {
+                const int col = v >> 1, st2 = v & 1;
+                double acc = 0.0;
+                for (int rl = 0; rl < RPI; ++rl) acc += (double)red[(rl * BN + col) * 2 + st2];
+                if (n0 + col < a.Cout) a.stats[((long)ptile * 2 + st2) * a.Cout + n0 + col] = (float)acc;
+            }
+        }
     }
 }
 
@@ -351,6 +385,11 @@ int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
         M * a.Cout * (long)sizeof(T) >= (1L << 31))
         return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
     const long tiles = (long)a.B * cdiv(a.Ho, TH) * cdiv(a.Wo, Cfg::TW) * cdiv(a.Cout, BN);
+    const long ptiles = tiles / cdiv(a.Cout, BN);
+    if (a.stats && a.stats_rows) {
+        if (ptiles * 2 * a.Cout <= a.stats_cap) *a.stats_rows = (int)ptiles;
+        else { a.stats = nullptr; *a.stats_rows = 0; }
+    } else a.stats = nullptr;
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);
     kern<<<dim3((unsigned)tiles), dim3(256), Cfg::SMEM, st>>>(a);
     if (prof_on()) prof_end(st);

@@ -578,6 +578,7 @@ static int halo_on() {
 }
 
 int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
+    if (a.stats_rows) *a.stats_rows = 0;          // set by the schedules that produce the fused BN statistics
     if (conv_impl() == 1) {
         if (halo_on()) {
             const int w = try_conv_ws(dtype, mode, a, st);

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(npix * a.Cout * 2L), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask ? a.mask : a.out), 0,
                                                                           (int)(npix * a.Cout * 2L), 0x00020000);
+    float stat_acc = 0.f;     // fused BN statistics: lane L of a wave owns value L = (channel group, channel, sum | sum^2)
     int buf = 0;
     for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
         const int poff = Cfg::STAGE + (buf ? 0 : Cfg::PATCH);
@@ -230,6 +231,9 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
             int b, y0, x0; tile_coords(tile, b, y0, x0);
             const int obase = ((b * H + y0) * W + x0) * a.Cout * 2;          // scalar part of the output offset
             const bool xok0 = x0 + (lane >> 2) < W, xok1 = x0 + 16 + (lane >> 2) < W;
+            float tsum[8], tsq[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { tsum[e] = 0.f; tsq[e] = 0.f; }
 #pragma unroll
             for (int it = 0; it < Cfg::WPX / 16; ++it) {             // 4 lanes per pixel: 64 contiguous bytes
                 const int j = it >> 1;                               // pixel row of this wave, column (it&1)*16 + lane>>2
@@ -248,7 +252,41 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
                     val.z = keep(mk.z, val.z); val.w = keep(mk.w, val.w);
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(val, rso, off, 0, 0);
+                if (a.stats && ok) {
+                    const uint32_t wv[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = __uint_as_float(wv[e] << 16), hi = __uint_as_float(wv[e] & 0xffff0000u);
+                        tsum[2 * e] += lo; tsq[2 * e] += lo * lo; tsum[2 * e + 1] += hi; tsq[2 * e + 1] += hi * hi;
+                    }
+                }
             }
+            if (a.stats) {     // transpose-reduce over the 16 pixel-lanes through the wave's own staging rows (now free)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                float* tb = (float*)wstage;                          // [16 pixel-lanes][64 values]
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    tb[(lane >> 2) * 64 + (lane & 3) * 16 + 2 * e] = tsum[e];
+                    tb[(lane >> 2) * 64 + (lane & 3) * 16 + 2 * e + 1] = tsq[e];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                float s = 0.f;
+#pragma unroll
+                for (int pl = 0; pl < 16; ++pl) s += tb[pl * 64 + lane];
+                stat_acc += s;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // before the next tile's staging writes
+            }
+        }
+    }
+    if (a.stats) {             // one partial row per workgroup: the two pixel-row waves of a channel half are combined
+        __syncthreads();
+        float* cb = (float*)smem;                                    // [4 waves][64]
+        cb[wave * 64 + lane] = stat_acc;
+        __syncthreads();
+        if (wm == 0) {
+            const float v = cb[wave * 64 + lane] + cb[(wave + 2) * 64 + lane];
+            const int ch = wn * 32 + (lane >> 4) * 8 + ((lane & 15) >> 1), st2 = lane & 1;
+            if (ch < a.Cout) a.stats[((long)blockIdx.x * 2 + st2) * a.Cout + ch] = v;
         }
     }
 }
@@ -276,6 +314,8 @@ int launch_ws(const ConvArgs& a_in, hipStream_t st) {
     const long tx = cdiv(a.Wo, Cfg::TW), ty = cdiv(a.Ho, TH);
     if (tiles * (tx > ty ? tx : ty) >= (1L << 32)) return fail(MPU_EUNSUPPORTED, "%s", "conv: too many tiles");
     const unsigned mx = (unsigned)(((1UL << 32) + tx - 1) / tx), my = (unsigned)(((1UL << 32) + ty - 1) / ty);
+    if (a.stats && a.stats_rows && (long)grid * 2 * a.Cout <= a.stats_cap) *a.stats_rows = grid;
+    else a.stats = nullptr;
     kern<<<dim3((unsigned)grid), dim3(256), Cfg::SMEM, st>>>(a, (int)tiles, mx, my);
     if (prof_on()) prof_end(st);
     return launch_ok();

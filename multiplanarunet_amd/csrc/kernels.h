@@ -18,6 +18,10 @@ struct ConvArgs {
     float* partial;              // split-K scratch [ksplit][M][Cout] f32 (NULL = never split)
     long partial_cap;            // floats available at `partial`
     int ksplit;                  // set by the launcher
+    // Optional fused BatchNorm statistics of the STORED output (training forward): the kernel writes per-workgroup
+    // column sums [row][2][Cout] (sum x, sum x^2) to `stats` and the launcher sets *stats_rows to the number of rows
+    // (0: the schedule chosen for this shape does not produce them; the caller runs the column reduction instead).
+    float* stats; int* stats_rows; long stats_cap;              // capacity of `stats` in floats
 };
 struct WgradArgs {
     const void* x0; const void* x1; int C0, C1;
@@ -73,7 +77,7 @@ int launch_cast_pad(int dtype, const float* x, long M, int Cin, int Cpad, void* 
 int launch_bn_stats(int dtype, const void* x, long M, int C, float* partial,
                     const float* gamma, const float* beta, float* moving_mean, float* moving_var,
                     float* mean, float* invstd, float* scale, float* shift, float eps, float momentum,
-                    hipStream_t st);
+                    int ready_rows /* > 0: partial already holds that many [2][C] rows */, hipStream_t st);
 // inference: scale/shift from the moving statistics
 int launch_bn_infer_coeffs(const float* gamma, const float* beta, const float* moving_mean,
                            const float* moving_var, int C, float eps, float* scale, float* shift, hipStream_t st);

@@ -105,7 +105,7 @@ struct Plan {
     std::vector<long> c1, c2, n, p, dskip;          // encoder levels
     long c1b, c2b, nb;
     std::vector<long> u1, n1, c2u, c3u, n2;         // up levels
-    long probs, gA, gB, gC, partial, partial2, wpartial, wpartial_floats, coeffs, stats, total;
+    long probs, gA, gB, gC, partial, partial_floats, partial2, wpartial, wpartial_floats, coeffs, stats, total;
 };
 
 Plan make_plan(const mpu_unet* m, int B) {
@@ -136,7 +136,9 @@ Plan make_plan(const mpu_unet* m, int B) {
     long pe = (long)RED_MAX_BLOCKS * 2 * m->cmax;
     const long he = (long)RED_MAX_BLOCKS * (m->head_C * m->cfg.n_classes + m->cfg.n_classes);
     if (he > pe) pe = he;
+    if (pe < (4L << 20)) pe = 4L << 20;         // room for the per-tile BN statistics rows of the fused conv epilogues
     P.partial = take(pe * 4);
+    P.partial_floats = pe;
     P.partial2 = take((long)RED_MAX_BLOCKS * m->cmax * 4);
     long we = 0;
     for (size_t i = 0; i < m->conv.size(); ++i) {
@@ -185,8 +187,13 @@ double conv_flops(const Run& r, const Conv& c, int lvl, int n_cnt_logical = -1) 
 }
 
 int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* in1, int C1, void* out, int lvl,
-             const float* post_scale = nullptr, const float* post_shift = nullptr) {
+             const float* post_scale = nullptr, const float* post_shift = nullptr, int* stats_rows = nullptr) {
     ConvArgs a;
+    // training: the conv in front of a BatchNormalization also produces the per-tile column sums of its output
+    static int fused_stats = -1;
+    if (fused_stats < 0) { const char* e = getenv("MPU_FUSED_BN_STATS"); fused_stats = (e && e[0] == '0') ? 0 : 1; }
+    if (!fused_stats) stats_rows = nullptr;
+    a.stats = stats_rows ? (float*)r.at(r.P.partial) : nullptr; a.stats_rows = stats_rows; a.stats_cap = r.P.partial_floats;
     a.flops = conv_flops(r, c, lvl); a.w_elems = 0;
     a.partial = r.overlap ? nullptr : (float*)r.at(r.P.wpartial); a.partial_cap = r.P.wpartial_floats; a.ksplit = 1;
     a.post_scale = post_scale; a.post_shift = post_shift;
@@ -201,6 +208,7 @@ int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* i
 int conv_dgrad(const Run& r, const Conv& c, const void* dz, const void* mask, void* out, int out_lvl,
                int n_off, int n_cnt) {
     ConvArgs a;
+    a.stats = nullptr; a.stats_rows = nullptr; a.stats_cap = 0;
     a.in0 = dz; a.in1 = nullptr; a.C0 = c.Cout; a.C1 = 0; a.w_elems = 0;
     a.partial = r.overlap ? nullptr : (float*)r.at(r.P.wpartial); a.partial_cap = r.P.wpartial_floats; a.ksplit = 1;
     a.post_scale = nullptr; a.post_shift = nullptr;
@@ -248,14 +256,14 @@ int wgrad_join(const Run& r) {
     return MPU_OK;
 }
 
-int bn_fwd(const Run& r, const BN& b, const void* x, int lvl, int training, void* y, void* pooled) {
+int bn_fwd(const Run& r, const BN& b, const void* x, int lvl, int training, void* y, void* pooled, int stats_rows = 0) {
     const int H = r.m->cfg.H >> lvl, W = r.m->cfg.W >> lvl;
     const long M = (long)r.B * H * W;
     int rc;
-    if (training)
+    if (training)   // stats_rows > 0: the producing conv already wrote that many partial rows (sum, sum of squares)
         rc = launch_bn_stats(r.m->cfg.dtype, x, M, b.C, (float*)r.at(r.P.partial), r.params + b.g, r.params + b.b,
                              r.state + b.mm, r.state + b.mv, r.stat(b, 0), r.stat(b, 1), r.stat(b, 2), r.stat(b, 3),
-                             BN_EPS, BN_MOM, r.st);
+                             BN_EPS, BN_MOM, stats_rows, r.st);
     else
         rc = launch_bn_infer_coeffs(r.params + b.g, r.params + b.b, r.state + b.mm, r.state + b.mv, b.C, BN_EPS,
                                     r.stat(b, 2), r.stat(b, 3), r.st);
@@ -316,21 +324,27 @@ int run_forward(const Run& r, const float* d_x, int training, float* d_out) {
     const void* cur = r.at(P.xin); int Ccur = m->cin_pad;
     for (int i = 0; i < D; ++i) {
         RC(conv_fwd(r, m->conv[m->enc_c1(i)], cur, Ccur, nullptr, 0, r.at(P.c1[i]), i));
-        RC(conv_fwd(r, m->conv[m->enc_c2(i)], r.at(P.c1[i]), m->F[i], nullptr, 0, r.at(P.c2[i]), i));
-        RC(bn_fwd(r, m->bn[m->enc_bn(i)], r.at(P.c2[i]), i, training, r.at(P.n[i]), r.at(P.p[i])));
+        int rows = 0;
+        RC(conv_fwd(r, m->conv[m->enc_c2(i)], r.at(P.c1[i]), m->F[i], nullptr, 0, r.at(P.c2[i]), i, nullptr, nullptr, &rows));
+        RC(bn_fwd(r, m->bn[m->enc_bn(i)], r.at(P.c2[i]), i, training, r.at(P.n[i]), r.at(P.p[i]), rows));
         cur = r.at(P.p[i]); Ccur = m->F[i];
     }
     RC(conv_fwd(r, m->conv[m->bot_c1()], cur, Ccur, nullptr, 0, r.at(P.c1b), D));
-    RC(conv_fwd(r, m->conv[m->bot_c2()], r.at(P.c1b), m->F[D], nullptr, 0, r.at(P.c2b), D));
-    RC(bn_fwd(r, m->bn[m->bot_bn()], r.at(P.c2b), D, training, r.at(P.nb), nullptr));
+    {
+        int rows = 0;
+        RC(conv_fwd(r, m->conv[m->bot_c2()], r.at(P.c1b), m->F[D], nullptr, 0, r.at(P.c2b), D, nullptr, nullptr, &rows));
+        RC(bn_fwd(r, m->bn[m->bot_bn()], r.at(P.c2b), D, training, r.at(P.nb), nullptr, rows));
+    }
     const void* prev = r.at(P.nb); int Cprev = m->F[D];
     for (int j = 0; j < D; ++j) {
         const int lvl = D - 1 - j, f = m->F[lvl];
-        RC(conv_fwd(r, m->conv[m->up_c(j, 0)], prev, Cprev, nullptr, 0, r.at(P.u1[j]), lvl));
-        RC(bn_fwd(r, m->bn[m->up_bn(j, 0)], r.at(P.u1[j]), lvl, training, r.at(P.n1[j]), nullptr));
+        int rows = 0;
+        RC(conv_fwd(r, m->conv[m->up_c(j, 0)], prev, Cprev, nullptr, 0, r.at(P.u1[j]), lvl, nullptr, nullptr, &rows));
+        RC(bn_fwd(r, m->bn[m->up_bn(j, 0)], r.at(P.u1[j]), lvl, training, r.at(P.n1[j]), nullptr, rows));
         RC(conv_fwd(r, m->conv[m->up_c(j, 1)], r.at(P.n[lvl]), f, r.at(P.n1[j]), f, r.at(P.c2u[j]), lvl));
-        RC(conv_fwd(r, m->conv[m->up_c(j, 2)], r.at(P.c2u[j]), f, nullptr, 0, r.at(P.c3u[j]), lvl));
-        RC(bn_fwd(r, m->bn[m->up_bn(j, 1)], r.at(P.c3u[j]), lvl, training, r.at(P.n2[j]), nullptr));
+        rows = 0;
+        RC(conv_fwd(r, m->conv[m->up_c(j, 2)], r.at(P.c2u[j]), f, nullptr, 0, r.at(P.c3u[j]), lvl, nullptr, nullptr, &rows));
+        RC(bn_fwd(r, m->bn[m->up_bn(j, 1)], r.at(P.c3u[j]), lvl, training, r.at(P.n2[j]), nullptr, rows));
         prev = r.at(P.n2[j]); Cprev = f;
     }
     float* out = d_out ? d_out : (float*)r.at(P.probs);
@@ -616,6 +630,7 @@ int mpu_conv2d_igemm(int32_t dtype, int32_t mode, const void* d_in0, int32_t C0,
     a.in0 = d_in0; a.in1 = d_in1; a.C0 = C0; a.C1 = C1; a.w = d_w_packed; a.w_tap_stride = w_tap_stride;
     a.w_row_stride = w_row_stride; a.bias = d_bias; a.mask = d_mask; a.out = d_out;
     a.B = B; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.relu = relu; a.flops = 0; a.w_elems = 0; a.partial = nullptr; a.partial_cap = 0; a.ksplit = 1;
+    a.stats = nullptr; a.stats_rows = nullptr; a.stats_cap = 0;
     a.post_scale = nullptr; a.post_shift = nullptr;
     return launch_conv(dtype, mode, a, (hipStream_t)stream);
 }

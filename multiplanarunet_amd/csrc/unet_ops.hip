@@ -400,10 +400,12 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
 
 int launch_bn_stats(int dtype, const void* x, long M, int C, float* partial, const float* gamma, const float* beta,
                     float* mmean, float* mvar, float* mean, float* invstd, float* scale, float* shift,
-                    float eps, float momentum, hipStream_t st) {
-    int nblk;
-    int rc = launch_colreduce<0>(dtype, x, nullptr, M, C, nullptr, nullptr, partial, &nblk, st);
-    if (rc) return rc;
+                    float eps, float momentum, int ready_rows, hipStream_t st) {
+    int nblk = ready_rows;                       // > 0: `partial` already holds that many rows from the conv epilogue
+    if (nblk <= 0) {
+        int rc = launch_colreduce<0>(dtype, x, nullptr, M, C, nullptr, nullptr, partial, &nblk, st);
+        if (rc) return rc;
+    }
     bn_stats_finalize_kernel<<<cdiv(C, FIN_COLS), 256, 0, st>>>(partial, nblk, C, M, gamma, beta, mmean, mvar, mean,
                                                            invstd, scale, shift, eps, momentum);
     return launch_ok();
