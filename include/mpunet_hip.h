@@ -267,6 +267,15 @@ int mpu_unet_backward_events(const mpu_unet* m, int32_t batch, const uint8_t* d_
                              float* d_bn_state, void* d_workspace, float* d_grads, float* d_loss,
                              void* const* ready_events, int32_t n_events, void* stream);
 
+/* kernel_regularizer=regularizers.l2(l2) of the encoder / bottom / up-sampling conv kernels (mpunet/models/unet.py:
+ * 122-177,189; the 1x1 output conv at :211, biases and BatchNorm carry none): d_grads += 2*l2*W over those tensors,
+ * to be called after mpu_unet_backward (after the replica all-reduce under data parallelism) and before the Adam
+ * step. d_reg_loss (optional, 1 float) receives l2 * sum W^2, the term Keras adds to the reported loss; it needs
+ * d_partial = mpu_unet_l2_workspace_doubles() doubles of scratch. Deterministic summation order. */
+int mpu_unet_l2_regularizer(const mpu_unet* m, const float* d_params, float* d_grads, double l2, double* d_partial,
+                            float* d_reg_loss, void* stream);
+int64_t mpu_unet_l2_workspace_doubles(void);
+
 /* Keras Adam (TF ApplyAdam form), t = 1-based step; YAML defaults
  * lr 5e-5, beta_1 .9, beta_2 .999, epsilon 1e-8
  * (mpunet/bin/defaults/MultiPlanar/train_hparams.yaml:126). */

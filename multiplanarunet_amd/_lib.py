@@ -112,6 +112,8 @@ _SIGS = {
     "mpu_unet_grad_ready_points": (C.c_int32, [c_p, c_p, C.c_int32]),
     "mpu_unet_backward_events": (C.c_int, [c_p, C.c_int32] + [c_p] * 8 + [c_p, C.c_int32, c_p]),
     "mpu_adam_step_device_counter": (C.c_int, [c_p, c_p, c_p, c_p, i64, c_p, f64, f64, f64, f64, c_p]),
+    "mpu_unet_l2_regularizer": (C.c_int, [c_p, c_p, c_p, f64, c_p, c_p, c_p]),
+    "mpu_unet_l2_workspace_doubles": (i64, []),
     "mpu_conv2d_pack_weights": (C.c_int, [i32, i32, c_p, i32, i32, c_p, c_p, c_p]),
     "mpu_conv2d_igemm": (C.c_int, [i32, i32, c_p, i32, c_p, i32, c_p, i64, i32, c_p, c_p, c_p,
                                    i32, i32, i32, i32, i32, c_p]),

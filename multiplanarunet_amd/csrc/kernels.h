@@ -108,6 +108,11 @@ int launch_head_backward(int dtype, const void* n, const float* probs, const uin
                          const float* Wh, int ldw, float* partial, void* dn, float* dWh, float* dbh,
                          float* loss, hipStream_t st);
 
+// l2 kernel regulariser: grads += 2*l2*W over the listed tensors; reg_loss (optional) = l2 * sum W^2
+struct L2Table { int njobs, _pad; long off[PACK_MAX_JOBS]; long n[PACK_MAX_JOBS]; };
+constexpr int L2_PARTIAL_DOUBLES = PACK_MAX_JOBS * 64;
+int launch_l2_regularizer(const L2Table& tab, const float* params, float* grads, float l2, double* partial,
+                          float* reg_loss, hipStream_t st);
 int launch_adam_dev(float* p, const float* g, float* m, float* v, long n, long long* step, double lr, double b1,
                     double b2, float eps, hipStream_t st);
 int launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha, float b1, float b2,

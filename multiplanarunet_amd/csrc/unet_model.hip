@@ -596,6 +596,21 @@ int mpu_unet_backward_events(const mpu_unet* m, int32_t batch, const uint8_t* d_
     return run_backward(r, d_y, d_sample_weight, d_loss);
 }
 
+int mpu_unet_l2_regularizer(const mpu_unet* m, const float* d_params, float* d_grads, double l2, double* d_partial,
+                            float* d_reg_loss, void* stream) {
+    MPU_REQUIRE(m && d_params && d_grads, "mpu_unet_l2_regularizer: null argument");
+    MPU_REQUIRE(l2 >= 0.0 && (!d_reg_loss || d_partial), "mpu_unet_l2_regularizer: bad argument");
+    L2Table tab; tab.njobs = 0; tab._pad = 0;
+    for (const Conv& c : m->conv) {
+        if (c.mode == CONV1) continue;                      // the 1x1 output conv carries no regulariser (unet.py:211)
+        MPU_REQUIRE(tab.njobs < PACK_MAX_JOBS, "mpu_unet_l2_regularizer: too many layers");
+        const int k = c.mode == UPCONV2 ? 2 : 3;
+        tab.off[tab.njobs] = c.w; tab.n[tab.njobs] = (long)k * k * c.Cin * c.Cout; ++tab.njobs;
+    }
+    return launch_l2_regularizer(tab, d_params, d_grads, (float)l2, d_partial, d_reg_loss, (hipStream_t)stream);
+}
+int64_t mpu_unet_l2_workspace_doubles(void) { return L2_PARTIAL_DOUBLES; }
+
 int mpu_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t n, int64_t t,
                   double lr, double beta1, double beta2, double eps, void* stream) {
     MPU_REQUIRE(d_params && d_grads && d_m && d_v && n >= 0 && t >= 1, "mpu_adam_step: bad argument");

@@ -898,6 +898,41 @@ int launch_adam_dev(float* p, const float* g, float* m, float* v, long n, long l
     return launch_ok();
 }
 
+// kernel_regularizer=l2(lambda) of the 3x3 / 2x2 conv kernels (reference unet.py:122-177,189): g += 2*lambda*W and,
+// when wanted, lambda * sum W^2 (fixed summation order: L2_BLOCKS partial sums per kernel tensor, combined by one block)
+constexpr int L2_BLOCKS = 64;
+__global__ __launch_bounds__(256) void l2_grad_kernel(L2Table tab, const float* __restrict__ p, float* __restrict__ g,
+                                                      float two_l2, double* __restrict__ partial) {
+    const long off = tab.off[blockIdx.y], n = tab.n[blockIdx.y];
+    double acc = 0.0;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)L2_BLOCKS * 256) {
+        const float w = p[off + e];
+        g[off + e] = g[off + e] + two_l2 * w;
+        acc += (double)w * (double)w;
+    }
+    if (!partial) return;
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(long)blockIdx.y * L2_BLOCKS + blockIdx.x] = red[0];
+}
+__global__ void l2_loss_kernel(const double* __restrict__ partial, int n, float l2, float* __restrict__ out) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    *out = (float)(s * (double)l2);
+}
+int launch_l2_regularizer(const L2Table& tab, const float* params, float* grads, float l2, double* partial,
+                          float* reg_loss, hipStream_t st) {
+    if (tab.njobs == 0) return MPU_OK;
+    l2_grad_kernel<<<dim3(L2_BLOCKS, tab.njobs), 256, 0, st>>>(tab, params, grads, 2.f * l2, reg_loss ? partial : nullptr);
+    if (reg_loss) l2_loss_kernel<<<1, 1, 0, st>>>(partial, tab.njobs * L2_BLOCKS, l2, reg_loss);
+    return launch_ok();
+}
+
 int launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha, float b1, float b2, float eps,
                 hipStream_t st) {
     adam_kernel<<<ew_grid(n), 256, 0, st>>>(p, g, m, v, n, alpha, b1, b2, eps);

@@ -80,8 +80,6 @@ class UNet:
                                       "are on the MI355X path")
         if out_activation not in ("softmax", "linear"):
             raise NotImplementedError("out_activation must be 'softmax' or 'linear'")
-        if l2_reg:
-            raise NotImplementedError("l2_reg is not supported (default YAML: False)")
         if img_rows % (2 ** depth) or img_cols % (2 ** depth):
             raise NotImplementedError("image dims must be multiples of 2**depth (no cropping path)")
         self.dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "float32": torch.float32,
@@ -126,6 +124,8 @@ class UNet:
         self._ws_batch = 0
         self.optimizer_kwargs = dict(lr=5e-5, beta_1=0.9, beta_2=0.999, epsilon=1e-8)
         self.iterations = 0
+        self._l2_ws = None
+        self.reg_loss = None
         self._grad_hook = None         # e.g. an all-reduce over RCCL (multiplanarunet_amd.distributed)
         self._init_weights(seed)
 
@@ -414,6 +414,19 @@ class UNet:
                       _lib.ptr(loss), arr, len(ready_events), _lib.stream_ptr())
         return probs, loss
 
+    def _add_l2(self, want_loss=False):
+        """kernel_regularizer=l2(self.l2_reg) (unet.py:189): grads += 2*l2*W on the 3x3 / 2x2 conv kernels; the
+        term l2*sum(W^2) that Keras adds to the reported loss lands in self.reg_loss (device scalar)."""
+        if not self.l2_reg:
+            return
+        if self._l2_ws is None:
+            n = int(_lib.load().mpu_unet_l2_workspace_doubles())
+            self._l2_ws = torch.empty(n, dtype=torch.float64, device=self.device)
+            self.reg_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        _lib.call("mpu_unet_l2_regularizer", self._h, _lib.ptr(self.params), _lib.ptr(self.grads),
+                  float(self.l2_reg), _lib.ptr(self._l2_ws), _lib.ptr(self.reg_loss) if want_loss else None,
+                  _lib.stream_ptr())
+
     def apply_gradients(self):
         """Keras Adam on the flat parameter buffer, then refresh the packed MFMA operands."""
         self._ensure_adam()
@@ -442,6 +455,7 @@ class UNet:
 
         def body():
             self.forward_backward(x, y, sample_weight, want_loss=False)
+            self._add_l2()
             _lib.call("mpu_adam_step_device_counter", _lib.ptr(self.params), _lib.ptr(self.grads),
                       _lib.ptr(self._adam_m), _lib.ptr(self._adam_v), self.params.numel(), _lib.ptr(step_dev),
                       float(k["lr"]), float(k["beta_1"]), float(k["beta_2"]), float(k["epsilon"]), _lib.stream_ptr())
@@ -472,11 +486,14 @@ class UNet:
         _, loss = self.forward_backward(x, y, sample_weight, want_loss, ready_events=events)
         if hook is not None:
             hook(self.grads)                     # data-parallel: SUM of replica gradients
+        self._add_l2(want_loss)                  # once, after the replica sum (Keras scales it 1/replicas per replica)
         self.apply_gradients()
         return loss
 
     def train_on_batch(self, x, y, sample_weight=None):
-        return float(self.train_step(x, y, sample_weight).mean().item())
+        """Scalar Keras reports for the step: mean of the weighted per-pixel loss (+ the l2 term when l2_reg is set)."""
+        loss = float(self.train_step(x, y, sample_weight).mean().item())
+        return loss + float(self.reg_loss.item()) if self.l2_reg else loss
 
     def fit(self, data, steps_per_epoch, epochs=1, callbacks=None, initial_epoch=0, verbose=0, **kwargs):
         """Minimal Model.fit over an iterator of (x, y, w) batches (trainer.py:246-257)."""

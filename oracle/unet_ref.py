@@ -200,11 +200,13 @@ def adam_update(theta, g, m, v, t, lr=5e-5, b1=0.9, b2=0.999, eps=1e-8):
 
 
 def train_step(w, x, y, sample_w, opt=None, depth=4, dtype=torch.float32,
-               lr=5e-5, b1=0.9, b2=0.999, eps=1e-8, grad_scale_replicas=None):
+               lr=5e-5, b1=0.9, b2=0.999, eps=1e-8, grad_scale_replicas=None, l2_reg=None):
     """
     One Keras Model.fit inner step. x [B,H,W,C] f32,
     y [B,H,W] (or [B,H*W,1]) u8, sample_w [B]. Returns dict(loss [B,H,W],
     grads {name: np}, weights (updated, incl. BN moving stats), opt state).
+    l2_reg: regularizers.l2(l2_reg) on every 3x3 / 2x2 conv kernel -- not on the 1x1 output conv, biases or
+    BatchNorm (unet.py:122-177,189,211): Keras adds l2_reg * sum(W^2) per kernel to the differentiated total.
     """
     p = to_torch(w, dtype, requires_grad=True)
     B, H, W = x.shape[:3]
@@ -213,7 +215,12 @@ def train_step(w, x, y, sample_w, opt=None, depth=4, dtype=torch.float32,
     probs = forward(p, torch.tensor(x, dtype=dtype), depth, True, "softmax",
                     new_stats)
     loss = keras_sparse_ce(probs, yt, torch.tensor(np.asarray(sample_w), dtype=dtype))
-    loss.sum().backward()
+    total = loss.sum()
+    reg = None
+    if l2_reg:
+        reg = sum((p[k] ** 2).sum() for k in p if k.endswith("/kernel") and not k.startswith("conv2d/")) * l2_reg
+        total = total + reg
+    total.backward()
     names = trainable_names(w)
     grads = {k: p[k].grad.numpy().astype(np.float64 if dtype == torch.float64
                                          else np.float32) for k in names}
@@ -231,7 +238,8 @@ def train_step(w, x, y, sample_w, opt=None, depth=4, dtype=torch.float32,
     for k, v in new_stats.items():
         new_w[k] = v.numpy().astype(np.float32)
     return {"loss": loss.detach().numpy(), "probs": probs.detach().numpy(),
-            "grads": grads, "weights": new_w, "opt": new_opt}
+            "grads": grads, "weights": new_w, "opt": new_opt,
+            "reg_loss": None if reg is None else float(reg.detach())}
 
 
 def bf16_autograd_grads(w, x, y, sample_w, depth=4):

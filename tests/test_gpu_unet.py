@@ -227,3 +227,56 @@ def test_backward_ready_events_same_gradients():
     torch.cuda.synchronize()
     assert all(e is None or e.query() for e in evs)
     assert torch.equal(m.grads, g0)
+
+
+def test_l2_kernel_regulariser_vs_oracle():
+    """l2_reg (unet.py:189): gradients of the regularised total and the reported l2 term vs the f64 oracle; the
+    1x1 output conv, biases and BatchNorm parameters carry no regulariser (their gradients are unchanged, bitwise)."""
+    from multiplanarunet_amd.unet import UNet
+    from oracle import unet_ref as U
+    K, C, D, cf, H, W, B = 3, 1, 2, 1, 32, 32, 2
+    l2 = 0.05
+    w = rand_weights(U, K, C, D, cf, seed=9)
+    rng = np.random.RandomState(2)
+    x = rng.randn(B, H, W, C).astype(np.float32)
+    y = rng.randint(0, K, (B, H * W, 1)).astype(np.uint8)
+    sw = np.array([1.0, 0.33], np.float32)
+    ref = U.train_step(w, x, y, sw, depth=D, dtype=torch.float64, l2_reg=l2)
+    ref32 = U.train_step(w, x, y, sw, depth=D, dtype=torch.float32, l2_reg=l2)
+    mk = lambda reg: UNet(n_classes=K, img_rows=H, img_cols=W, n_channels=C, depth=D, complexity_factor=cf,
+                          dtype="f32", logger=quiet, flatten_output=True, l2_reg=reg)
+    m, m0 = mk(l2), mk(None)
+    for mm in (m, m0):
+        mm.set_weights_dict(w)
+        mm.forward_backward(x, y, sw)
+    g0 = m0.grads.clone()
+    assert torch.equal(m.grads, g0)
+    m._add_l2(want_loss=True)
+    np.testing.assert_allclose(float(m.reg_loss.item()), ref["reg_loss"], rtol=1e-6)
+    g = m.grads.cpu().numpy()
+    for name, gr in ref["grads"].items():
+        kind, off, ps, ls = m._tensors[name]
+        n = int(np.prod(ps))
+        a = m._from_stored(name, g[off:off + n].reshape(ps), ps, ls)
+        regularised = name.endswith("/kernel") and not name.startswith("conv2d/")
+        if not regularised:
+            assert torch.equal(m.grads[off:off + n], g0[off:off + n]), name
+        else:
+            plain = m._from_stored(name, g0[off:off + n].cpu().numpy().reshape(ps), ps, ls)
+            np.testing.assert_allclose(a - plain, 2 * l2 * w[name], rtol=0, atol=1e-6 * np.abs(a).max() + 1e-7)
+        scale = np.abs(gr).max() + 1e-12
+        noise = np.abs(ref32["grads"][name] - gr).max() / scale
+        assert np.abs(a - gr).max() / scale <= max(2e-3, 3 * noise), name
+    # the full step (train_on_batch reports loss + l2 term) and the graphed step both apply it
+    ref_loss = float(ref["loss"].mean()) + ref["reg_loss"]
+    got = mk(l2)
+    got.set_weights_dict(w)
+    assert abs(got.train_on_batch(x, y, sw) - ref_loss) <= 1e-4 * abs(ref_loss)
+    a = mk(l2); a.set_weights_dict(w)
+    xd, yd = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    swd = torch.tensor(sw, device="cuda")
+    step = a.make_graphed_train_step(xd, yd, swd)      # the warm-up inside is step 1
+    assert torch.equal(a.params, got.params)
+    step(); got.train_step(xd, yd, swd, want_loss=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a.params, got.params)

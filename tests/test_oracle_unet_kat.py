@@ -175,3 +175,26 @@ def test_adam_three_step_trajectory():
         ref.append(th2)
     np.testing.assert_allclose(out, ref, rtol=1e-13)
     np.testing.assert_allclose(out[0], 1 - 5e-5 * 0.5 / (0.5 + 1e-8 / np.sqrt(1e-3) * 1.0), rtol=1e-9)
+
+
+def test_l2_kernel_regulariser_known_answer():
+    """regularizers.l2(l) on the 3x3 / 2x2 conv kernels only (unet.py:122-177,189): the gradient grows by exactly
+    2*l*W there and nowhere else; the reported term is l * sum W^2."""
+    w = small_weights(6)
+    rng = np.random.RandomState(8)
+    x = rng.randn(2, 4, 4, 2)
+    y = rng.randint(0, 3, (2, 4, 4)).astype(np.uint8)
+    sw = np.array([1.0, 0.33])
+    l2 = 0.25
+    r0 = U.train_step(w, x, y, sw, depth=1, dtype=torch.float64)
+    r1 = U.train_step(w, x, y, sw, depth=1, dtype=torch.float64, l2_reg=l2)
+    assert r0["reg_loss"] is None
+    tot = 0.0
+    for name in r0["grads"]:
+        d = r1["grads"][name] - r0["grads"][name]
+        if name.endswith("/kernel") and not name.startswith("conv2d/"):
+            np.testing.assert_allclose(d, 2 * l2 * np.asarray(w[name], np.float64), rtol=0, atol=1e-12)
+            tot += float((np.asarray(w[name], np.float64) ** 2).sum())
+        else:
+            assert np.abs(d).max() <= 1e-13, name
+    np.testing.assert_allclose(r1["reg_loss"], l2 * tot, rtol=1e-12)
