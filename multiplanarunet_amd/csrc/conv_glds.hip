@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
 
 // out = act(sum_z partial[z] + bias) (* ReLU mask), 16 bytes of output per thread (one 16-byte load of the mask, one
 // 16-byte store). STATS: also the fused BatchNorm statistics of the stored values - the grid is sized so that a
-// thread keeps its channel group over all its rows; per-block column sums go to stats[blockIdx][2][Cout].
+// thread keeps its channel group over all its rows; per-block column sums go to stats[2][Cout][blocks].
 template <typename T, bool STATS>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ partial, int ks, long M, int Cout,
                                                             const float* __restrict__ bias, const T* __restrict__ mask,
@@ -387,15 +387,25 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
             const float4 b4 = bias ? *(const float4*)(bias + n + k) : make_float4(0.f, 0.f, 0.f, 0.f);
             v[k] = b4.x; v[k + 1] = b4.y; v[k + 2] = b4.z; v[k + 3] = b4.w;
         }
-        for (int z = 0; z < ks; ++z) {
+        uint4 mk = make_uint4(0, 0, 0, 0);              // requested together with the first partials
+        if (mask) mk = *(const uint4*)(mask + e * EPC);
+        for (int z0 = 0; z0 < ks; z0 += 4) {            // four splits per round trip (clamped, unconditional loads;
+            float4 p[4][EPC / 4];                       //  the adds keep the order z = 0, 1, 2, ...)
 #pragma unroll
-            for (int k = 0; k < EPC; k += 4) {
-                const float4 p = *(const float4*)(partial + z * stride + e * EPC + k);
-                v[k] += p.x; v[k + 1] += p.y; v[k + 2] += p.z; v[k + 3] += p.w;
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < EPC; k += 4)
+                    p[u][k / 4] = *(const float4*)(partial + (z0 + u < ks ? z0 + u : ks - 1) * stride + e * EPC + k);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {               // surplus splits add +0 through a select (a branch would pull
+                const bool on = z0 + u < ks;            // their loads in and wait for each on the spot)
+#pragma unroll
+                for (int k = 0; k < EPC; k += 4) {
+                    v[k] += on ? p[u][k / 4].x : 0.f; v[k + 1] += on ? p[u][k / 4].y : 0.f;
+                    v[k + 2] += on ? p[u][k / 4].z : 0.f; v[k + 3] += on ? p[u][k / 4].w : 0.f;
+                }
             }
         }
-        uint4 mk = make_uint4(0, 0, 0, 0);
-        if (mask) mk = *(const uint4*)(mask + e * EPC);
 #pragma unroll
         for (int k = 0; k < EPC; ++k) {
             if (relu) v[k] = fmaxf(v[k], 0.f);
@@ -448,7 +458,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
             const int col = vv >> 1, st2 = vv & 1, cg2 = col / EPC, k = col % EPC;
             double acc = 0.0;
             for (int rl = 0; rl < nl; ++rl) acc += (double)red[(((rl * cpr) + cg2) * EPC + k) * 2 + st2];
-            stats[((long)blockIdx.x * 2 + st2) * Cout + col] = (float)acc;
+            stats[((long)st2 * Cout + col) * gridDim.x + blockIdx.x] = (float)acc;          // [2][Cout][blocks]
         }
         (void)cgi;
     }

@@ -361,7 +361,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
                 const int col = v >> 1, st2 = v & 1;
                 double acc = 0.0;
                 for (int rl = 0; rl < RPI; ++rl) acc += (double)red[(rl * BN + col) * 2 + st2];
-                if (n0 + col < a.Cout) a.stats[((long)ptile * 2 + st2) * a.Cout + n0 + col] = (float)acc;
+                // layout [2][Cout][pixel tiles]: the finalize reads each column's partials as one contiguous run
+                if (n0 + col < a.Cout) a.stats[((long)st2 * a.Cout + n0 + col) * (gridDim.x / tiles_n) + ptile] = (float)acc;
             }
         }
     }

@@ -469,9 +469,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #pragma unroll
             for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
         }
-        for (; k < ksplit; ++k) {
-            const float4 v = p4[(long)k * n4 + e];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        if (k < ksplit) {       // tail in ONE round trip: clamped unconditional loads, the surplus ones add +0 (a select,
+            float4 v[3];        // not a branch: the compiler sinks loads into branches and waits for each on the spot)
+#pragma unroll
+            for (int u = 0; u < 3; ++u) v[u] = p4[(long)(k + u < ksplit ? k + u : k) * n4 + e];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const bool on = k + u < ksplit;
+                s.x += on ? v[u].x : 0.f; s.y += on ? v[u].y : 0.f; s.z += on ? v[u].z : 0.f; s.w += on ? v[u].w : 0.f;
+            }
         }
         reinterpret_cast<float4*>(dW)[e] = s;
     }
@@ -500,9 +506,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kl4_kernel(const float* __re
 #pragma unroll
             for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
         }
-        for (; k < ksplit; k += 4) {
-            const float4 v = p4[(long)k * n4 + e];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        if (k < ksplit) {       // tail in one round trip (clamped loads, surplus ones add +0 through a select)
+            float4 v[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) v[u] = p4[(long)(k + 4 * u < ksplit ? k + 4 * u : k) * n4 + e];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const bool on = k + 4 * u < ksplit;
+                s.x += on ? v[u].x : 0.f; s.y += on ? v[u].y : 0.f; s.z += on ? v[u].z : 0.f; s.w += on ? v[u].w : 0.f;
+            }
         }
     }
     red[threadIdx.x] = s;
@@ -581,6 +593,8 @@ int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
     if (a.stats_rows) *a.stats_rows = 0;          // set by the schedules that produce the fused BN statistics
     if (conv_impl() == 1) {
         if (halo_on()) {
+            const int c = try_conv_c8(dtype, mode, a, st);
+            if (c != 0) return c < 0 ? c : MPU_OK;
             const int w = try_conv_ws(dtype, mode, a, st);
             if (w != 0) return w < 0 ? w : MPU_OK;
             const int h = try_conv_halo(dtype, mode, a, st);

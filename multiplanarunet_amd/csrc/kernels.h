@@ -19,7 +19,8 @@ struct ConvArgs {
     long partial_cap;            // floats available at `partial`
     int ksplit;                  // set by the launcher
     // Optional fused BatchNorm statistics of the STORED output (training forward): the kernel writes per-workgroup
-    // column sums [row][2][Cout] (sum x, sum x^2) to `stats` and the launcher sets *stats_rows to the number of rows
+    // column sums [2][Cout][rows] (sum x, sum x^2; a column's partials contiguous) to `stats` and the launcher sets
+    // *stats_rows to the number of rows
     // (0: the schedule chosen for this shape does not produce them; the caller runs the column reduction instead).
     float* stats; int* stats_rows; long stats_cap;              // capacity of `stats` in floats
 };
@@ -43,6 +44,7 @@ void prof_end(hipStream_t st);
 
 int  launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // dispatches on MPU_CONV_IMPL
 int  launch_conv_glds(int dtype, int mode, const ConvArgs& a, hipStream_t st);  // LDS-DMA variant (conv_glds.hip)
+int  try_conv_c8(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // <= 8 input channels: first layer (conv_c8.hip)
 int  try_conv_ws(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // register-stationary weights, persistent (conv_ws.hip)
 int  try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st);     // LDS-resident patch variant (conv_halo.hip)
 long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out);
@@ -59,6 +61,7 @@ bool wgrad_glds_supported(int dtype, int mode, const WgradArgs& a);
 
 // ---- unet_ops.hip ---------------------------------------------------------
 constexpr int RED_MAX_BLOCKS = 256;
+constexpr int HEAD_BWD_MAX_BLOCKS = 1024;      // partial rows of the head weight and bias gradient (4 workgroups per CU; 2048: slower)
 
 // fp32 master [taps][Cin][Cout] -> packed operands in T
 // one launch for every 3x3 / up-conv layer of a model (offsets in ELEMENTS of params / the packed buffer)
@@ -77,7 +80,8 @@ int launch_cast_pad(int dtype, const float* x, long M, int Cin, int Cpad, void* 
 int launch_bn_stats(int dtype, const void* x, long M, int C, float* partial,
                     const float* gamma, const float* beta, float* moving_mean, float* moving_var,
                     float* mean, float* invstd, float* scale, float* shift, float eps, float momentum,
-                    int ready_rows /* > 0: partial already holds that many [2][C] rows */, hipStream_t st);
+                    int ready_rows /* > 0: partial already holds [2][C][ready_rows] sums from the conv epilogue */,
+                    hipStream_t st);
 // inference: scale/shift from the moving statistics
 int launch_bn_infer_coeffs(const float* gamma, const float* beta, const float* moving_mean,
                            const float* moving_var, int C, float eps, float* scale, float* shift, hipStream_t st);

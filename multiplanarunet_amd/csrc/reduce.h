@@ -25,7 +25,10 @@ __device__ __forceinline__ void partial_sums(const float* __restrict__ partial, 
             for (int u = 0; u < 16; ++u) {
                 const int k = base + kl + u * FIN_KL;
 #pragma unroll
-                for (int i = 0; i < NS; ++i) v[i][u] = k < nblk ? partial[(long)k * stride + i * stat_stride + col] : 0.f;
+                for (int i = 0; i < NS; ++i) {       // clamped, unconditional load: a predicated one is waited for on the spot
+                    const float x = partial[(long)(k < nblk ? k : nblk - 1) * stride + i * stat_stride + col];
+                    v[i][u] = k < nblk ? x : 0.f;
+                }
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u)
@@ -40,6 +43,45 @@ __device__ __forceinline__ void partial_sums(const float* __restrict__ partial, 
         double t = 0.0;
         if (kl == 0)
             for (int j = 0; j < FIN_KL; ++j) t += red[j * FIN_COLS + (threadIdx.x % FIN_COLS)];
+        out[i] = t;
+        __syncthreads();
+    }
+}
+
+// Same for partials stored column-major, partial[(s*C + col)*nblk + k] (the conv epilogues' BN statistics): thread
+// (col = tid / FIN_KL, k-lane = tid % FIN_KL) reads 64 consecutive floats per wave. out[] valid on k-lane 0.
+template <int NS>
+__device__ __forceinline__ void partial_sums_colmajor(const float* __restrict__ partial, int nblk, int C, int col,
+                                                      bool valid, double* red /*[256]*/, double* out /*[NS]*/) {
+    const int kl = threadIdx.x % FIN_KL, cl = threadIdx.x / FIN_KL;
+    double s[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s[i] = 0.0;
+    if (valid) {
+        for (int base = 0; base < nblk; base += 16 * FIN_KL) {
+            float v[NS][16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = base + kl + u * FIN_KL;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const float x = partial[((long)i * C + col) * nblk + (k < nblk ? k : nblk - 1)];
+                    v[i][u] = k < nblk ? x : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int i = 0; i < NS; ++i) s[i] += (double)v[i][u];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        red[threadIdx.x] = s[i];
+        __syncthreads();
+        double t = 0.0;
+        if (kl == 0)
+            for (int j = 0; j < FIN_KL; ++j) t += red[cl * FIN_KL + j];
         out[i] = t;
         __syncthreads();
     }

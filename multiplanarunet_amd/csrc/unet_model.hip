@@ -134,7 +134,7 @@ Plan make_plan(const mpu_unet* m, int B) {
     }
     P.gA = take(gmax * esz); P.gB = take(gmax * esz); P.gC = take(gmax * esz);
     long pe = (long)RED_MAX_BLOCKS * 2 * m->cmax;
-    const long he = (long)RED_MAX_BLOCKS * (m->head_C * m->cfg.n_classes + m->cfg.n_classes);
+    const long he = (long)HEAD_BWD_MAX_BLOCKS * (m->head_C * m->cfg.n_classes + m->cfg.n_classes);
     if (he > pe) pe = he;
     if (pe < (4L << 20)) pe = 4L << 20;         // room for the per-tile BN statistics rows of the fused conv epilogues
     P.partial = take(pe * 4);

@@ -378,14 +378,21 @@ static int launch_colreduce(int dtype, const void* a, const void* b, long M, int
 }
 
 
+// COLMAJOR: partial is [2][C][nblk] (written by the conv epilogues), else [nblk][2][C] (colreduce)
+template <bool COLMAJOR>
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
                                          const float* gamma, const float* beta, float* mmean, float* mvar,
                                          float* mean, float* invstd, float* scale, float* shift, float eps, float mom) {
     __shared__ double red[256];
-    const int c = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
+    const int c = blockIdx.x * FIN_COLS + (COLMAJOR ? threadIdx.x / FIN_KL : threadIdx.x % FIN_COLS);
     double st[2];
-    partial_sums<2>(partial, nblk, 2L * C, C, c, c < C, red, st);
-    if (c >= C || threadIdx.x >= FIN_COLS) return;
+    if (COLMAJOR) {
+        partial_sums_colmajor<2>(partial, nblk, C, c, c < C, red, st);
+        if (c >= C || threadIdx.x % FIN_KL) return;
+    } else {
+        partial_sums<2>(partial, nblk, 2L * C, C, c, c < C, red, st);
+        if (c >= C || threadIdx.x >= FIN_COLS) return;
+    }
     const double s = st[0], ss = st[1];
     const double mu = s / (double)M;
     double var = ss / (double)M - mu * mu;
@@ -406,8 +413,12 @@ int launch_bn_stats(int dtype, const void* x, long M, int C, float* partial, con
         int rc = launch_colreduce<0>(dtype, x, nullptr, M, C, nullptr, nullptr, partial, &nblk, st);
         if (rc) return rc;
     }
-    bn_stats_finalize_kernel<<<cdiv(C, FIN_COLS), 256, 0, st>>>(partial, nblk, C, M, gamma, beta, mmean, mvar, mean,
-                                                           invstd, scale, shift, eps, momentum);
+    if (ready_rows > 0)
+        bn_stats_finalize_kernel<true><<<cdiv(C, FIN_COLS), 256, 0, st>>>(partial, nblk, C, M, gamma, beta, mmean, mvar,
+                                                                          mean, invstd, scale, shift, eps, momentum);
+    else
+        bn_stats_finalize_kernel<false><<<cdiv(C, FIN_COLS), 256, 0, st>>>(partial, nblk, C, M, gamma, beta, mmean, mvar,
+                                                                           mean, invstd, scale, shift, eps, momentum);
     return launch_ok();
 }
 
@@ -815,9 +826,19 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const T* __restrict_
             Vec<T>::store(dn + m * C + (long)sub * N, d);
         }
     }
-    // block reduction through LDS atomics-free: serialise by pixel-slot
-    for (int slot = 0; slot < (int)ppb; ++slot) {
-        if ((int)(threadIdx.x / G) == slot && act) {
+    // block reduction, fixed order: butterfly over the pixel slots of a wave (lanes that share `sub` are G apart),
+    // then the four waves one after the other through LDS
+    for (int o = G; o < 64; o <<= 1) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int k = 0; k < K; ++k) aw[i][k] += __shfl_xor(aw[i][k], o, 64);
+#pragma unroll
+        for (int k = 0; k < K; ++k) ab[k] += __shfl_xor(ab[k], o, 64);
+    }
+    for (int wv = 0; wv < 4; ++wv) {                             // G <= 64: lanes 0..G-1 of each wave hold its totals
+        const bool mine = (int)(threadIdx.x >> 6) == wv && act && (int)(threadIdx.x & 63) < G;
+        if (mine) {
 #pragma unroll
             for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -851,7 +872,7 @@ int launch_head_backward(int dtype, const void* n, const float* probs, const uin
         return fail(MPU_EUNSUPPORTED, "%s", "head backward: at most 64 16-byte channel chunks");
     int G = 1; while (G < cpr) G <<= 1;
     const long ppb = 256 / G;
-    long blocks = (M + ppb - 1) / ppb; if (blocks > RED_MAX_BLOCKS) blocks = RED_MAX_BLOCKS;
+    long blocks = (M + ppb - 1) / ppb; if (blocks > HEAD_BWD_MAX_BLOCKS) blocks = HEAD_BWD_MAX_BLOCKS;
     if (dtype == MPU_BF16) {
         MPU_HEAD_DISPATCH_K(K, (head_backward_kernel<bf16_t, KK><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)n, probs, y, sw, M, ppi, C, Wh, ldw, partial, (bf16_t*)dn, loss)))
     } else {
