@@ -336,7 +336,21 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
     {
         constexpr int CPRO = BN * (int)sizeof(T) / 16;
         T* out = (T*)a.out; const T* mask = (const T*)a.mask;
-        for (int idx = tid; idx < BM * CPRO; idx += 256) {
+        constexpr int NIT = BM * CPRO / 256;
+        static_assert(BM * CPRO % 256 == 0, "whole passes");
+        uint4 mkv[NIT];                         // ReLU masks of the data-gradient launches, requested up front (clamped
+        if (mask) {                             // addresses: a load inside the pass is one exposed round trip per pass)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * 256, row = idx / CPRO, c = idx % CPRO;
+                const long m = m0 + row;
+                const int n = n0 + c * EPC;
+                mkv[it] = *(const uint4*)(mask + ((m < M && n < a.Cout) ? m * a.Cout + n : 0));
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256;
             const int row = idx / CPRO, c = idx % CPRO;
             const long m = m0 + row;
             const int n = n0 + c * EPC;
@@ -344,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
             uint4 val = *(const uint4*)(smem + row * OROW + c * 16);
             const long o = m * a.Cout + n;
             if (mask) {
-                const uint4 mk = *(const uint4*)(mask + o);
+                const uint4 mk = mkv[it];
                 if (sizeof(T) == 2) {
                     auto keep = [](uint32_t mw, uint32_t vw) {
                         const uint32_t lo = ((mw & 0x8000u) == 0 && (mw & 0x7fffu) != 0) ? 0x0000ffffu : 0u;

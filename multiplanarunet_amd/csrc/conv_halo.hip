@@ -306,8 +306,19 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
         float ssum[EPC], ssq[EPC];                                                // fused BN statistics (a.stats)
 #pragma unroll
         for (int e = 0; e < EPC; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+        // ReLU masks of the data-gradient launches: every pass's 16 bytes requested up front (a load inside the
+        // pass would be waited for on the spot, together with the previous pass's store: one round trip per pass).
+        // Launches without a mask request nothing (out-of-range marker).
+        constexpr int NIT = BM / RPI;
+        u32x4 mkv[NIT];
 #pragma unroll
-        for (int it = 0; it < BM / RPI; ++it) {
+        for (int it = 0; it < NIT; ++it) {
+            const int yy = it / XPI, xx = (it % XPI) * RPI;
+            const bool ok = a.mask && n_ok && (y0 + yy < H) && (x0 + xx + r0 < W);
+            mkv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsm, ok ? (unsigned)(obase + lane_off + (yy * W + xx) * pixB) : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
             const int yy = it / XPI, xx = (it % XPI) * RPI;                       // tile row / column offset of this pass
             const bool ok = n_ok && (y0 + yy < H) && (x0 + xx + r0 < W);
             u32x4 val = *(const u32x4*)(srow + it * RPI * OROW);
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
             // the out-of-range marker of masked lanes back into the buffer)
             const unsigned off = ok ? (unsigned)(obase + lane_off + (yy * W + xx) * pixB) : OOB;
             if (a.mask) {
-                const u32x4 mk = __builtin_amdgcn_raw_buffer_load_b128(rsm, off, 0, 0);
+                const u32x4 mk = mkv[it];
                 if (sizeof(T) == 2) {
                     auto keep = [](uint32_t mw, uint32_t vw) {
                         const uint32_t lo16 = ((mw & 0x8000u) == 0 && (mw & 0x7fffu) != 0) ? 0x0000ffffu : 0u;

@@ -234,6 +234,14 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
             float tsum[8], tsq[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { tsum[e] = 0.f; tsq[e] = 0.f; }
+            u32x4 mkv[Cfg::WPX / 16];                                // ReLU masks (data-gradient launches): all requested
+#pragma unroll                                                       // up front, not one round trip per pass
+            for (int it = 0; it < Cfg::WPX / 16; ++it) {
+                const int j = it >> 1;
+                const bool ok = a.mask && n_ok && ((it & 1) ? xok1 : xok0) && (y0 + wm * TM + j < H);
+                mkv[it] = __builtin_amdgcn_raw_buffer_load_b128(
+                    rsm, ok ? (unsigned)(obase + out_l + (j * W + (it & 1) * 16) * a.Cout * 2) : OOB, 0, 0);
+            }
 #pragma unroll
             for (int it = 0; it < Cfg::WPX / 16; ++it) {             // 4 lanes per pixel: 64 contiguous bytes
                 const int j = it >> 1;                               // pixel row of this wave, column (it&1)*16 + lane>>2
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
                 // (no scalar offset operand: it would be added after the range check and wrap the out-of-range marker)
                 const unsigned off = ok ? (unsigned)(obase + out_l + (j * W + (it & 1) * 16) * a.Cout * 2) : OOB;
                 if (a.mask) {
-                    const u32x4 mk = __builtin_amdgcn_raw_buffer_load_b128(rsm, off, 0, 0);
+                    const u32x4 mk = mkv[it];
                     auto keep = [](uint32_t mw, uint32_t vw) {
                         const uint32_t lo = ((mw & 0x8000u) == 0 && (mw & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
                         const uint32_t hi = ((mw & 0x80000000u) == 0 && (mw & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
