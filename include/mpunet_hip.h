@@ -306,6 +306,16 @@ int mpu_conv2d_wgrad(int32_t dtype, int32_t mode, const void* d_x0, int32_t C0, 
                      int32_t C1, const void* d_dz, int32_t Cout, int32_t B, int32_t Ho, int32_t Wo,
                      float* d_workspace, float* d_dW, void* stream);
 
+/* Weight and bias gradient of the FIRST layer (Conv2D(F, 3) on the n_channels-channel input image,
+ * mpunet/models/unet.py:120-123): d_x holds the image in 8-channel pixel records of which the first
+ * n_image_channels are real (the rest zero). d_dW is the fp32 kernel gradient [9][8][Cout] (zeros for the padding
+ * channels), d_db (optional) the bias gradient [Cout]. With 1-2 image channels in bf16 this is a dedicated HBM-bound
+ * kernel (wgrad_c8.hip); other shapes take the general path. Workspace: ..._workspace_floats(Cout, B*H*W) floats. */
+int64_t mpu_conv2d_wgrad_first_layer_workspace_floats(int32_t Cout, int64_t M);
+int mpu_conv2d_wgrad_first_layer(int32_t dtype, const void* d_x, int32_t n_image_channels, const void* d_dz,
+                                 int32_t Cout, int32_t B, int32_t H, int32_t W, float* d_workspace, float* d_dW,
+                                 float* d_db, void* stream);
+
 /* Measurement aid (bench.py roofline leg; no reference counterpart): when
  * enabled, every MFMA convolution launch is bracketed by HIP events recorded on
  * its own stream. mpu_profile_summary synchronises on them and returns the summed

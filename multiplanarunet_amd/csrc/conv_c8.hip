@@ -20,10 +20,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 namespace {
 
-constexpr int C8_ROWS = 16;                                     // output rows per workgroup (4 per wave, interleaved)
+constexpr int C8_ROWS_DEFAULT = 16;                             // output rows per workgroup (4 waves, interleaved rows)
 
 template <int NB>
-__global__ __launch_bounds__(256) void conv_c8_kernel(ConvArgs a, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) void conv_c8_kernel(ConvArgs a, int tiles_x, int tiles_y, int nseg) {
     constexpr int ROWB = NB * 64 + 16;                           // staging row of one pixel: NB*32 channels + pad
     constexpr int CPP = NB * 4;                                  // 16-byte chunks per staged pixel
     constexpr unsigned OOB = 0xfffffff0u;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void conv_c8_kernel(ConvArgs a, int tiles_x, i
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
-    const int x0 = tx * 32, y0 = ty * C8_ROWS;
+    const int x0 = tx * 32, y0 = ty * nseg * 4;                  // nseg row segments per wave
     const long npix = (long)a.B * H * W;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.in0, 0, (int)(npix * 16L), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)(a.w_elems * 2L), 0x00020000);
@@ -83,9 +83,9 @@ __global__ __launch_bounds__(256) void conv_c8_kernel(ConvArgs a, int tiles_x, i
     u32x4 cur[5], nxt[5];
     int y = y0 + wave;
     if (y < H) load_row(y, cur);
-    for (int s = 0; s < C8_ROWS / 4; ++s, y += 4) {
+    for (int s = 0; s < nseg; ++s, y += 4) {
         if (y >= H) break;                                       // wave-uniform
-        if (s + 1 < C8_ROWS / 4 && y + 4 < H) load_row(y + 4, nxt);      // next segment in flight during this one
+        if (s + 1 < nseg && y + 4 < H) load_row(y + 4, nxt);     // next segment in flight during this one
         f32x16 acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -137,11 +137,20 @@ int launch_c8(const ConvArgs& a_in, hipStream_t st) {
     const long M = (long)a.B * a.Ho * a.Wo;
     if (M * 16L >= (1L << 31) || M * a.Cout * 2L >= (1L << 31) || a.w_elems * 2L >= (1L << 31))
         return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
-    const int tx = cdiv(a.Wo, 32), ty = cdiv(a.Ho, C8_ROWS);
+    static int rows_env = -1;
+    if (rows_env < 0) {
+        const char* e = getenv("MPU_C8_ROWS");
+        rows_env = e ? atoi(e) : 0;
+        if (rows_env < 4 || rows_env % 4) rows_env = 0;
+    }
+    // measured (B=16 128x128 / B=138 256x256, 64 channels): 16 rows 12.7 / 357 us, 32 rows 15.0 / 342 us, 8 rows 13.4 / 377 us
+    int rows = rows_env ? rows_env : C8_ROWS_DEFAULT;
+    if (!rows_env && (long)a.B * cdiv(a.Wo, 32) * cdiv(a.Ho, C8_ROWS_DEFAULT) >= 4096) rows = 2 * C8_ROWS_DEFAULT;
+    const int tx = cdiv(a.Wo, 32), ty = cdiv(a.Ho, rows);
     const long tiles = (long)a.B * tx * ty;
     if (tiles >= (1L << 31)) return fail(MPU_EUNSUPPORTED, "%s", "conv: too many tiles");
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * 9 * a.C0, st);
-    conv_c8_kernel<NB><<<dim3((unsigned)tiles), dim3(256), 0, st>>>(a, tx, ty);
+    conv_c8_kernel<NB><<<dim3((unsigned)tiles), dim3(256), 0, st>>>(a, tx, ty, rows / 4);
     if (prof_on()) prof_end(st);
     return launch_ok();
 }

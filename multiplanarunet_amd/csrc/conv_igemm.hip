@@ -649,6 +649,10 @@ template <typename T, int MODE>
 static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
     const int Cin = a.C0 + a.C1;
     const int dt_ = sizeof(T) == 2 ? MPU_BF16 : MPU_F32;
+    if (conv_impl() == 1) {                      // first layer: 1-2 image channels in 8-channel records
+        const int c8 = try_wgrad_c8(dt_, MODE, a, dW, st);
+        if (c8 != 0) return c8 < 0 ? c8 : MPU_OK;
+    }
     TapsPlan taps; taps.use = 0;
     if (conv_impl() == 1) taps = wgrad_taps_plan(dt_, MODE, a.B, a.Ho, a.Wo, a.C0, a.C1, a.Cout);
     if (taps.use) a.ksplit = (taps.nstrips + 1) / 2;   // one partial copy per pair of pixel strips

@@ -34,6 +34,7 @@ struct WgradArgs {
     float* db;                   // bias gradient sum_m dz[m][co] (NULL = not wanted)
     float* colsum_scratch;       // [RED_MAX_BLOCKS][Cout] scratch for the unfused bias-gradient path
     int fuse_db;                 // set by the launcher: the wgrad kernel also produces the db partials
+    int c0_logical;              // image channels actually present in an 8-channel x0 (first layer); 0 = unknown
 };
 
 // ---- profile.hip: optional per-launch HIP-event timing of the MFMA kernels ----
@@ -56,6 +57,7 @@ constexpr int TAPS_MAX_WGS = 1024;             // strips * 64x64 tiles; bounds t
 TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout);
 int  launch_wgrad_taps(int mode, const WgradArgs& a, const TapsPlan& p, hipStream_t st);
 int  launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st);
+int  try_wgrad_c8(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st);   // first layer (wgrad_c8.hip)
 int  try_wgrad_glds(int dtype, int mode, const WgradArgs& a, hipStream_t st);   // 1 launched, 0 unsupported shape
 bool wgrad_glds_supported(int dtype, int mode, const WgradArgs& a);
 

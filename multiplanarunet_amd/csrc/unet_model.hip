@@ -230,6 +230,7 @@ int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* 
     const long M = (long)a.B * a.Ho * a.Wo;
     wgrad_partial_elems(c.mode, c.Cin, c.Cout, M, &a.ksplit, &a.mchunk);
     a.db = r.grads + c.b; a.db_partial = nullptr; a.colsum_scratch = (float*)r.at(r.P.partial2); a.fuse_db = 0;
+    a.c0_logical = (C1 == 0 && C0 == c.Cin) ? c.lCin : 0;
     if (!r.overlap) return launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st);
     // fork: the side stream waits until dz (and everything before it) is produced on the main stream
     MPU_CHECK_HIP(hipEventRecord(r.m->ev_ready, r.st));
@@ -662,8 +663,29 @@ int mpu_conv2d_wgrad(int32_t dtype, int32_t mode, const void* d_x0, int32_t C0, 
     WgradArgs a;
     a.x0 = d_x0; a.x1 = d_x1; a.C0 = C0; a.C1 = C1; a.dz = d_dz; a.Cout = Cout; a.partial = d_workspace;
     a.B = B; a.Ho = Ho; a.Wo = Wo; a.flops = 0; a.db = nullptr; a.db_partial = nullptr; a.colsum_scratch = nullptr; a.fuse_db = 0;
+    a.c0_logical = 0;
     wgrad_partial_elems(mode, C0 + C1, Cout, (long)B * Ho * Wo, &a.ksplit, &a.mchunk);
     return launch_wgrad(dtype, mode, a, d_dW, (hipStream_t)stream);
+}
+
+/* first layer: x0 holds n_image_channels (<= 8) real channels in 8-channel pixel records */
+int mpu_conv2d_wgrad_first_layer(int32_t dtype, const void* d_x, int32_t n_image_channels, const void* d_dz, int32_t Cout,
+                                 int32_t B, int32_t H, int32_t W, float* d_workspace, float* d_dW, float* d_db,
+                                 void* stream) {
+    MPU_REQUIRE(d_x && d_dz && d_workspace && d_dW, "mpu_conv2d_wgrad_first_layer: null argument");
+    MPU_REQUIRE(n_image_channels >= 1 && n_image_channels <= 8 && Cout >= 8 && Cout % 8 == 0 && B >= 1 && H >= 1 && W >= 1,
+                "mpu_conv2d_wgrad_first_layer: bad shape");
+    WgradArgs a;
+    a.x0 = d_x; a.x1 = nullptr; a.C0 = 8; a.C1 = 0; a.dz = d_dz; a.Cout = Cout; a.partial = d_workspace;
+    a.B = B; a.Ho = H; a.Wo = W; a.flops = 0; a.db = d_db; a.db_partial = nullptr; a.fuse_db = 0;
+    a.c0_logical = n_image_channels;
+    const long M = (long)B * H * W;
+    const long we = wgrad_partial_elems(CONV3, 8, Cout, M, &a.ksplit, &a.mchunk);
+    a.colsum_scratch = d_workspace + we;             // (the workspace query below includes this tail)
+    return launch_wgrad(dtype, CONV3, a, d_dW, (hipStream_t)stream);
+}
+int64_t mpu_conv2d_wgrad_first_layer_workspace_floats(int32_t Cout, int64_t M) {
+    return wgrad_partial_elems(CONV3, 8, Cout, M, nullptr, nullptr) + (int64_t)RED_MAX_BLOCKS * Cout;
 }
 
 }  // extern "C"

@@ -1,0 +1,160 @@
+// wgrad_c8_kernel: weight and bias gradient of the first U-Net layer (3x3 conv, CI = 1 or 2 image channels stored in
+// 8-channel pixel records, Cout <= 128):  dW[tap][ci][co] = sum_px x[px + tap][ci] * dz[px][co],  db[co] = sum_px dz.
+// The MFMA weight-gradient kernels treat the layer as a 64-input-channel one (63/64 of their work is zero padding);
+// here the arithmetic is 9 * CI * Cout FMAs per pixel on the vector ALU and the kernel is bound by streaming dz once
+// (algorithmic bytes: M * Cout * 2 for dz + M * 16 for x; HBM roofline).
+//   thread = (pixel lane, group of 8 output channels): one 16-byte dz load per pixel, nine 4-byte x loads (clamped
+//   addresses + select, so that all ten are in flight together), 72 * CI accumulators in registers;
+//   workgroup = a strip of image rows; wave butterfly over the pixel lanes, then the four waves through LDS in a
+//   fixed order -> one compact fp32 partial row [9][CI][Cout] (+ [Cout]) per workgroup;
+//   wgrad_c8_finalize_kernel sums the rows (double, fixed order), writes dW in the padded [9][8][Cout] master layout
+//   (zeros for the padding channels) and db.
+#include <stdlib.h>
+#include "kernels.h"
+#include "reduce.h"
+
+namespace mpu {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+namespace {
+
+template <int CI>
+__global__ __launch_bounds__(256) void wgrad_c8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dz, int H, int W,
+                                                       int Cout, int R, int strips, float* __restrict__ partial) {
+    constexpr int NA = 9 * CI * 8;                               // accumulators per thread
+    const int groups = Cout >> 3;                                // power of two <= 16 (host-checked)
+    const int tid = threadIdx.x;
+    const int g = tid & (groups - 1), pl = tid / groups, npl = 256 / groups;
+    const int b = blockIdx.x / strips, y0 = (blockIdx.x - b * strips) * R;
+    const int y1 = y0 + R < H ? y0 + R : H;
+    float acc[NA], db[8];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) db[k] = 0.f;
+    // buffer loads: out-of-image taps / lanes past the row end use the out-of-range marker and read 0 -- one
+    // unconditional instruction each (a select around a plain load becomes a branch that is waited for on the spot)
+    constexpr unsigned OOB = 0xfffffff0u;
+    const long npix = (long)(gridDim.x / strips) * H * W;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(npix * 16L), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, (int)(npix * Cout * 2L), 0x00020000);
+    for (int y = y0; y < y1; ++y) {
+        for (int xb = 0; xb < W; xb += npl) {
+            const int xx = xb + pl;
+            const bool live = xx < W;
+            const u32x4 zq = __builtin_amdgcn_raw_buffer_load_b128(
+                rsz, live ? (unsigned)(((((long)b * H + y) * W + xx) * Cout + g * 8) * 2) : OOB, 0, 0);
+            uint32_t xr[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xq = xx + t % 3 - 1;
+                const bool ok = live && (unsigned)yy < (unsigned)H && (unsigned)xq < (unsigned)W;
+                xr[t] = __builtin_amdgcn_raw_buffer_load_b32(rsx, ok ? (unsigned)((((long)b * H + yy) * W + xq) * 16) : OOB, 0, 0);
+            }
+            const uint32_t zw[4] = {zq.x, zq.y, zq.z, zq.w};
+            float zf[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                zf[2 * q] = __uint_as_float(zw[q] << 16);
+                zf[2 * q + 1] = __uint_as_float(zw[q] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) db[k] += zf[k];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float x0f = __uint_as_float(xr[t] << 16), x1f = __uint_as_float(xr[t] & 0xffff0000u);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    acc[(t * CI) * 8 + k] += x0f * zf[k];
+                    if (CI > 1) acc[(t * CI + 1) * 8 + k] += x1f * zf[k];
+                }
+            }
+        }
+    }
+    // wave butterfly over the pixel lanes (lanes that share g are `groups` apart), fixed order
+    for (int o = groups; o < 64; o <<= 1) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) db[k] += __shfl_xor(db[k], o, 64);
+    }
+    __shared__ float red[4][16 * (NA + 8)];
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane < groups) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) red[wave][lane * (NA + 8) + i] = acc[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[wave][lane * (NA + 8) + NA + k] = db[k];
+    }
+    __syncthreads();
+    // compact partial row: [9 * CI][Cout] then [Cout]
+    const int ncol = 9 * CI * Cout + Cout;
+    float* prow = partial + (long)blockIdx.x * ncol;
+    for (int c = tid; c < ncol; c += 256) {
+        int gi, idx;
+        if (c < 9 * CI * Cout) { const int r = c / Cout, co = c - r * Cout; gi = co >> 3; idx = r * 8 + (co & 7); }
+        else { const int co = c - 9 * CI * Cout; gi = co >> 3; idx = NA + (co & 7); }
+        const int o = gi * (NA + 8) + idx;
+        prow[c] = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+    }
+}
+
+// dW[(tap * 8 + ci) * Cout + co] = sum_rows partial[row][(tap * CI + ci) * Cout + co] (0 for ci >= CI); db likewise
+__global__ __launch_bounds__(256) void wgrad_c8_finalize_kernel(const float* __restrict__ partial, int rows, int CI, int Cout,
+                                                                int sum_blocks, float* __restrict__ dW, float* __restrict__ db) {
+    if ((int)blockIdx.x >= sum_blocks) {                         // tail blocks: zeros for the padding channels [9][8 - CI][Cout]
+        const int e = ((int)blockIdx.x - sum_blocks) * 256 + threadIdx.x, per = (8 - CI) * Cout;
+        if (e < 9 * per) { const int tap = e / per; dW[((long)tap * 8 + CI) * Cout + (e - tap * per)] = 0.f; }
+        return;
+    }
+    __shared__ double red[256];
+    const int ncol = 9 * CI * Cout + Cout;
+    const int c = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
+    double s;
+    partial_sums<1>(partial, rows, ncol, 0, c, c < ncol, red, &s);
+    if (c >= ncol || threadIdx.x >= FIN_COLS) return;
+    if (c < 9 * CI * Cout) {
+        const int r = c / Cout, co = c - r * Cout, tap = r / CI, ci = r - tap * CI;
+        dW[((long)tap * 8 + ci) * Cout + co] = (float)s;
+    } else if (db) {
+        db[c - 9 * CI * Cout] = (float)s;
+    }
+}
+
+}  // namespace
+
+// 1 = handled (dW and, if wanted, db written), 0 = shape not suited, < 0 = error
+int try_wgrad_c8(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MPU_WGRAD_C8"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (!on || dtype != MPU_BF16 || mode != CONV3 || a.C1 != 0 || a.x1 || a.C0 != 8) return 0;
+    if (a.c0_logical < 1 || a.c0_logical > 2) return 0;
+    const int groups = a.Cout / 8;
+    if (a.Cout % 8 || groups < 1 || groups > 16 || (groups & (groups - 1))) return 0;
+    const long rows_all = (long)a.B * a.Ho;
+    const int R = (int)((rows_all + 1023) / 1024);
+    const int strips = cdiv(a.Ho, R);
+    const long wgs = (long)a.B * strips;
+    if (wgs > 2048 || a.Wo < 1) return 0;                        // partial rows bounded by the all-taps workspace plan
+    const long M = (long)a.B * a.Ho * a.Wo;
+    if (M * 16L >= (1L << 31) || M * a.Cout * 2L >= (1L << 31)) return 0;   // 32-bit buffer offsets
+    if (prof_on()) prof_begin(PROF_WGRAD, a.flops > 0 ? a.flops : 2.0 * M * 9 * a.C0 * a.Cout, st);
+    if (a.c0_logical == 1)
+        wgrad_c8_kernel<1><<<dim3((unsigned)wgs), dim3(256), 0, st>>>((const bf16_t*)a.x0, (const bf16_t*)a.dz, a.Ho, a.Wo,
+                                                                      a.Cout, R, strips, a.partial);
+    else
+        wgrad_c8_kernel<2><<<dim3((unsigned)wgs), dim3(256), 0, st>>>((const bf16_t*)a.x0, (const bf16_t*)a.dz, a.Ho, a.Wo,
+                                                                      a.Cout, R, strips, a.partial);
+    if (prof_on()) prof_end(st);
+    int rc = launch_ok();
+    if (rc) return rc;
+    const int ncol = 9 * a.c0_logical * a.Cout + a.Cout;
+    const int sum_blocks = cdiv(ncol, FIN_COLS), npad = 9 * (8 - a.c0_logical) * a.Cout;
+    wgrad_c8_finalize_kernel<<<sum_blocks + cdiv(npad, 256), 256, 0, st>>>(a.partial, (int)wgs, a.c0_logical, a.Cout,
+                                                                          sum_blocks, dW, a.db);
+    rc = launch_ok();
+    return rc ? rc : 1;
+}
+
+}  // namespace mpu

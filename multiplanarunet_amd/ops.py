@@ -43,6 +43,19 @@ def conv2d(mode, x0, w_packed, cout, out_hw, bias=None, x1=None, mask=None, relu
     return out
 
 
+def conv2d_wgrad_first_layer(x, n_image_channels, dz):
+    """(dW [9, 8, Cout], db [Cout]) f32 of the first 3x3 conv: x [B,H,W,8] holds n_image_channels real channels."""
+    B, H, W, cout = dz.shape
+    assert x.shape[-1] == 8
+    n = _lib.load().mpu_conv2d_wgrad_first_layer_workspace_floats(cout, B * H * W)
+    ws = torch.empty(n, dtype=torch.float32, device=dz.device)
+    dW = torch.empty((9, 8, cout), dtype=torch.float32, device=dz.device)
+    db = torch.empty(cout, dtype=torch.float32, device=dz.device)
+    _lib.call("mpu_conv2d_wgrad_first_layer", _dt(dz.dtype), _lib.ptr(x), n_image_channels, _lib.ptr(dz), cout,
+              B, H, W, _lib.ptr(ws), _lib.ptr(dW), _lib.ptr(db), _lib.stream_ptr())
+    return dW, db
+
+
 def conv2d_wgrad(mode, x0, dz, x1=None):
     """dW [taps, Cin, Cout] f32 of the conv whose input was concat(x0,x1) and output gradient dz."""
     B, Ho, Wo, cout = dz.shape

@@ -163,3 +163,38 @@ def test_bf16_kernels_agree_with_exact_f32_kernels_on_random_shapes(case):
         s = float(r.abs().max()) + 1e-30
         err = float((a - r).abs().max()) / s
         assert err <= tol, (name, case, err)
+
+
+@pytest.mark.parametrize("case", [
+    # B, H,   W,   Cout, image channels
+    (16, 128, 128, 64, 1),        # BASELINE configs[1] first layer: dedicated HBM-bound kernel, 1024 strips
+    (3, 20, 50, 64, 2),           # two image channels, ragged row passes (50 = 32 + 18)
+    (2, 16, 24, 128, 1),          # 16 channel groups: 16 pixel lanes per pass
+    (5, 9, 7, 8, 2),              # one channel group: 256 pixel lanes, rows shorter than a pass
+    (2, 12, 40, 24, 1),           # 3 channel groups (not a power of two): general path, same entry point
+    (2, 16, 16, 64, 3),           # three image channels: general path
+])
+def test_first_layer_weight_gradient(case):
+    """mpu_conv2d_wgrad_first_layer (wgrad_c8.hip) vs an f64 evaluation of dW[t][ci][co] = sum x[px+t][ci] dz[px][co]
+    and db = sum dz on the same bf16-rounded operands; padding channels of dW must be exactly zero."""
+    from multiplanarunet_amd import ops
+    B, H, W, Cout, CI = case
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + CI)
+    x = torch.zeros(B, H, W, 8)
+    x[..., :CI] = torch.randn(B, H, W, CI, generator=g)
+    x = x.bfloat16()
+    dz = torch.randn(B, H, W, Cout, generator=g).bfloat16()
+    dW, db = ops.conv2d_wgrad_first_layer(x.cuda(), CI, dz.cuda())
+    xd, zd = x.double(), dz.double()
+    xp = F.pad(xd.permute(0, 3, 1, 2), (1, 1, 1, 1)).permute(0, 2, 3, 1)        # [B, H+2, W+2, 8]
+    ref = torch.stack([torch.einsum("bhwi,bhwo->io", xp[:, ky:ky + H, kx:kx + W], zd)
+                       for ky in range(3) for kx in range(3)])                   # [9, 8, Cout]
+    dWc = dW.cpu().double()
+    assert torch.count_nonzero(dWc[:, CI:]) == 0
+    s = float(ref.abs().max())
+    assert float((dWc - ref).abs().max()) <= 2e-3 * s
+    rb = zd.sum((0, 1, 2))
+    assert float((db.cpu().double() - rb).abs().max()) <= 2e-3 * float(rb.abs().max()) + 1e-3
+    # the general-purpose entry point agrees (it has no channel-count hint and runs the MFMA kernels)
+    dWg = ops.conv2d_wgrad(CONV3, x.cuda(), dz.cuda()).cpu().double()
+    assert float((dWg - ref).abs().max()) <= 2e-3 * s

@@ -1,10 +1,12 @@
 """Micro-benchmark of the conv kernels on the cfg2 layer shapes (dev tool). usage: bench_conv.py [fwd|wgrad] [reps]"""
-import sys, time
+import sys, time, os
 import numpy as np, torch
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multiplanarunet_amd import ops
 CONV3, UPCONV2, CONV3S2, CONV1 = 0, 1, 2, 3
-B = 16
+B = int(os.environ.get("BENCH_B", "16"))
+SCALE = int(os.environ.get("BENCH_SCALE", "1"))          # multiplies every layer's H (cfg4 / predict shapes)
+ONLY = os.environ.get("BENCH_ONLY")                      # comma-separated layer names
 # name, mode, H(out), C0, C1, Cout
 LAYERS = [("enc0c1", 0, 128, 8, 0, 64), ("enc0c2", 0, 128, 64, 0, 64), ("enc1c1", 0, 64, 64, 0, 128), ("enc1c2", 0, 64, 128, 0, 128),
           ("enc2c1", 0, 32, 128, 0, 256), ("enc2c2", 0, 32, 256, 0, 256), ("enc3c1", 0, 16, 256, 0, 512), ("enc3c2", 0, 16, 512, 0, 512),
@@ -19,6 +21,9 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dt = torch.bfloat16
 tot_t = tot_f = 0
 for name, mode, H, C0, C1, Cout in LAYERS:
+    if ONLY and name not in ONLY.split(","):
+        continue
+    H *= SCALE
     k = {0: 3, 1: 2, 2: 3, 3: 1}[mode]
     Hi = H // 2 if mode == 1 else (2 * H if mode == 2 else H)
     Cin = C0 + C1
