@@ -251,9 +251,9 @@ __global__ __launch_bounds__(256) void map_fuse_kernel(FuseArgs a) {
         for (int k = 0; k < K; ++k) w[k] = a.sum_fusion ? 1.f : a.W[v * K + k];
 #pragma unroll
         for (int u = 0; u < FZ; ++u) {
-            float x[K];                                   // one K-wide gather per voxel and view
-            if (off[u] >= 0) __builtin_memcpy(x, vw.pred + off[u], K * sizeof(float));
-            else {
+            float x[K];                                   // one K-wide gather per voxel and view: unconditional (clamped
+            __builtin_memcpy(x, vw.pred + (off[u] >= 0 ? off[u] : 0), K * sizeof(float));   // offset), the four of a view in
+            if (off[u] < 0) {                                                              // flight together
 #pragma unroll
                 for (int k = 0; k < K; ++k) x[k] = k == 0 ? 1.f : 0.f;
             }

@@ -247,17 +247,35 @@ int launch_pack_weights(int dtype, int mode, const float* W, int Cin, int Cout, 
     return launch_ok();
 }
 
+// one thread = one group of 8 output channels of one pixel (Cpad % 8 == 0): clamped unconditional loads (a predicated
+// scalar load per element is waited for on the spot), 16-byte stores
 template <typename T>
 __global__ void cast_pad_kernel(const float* __restrict__ x, long M, int Cin, int Cpad, T* __restrict__ out) {
-    const long n = M * Cpad;
+    const int gpp = Cpad >> 3;
+    const long n = M * gpp;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const long m = e / Cpad; const int c = (int)(e % Cpad);
-        out[e] = from_f32<T>(c < Cin ? x[m * Cin + c] : 0.f);
+        const long m = e / gpp; const int c0 = (int)(e - m * gpp) * 8;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = c0 + i;
+            const float t = x[m * Cin + (c < Cin ? c : Cin - 1)];
+            v[i] = c < Cin ? t : 0.f;
+        }
+        constexpr int N = Vec<T>::N;
+#pragma unroll
+        for (int h = 0; h < 8 / N; ++h) {
+            float w[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) w[i] = v[h * N + i];
+            Vec<T>::store(out + e * 8 + h * N, w);
+        }
     }
 }
 int launch_cast_pad(int dtype, const float* x, long M, int Cin, int Cpad, void* out, hipStream_t st) {
-    if (dtype == MPU_BF16) cast_pad_kernel<bf16_t><<<ew_grid(M * Cpad), 256, 0, st>>>(x, M, Cin, Cpad, (bf16_t*)out);
-    else cast_pad_kernel<float><<<ew_grid(M * Cpad), 256, 0, st>>>(x, M, Cin, Cpad, (float*)out);
+    if (Cpad % 8 || Cin < 1 || Cin > Cpad) return fail(MPU_EINVAL, "%s", "cast_pad: padded channel count must be a multiple of 8");
+    if (dtype == MPU_BF16) cast_pad_kernel<bf16_t><<<ew_grid(M * Cpad / 8), 256, 0, st>>>(x, M, Cin, Cpad, (bf16_t*)out);
+    else cast_pad_kernel<float><<<ew_grid(M * Cpad / 8), 256, 0, st>>>(x, M, Cin, Cpad, (float*)out);
     return launch_ok();
 }
 
@@ -690,19 +708,15 @@ __global__ __launch_bounds__(256) void head_forward_kernel(const T* __restrict__
     int G = 1; while (G < cpr && G < 64) G <<= 1;        // lanes per pixel (power of two)
     const int sub = threadIdx.x % G;
     const long ppb = 256 / G;
-    for (long m = (long)blockIdx.x * ppb + threadIdx.x / G; m < M; m += (long)gridDim.x * ppb) {
-        // the G lanes of a group share m, so a group is active or idle as a whole
-        float z[K];
+    const bool single = cpr <= G;                        // one 16-byte chunk per lane: its weights live in registers
+    float wr[N][K];
+    if (single && sub < cpr) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) z[k] = 0.f;
-        for (int c = sub; c < cpr; c += G) {
-            float v[N];
-            Vec<T>::load(n + m * C + (long)c * N, v);
+        for (int i = 0; i < N; ++i)
 #pragma unroll
-            for (int i = 0; i < N; ++i)
-#pragma unroll
-                for (int k = 0; k < K; ++k) z[k] += v[i] * w[(c * N + i) * K + k];
-        }
+            for (int k = 0; k < K; ++k) wr[i][k] = w[(sub * N + i) * K + k];
+    }
+    auto finish = [&](long m, float (&z)[K]) {           // the G lanes of a group share m: reduce, bias, softmax, store
         for (int off = G >> 1; off > 0; off >>= 1)
 #pragma unroll
             for (int k = 0; k < K; ++k) z[k] += __shfl_xor(z[k], off, 64);
@@ -722,6 +736,48 @@ __global__ __launch_bounds__(256) void head_forward_kernel(const T* __restrict__
 #pragma unroll
             for (int k = 0; k < K; ++k) out[m * K + k] = z[k];
         }
+    };
+    const long stride = (long)gridDim.x * ppb;
+    long m = (long)blockIdx.x * ppb + threadIdx.x / G;
+    if (single) {
+        const bool lane_on = sub < cpr;
+        for (; m < M; m += 2 * stride) {                 // two pixels per pass: both loads in flight together
+            const long m2 = m + stride;
+            const bool on2 = m2 < M;                     // (uniform over the G lanes of a group)
+            float va[N], vb[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) { va[i] = 0.f; vb[i] = 0.f; }
+            if (lane_on) {
+                Vec<T>::load(n + m * C + (long)sub * N, va);
+                Vec<T>::load(n + (on2 ? m2 : m) * C + (long)sub * N, vb);
+            }
+            float za[K], zb[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) { za[k] = 0.f; zb[k] = 0.f; }
+            if (lane_on) {
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { za[k] += va[i] * wr[i][k]; zb[k] += vb[i] * wr[i][k]; }
+            }
+            finish(m, za);
+            if (on2) finish(m2, zb);
+        }
+        return;
+    }
+    for (; m < M; m += stride) {
+        float z[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) z[k] = 0.f;
+        for (int c = sub; c < cpr; c += G) {
+            float v[N];
+            Vec<T>::load(n + m * C + (long)c * N, v);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int k = 0; k < K; ++k) z[k] += v[i] * w[(c * N + i) * K + k];
+        }
+        finish(m, z);
     }
 }
 
