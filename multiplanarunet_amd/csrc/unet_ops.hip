@@ -145,8 +145,10 @@ __device__ __forceinline__ void pack_fwd_tile(const PackJob& j, int t, const flo
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int cil = ty + 16 * k, ci = ci0 + cil, co = co0 + tx4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci < Cin && co < Cout) v = *reinterpret_cast<const float4*>(src + (long)ci * Cout + co);   // Cout % 8 == 0
+            // clamped, unconditional load + select (Cout % 8 == 0): the four loads of a thread are in flight together
+            const bool in = ci < Cin && co < Cout;
+            float4 v = *reinterpret_cast<const float4*>(src + (long)(ci < Cin ? ci : Cin - 1) * Cout + (co < Cout ? co : Cout - 4));
+            if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
             tile[cil][tx4] = v.x; tile[cil][tx4 + 1] = v.y; tile[cil][tx4 + 2] = v.z; tile[cil][tx4 + 3] = v.w;
         }
     }
