@@ -20,8 +20,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 namespace {
 
 template <int CI>
-__global__ __launch_bounds__(256) void wgrad_c8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dz, int H, int W,
-                                                       int Cout, int R, int strips, float* __restrict__ partial) {
+__device__ __forceinline__ void wgrad_c8_body(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dz, int H, int W,
+                                              int Cout, int R, int strips, float* __restrict__ partial) {
     constexpr int NA = 9 * CI * 8;                               // accumulators per thread
     const int groups = Cout >> 3;                                // power of two <= 16 (host-checked)
     const int tid = threadIdx.x;
@@ -39,37 +39,57 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const bf16_t* __restrict_
     const long npix = (long)(gridDim.x / strips) * H * W;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(npix * 16L), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, (int)(npix * Cout * 2L), 0x00020000);
+    // two pixels per pass: their 2 x (one 16-byte dz load + nine 4-byte x loads) are requested before the first FMA
+    // (one pixel per pass left each wave with a single exposed round trip per pixel: 21 us for 33 MB)
+    // 32-bit offsets (host-checked ranges): pixel base once, per-tap deltas are scalars, validity = an OR-mask that
+    // turns the offset into the out-of-range marker: column masks per lane (3 per pixel), row masks per wave (uniform).
+    // The masks go through an empty asm so that the compiler cannot turn them back into branches around the loads
+    // (it duplicates the load on both sides and waits in between). The address arithmetic of the first version
+    // (64-bit products per tap) cost more vector instructions than the FMAs.
+    auto vmask = [](bool ok) { int m = ok ? 0 : (int)OOB; asm volatile("" : "+v"(m)); return (unsigned)m; };
+    auto smask = [](bool ok) { int m = ok ? 0 : (int)OOB; asm volatile("" : "+s"(m)); return (unsigned)m; };
+    const unsigned zpix = (unsigned)Cout * 2u;
+    auto issue = [&](int y, int xx, u32x4& zq, uint32_t (&xr)[9]) {
+        const unsigned pix = (unsigned)((b * H + y) * W + xx);
+        const bool live = xx < W;
+        const unsigned cm[3] = {vmask(live && xx >= 1), vmask(live), vmask(live && xx + 1 < W)};
+        const unsigned rm[3] = {smask(y >= 1), 0u, smask(y + 1 < H)};
+        zq = __builtin_amdgcn_raw_buffer_load_b128(rsz, (pix * zpix + (unsigned)g * 16u) | cm[1], 0, 0);
+        const unsigned pbase = pix * 16u;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3, dx = t % 3;
+            const unsigned delta = (unsigned)(((dy - 1) * W + (dx - 1)) * 16);          // uniform
+            xr[t] = __builtin_amdgcn_raw_buffer_load_b32(rsx, (pbase + delta) | cm[dx] | rm[dy], 0, 0);
+        }
+    };
+    auto consume = [&](const u32x4& zq, const uint32_t (&xr)[9]) {       // a dead lane read zeros everywhere
+        const uint32_t zw[4] = {zq.x, zq.y, zq.z, zq.w};
+        float zf[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            zf[2 * q] = __uint_as_float(zw[q] << 16);
+            zf[2 * q + 1] = __uint_as_float(zw[q] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) db[k] += zf[k];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float x0f = __uint_as_float(xr[t] << 16), x1f = __uint_as_float(xr[t] & 0xffff0000u);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                acc[(t * CI) * 8 + k] += x0f * zf[k];
+                if (CI > 1) acc[(t * CI + 1) * 8 + k] += x1f * zf[k];
+            }
+        }
+    };
     for (int y = y0; y < y1; ++y) {
-        for (int xb = 0; xb < W; xb += npl) {
-            const int xx = xb + pl;
-            const bool live = xx < W;
-            const u32x4 zq = __builtin_amdgcn_raw_buffer_load_b128(
-                rsz, live ? (unsigned)(((((long)b * H + y) * W + xx) * Cout + g * 8) * 2) : OOB, 0, 0);
-            uint32_t xr[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int yy = y + t / 3 - 1, xq = xx + t % 3 - 1;
-                const bool ok = live && (unsigned)yy < (unsigned)H && (unsigned)xq < (unsigned)W;
-                xr[t] = __builtin_amdgcn_raw_buffer_load_b32(rsx, ok ? (unsigned)((((long)b * H + yy) * W + xq) * 16) : OOB, 0, 0);
-            }
-            const uint32_t zw[4] = {zq.x, zq.y, zq.z, zq.w};
-            float zf[8];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                zf[2 * q] = __uint_as_float(zw[q] << 16);
-                zf[2 * q + 1] = __uint_as_float(zw[q] & 0xffff0000u);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) db[k] += zf[k];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float x0f = __uint_as_float(xr[t] << 16), x1f = __uint_as_float(xr[t] & 0xffff0000u);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    acc[(t * CI) * 8 + k] += x0f * zf[k];
-                    if (CI > 1) acc[(t * CI + 1) * 8 + k] += x1f * zf[k];
-                }
-            }
+        for (int xb = 0; xb < W; xb += 2 * npl) {
+            u32x4 za, zb; uint32_t xa[9], xb9[9];
+            issue(y, xb + pl, za, xa);
+            issue(y, xb + npl + pl, zb, xb9);
+            consume(za, xa);
+            consume(zb, xb9);
         }
     }
     // wave butterfly over the pixel lanes (lanes that share g are `groups` apart), fixed order
@@ -98,6 +118,18 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const bf16_t* __restrict_
         const int o = gi * (NA + 8) + idx;
         prow[c] = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
     }
+}
+
+// one image channel: 4 waves per SIMD (<= 128 registers) so that the 1024 strips of configs[1] are resident at once
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void wgrad_c8_kernel_1(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dz, int H, int W, int Cout, int R, int strips,
+                       float* __restrict__ partial) {
+    wgrad_c8_body<1>(x, dz, H, W, Cout, R, strips, partial);
+}
+__global__ __launch_bounds__(256)
+void wgrad_c8_kernel_2(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dz, int H, int W, int Cout, int R, int strips,
+                       float* __restrict__ partial) {
+    wgrad_c8_body<2>(x, dz, H, W, Cout, R, strips, partial);
 }
 
 // dW[(tap * 8 + ci) * Cout + co] = sum_rows partial[row][(tap * CI + ci) * Cout + co] (0 for ci >= CI); db likewise
@@ -141,10 +173,10 @@ int try_wgrad_c8(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t
     if (M * 16L >= (1L << 31) || M * a.Cout * 2L >= (1L << 31)) return 0;   // 32-bit buffer offsets
     if (prof_on()) prof_begin(PROF_WGRAD, a.flops > 0 ? a.flops : 2.0 * M * 9 * a.C0 * a.Cout, st);
     if (a.c0_logical == 1)
-        wgrad_c8_kernel<1><<<dim3((unsigned)wgs), dim3(256), 0, st>>>((const bf16_t*)a.x0, (const bf16_t*)a.dz, a.Ho, a.Wo,
+        wgrad_c8_kernel_1<<<dim3((unsigned)wgs), dim3(256), 0, st>>>((const bf16_t*)a.x0, (const bf16_t*)a.dz, a.Ho, a.Wo,
                                                                       a.Cout, R, strips, a.partial);
     else
-        wgrad_c8_kernel<2><<<dim3((unsigned)wgs), dim3(256), 0, st>>>((const bf16_t*)a.x0, (const bf16_t*)a.dz, a.Ho, a.Wo,
+        wgrad_c8_kernel_2<<<dim3((unsigned)wgs), dim3(256), 0, st>>>((const bf16_t*)a.x0, (const bf16_t*)a.dz, a.Ho, a.Wo,
                                                                       a.Cout, R, strips, a.partial);
     if (prof_on()) prof_end(st);
     int rc = launch_ok();
