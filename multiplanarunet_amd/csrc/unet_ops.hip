@@ -655,12 +655,21 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const T* __restric
             for (int d = 1; d < 4; ++d) if (v[d][i] > m) { m = v[d][i]; a = d; }
             arg[i] = a;
         }
+        float sk[4][N];                                          // the four skip-gradient pieces: one round trip, not one
+        if (dskip) {                                             // per window position (a load inside the loop below is
+#pragma unroll                                                   // waited for together with the previous store)
+            for (int d = 0; d < 4; ++d) Vec<T>::load(dskip + o[d], sk[d]);
+        } else {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int i = 0; i < N; ++i) sk[d][i] = 0.f;
+        }
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             float s[N];
-            if (dskip) Vec<T>::load(dskip + o[d], s);
 #pragma unroll
-            for (int i = 0; i < N; ++i) s[i] = (dskip ? s[i] : 0.f) + (arg[i] == d ? g[i] : 0.f);
+            for (int i = 0; i < N; ++i) s[i] = sk[d][i] + (arg[i] == d ? g[i] : 0.f);
             Vec<T>::store(dn + o[d], s);
         }
     }
