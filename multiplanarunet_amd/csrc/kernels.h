@@ -95,10 +95,15 @@ int launch_bn_apply(int dtype, const void* x, int B, int H, int W, int C, const 
 // BN backward: dgamma, dbeta and dz = (x>0) * d(x) where x is the post-ReLU BN input
 int launch_bn_backward(int dtype, const void* dn, const void* x, long M, int C, float* partial,
                        const float* gamma, const float* mean, const float* invstd,
-                       float* dgamma, float* dbeta, float* coeffs /*[3][C]*/, void* dz, hipStream_t st);
+                       float* dgamma, float* dbeta, float* coeffs /*[3][C]*/, void* dz,
+                       int ready_rows /* > 0: partial already holds that many [2][C] rows */, hipStream_t st);
 // dn = dskip + unpool(dp) (gradient of MaxPooling2D routed to the first max of each window)
 int launch_maxpool_bwd_add(int dtype, const void* n, const void* dskip, const void* dp,
                            int B, int H, int W, int C, void* dn, hipStream_t st);
+// ... and the BN-backward partial sums (sum dn, sum dn * xhat) of the level's BatchNorm in the same pass
+int launch_maxpool_bwd_add_stats(int dtype, const void* n, const void* dskip, const void* dp, int B, int H, int W, int C,
+                                 void* dn, const void* x, const float* mean, const float* invstd, float* partial,
+                                 long partial_cap, int* rows, hipStream_t st);
 // db[c] = sum_m dz[m][c]
 int launch_colsum(int dtype, const void* dz, long M, int C, float* partial, float* out, hipStream_t st);
 // out[c] = sum_k partial[k*C + c], k < nblk (second stage only)

@@ -272,10 +272,10 @@ int bn_fwd(const Run& r, const BN& b, const void* x, int lvl, int training, void
     return launch_bn_apply(r.m->cfg.dtype, x, r.B, H, W, b.C, r.stat(b, 2), r.stat(b, 3), y, pooled, r.st);
 }
 
-int bn_bwd(const Run& r, const BN& b, const void* dn, const void* x, int lvl, void* dz) {
+int bn_bwd(const Run& r, const BN& b, const void* dn, const void* x, int lvl, void* dz, int ready_rows = 0) {
     const long M = (long)r.B * (r.m->cfg.H >> lvl) * (r.m->cfg.W >> lvl);
     return launch_bn_backward(r.m->cfg.dtype, dn, x, M, b.C, (float*)r.at(r.P.partial), r.params + b.g, r.stat(b, 0),
-                              r.stat(b, 1), r.grads + b.g, r.grads + b.b, (float*)r.at(r.P.coeffs), dz, r.st);
+                              r.stat(b, 1), r.grads + b.g, r.grads + b.b, (float*)r.at(r.P.coeffs), dz, ready_rows, r.st);
 }
 
 #define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
@@ -416,8 +416,13 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
         const Conv& c1 = m->conv[m->enc_c1(i)]; const Conv& c2 = m->conv[m->enc_c2(i)];
         const int H = m->cfg.H >> i, W = m->cfg.W >> i;
         RC(wgrad_join(r));                                                                 // gA is about to be written
-        RC(launch_maxpool_bwd_add(dt, r.at(P.n[i]), r.at(P.dskip[i]), gB, r.B, H, W, m->F[i], gA, r.st));
-        RC(bn_bwd(r, m->bn[m->enc_bn(i)], gA, r.at(P.c2[i]), i, gB));
+        // skip gradient + un-pooled gradient, and in the same pass the BN-backward sums of the result
+        const BN& eb = m->bn[m->enc_bn(i)];
+        int bwd_rows = 0;
+        RC(launch_maxpool_bwd_add_stats(dt, r.at(P.n[i]), r.at(P.dskip[i]), gB, r.B, H, W, m->F[i], gA, r.at(P.c2[i]),
+                                        r.stat(eb, 0), r.stat(eb, 1), (float*)r.at(P.partial), P.partial_floats, &bwd_rows,
+                                        r.st));
+        RC(bn_bwd(r, eb, gA, r.at(P.c2[i]), i, gB, bwd_rows));
         RC(conv_wgrad(r, c2, r.at(P.c1[i]), m->F[i], nullptr, 0, gB, i));
         RC(conv_dgrad(r, c2, gB, r.at(P.c1[i]), gA, i, 0, m->F[i]));
         const void* xin = i > 0 ? r.at(P.p[i - 1]) : r.at(P.xin);

@@ -612,9 +612,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 int launch_bn_backward(int dtype, const void* dn, const void* x, long M, int C, float* partial, const float* gamma,
                        const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coeffs, void* dz,
-                       hipStream_t st) {
-    int nblk;
-    int rc = launch_colreduce<1>(dtype, dn, x, M, C, mean, invstd, partial, &nblk, st);
+                       int ready_rows, hipStream_t st) {
+    int nblk = ready_rows;                       // > 0: the producer of dn already wrote that many [2][C] partial rows
+    int rc = 0;
+    if (nblk <= 0) rc = launch_colreduce<1>(dtype, dn, x, M, C, mean, invstd, partial, &nblk, st);
     if (rc) return rc;
     bn_bwd_finalize_kernel<<<cdiv(C, FIN_COLS), 256, 0, st>>>(partial, nblk, C, M, gamma, mean, invstd, dgamma, dbeta, coeffs);
     rc = launch_ok();
@@ -627,13 +628,24 @@ int launch_bn_backward(int dtype, const void* dn, const void* x, long M, int C, 
     return launch_ok();
 }
 
-template <typename T>
+// STATS: also the BatchNorm-backward sums of the level's BN over the STORED dn (sum dn, sum dn * xhat, xhat from the BN
+// input x): the grid is sized so that a thread keeps its channel chunk over all its elements ((gridDim.x * 256) % cpr
+// == 0); per-block partial row [2][C] in the layout of colreduce<1>, which this replaces for the encoder levels.
+template <typename T, bool STATS>
 __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const T* __restrict__ n, const T* __restrict__ dskip,
                                                               const T* __restrict__ dp, int B, int H, int W, int C,
-                                                              T* __restrict__ dn) {
+                                                              T* __restrict__ dn, const T* __restrict__ x,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              float* __restrict__ partial) {
     constexpr int N = Vec<T>::N;
     const int cpr = C / N, Hp = H / 2, Wp = W / 2;
     const long total = (long)B * Hp * Wp * cpr;
+    float s0[N], s1[N], mu[N], is[N];
+    if (STATS) {
+        const int c = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpr);
+#pragma unroll
+        for (int i = 0; i < N; ++i) { s0[i] = 0.f; s1[i] = 0.f; mu[i] = mean[c * N + i]; is[i] = invstd[c * N + i]; }
+    }
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int c = (int)(e % cpr); long t = e / cpr;
         const int px = (int)(t % Wp); t /= Wp;
@@ -665,12 +677,37 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const T* __restric
 #pragma unroll
                 for (int i = 0; i < N; ++i) sk[d][i] = 0.f;
         }
+        float xv[4][N];
+        if (STATS) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) Vec<T>::load(x + o[d], xv[d]);
+        }
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             float s[N];
 #pragma unroll
             for (int i = 0; i < N; ++i) s[i] = sk[d][i] + (arg[i] == d ? g[i] : 0.f);
             Vec<T>::store(dn + o[d], s);
+            if (STATS) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const float r = to_f32<T>(from_f32<T>(s[i]));        // the value colreduce would read back
+                    s0[i] += r; s1[i] += r * ((xv[d][i] - mu[i]) * is[i]);
+                }
+            }
+        }
+    }
+    if (STATS) {      // block reduction over the 256 / cpr threads that share a channel chunk (fixed order)
+        __shared__ float red[256 * N * 2];
+        const int nl = 256 / cpr;
+#pragma unroll
+        for (int i = 0; i < N; ++i) { red[(threadIdx.x * N + i) * 2] = s0[i]; red[(threadIdx.x * N + i) * 2 + 1] = s1[i]; }
+        __syncthreads();
+        for (int v = threadIdx.x; v < C * 2; v += 256) {
+            const int st2 = v / C, col = v - st2 * C, cg = col / N, i = col - cg * N;
+            double acc = 0.0;
+            for (int rl = 0; rl < nl; ++rl) acc += (double)red[((rl * cpr + cg) * N + i) * 2 + st2];
+            partial[((long)blockIdx.x * 2 + st2) * C + col] = (float)acc;
         }
     }
 }
@@ -679,9 +716,30 @@ int launch_maxpool_bwd_add(int dtype, const void* n, const void* dskip, const vo
                            void* dn, hipStream_t st) {
     const long work = (long)B * (H / 2) * (W / 2) * C / 8;
     if (dtype == MPU_BF16)
-        maxpool_bwd_add_kernel<bf16_t><<<ew_grid(work), 256, 0, st>>>((const bf16_t*)n, (const bf16_t*)dskip, (const bf16_t*)dp, B, H, W, C, (bf16_t*)dn);
+        maxpool_bwd_add_kernel<bf16_t, false><<<ew_grid(work), 256, 0, st>>>((const bf16_t*)n, (const bf16_t*)dskip, (const bf16_t*)dp, B, H, W, C, (bf16_t*)dn, nullptr, nullptr, nullptr, nullptr);
     else
-        maxpool_bwd_add_kernel<float><<<ew_grid(work), 256, 0, st>>>((const float*)n, (const float*)dskip, (const float*)dp, B, H, W, C, (float*)dn);
+        maxpool_bwd_add_kernel<float, false><<<ew_grid(work), 256, 0, st>>>((const float*)n, (const float*)dskip, (const float*)dp, B, H, W, C, (float*)dn, nullptr, nullptr, nullptr, nullptr);
+    return launch_ok();
+}
+
+// Same, plus the BN-backward partial sums of dn against the BN input x (see the kernel). *rows = partial rows written
+// ([rows][2][C]); 0 = shape not suited (plain kernel launched, the caller runs the column reduction).
+int launch_maxpool_bwd_add_stats(int dtype, const void* n, const void* dskip, const void* dp, int B, int H, int W, int C,
+                                 void* dn, const void* x, const float* mean, const float* invstd, float* partial,
+                                 long partial_cap, int* rows, hipStream_t st) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MPU_FUSED_BN_BWD"); on = (e && e[0] == '0') ? 0 : 1; }
+    const int N = dtype == MPU_BF16 ? 8 : 4, cpr = C / N;
+    const long work = (long)B * (H / 2) * (W / 2) * cpr;
+    long blocks = (work + 255) / 256; if (blocks > 1024) blocks = 1024;
+    *rows = 0;
+    if (!on || C % N || cpr < 1 || cpr > 256 || 256 % cpr || blocks * 2 * C > partial_cap)
+        return launch_maxpool_bwd_add(dtype, n, dskip, dp, B, H, W, C, dn, st);
+    if (dtype == MPU_BF16)
+        maxpool_bwd_add_kernel<bf16_t, true><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)n, (const bf16_t*)dskip, (const bf16_t*)dp, B, H, W, C, (bf16_t*)dn, (const bf16_t*)x, mean, invstd, partial);
+    else
+        maxpool_bwd_add_kernel<float, true><<<(unsigned)blocks, 256, 0, st>>>((const float*)n, (const float*)dskip, (const float*)dp, B, H, W, C, (float*)dn, (const float*)x, mean, invstd, partial);
+    *rows = (int)blocks;
     return launch_ok();
 }
 
