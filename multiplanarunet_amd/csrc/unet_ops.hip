@@ -863,6 +863,81 @@ __global__ __launch_bounds__(256) void head_forward_kernel(const T* __restrict__
         default: return fail(MPU_EUNSUPPORTED, "%s", "U-Net head supports 1..8 classes"); \
     }
 
+// head_forward_rs_kernel: same result for C / N == GS lanes per pixel (GS = 8 or 16: a 64-channel last block in bf16 /
+// f32) and GS * K <= 64. A group of GS lanes works on GS consecutive pixels per pass: every lane multiplies its 16-byte
+// channel chunk of all GS pixels (GS independent loads in flight), the GS x K partial sums are reduce-scattered over the
+// group (log2 GS exchange steps; lane `sub` ends up with the complete logits of pixel m0 + sub), and EVERY lane then
+// finishes one pixel (bias, softmax, store). In head_forward_kernel the softmax of one pixel occupied all GS lanes
+// and only two loads were in flight.
+template <typename T, int K, int GS>
+__global__ __launch_bounds__(256) void head_forward_rs_kernel(const T* __restrict__ n, long M, int C, const float* __restrict__ Wh,
+                                                              int ldw, const float* __restrict__ bh, int softmax,
+                                                              float* __restrict__ out) {
+    constexpr int N = Vec<T>::N;
+    const int sub = threadIdx.x % GS;
+    float wr[N][K];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int k = 0; k < K; ++k) wr[i][k] = Wh[(long)(sub * N + i) * ldw + k];
+    float bias[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) bias[k] = bh[k];
+    constexpr int PPB = 256;                                     // pixels per block and pass (256 / GS groups x GS pixels)
+    for (long m0 = ((long)blockIdx.x * (256 / GS) + threadIdx.x / GS) * GS; m0 < M; m0 += (long)gridDim.x * PPB) {
+        const long left = M - m0;
+        const int nv = left < GS ? (int)left : GS;
+        float z[GS][K];
+#pragma unroll
+        for (int h = 0; h < GS; h += 4) {                        // four pixels per round: registers for 4 chunks at a time
+            float v[4][N];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)                          // (clamped: surplus pixels re-read the last one, never stored)
+                Vec<T>::load(n + (m0 + (h + u < nv ? h + u : nv - 1)) * C + (long)sub * N, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) acc += v[u][i] * wr[i][k];
+                    z[h + u][k] = acc;
+                }
+        }
+        // reduce-scatter: after the step with distance s a lane holds the sums over its 2*... partners of the s pixels
+        // whose index agrees with its own in the bits above s; at the end z[0] = logits of pixel m0 + sub
+#pragma unroll
+        for (int s = GS / 2; s >= 1; s >>= 1) {
+            const bool upper = (sub & s) != 0;
+#pragma unroll
+            for (int q = 0; q < s; ++q)
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float keep = upper ? z[s + q][k] : z[q][k];
+                    const float send = upper ? z[q][k] : z[s + q][k];
+                    z[q][k] = keep + __shfl_xor(send, s, 64);
+                }
+        }
+        if (sub < nv) {
+            float zz[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) zz[k] = z[0][k] + bias[k];
+            if (softmax) {
+                float mx = zz[0];
+#pragma unroll
+                for (int k = 1; k < K; ++k) mx = fmaxf(mx, zz[k]);
+                float ssum = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) { zz[k] = expf(zz[k] - mx); ssum += zz[k]; }
+#pragma unroll
+                for (int k = 0; k < K; ++k) zz[k] = zz[k] / ssum;
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) out[(m0 + sub) * K + k] = zz[k];
+        }
+    }
+}
+
 int launch_head_forward(int dtype, const void* n, long M, int C, int K, const float* Wh, int ldw, const float* bh,
                         int softmax, float* out, hipStream_t st) {
     if (C > HEAD_MAXC) return fail(MPU_EUNSUPPORTED, "%s", "head: more than 512 input channels");
@@ -870,6 +945,17 @@ int launch_head_forward(int dtype, const void* n, long M, int C, int K, const fl
     int G = 1; while (G < C / N && G < 64) G <<= 1;
     const long ppb = 256 / G;
     long blocks = (M + ppb - 1) / ppb; if (blocks > 4096) blocks = 4096;
+    static int rs_on = -1;
+    if (rs_on < 0) { const char* e = getenv("MPU_HEAD_RS"); rs_on = (e && e[0] == '0') ? 0 : 1; }
+    if (rs_on && C == 64 && K * (C / N) <= 64) {                 // reduce-scatter variant: every lane finishes a pixel
+        long rb = (M + 255) / 256; if (rb > 4096) rb = 4096;
+        if (dtype == MPU_BF16) {
+            MPU_HEAD_DISPATCH_K(K, (head_forward_rs_kernel<bf16_t, KK, 8><<<(unsigned)rb, 256, 0, st>>>((const bf16_t*)n, M, C, Wh, ldw, bh, softmax, out)))
+        } else {
+            MPU_HEAD_DISPATCH_K(K, (head_forward_rs_kernel<float, (KK <= 4 ? KK : 1), 16><<<(unsigned)rb, 256, 0, st>>>((const float*)n, M, C, Wh, ldw, bh, softmax, out)))
+        }
+        return launch_ok();
+    }
     if (dtype == MPU_BF16) {
         MPU_HEAD_DISPATCH_K(K, (head_forward_kernel<bf16_t, KK><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)n, M, C, Wh, ldw, bh, softmax, out)))
     } else {
