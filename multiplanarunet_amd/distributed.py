@@ -63,6 +63,25 @@ def allreduce_sum_(flat, bucket_bytes=64 << 20):
     return flat
 
 
+def plan_buckets(ready_points, n, bucket_bytes, elem_bytes=4):
+    """
+    Gradient buckets for the overlapped all-reduce. ready_points: descending float offsets; after point k every
+    gradient at offset >= ready_points[k] is final (the backward pass fills the flat buffer from its end). Returns
+    [(point index, lo, hi)] in completion order: bucket [lo, hi) may be reduced once point `index` has fired. A
+    bucket is closed at the first ready point that makes it >= bucket_bytes; the last one takes whatever remains, so
+    the buckets tile [0, n) exactly once.
+    """
+    step = max(1, bucket_bytes // elem_bytes)
+    buckets, hi = [], n
+    for k, off in enumerate(ready_points):
+        last = k == len(ready_points) - 1
+        lo = 0 if last else off
+        if hi - lo >= step or (last and (hi > lo or not buckets)):
+            buckets.append((k, lo, hi))
+            hi = lo
+    return buckets
+
+
 class DataParallelTrainer:
     """
     Wires the gradient all-reduce into UNet.train_step (model._grad_hook).
@@ -86,20 +105,12 @@ class DataParallelTrainer:
         self.buckets = []                          # (point index, lo, hi) in the order the backward pass completes them
         if self.overlap:
             pts = model.grad_ready_points()
-            n = model.grads.numel()
-            hi = n
+            self.buckets = plan_buckets(pts, model.grads.numel(), bucket_bytes)
             self.ready_events = [None] * len(pts)
-            step = max(1, bucket_bytes // 4)
-            for k, off in enumerate(pts):
-                last = k == len(pts) - 1
-                if hi - off >= step or (last and hi > off) or (last and not self.buckets):
-                    ev = torch.cuda.Event()
-                    ev.record()                    # forces the underlying hipEvent_t into existence
-                    self.ready_events[k] = ev
-                    self.buckets.append((k, off if not last else 0, hi))
-                    hi = off if not last else 0
-            if hi > 0:                             # ready points always end at offset 0; defensive
-                self.buckets[-1] = (self.buckets[-1][0], 0, self.buckets[-1][2])
+            for k, _, _ in self.buckets:
+                ev = torch.cuda.Event()
+                ev.record()                        # forces the underlying hipEvent_t into existence
+                self.ready_events[k] = ev
             self.comm = torch.cuda.Stream(device=model.device)
             torch.cuda.synchronize()
         model._grad_hook = self

@@ -26,6 +26,30 @@ def test_plane_work_items_cover_every_plane_once():
         assert owners == [1] * V          # exactly one rank adds each view's OOB term
 
 
+def test_gradient_buckets_tile_the_flat_buffer():
+    """plan_buckets (overlapped all-reduce): buckets tile [0, n) exactly once, in completion order (descending
+    offsets), each is released by a ready point at or below its low end, and every bucket but the last holds at
+    least bucket_bytes."""
+    rng = np.random.RandomState(0)
+    for trial in range(200):
+        n = int(rng.randint(1, 10 ** 6))
+        k = int(rng.randint(1, 12))
+        pts = sorted({int(v) for v in rng.randint(0, n, size=k - 1)} - {0}, reverse=True) + [0]
+        bb = int(rng.choice([4, 1024, 1 << 16, 1 << 22]))
+        b = D.plan_buckets(pts, n, bb)
+        assert b and b[0][2] == n and b[-1][1] == 0
+        for (k0, lo0, hi0), (k1, lo1, hi1) in zip(b[:-1], b[1:]):
+            assert lo0 == hi1 and k1 > k0 and hi0 > lo0
+        for i, (kk, lo, hi) in enumerate(b):
+            assert pts[kk] <= lo                       # everything in [lo, hi) is final once point kk has fired
+            if i < len(b) - 1:
+                assert (hi - lo) * 4 >= bb
+    # BASELINE configs[1]: 124 MB of fp32 gradients, 32 MB buckets -> a handful of buckets, the first closed early
+    pts = [31030720, 30900000, 28000000, 20000000, 12000000, 4700000, 1200000, 300000, 40000, 0]
+    b = D.plan_buckets(pts, 31046339, 32 << 20)
+    assert [x[0] for x in b] == [3, 5, 9] and b[0][1] == 20000000
+
+
 def test_slab_bounds():
     for X, w in ((256, 8), (30, 4), (7, 8)):
         b = D.slab_bounds(X, w)
