@@ -77,7 +77,8 @@ def load_or_create_views(project_dir, n_views, seed=None):
 
 
 def fill_build_from_data(hp, volumes, n_classes=None):
-    """What Auditor.fill writes back into the YAML: dim, real_space_span, n_channels, n_classes."""
+    """What Auditor.fill writes back into the YAML: dim, real_space_span, n_channels, n_classes
+    (mpunet/image/auditor.py:100-120,199-209). Call on the FULL training set (before --just_one truncation)."""
     b, f = hp["build"], hp["fit"]
     dim, span = audit_dim_and_span(volumes, min_dim=32)
     if not b.get("dim"):
@@ -87,6 +88,53 @@ def fill_build_from_data(hp, volumes, n_classes=None):
     if not b.get("n_channels"):
         b["n_channels"] = volumes[0].n_channels
     if not b.get("n_classes"):
-        mx = max(int(v.labels.max().item()) for v in volumes if v.labels is not None)
-        b["n_classes"] = n_classes or mx + 1
+        labelled = [int(v.labels.max().item()) for v in volumes if v.labels is not None]
+        if n_classes is None and not labelled:
+            raise ValueError("build.n_classes is not set and no labelled volume is available to audit it from")
+        b["n_classes"] = n_classes or max(labelled) + 1
     return hp
+
+
+AUDITED_KEYS = (("build", "dim"), ("build", "n_channels"), ("build", "n_classes"), ("fit", "real_space_span"))
+
+
+def save_audited_hparams(project_dir, hp):
+    """Write the audited values back into train_hparams.yaml (the reference's Auditor.fill +
+    YAMLHParams.save_current, mpunet/bin/train.py:210-228), so that `mp predict` / `mp train_fusion` use the
+    geometry the model was trained with instead of re-auditing whatever volumes they are given."""
+    path = os.path.join(project_dir, "train_hparams.yaml")
+    with open(path) as f:
+        raw = yaml.safe_load(f) or {}
+    changed = False
+    for sec, key in AUDITED_KEYS:
+        val = hp[sec].get(key)
+        if val is None:
+            continue
+        val = float(val) if key == "real_space_span" else int(val)
+        if not isinstance(raw.get(sec), dict):
+            raw[sec] = {}
+        if raw[sec].get(key) != val:
+            raw[sec][key] = val
+            changed = True
+    if changed:
+        tmp = path + ".tmp"
+        with open(tmp, "w") as f:
+            yaml.safe_dump(raw, f, sort_keys=False)
+        os.replace(tmp, path)
+    return changed
+
+
+def require_audited_hparams(hp, what):
+    """`mp predict` / `mp train_fusion`: the model geometry must come from the training session's YAML."""
+    missing = ["%s.%s" % (sec, key) for sec, key in AUDITED_KEYS if not hp[sec].get(key)]
+    if missing:
+        raise RuntimeError("%s: train_hparams.yaml lacks %s -- these are written by `mp train` (Auditor); "
+                           "run it first or set them by hand. Re-auditing the volumes given here could silently "
+                           "change the sampling geometry the weights were trained with." % (what, ", ".join(missing)))
+
+
+def fusion_weights_path(model_dir, weights_path):
+    """<model>/fusion_weights/<checkpoint name>_fusion_weights.npz (mpunet/bin/predict.py:222-229,
+    mpunet/bin/train_fusion.py:318-325): fusion weights belong to ONE U-Net checkpoint."""
+    base = os.path.splitext(os.path.basename(weights_path))[0]
+    return os.path.join(model_dir, "fusion_weights", "%s_fusion_weights.npz" % base)

@@ -8,7 +8,8 @@ from argparse import ArgumentParser
 import numpy as np
 import torch
 
-from .common import validate_project_dir, load_hparams, load_dataset
+from .common import (validate_project_dir, load_hparams, load_dataset, require_audited_hparams,
+                     fusion_weights_path)
 
 
 def get_argparser():
@@ -76,9 +77,7 @@ def run(args):
         vols = load_dataset(hp[key], project_dir, hp, device, args.synthetic, seed=5000, need_labels=False)
     if not vols:
         raise OSError("no volumes to predict on")
-    if not build.get("dim") or not fit.get("real_space_span") or not build.get("n_classes"):
-        from .common import fill_build_from_data
-        fill_build_from_data(hp, vols)
+    require_audited_hparams(hp, "mp predict")             # geometry of the training session, never re-audited here
     views = np.load(os.path.join(project_dir, "views.npz"))["arr_0"]
     bkw = {k: v for k, v in build.items() if k != "model_class_name"}
     model = UNet(logger=log, dtype=args.dtype, device=device, **bkw)
@@ -88,12 +87,13 @@ def run(args):
     fm = None
     if not args.sum_fusion:
         fm = FusionModel(len(views), build["n_classes"], verbose=False, device=device)
-        fdir = os.path.join(project_dir, "model", "fusion_weights")
-        cands = sorted(os.listdir(fdir)) if os.path.isdir(fdir) else []
-        if cands:
-            fm.load_weights(os.path.join(fdir, cands[0]))
+        fpath = fusion_weights_path(os.path.join(project_dir, "model"), wpath)
+        if os.path.exists(fpath):
+            fm.load_weights(fpath)
+            log("Loaded fusion weights:", fpath)
         else:
-            log("[OBS] no fusion weights found: using the FusionLayer initialisation (W=1, b=0)")
+            log("[OBS] no fusion weights for this checkpoint (%s): using the FusionLayer initialisation "
+                "(W=1, b=0)" % os.path.basename(fpath))
     out_dir = os.path.join(project_dir, args.out_dir) if not os.path.isabs(args.out_dir) else args.out_dir
     nii = os.path.join(out_dir, "nii_files")
     if rank == 0:
@@ -119,7 +119,7 @@ def run(args):
                 out["probs"] = probs.cpu().numpy()
             np.savez_compressed(dst, **out)
             if v.labels is not None and not args.no_eval:
-                d = dice_all(v.labels, labels, build["n_classes"], ignore_zero=True)
+                d = dice_all(v.labels, labels, n_classes=build["n_classes"], ignore_zero=True)
                 results[v.identifier] = d
                 log("%s: dices %s mean %.4f" % (v.identifier, np.round(d, 4), float(np.nanmean(d))))
     if rank == 0 and results:

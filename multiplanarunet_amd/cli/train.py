@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .common import (validate_project_dir, load_hparams, load_dataset, load_or_create_views,
-                     fill_build_from_data)
+                     fill_build_from_data, save_audited_hparams)
 
 
 def get_argparser():
@@ -63,25 +63,31 @@ def run(args):
     rank, world, device = D.init_from_env()
     log = (lambda *a, **k: print(*a, flush=True)) if rank == 0 else (lambda *a, **k: None)
     model_dir = os.path.join(project_dir, "model")
-    if rank == 0:
-        if os.path.exists(model_dir) and os.listdir(model_dir) and not (args.overwrite or args.continue_training):
-            raise OSError("There seems to be existing files in the project 'model' folder. "
-                          "Use --overwrite or --continue_training.")
-        if args.overwrite and os.path.exists(model_dir):
-            shutil.rmtree(model_dir)
-        os.makedirs(model_dir, exist_ok=True)
-        os.makedirs(os.path.join(project_dir, "logs"), exist_ok=True)
+    # checks that can fail run on EVERY rank before the first barrier (a rank-0-only raise would leave the
+    # others waiting in it); only rank 0 then touches the project folder
+    if os.path.exists(model_dir) and os.listdir(model_dir) and not (args.overwrite or args.continue_training):
+        raise OSError("There seems to be existing files in the project 'model' folder. "
+                      "Use --overwrite or --continue_training.")
     hp = load_hparams(project_dir)
     train = load_dataset(hp["train_data"], project_dir, hp, device, args.synthetic, seed=0)
     val = [] if args.no_val else load_dataset(hp["val_data"], project_dir, hp, device,
                                               max(1, args.synthetic // 4) if args.synthetic else 0, seed=1000)
     if not train:
         raise OSError("no training volumes (set train_data.base_dir to a folder with images/*.npz, or --synthetic N)")
+    fill_build_from_data(hp, train)                        # audit the FULL training set (before --just_one)
     if args.just_one:
         train, val = train[:1], val[:1]
-    fill_build_from_data(hp, train)
     fit, build = hp["fit"], hp["build"]
-    views = load_or_create_views(project_dir, fit["views"], seed=0) if rank == 0 else None
+    if world > 1:
+        torch.distributed.barrier()                        # every rank has passed the checks and read the YAML
+    views = None
+    if rank == 0:
+        if args.overwrite and os.path.exists(model_dir):
+            shutil.rmtree(model_dir)
+        os.makedirs(model_dir, exist_ok=True)
+        os.makedirs(os.path.join(project_dir, "logs"), exist_ok=True)
+        save_audited_hparams(project_dir, hp)              # Auditor.fill: predict / train_fusion read them back
+        views = load_or_create_views(project_dir, fit["views"], seed=0)
     if world > 1:
         torch.distributed.barrier()
     if views is None:
@@ -105,7 +111,7 @@ def run(args):
     if augs:
         log("Augmenters:", ", ".join(str(a) for a in augs))
     tr = mk(train, fit["noise_sd"], 17 + rank, augs)
-    va = mk(val, 0.0, 99, None) if val else None
+    va = mk(val, 0.0, 99 + rank, None) if val else None      # distinct planes per rank; counts are SUM-reduced
     epochs = args.epochs or int(fit["n_epochs"])
     steps = max(1, int(np.ceil(args.train_images_per_epoch / B)))
     vsteps = max(1, int(np.ceil(args.val_images_per_epoch / B)))
@@ -123,6 +129,10 @@ def run(args):
             for _ in range(steps):
                 x, y, w = tr()
                 tot += float(model.train_step(x, y, w).mean().item())
+            if world > 1:                                  # the logged loss is the mean over all replicas' slices
+                t = torch.tensor([tot], dtype=torch.float64, device=device)
+                torch.distributed.all_reduce(t)
+                tot = float(t.item()) / world
             logs = {"loss": tot / steps}
             if validation is not None:
                 validation.on_epoch_end(model, ep, logs)

@@ -11,7 +11,8 @@ from argparse import ArgumentParser
 import numpy as np
 import torch
 
-from .common import validate_project_dir, load_hparams, load_dataset
+from .common import (validate_project_dir, load_hparams, load_dataset, require_audited_hparams,
+                     fusion_weights_path)
 from .predict import best_model_path
 
 
@@ -56,7 +57,7 @@ def collect_points(model, sampler, volumes, views, n_classes, batch_size, log, e
             mapped, (yv, pred) = predict_and_map(model, sampler, vol, view, batch_size)
             pts[:, k, :] = mapped
             if rng.rand() <= eval_prob:
-                d = dice_all(vol.labels.reshape(-1), mapped.argmax(-1), n_classes, ignore_zero=False)
+                d = dice_all(vol.labels.reshape(-1), mapped.argmax(-1), n_classes=n_classes, ignore_zero=False)
                 log("  %s view %s: mapped dice %s" % (vol.identifier, np.round(view, 3), np.round(d, 4)))
         xs.append(pts)
         ys.append(vol.labels.reshape(-1).to(torch.uint8))
@@ -79,8 +80,8 @@ def run(args):
     views = np.load(os.path.join(project_dir, "views.npz"))["arr_0"]
     model_dir = os.path.join(project_dir, "model")
     wpath = best_model_path(model_dir)
-    fdir = os.path.join(model_dir, "fusion_weights")
-    fpath = os.path.join(fdir, "%s_fusion_weights.npz" % os.path.splitext(os.path.basename(wpath))[0])
+    fpath = fusion_weights_path(model_dir, wpath)
+    fdir = os.path.dirname(fpath)
     if os.path.exists(fpath) and not (args.overwrite or args.continue_training):
         raise OSError("Fusion weights already exist at '%s' (use --overwrite or --continue_training)" % fpath)
     # validation images first; training images are added when there are fewer than 15 (train_fusion.py:283-312)
@@ -93,9 +94,7 @@ def run(args):
             images += [extra[i] for i in idx]
     if not images:
         raise OSError("no images to fit the fusion model on")
-    if not build.get("dim") or not fit.get("real_space_span") or not build.get("n_classes"):
-        from .common import fill_build_from_data
-        fill_build_from_data(hp, images)
+    require_audited_hparams(hp, "mp train_fusion")
     n_classes = int(build["n_classes"])
     bkw = {k: v for k, v in build.items() if k != "model_class_name"}
     unet = UNet(logger=log, dtype=args.dtype, device=device, **bkw)

@@ -472,36 +472,35 @@ mpu_unet* mpu_unet_create(const mpu_unet_config* cfg) {
         if (fl < 1) { delete m; fail(MPU_EINVAL, "%s", "mpu_unet_create: filters[] must be positive"); return nullptr; }
         m->Fl.push_back(fl); m->F.push_back(pad8(fl));
     }
+    // Flat-buffer layout = Keras layer creation order (unet.py:114-216): each block's BatchNormalization
+    // gamma/beta directly follow that block's convs, so that a block's whole gradient (convs AND BN) is final
+    // at the block's gradient-ready point (mpu_unet_grad_ready_points; the backward pass completes the buffer
+    // from its end towards its start).
     char buf[64];
     int cin = m->cin_pad, lcin = cfg->n_channels;
     for (int i = 0; i < D; ++i) {
         snprintf(buf, sizeof(buf), "encoder_L%d", i);
         add_conv(m, std::string(buf) + "_conv1", CONV3, cin, m->F[i], lcin, m->Fl[i]);
         add_conv(m, std::string(buf) + "_conv2", CONV3, m->F[i], m->F[i], m->Fl[i], m->Fl[i]);
+        add_bn(m, std::string(buf) + "_BN", m->F[i], m->Fl[i]);
         cin = m->F[i]; lcin = m->Fl[i];
     }
     add_conv(m, "bottom_conv1", CONV3, cin, m->F[D], lcin, m->Fl[D]);
     add_conv(m, "bottom_conv2", CONV3, m->F[D], m->F[D], m->Fl[D], m->Fl[D]);
+    add_bn(m, "bottom_BN", m->F[D], m->Fl[D]);
     cin = m->F[D]; lcin = m->Fl[D];
     for (int j = 0; j < D; ++j) {
         const int lvl = D - 1 - j;
         snprintf(buf, sizeof(buf), "upsample_L%d", j);
         add_conv(m, std::string(buf) + "_conv1", UPCONV2, cin, m->F[lvl], lcin, m->Fl[lvl]);
+        add_bn(m, std::string(buf) + "_BN1", m->F[lvl], m->Fl[lvl]);
         add_conv(m, std::string(buf) + "_conv2", CONV3, 2 * m->F[lvl], m->F[lvl], 2 * m->Fl[lvl], m->Fl[lvl]);
         add_conv(m, std::string(buf) + "_conv3", CONV3, m->F[lvl], m->F[lvl], m->Fl[lvl], m->Fl[lvl]);
+        add_bn(m, std::string(buf) + "_BN2", m->F[lvl], m->Fl[lvl]);
         cin = m->F[lvl]; lcin = m->Fl[lvl];
     }
     add_conv(m, "conv2d", CONV1, cin, cfg->n_classes, lcin, cfg->n_classes);
     m->head_C = cin; m->head_w = m->conv.back().w; m->head_b = m->conv.back().b;
-    // BN layers are appended after the convs in the flat tables (order inside the
-    // tables is irrelevant to callers: they address tensors by name)
-    for (int i = 0; i < D; ++i) { snprintf(buf, sizeof(buf), "encoder_L%d_BN", i); add_bn(m, buf, m->F[i], m->Fl[i]); }
-    add_bn(m, "bottom_BN", m->F[D], m->Fl[D]);
-    for (int j = 0; j < D; ++j) {
-        const int lvl = D - 1 - j;
-        snprintf(buf, sizeof(buf), "upsample_L%d_BN1", j); add_bn(m, buf, m->F[lvl], m->Fl[lvl]);
-        snprintf(buf, sizeof(buf), "upsample_L%d_BN2", j); add_bn(m, buf, m->F[lvl], m->Fl[lvl]);
-    }
     m->infer_off = (m->n_packed * (cfg->dtype == MPU_BF16 ? 2 : 4) + 255) / 256 * 256;
     return m;
 }

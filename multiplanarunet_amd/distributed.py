@@ -126,9 +126,17 @@ class DataParallelTrainer:
             allreduce_sum_(grads, self.bucket_bytes)
             return
         works = []
+        # The comm stream is ordered behind the backward pass ONLY through the ready events. If this step's
+        # backward did not record them (forward_backward called without ready_events), they are stale: order
+        # the comm stream behind everything enqueued so far instead (no overlap, but never a race).
+        fresh = getattr(self.model, "_ready_events_fresh", False)
+        self.model._ready_events_fresh = False
+        if not fresh:
+            self.comm.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm):
             for k, lo, hi in self.buckets:
-                self.comm.wait_event(self.ready_events[k])
+                if fresh:
+                    self.comm.wait_event(self.ready_events[k])
                 works.append(dist.all_reduce(grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         for w in works:
             w.wait()                               # the compute stream waits for the collectives
@@ -165,23 +173,40 @@ def slab_bounds(X, world):
     return [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:])]
 
 
-def reduce_scatter_slabs(z_partial):
+def reduce_scatter_slabs(z_partial, force_pad=False):
     """
-    SUM over ranks of z_partial [X,...]; each rank keeps its X-slab
-    (slab_bounds). Equal slabs -> one reduce_scatter_tensor (RCCL); otherwise,
-    or on gloo (no reduce-scatter), all-reduce + slice.
+    SUM over ranks of z_partial [X,...]; each rank keeps its X-slab (slab_bounds). RCCL: one
+    reduce_scatter_tensor; a ragged X (X % world != 0) is handled by scattering equal slabs of
+    ceil(X / world) planes cut from a zero-padded copy laid out slab by slab (each rank's real planes first),
+    so the traffic stays 1/world of an all-reduce. gloo has no reduce-scatter: all-reduce + slice
+    (force_pad exercises the padded layout there too).
     """
     world = world_size()
     if world == 1:
         return z_partial, (0, z_partial.shape[0])
     rank = dist.get_rank()
     X = z_partial.shape[0]
-    lo, hi = slab_bounds(X, world)[rank]
-    if X % world == 0 and dist.get_backend() == "nccl":
+    bounds = slab_bounds(X, world)
+    lo, hi = bounds[rank]
+    nccl = dist.get_backend() == "nccl"
+    if X % world == 0 and nccl and not force_pad:
         out = torch.empty((X // world,) + tuple(z_partial.shape[1:]), dtype=z_partial.dtype,
                           device=z_partial.device)
         dist.reduce_scatter_tensor(out, z_partial.contiguous(), op=dist.ReduceOp.SUM)
         return out, (lo, hi)
+    if nccl or force_pad:
+        w = max(b - a for a, b in bounds)
+        padded = torch.zeros((world * w,) + tuple(z_partial.shape[1:]), dtype=z_partial.dtype,
+                             device=z_partial.device)
+        for r, (a, b) in enumerate(bounds):
+            padded[r * w:r * w + (b - a)] = z_partial[a:b]
+        if nccl:
+            out = torch.empty((w,) + tuple(z_partial.shape[1:]), dtype=z_partial.dtype, device=z_partial.device)
+            dist.reduce_scatter_tensor(out, padded, op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(padded, op=dist.ReduceOp.SUM)
+            out = padded[rank * w:(rank + 1) * w]
+        return out[:hi - lo].contiguous(), (lo, hi)
     dist.all_reduce(z_partial, op=dist.ReduceOp.SUM)
     return z_partial[lo:hi].contiguous(), (lo, hi)
 
@@ -201,11 +226,24 @@ def all_gather_slabs(slab, X):
 
 
 def multi_view_predict_sharded(model, volume, views, dim, real_space_span, fusion_model=None,
-                               sum_fusion=False, batch_size=None, n_planes="same+20"):
+                               sum_fusion=False, batch_size=None, n_planes="same+20", exchange=None):
     """
     multiplanarunet_amd.predict.multi_view_predict over all ranks. Every rank
     holds the full input volume; returns the full uint8 label volume on every rank.
+
+    exchange="reduce_scatter" (default; MPU_PREDICT_EXCHANGE overrides): plane-chunk work items, partial
+    fusion sums, reduce-scatter + label all-gather (module docstring). exchange="all_gather": the literal
+    scheme of the north star / mpunet/bin/predict.py:307-366 -- whole views dealt over ranks, every rank maps
+    its views to the voxel grid (`mapped_v [X,Y,Z,K]`), ALL-GATHER of the per-view volumes rebuilds
+    `combined [V,X,Y,Z,K]` on every rank, then the FusionLayer + argmax runs locally. V times the traffic and
+    at most V busy ranks; kept for equivalence testing and for fusion models that are not linear in the views.
     """
+    exchange = exchange or os.environ.get("MPU_PREDICT_EXCHANGE") or "reduce_scatter"
+    if exchange == "all_gather":
+        return _multi_view_predict_allgather(model, volume, views, dim, real_space_span, fusion_model,
+                                             sum_fusion, batch_size, n_planes)
+    if exchange != "reduce_scatter":
+        raise ValueError("exchange must be 'reduce_scatter' or 'all_gather'")
     from .interpolation import ViewGeometry, sample_view, map_accumulate, fusion_finalize
     world = world_size()
     rank = dist.get_rank() if world > 1 else 0
@@ -233,3 +271,42 @@ def multi_view_predict_sharded(model, volume, views, dim, real_space_span, fusio
     b = None if sum_fusion else fusion_model.b
     _, labels = fusion_finalize(zs, b, sum_fusion=sum_fusion, want_probs=False)
     return all_gather_slabs(labels, X)
+
+
+def _multi_view_predict_allgather(model, volume, views, dim, real_space_span, fusion_model, sum_fusion,
+                                  batch_size, n_planes):
+    from .interpolation import ViewGeometry, sample_view, map_real_space_pred, pred_to_class
+    world = world_size()
+    rank = dist.get_rank() if world > 1 else 0
+    K, V = model.n_classes, len(views)
+    X, Y, Z = (int(v) for v in volume.image.shape[:3])
+    dev = volume.device
+    rounds = -(-V // world)
+    combined = torch.empty((V, X, Y, Z, K), dtype=torch.float32, device=dev)
+    for r in range(rounds):
+        vi = r * world + rank                               # view of this rank in this round (or none)
+        mine = torch.zeros((X, Y, Z, K), dtype=torch.float32, device=dev)
+        if vi < V:
+            g = ViewGeometry(views[vi], dim, real_space_span, n_planes)
+            Xs, _ = sample_view(volume, g, want_labels=False)
+            pred = model.predict(Xs, batch_size=batch_size)
+            if pred.ndim == 3:
+                pred = pred.reshape(Xs.shape[0], dim, dim, -1)
+            mine = map_real_space_pred(pred.permute(1, 2, 0, 3), (g.real_axis, g.real_axis, g.offsets),
+                                       g.inv_basis, volume)
+        if world > 1:
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+        else:
+            parts = [mine]
+        for q, part in enumerate(parts):
+            if r * world + q < V:
+                combined[r * world + q] = part
+    x = torch.movedim(combined, 0, -2).reshape(-1, V, K)    # predict.py:354-356
+    if sum_fusion:
+        merged = x.sum(dim=1)
+    else:
+        merged = fusion_model.predict(x, batch_size=10 ** 4)
+        if not torch.is_tensor(merged):
+            merged = torch.as_tensor(merged, device=dev)
+    return pred_to_class(merged.reshape(X, Y, Z, K), img_dims=3)

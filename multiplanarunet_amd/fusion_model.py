@@ -160,7 +160,7 @@ class FusionModel:
             msg = "Epoch %d/%d - loss: %.6f" % (ep + 1, epochs, hist["loss"][-1])
             if validation_data is not None:
                 pred = self.predict(xv).argmax(-1)
-                d = dice_all(yv, pred, self.n_classes, ignore_zero=True)
+                d = dice_all(yv, pred, n_classes=self.n_classes, ignore_zero=True)
                 vd = float(np.nanmean(d))
                 hist["val_dice"].append(vd)
                 msg += " - val_dice: %.4f (per class %s)" % (vd, np.round(d, 4))

@@ -264,11 +264,6 @@ class _ViewPredHolder:
         self.struct = s
 
 
-def _plane_major(pred):
-    """Accept the reference layout [dim,dim,P,K] (a permuted view) or [P,dim,dim,K]."""
-    return pred
-
-
 def predict_volume(model, X, batch_size=8, axis=0):
     """fuse_and_predict.py:81-89: move `axis` first, model.predict, move back."""
     X = torch.movedim(X, axis, 0) if torch.is_tensor(X) else np.moveaxis(X, axis, 0)
@@ -343,22 +338,43 @@ def fusion_finalize(z, b=None, sum_fusion=False, want_probs=True):
     return probs, labels
 
 
-def pred_to_class(t):
-    """utils.pred_to_class multi-class branch: argmax(-1) -> uint8."""
-    return t.argmax(-1).to(torch.uint8)
+def pred_to_class(tensor, img_dims=3, threshold=0.5, has_batch_dim=False):
+    """mpunet/utils/utils.py:311-328: integer maps pass through, single-channel scores are thresholded,
+    multi-class scores -> argmax(-1) as uint8. Accepts device tensors (stays on the device) or ndarrays."""
+    is_t = torch.is_tensor(tensor)
+    is_int = (not tensor.dtype.is_floating_point and tensor.dtype != torch.bool) if is_t \
+        else np.issubdtype(tensor.dtype, np.integer)
+    if len(tensor.shape) == img_dims + int(has_batch_dim):
+        return tensor if is_int else tensor >= threshold
+    if tensor.shape[-1] == 1:
+        if is_int:
+            return tensor.squeeze() if is_t else np.squeeze(tensor)
+        return tensor >= threshold
+    return tensor.argmax(-1).to(torch.uint8) if is_t else tensor.argmax(-1).astype(np.uint8)
 
 
-def dice_all(y_true, y_pred, n_classes, smooth=1.0, ignore_zero=True):
-    """mpunet/evaluate/metrics.py:13-52 on label volumes (host ints; parity metric)."""
+def dice(y_true, y_pred, smooth=1.0):
+    """mpunet/evaluate/metrics.py:13-23 (binary sets)."""
+    s1 = np.asarray(y_true).ravel().astype(bool)
+    s2 = np.asarray(y_pred).ravel().astype(bool)
+    return (smooth + 2 * np.logical_and(s1, s2).sum()) / (smooth + s1.sum() + s2.sum())
+
+
+def dice_all(y_true, y_pred, smooth=1.0, n_classes=None, ignore_zero=True, skip_if_no_y=False):
+    """mpunet/evaluate/metrics.py:26-52 -- same positional order as the reference: per class
+    (smooth + 2 n(A&B)) / (smooth + n(A) + n(B)), NaN where the class is in neither volume (or not in y_true
+    with skip_if_no_y); classes = unique(y_true) when n_classes is None. Host integers (the parity metric)."""
     y_true = y_true.cpu().numpy() if torch.is_tensor(y_true) else np.asarray(y_true)
     y_pred = y_pred.cpu().numpy() if torch.is_tensor(y_pred) else np.asarray(y_pred)
-    classes = np.arange(max(2, n_classes))
+    classes = np.unique(y_true) if n_classes is None else np.arange(max(2, n_classes))
     if ignore_zero:
-        classes = classes[classes != 0]
+        classes = classes[np.where(classes != 0)]
     out = np.full(classes.shape, np.nan, dtype=np.float32)
     for i, c in enumerate(classes):
-        s1, s2 = (y_true == c), (y_pred == c)
-        n1, n2 = int(s1.sum()), int(s2.sum())
-        if n1 or n2:
-            out[i] = (smooth + 2 * int(np.logical_and(s1, s2).sum())) / (smooth + n1 + n2)
+        s1 = y_true == c
+        if skip_if_no_y and not np.any(s1):
+            continue
+        s2 = y_pred == c
+        if np.any(s1) or np.any(s2):
+            out[i] = dice(s1, s2, smooth=smooth)
     return out

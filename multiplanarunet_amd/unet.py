@@ -412,6 +412,7 @@ class UNet:
             _lib.call("mpu_unet_backward_events", self._h, B, _lib.ptr(y), _lib.ptr(sw), _lib.ptr(self.params),
                       _lib.ptr(self.packed), _lib.ptr(self.bn_state), _lib.ptr(self._ws), _lib.ptr(self.grads),
                       _lib.ptr(loss), arr, len(ready_events), _lib.stream_ptr())
+        self._ready_events_fresh = ready_events is not None      # the DP hook falls back to a full stream wait otherwise
         return probs, loss
 
     def _add_l2(self, want_loss=False):

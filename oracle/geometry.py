@@ -293,14 +293,16 @@ def pred_to_class(t):
     return t.argmax(-1).astype(np.uint8)
 
 
-def dice_all(y_true, y_pred, n_classes, smooth=1.0, ignore_zero=True):
-    """mpunet/evaluate/metrics.py:13-52 (dice, dice_all)."""
-    classes = np.arange(max(2, n_classes))
+def dice_all(y_true, y_pred, smooth=1.0, n_classes=None, ignore_zero=True, skip_if_no_y=False):
+    """mpunet/evaluate/metrics.py:13-52 (dice, dice_all), same argument order."""
+    classes = np.unique(y_true) if n_classes is None else np.arange(max(2, n_classes))
     if ignore_zero:
         classes = classes[classes != 0]
     out = np.full(classes.shape, np.nan, dtype=np.float32)
     for i, c in enumerate(classes):
         s1 = (y_true == c).ravel()
+        if skip_if_no_y and not s1.any():
+            continue
         s2 = (y_pred == c).ravel()
         if s1.any() or s2.any():
             out[i] = (smooth + 2 * np.logical_and(s1, s2).sum()) / \

@@ -71,3 +71,30 @@ def test_plane_basis_fast_agrees_with_reference_construction():
         b = np.array(plane_basis_fast(v, nz)).reshape(3, 3)
         assert np.abs(a - b).max() < 1e-6
         assert np.abs(b.T @ b - np.eye(3)).max() < 1e-6          # orthonormal
+
+
+def test_audited_hparams_are_persisted_and_required(tmp_path):
+    """Auditor write-back: dim / real_space_span / n_channels / n_classes land in train_hparams.yaml at train time;
+    predict / train_fusion refuse to re-audit (mpunet/bin/train.py:210-228)."""
+    (tmp_path / "train_hparams.yaml").write_text(
+        "build:\n  model_class_name: UNet\n  complexity_factor: 1\nfit:\n  batch_size: 8\n__VERSION__: Null\n")
+    hp = C.load_hparams(str(tmp_path))
+    with pytest.raises(RuntimeError) as e:
+        C.require_audited_hparams(hp, "mp predict")
+    assert "build.dim" in str(e.value) and "fit.real_space_span" in str(e.value)
+    hp["build"].update(dim=64, n_channels=1, n_classes=3)
+    hp["fit"]["real_space_span"] = np.float64(63.5)
+    assert C.save_audited_hparams(str(tmp_path), hp)
+    assert not C.save_audited_hparams(str(tmp_path), hp)               # idempotent
+    hp2 = C.load_hparams(str(tmp_path))
+    C.require_audited_hparams(hp2, "mp predict")
+    assert hp2["build"]["dim"] == 64 and hp2["build"]["n_classes"] == 3 and hp2["build"]["n_channels"] == 1
+    assert hp2["fit"]["real_space_span"] == 63.5 and hp2["fit"]["batch_size"] == 8
+    assert hp2["build"]["complexity_factor"] == 1                      # untouched keys survive the rewrite
+
+
+def test_fusion_weights_belong_to_one_checkpoint(tmp_path):
+    m = str(tmp_path / "model")
+    p = C.fusion_weights_path(m, os.path.join(m, "@epoch_07_val_dice_0.80011.npz"))
+    assert p == os.path.join(m, "fusion_weights", "@epoch_07_val_dice_0.80011_fusion_weights.npz")
+    assert C.fusion_weights_path(m, os.path.join(m, "model_weights.npz")).endswith("model_weights_fusion_weights.npz")

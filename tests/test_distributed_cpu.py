@@ -82,6 +82,12 @@ def _worker(rank, world, port, q):
     zs, (lo, hi) = D.reduce_scatter_slabs(z.clone())
     exp = (torch.ones((X, 2, 3, 2)) * 3 + 2 * torch.arange(X).reshape(X, 1, 1, 1))[lo:hi]
     ok3 = torch.equal(zs, exp)
+    # ragged X through the padded equal-slab layout RCCL's reduce_scatter_tensor needs (all-reduce stands in on gloo)
+    for Xr in (7, 9, 2, 1):
+        zr = torch.ones((Xr, 2, 3)) * (rank + 1) + torch.arange(Xr).reshape(Xr, 1, 1)
+        zp, (plo, phi) = D.reduce_scatter_slabs(zr.clone(), force_pad=True)
+        ok3 = ok3 and (plo, phi) == D.slab_bounds(Xr, world)[rank] and \
+            torch.equal(zp, (torch.ones((Xr, 2, 3)) * 3 + 2 * torch.arange(Xr).reshape(Xr, 1, 1))[plo:phi])
     lab = zs[..., 0].to(torch.uint8)
     full = D.all_gather_slabs(lab, X)
     ok3 = ok3 and full.shape == (X, 2, 3) and torch.equal(full, (3 + 2 * torch.arange(X)).reshape(X, 1, 1).expand(X, 2, 3).to(torch.uint8))

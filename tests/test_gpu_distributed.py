@@ -37,21 +37,38 @@ def _worker(rank, world, port, q):
     got2 = D.multi_view_predict_sharded(model, v, views, Dv, float(Dv), None, sum_fusion=True, batch_size=8)
     _, ref2 = multi_view_predict(model, v, views, Dv, float(Dv), None, sum_fusion=True, batch_size=8)
     ok_pred = ok_pred and bool((got2 != ref2).float().mean().item() <= 1e-4)
-    # data parallel: rank-specific batches, gradients summed, weights stay identical
-    m2 = UNet(n_classes=K, dim=32, depth=2, dtype="f32", logger=quiet, seed=10 + rank, device=dev)
-    D.DataParallelTrainer(m2)                              # broadcasts rank 0's weights
+    # the literal all-gather-of-per-view-volumes exchange gives the same label volume (ties aside)
+    got3 = D.multi_view_predict_sharded(model, v, views, Dv, float(Dv), fm, batch_size=8, exchange="all_gather")
+    ok_pred = ok_pred and tuple(got3.shape) == tuple(ref.shape) and bool((got3 != ref).float().mean().item() <= 1e-4)
+    got4 = D.multi_view_predict_sharded(model, v, views, Dv, float(Dv), None, sum_fusion=True, batch_size=8,
+                                        exchange="all_gather")
+    ok_pred = ok_pred and bool((got4 != ref2).float().mean().item() <= 1e-4)
+    # data parallel: rank-specific batches, gradients summed, weights stay identical. Both the overlapped path
+    # (ready events from mpu_unet_backward_events, buckets reduced on the comm stream while the backward pass
+    # still runs) and the plain path go through model.train_step and must give the same gradients and weights.
     x = np.random.RandomState(100 + rank).randn(2, 32, 32, 1).astype(np.float32)
     y = np.random.RandomState(200 + rank).randint(0, K, (2, 32 * 32, 1)).astype(np.uint8)
-    m2.forward_backward(x, y, None)
-    local = m2.grads.clone()
-    m2._grad_hook(m2.grads)
-    gathered = [torch.zeros_like(local) for _ in range(world)]
-    dist.all_gather(gathered, local)
-    ok_dp = torch.allclose(m2.grads, sum(gathered), rtol=1e-5, atol=1e-6)
-    m2.apply_gradients()
-    ps = [torch.zeros_like(m2.params) for _ in range(world)]
-    dist.all_gather(ps, m2.params)
-    ok_dp = ok_dp and torch.equal(ps[0], ps[1])
+    outs = []
+    for overlap in (True, False):
+        m2 = UNet(n_classes=K, dim=32, depth=2, dtype="f32", logger=quiet, seed=10 + rank, device=dev)
+        t = D.DataParallelTrainer(m2, bucket_bytes=1 << 16, overlap=overlap)     # small buckets: several ready points used
+        assert t.overlap == overlap and (not overlap or len(t.buckets) >= 3)
+        m2.forward_backward(x, y, None)                    # local gradients (no hook)
+        local = m2.grads.clone()
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        m2b = UNet(n_classes=K, dim=32, depth=2, dtype="f32", logger=quiet, seed=10 + rank, device=dev)
+        D.DataParallelTrainer(m2b, bucket_bytes=1 << 16, overlap=overlap)
+        for _ in range(2):
+            m2b.train_step(x, y, None, want_loss=False)    # hook + Adam inside; two steps: events are re-recorded
+        ps = [torch.zeros_like(m2b.params) for _ in range(world)]
+        dist.all_gather(ps, m2b.params)
+        # after forward_backward without events the hook must fall back to a full stream wait (stale events)
+        m2._grad_hook(m2.grads)
+        torch.cuda.synchronize()
+        ok = torch.allclose(m2.grads, sum(gathered), rtol=1e-5, atol=1e-6) and torch.equal(ps[0], ps[1])
+        outs.append((ok, m2b.params.clone(), m2b.grads.clone()))
+    ok_dp = outs[0][0] and outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
     q.put((rank, ok_pred, ok_dp))
     dist.destroy_process_group()
 
@@ -68,3 +85,50 @@ def test_two_ranks_sharded_predict_and_dp_training():
         p.join(60)
     for r in res:
         assert r[1] and r[2], r
+
+
+def _nccl_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("MPU_SHARE_GPU", None); os.environ.pop("MPU_DIST_BACKEND", None)
+    import torch.distributed as dist
+    from multiplanarunet_amd import distributed as D
+    from multiplanarunet_amd.unet import UNet
+    quiet = lambda *a, **k: None
+    r, w, dev = D.init_from_env()                          # backend nccl == RCCL, one GPU per rank
+    K = 3
+    x = np.random.RandomState(100 + rank).randn(2, 32, 32, 1).astype(np.float32)
+    y = np.random.RandomState(200 + rank).randint(0, K, (2, 32 * 32, 1)).astype(np.uint8)
+    res = []
+    for overlap in (True, False):
+        m = UNet(n_classes=K, dim=32, depth=2, dtype="f32", logger=quiet, seed=10 + rank, device=dev)
+        D.DataParallelTrainer(m, bucket_bytes=1 << 16, overlap=overlap)
+        for _ in range(3):
+            m.train_step(x, y, None, want_loss=False)
+        ps = [torch.zeros_like(m.params) for _ in range(world)]
+        dist.all_gather(ps, m.params)
+        res.append((torch.equal(ps[0], ps[1]), m.params.clone()))
+    ok = res[0][0] and res[1][0] and torch.allclose(res[0][1], res[1][1], rtol=0, atol=0)
+    # ragged reduce-scatter over RCCL (padded equal slabs)
+    z = torch.ones((7, 2, 3), device=dev) * (rank + 1) + torch.arange(7, device=dev).reshape(7, 1, 1)
+    zs, (lo, hi) = D.reduce_scatter_slabs(z.clone())
+    ok = ok and torch.equal(zs.cpu(), (torch.ones((7, 2, 3)) * 3 + 2 * torch.arange(7).reshape(7, 1, 1))[lo:hi])
+    q.put((rank, ok, dist.get_backend()))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_rccl_dp_training():
+    """RCCL proper: needs one GPU per rank (skipped on the 1-GPU test box; runs on a multi-GPU node)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 visible GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert r[1] and r[2] == "nccl", r

@@ -109,3 +109,31 @@ def test_axis_closed_forms_reproduce_the_arrays_bitwise(golden):
     assert n_closed >= 15
     odd = np.array([0.0, 1.0, 2.5, 7.0])                 # non-uniform axis: no closed form claimed
     assert _lib.make_axis(odd).kind == 0
+
+
+def test_product_dice_all_and_pred_to_class_match_reference_goldens(golden):
+    """G6 on the PRODUCT functions (reference argument order: y_true, y_pred, smooth, n_classes, ...;
+    mpunet/evaluate/metrics.py:26-52, mpunet/utils/utils.py:311-328)."""
+    import inspect
+    import torch
+    a, b = golden["g6_a"], golden["g6_b"]
+    assert list(inspect.signature(I.dice_all).parameters)[:6] == \
+        ["y_true", "y_pred", "smooth", "n_classes", "ignore_zero", "skip_if_no_y"]
+    np.testing.assert_array_equal(I.dice_all(a, b, 1.0, 5), golden["g6_dice_5"])
+    np.testing.assert_array_equal(I.dice_all(a, b, n_classes=5, ignore_zero=True), golden["g6_dice_5"])
+    np.testing.assert_array_equal(I.dice_all(a, b, n_classes=4, ignore_zero=False), golden["g6_dice_4_with0"])
+    np.testing.assert_array_equal(I.dice_all(torch.from_numpy(a), torch.from_numpy(b), n_classes=5), golden["g6_dice_5"])
+    # n_classes=None: the classes present in y_true; skip_if_no_y leaves NaN for classes absent from y_true
+    d = I.dice_all(a, b, ignore_zero=False)
+    assert d.shape == np.unique(a).shape and d.dtype == np.float32
+    only_pred = np.where(b == b.max(), 7, b)
+    assert np.isnan(I.dice_all(a, only_pred, n_classes=8, skip_if_no_y=True)[-1])
+    assert not np.isnan(I.dice_all(a, only_pred, n_classes=8)[-1])
+    p = golden["g6_probs"]
+    got = I.pred_to_class(p, img_dims=3)
+    assert got.dtype == np.uint8
+    np.testing.assert_array_equal(got, golden["g6_cls"])
+    np.testing.assert_array_equal(I.pred_to_class(torch.from_numpy(p)).numpy(), golden["g6_cls"])
+    ints = golden["g6_cls"]
+    assert I.pred_to_class(ints) is ints                                   # integer maps pass through
+    np.testing.assert_array_equal(I.pred_to_class(p[..., :1]), p[..., :1] >= 0.5)

@@ -77,8 +77,8 @@ def test_g5_map_real_space_pred(golden, an):
 
 def test_g6_dice_and_class(golden):
     a, b = golden["g6_a"], golden["g6_b"]
-    np.testing.assert_array_equal(G.dice_all(a, b, 5), golden["g6_dice_5"])
-    np.testing.assert_array_equal(G.dice_all(a, b, 4, ignore_zero=False),
+    np.testing.assert_array_equal(G.dice_all(a, b, n_classes=5), golden["g6_dice_5"])
+    np.testing.assert_array_equal(G.dice_all(a, b, n_classes=4, ignore_zero=False),
                                   golden["g6_dice_4_with0"])
     np.testing.assert_array_equal(G.pred_to_class(golden["g6_probs"]),
                                   golden["g6_cls"])
@@ -101,5 +101,5 @@ def test_g7_round_trip(golden, an):
             ref = golden["g7_map_" + key]
             assert (got != ref).mean() <= 1e-3
             if dim == 32 and an == "ident" and v in (0, 1):
-                d = G.dice_all(lab, got, 3)
+                d = G.dice_all(lab, got, n_classes=3)
                 assert np.all(d > 0.9), d

@@ -70,3 +70,33 @@ def test_no_cpu_execution_path():
     m = UNet(n_classes=3, dim=16, depth=1, logger=quiet, device="cpu")
     with pytest.raises(MpuError):
         m.predict_on_batch(np.zeros((1, 16, 16, 1), np.float32))
+
+
+def test_flat_layout_follows_keras_creation_order_and_ready_points():
+    """Each block's BatchNormalization gamma/beta sit next to that block's convs in the flat parameter buffer, so
+    every tensor lies at or above the gradient-ready point of its block and below the previous point
+    (mpu_unet_grad_ready_points: head, up blocks last->first, bottom, encoder levels last->first)."""
+    from multiplanarunet_amd.unet import UNet
+    for depth, cf in ((4, 1), (2, 2), (1, 1)):
+        m = UNet(n_classes=3, dim=32 * 2 ** max(0, depth - 2), depth=depth, complexity_factor=cf, device="cpu",
+                 logger=lambda *a, **k: None)
+        pts = m.grad_ready_points()
+        assert len(pts) == 2 * depth + 2 and pts == sorted(pts, reverse=True) and pts[-1] == 0
+        n = m.params.numel()
+        blocks = ["conv2d"] + ["upsample_L%d" % j for j in range(depth - 1, -1, -1)] + ["bottom"] + \
+                 ["encoder_L%d" % i for i in range(depth - 1, -1, -1)]
+        off_sorted = []
+        for nm in m._order:
+            kind, off, ps, ls = m._tensors[nm]
+            if kind != 0:
+                continue
+            off_sorted.append((off, nm))
+            k = [i for i, b in enumerate(blocks) if nm.startswith(b + "_") or nm.startswith(b + "/")]
+            assert len(k) == 1, nm
+            k = k[0]
+            hi = n if k == 0 else pts[k - 1]
+            assert pts[k] <= off and off + int(np.prod(ps)) <= hi, (nm, off, pts, k)
+        # trainable tensors appear in the buffer in Keras creation order (SURVEY Appendix B)
+        order = [nm for _, nm in sorted(off_sorted)]
+        keras = [nm for nm in m._keras_order() if not nm.endswith(("moving_mean", "moving_variance"))]
+        assert order == keras
