@@ -325,6 +325,14 @@ int mpu_conv2d_wgrad_first_layer(int32_t dtype, const void* d_x, int32_t n_image
 int mpu_profile_enable(int32_t on);
 int mpu_profile_summary(int32_t kind, double* total_ms, double* total_flops, int64_t* launches);
 
+/* Test aid (no reference counterpart): when enabled, every convolution / weight-gradient launch appends one text
+ * line naming the kernel schedule the dispatcher chose for the layer shape ("conv halo mode=0 B=.. H=.. W=.. Cin=..
+ * Cout=.. dgrad=0", "wgrad taps ... ksplit=.."), so that parity tests at the BASELINE shapes can assert that the
+ * schedules bench.py times are the ones they checked. mpu_schedule_log_enable(0|1) clears the log;
+ * mpu_schedule_log_read copies it (NUL-terminated, truncated to cap) and returns its full length. */
+int mpu_schedule_log_enable(int32_t on);
+int64_t mpu_schedule_log_read(char* buf, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -591,17 +591,24 @@ static int halo_on() {
 
 int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
     if (a.stats_rows) *a.stats_rows = 0;          // set by the schedules that produce the fused BN statistics
+    auto note = [&](const char* sched) {
+        if (sched_log_on())
+            sched_note("conv %s mode=%d B=%d H=%d W=%d Cin=%d Cout=%d dgrad=%d", sched, mode, a.B, a.Ho, a.Wo,
+                       a.C0 + a.C1, a.Cout, a.bias ? 0 : 1);
+    };
     if (conv_impl() == 1) {
         if (halo_on()) {
             const int c = try_conv_c8(dtype, mode, a, st);
-            if (c != 0) return c < 0 ? c : MPU_OK;
+            if (c != 0) { note("c8"); return c < 0 ? c : MPU_OK; }
             const int w = try_conv_ws(dtype, mode, a, st);
-            if (w != 0) return w < 0 ? w : MPU_OK;
+            if (w != 0) { note("ws"); return w < 0 ? w : MPU_OK; }
             const int h = try_conv_halo(dtype, mode, a, st);
-            if (h != 0) return h < 0 ? h : MPU_OK;
+            if (h != 0) { note("halo"); return h < 0 ? h : MPU_OK; }
         }
+        note("glds");
         return launch_conv_glds(dtype, mode, a, st);
     }
+    note("regs");
 #define MPU_CONV_CASE(TT)                                                          \
     switch (mode) {                                                                \
         case CONV3: return launch_conv_mode<TT, CONV3>(a, st);                     \
@@ -651,7 +658,10 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
     const int dt_ = sizeof(T) == 2 ? MPU_BF16 : MPU_F32;
     if (conv_impl() == 1) {                      // first layer: 1-2 image channels in 8-channel records
         const int c8 = try_wgrad_c8(dt_, MODE, a, dW, st);
-        if (c8 != 0) return c8 < 0 ? c8 : MPU_OK;
+        if (c8 != 0) {
+            if (sched_log_on()) sched_note("wgrad c8 mode=%d B=%d H=%d W=%d Cin=%d Cout=%d ksplit=1", MODE, a.B, a.Ho, a.Wo, Cin, a.Cout);
+            return c8 < 0 ? c8 : MPU_OK;
+        }
     }
     TapsPlan taps; taps.use = 0;
     if (conv_impl() == 1) taps = wgrad_taps_plan(dt_, MODE, a.B, a.Ho, a.Wo, a.C0, a.C1, a.Cout);
@@ -674,6 +684,9 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
     if (taps.use) { g_ = launch_wgrad_taps(MODE, a, taps, st); if (g_) return g_; g_ = 1; }
     else if (conv_impl() == 1) g_ = try_wgrad_glds(dt_, MODE, a, st);
     if (g_ < 0) return g_;
+    if (sched_log_on())
+        sched_note("wgrad %s mode=%d B=%d H=%d W=%d Cin=%d Cout=%d ksplit=%d", taps.use ? "taps" : (g_ == 1 ? "glds" : "regs"),
+                   MODE, a.B, a.Ho, a.Wo, Cin, a.Cout, a.ksplit);
     if (g_ == 1) big = true;                      // launched by an LDS-DMA kernel
     else
     if constexpr (sizeof(T) == 2) {

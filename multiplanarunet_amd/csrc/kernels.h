@@ -42,6 +42,8 @@ enum { PROF_CONV = 0, PROF_WGRAD = 1, PROF_KINDS = 2 };
 bool prof_on();
 void prof_begin(int kind, double flops, hipStream_t st);
 void prof_end(hipStream_t st);
+bool sched_log_on();                            // schedule log (mpu_schedule_log_*): one line per conv / wgrad launch
+void sched_note(const char* fmt, ...);
 
 int  launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // dispatches on MPU_CONV_IMPL
 int  launch_conv_glds(int dtype, int mode, const ConvArgs& a, hipStream_t st);  // LDS-DMA variant (conv_glds.hip)

@@ -1,6 +1,8 @@
 // Optional per-launch timing of the MFMA kernels with HIP events recorded on the
 // launch stream (bench.py's roofline leg). Off by default: zero overhead.
 #include <vector>
+#include <string>
+#include <stdarg.h>
 #include "kernels.h"
 
 namespace mpu {
@@ -22,6 +24,16 @@ void prof_begin(int kind, double flops, hipStream_t st) {
     g_recs.push_back(r);
 }
 void prof_end(hipStream_t st) { (void)hipEventRecord(g_recs.back().b, st); }
+
+// ---- schedule log: which kernel schedule each conv / wgrad launch took (tests assert the intended dispatch) ----
+namespace { bool g_sched_on = false; std::string g_sched; }
+bool sched_log_on() { return g_sched_on; }
+void sched_note(const char* fmt, ...) {
+    if (!g_sched_on) return;
+    char buf[256];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_sched += buf; g_sched += '\n';
+}
 }  // namespace mpu
 
 using namespace mpu;
@@ -51,6 +63,21 @@ int mpu_profile_summary(int32_t kind, double* total_ms, double* total_flops, int
     if (total_flops) *total_flops = fl;
     if (launches) *launches = n;
     return MPU_OK;
+}
+
+// Schedule log: one text line per conv / wgrad launch, "<family> <schedule> mode=.. B=.. H=.. W=.. Cin=.. Cout=.. ksplit=..".
+int mpu_schedule_log_enable(int32_t on) {
+    g_sched.clear();
+    g_sched_on = on != 0;
+    return MPU_OK;
+}
+// Copies the log (NUL-terminated, truncated to cap) and returns its full length in bytes.
+int64_t mpu_schedule_log_read(char* buf, int64_t cap) {
+    if (buf && cap > 0) {
+        const size_t n = g_sched.size() < (size_t)(cap - 1) ? g_sched.size() : (size_t)(cap - 1);
+        memcpy(buf, g_sched.data(), n); buf[n] = 0;
+    }
+    return (int64_t)g_sched.size();
 }
 
 }  // extern "C"

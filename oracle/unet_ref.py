@@ -116,29 +116,33 @@ def _bn(x, p, name, training, new_stats):
 
 
 def forward(p, x_nhwc, depth=4, training=False, out_activation="softmax",
-            new_stats=None, taps=None):
-    """U-Net forward on torch params p (same keys as init_weights). Returns NHWC."""
-    x = x_nhwc.permute(0, 3, 1, 2)
+            new_stats=None, taps=None, store=None):
+    """U-Net forward on torch params p (same keys as init_weights). Returns NHWC.
+    store: optional callable applied wherever the HIP path writes an activation to memory (network input, every
+    conv+ReLU output, every BatchNorm output, the pooled tensor, both concat inputs) -- identity for the
+    reference arithmetic; bf16_matched_grads passes a round-to-bf16 node to model the bf16 storage mode."""
+    st = store if store is not None else (lambda t: t)
+    x = st(x_nhwc.permute(0, 3, 1, 2))
     skips = []
     for i in range(depth):
         n = "encoder_L%d" % i
-        x = _conv(x, p[n + "_conv1/kernel"], p[n + "_conv1/bias"])
-        x = _conv(x, p[n + "_conv2/kernel"], p[n + "_conv2/bias"])
-        x = _bn(x, p, n + "_BN", training, new_stats)
+        x = st(_conv(x, p[n + "_conv1/kernel"], p[n + "_conv1/bias"]))
+        x = st(_conv(x, p[n + "_conv2/kernel"], p[n + "_conv2/bias"]))
+        x = st(_bn(x, p, n + "_BN", training, new_stats))
         skips.append(x)
-        x = F.max_pool2d(x, 2, 2)
-    x = _conv(x, p["bottom_conv1/kernel"], p["bottom_conv1/bias"])
-    x = _conv(x, p["bottom_conv2/kernel"], p["bottom_conv2/bias"])
-    x = _bn(x, p, "bottom_BN", training, new_stats)
+        x = st(F.max_pool2d(x, 2, 2))
+    x = st(_conv(x, p["bottom_conv1/kernel"], p["bottom_conv1/bias"]))
+    x = st(_conv(x, p["bottom_conv2/kernel"], p["bottom_conv2/bias"]))
+    x = st(_bn(x, p, "bottom_BN", training, new_stats))
     for i in range(depth):
         n = "upsample_L%d" % i
         x = F.interpolate(x, scale_factor=2, mode="nearest")
-        x = _conv(x, p[n + "_conv1/kernel"], p[n + "_conv1/bias"])
-        x = _bn(x, p, n + "_BN1", training, new_stats)
-        x = torch.cat([skips[depth - 1 - i], x], dim=1)      # skip first
-        x = _conv(x, p[n + "_conv2/kernel"], p[n + "_conv2/bias"])
-        x = _conv(x, p[n + "_conv3/kernel"], p[n + "_conv3/bias"])
-        x = _bn(x, p, n + "_BN2", training, new_stats)
+        x = st(_conv(x, p[n + "_conv1/kernel"], p[n + "_conv1/bias"]))
+        x = st(_bn(x, p, n + "_BN1", training, new_stats))
+        x = torch.cat([st(skips[depth - 1 - i]), st(x)], dim=1)      # skip first
+        x = st(_conv(x, p[n + "_conv2/kernel"], p[n + "_conv2/bias"]))
+        x = st(_conv(x, p[n + "_conv3/kernel"], p[n + "_conv3/bias"]))
+        x = st(_bn(x, p, n + "_BN2", training, new_stats))
         if taps is not None:
             taps[n + "_BN2"] = x.permute(0, 2, 3, 1)
     z = _conv(x, p["conv2d/kernel"], p["conv2d/bias"], relu=False)
@@ -257,3 +261,43 @@ def bf16_autograd_grads(w, x, y, sample_w, depth=4):
     loss = keras_sparse_ce(probs.float(), yt, torch.tensor(np.asarray(sample_w), dtype=torch.float32))
     loss.sum().backward()
     return {k: p[k].grad.float().numpy() for k in trainable_names(w)}
+
+
+class _StoreBF16(torch.autograd.Function):
+    """A tensor written to memory as bf16 (round-to-nearest-even) in the forward pass AND its gradient written
+    as bf16 in the backward pass; arithmetic around it stays fp32 (the MFMA accumulates in fp32)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+def bf16_matched_step(w, x, y, sample_w, depth=4, training=True):
+    """
+    Model of the bf16 STORAGE mode of the HIP path (dtype="bf16"), NOT of the reference: fp32 arithmetic with a
+    round-to-bf16 at exactly the points where the kernels store a tensor -- activations and their gradients
+    (forward(store=...)), and the 3x3 / 2x2 conv kernels as MFMA operands (straight-through: the gradient lands
+    on the fp32 master weight). Biases, BatchNorm parameters and the 1x1 head stay fp32, as in the kernels.
+    Against this model the bf16 kernels may differ only by fp32 summation order (which now and then flips one
+    bf16 rounding) and by the tap-combined up-conv data-gradient weights (rounded after combining), so per-tensor
+    gradient bounds can be tight; the comparison against the f64 oracle measures the storage mode itself.
+    Returns dict(probs, loss, grads).
+    """
+    p = to_torch(w, torch.float32, requires_grad=True)
+    q = {}
+    for k, t in p.items():
+        if k.endswith("/kernel") and not k.startswith("conv2d/"):
+            q[k] = t + (t.detach().to(torch.bfloat16).to(torch.float32) - t.detach())
+        else:
+            q[k] = t
+    B, H, W = x.shape[:3]
+    yt = torch.tensor(np.asarray(y).reshape(B, H, W).astype(np.int64))
+    probs = forward(q, torch.tensor(x, dtype=torch.float32), depth, training, "softmax", {}, store=_StoreBF16.apply)
+    loss = keras_sparse_ce(probs, yt, torch.tensor(np.asarray(sample_w), dtype=torch.float32))
+    loss.sum().backward()
+    return {"probs": probs.detach().numpy(), "loss": loss.detach().numpy(),
+            "grads": {k: p[k].grad.numpy() for k in trainable_names(w)}}
