@@ -301,6 +301,14 @@ int mpu_conv2d_igemm(int32_t dtype, int32_t mode, const void* d_in0, int32_t C0,
                      int64_t w_tap_stride, int32_t w_row_stride, const float* d_bias,
                      const void* d_mask, void* d_out, int32_t B, int32_t Ho, int32_t Wo,
                      int32_t Cout, int32_t relu, void* stream);
+/* Same, with a caller-owned scratch buffer: layers with few output tiles and a long reduction (the deep U-Net levels)
+ * split K over workgroups and need room for their f32 partial sums (8 * B*Ho*Wo * Cout floats always suffice; with
+ * less the split is reduced). mpu_unet_forward / backward pass their workspace the same way. */
+int mpu_conv2d_igemm_ws(int32_t dtype, int32_t mode, const void* d_in0, int32_t C0,
+                     const void* d_in1, int32_t C1, const void* d_w_packed,
+                     int64_t w_tap_stride, int32_t w_row_stride, const float* d_bias,
+                     const void* d_mask, void* d_out, int32_t B, int32_t Ho, int32_t Wo,
+                     int32_t Cout, int32_t relu, float* d_workspace, int64_t workspace_floats, void* stream);
 int64_t mpu_conv2d_wgrad_workspace_floats(int32_t mode, int32_t Cin, int32_t Cout, int64_t M);
 int mpu_conv2d_wgrad(int32_t dtype, int32_t mode, const void* d_x0, int32_t C0, const void* d_x1,
                      int32_t C1, const void* d_dz, int32_t Cout, int32_t B, int32_t Ho, int32_t Wo,
@@ -315,6 +323,14 @@ int64_t mpu_conv2d_wgrad_first_layer_workspace_floats(int32_t Cout, int64_t M);
 int mpu_conv2d_wgrad_first_layer(int32_t dtype, const void* d_x, int32_t n_image_channels, const void* d_dz,
                                  int32_t Cout, int32_t B, int32_t H, int32_t W, float* d_workspace, float* d_dW,
                                  float* d_db, void* stream);
+
+/* Epoch-end validation counting (Validation._count_cm_elements_from_queue, mpunet/callbacks/validation.py:115-125):
+ * p = argmax over the class axis of d_pred [n][n_classes] (f32 scores; first maximum, NaN counts as the maximum, as
+ * np.argmax), then per class TP = #(y == p == c), relevant = #(y == c), selected = #(p == c), ADDED to
+ * d_counts [3][n_classes] (int64; the caller zeroes it at the start of an epoch and may SUM all-reduce it across
+ * replicas). Targets >= n_classes count for no class. Integer work: exact and order-independent. 1 <= n_classes <= 16. */
+int mpu_validation_count(const float* d_pred, const uint8_t* d_y, int64_t n, int32_t n_classes, int64_t* d_counts,
+                         void* stream);
 
 /* Measurement aid (bench.py roofline leg; no reference counterpart): when
  * enabled, every MFMA convolution launch is bracketed by HIP events recorded on

@@ -117,11 +117,14 @@ _SIGS = {
     "mpu_conv2d_pack_weights": (C.c_int, [i32, i32, c_p, i32, i32, c_p, c_p, c_p]),
     "mpu_conv2d_igemm": (C.c_int, [i32, i32, c_p, i32, c_p, i32, c_p, i64, i32, c_p, c_p, c_p,
                                    i32, i32, i32, i32, i32, c_p]),
+    "mpu_conv2d_igemm_ws": (C.c_int, [i32, i32, c_p, i32, c_p, i32, c_p, i64, i32, c_p, c_p, c_p,
+                                      i32, i32, i32, i32, i32, c_p, i64, c_p]),
     "mpu_conv2d_wgrad_workspace_floats": (i64, [i32, i32, i32, i64]),
     "mpu_conv2d_wgrad_first_layer_workspace_floats": (i64, [i32, i64]),
     "mpu_conv2d_wgrad_first_layer": (C.c_int, [i32, c_p, i32, c_p, i32, i32, i32, i32, c_p, c_p, c_p, c_p]),
     "mpu_profile_enable": (C.c_int, [i32]),
     "mpu_profile_summary": (C.c_int, [i32, C.POINTER(f64), C.POINTER(f64), C.POINTER(i64)]),
+    "mpu_validation_count": (C.c_int, [c_p, c_p, i64, i32, c_p, c_p]),
     "mpu_schedule_log_enable": (C.c_int, [i32]),
     "mpu_schedule_log_read": (i64, [C.c_char_p, i64]),
     "mpu_conv2d_wgrad": (C.c_int, [i32, i32, c_p, i32, c_p, i32, c_p, i32, i32, i32, i32, c_p, c_p, c_p]),

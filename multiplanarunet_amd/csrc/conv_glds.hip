@@ -13,6 +13,7 @@
 //    num_records, for which the DMA writes zeros (verified on hardware, tools/probe_glds3.hip).
 //
 // Pipeline: NSTAGE LDS stages; the loads of tile t+NSTAGE-1 are issued before the MFMAs of tile t.
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace mpu {
@@ -478,6 +479,27 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     }
 }
 
+// second pass of a split-K launch: sum the partials in fixed order, apply the epilogue (and the fused BN statistics)
+template <typename T>
+static int launch_splitk_finish(const ConvArgs& a, int ks, long M, hipStream_t st) {
+    long work = M * a.Cout / (16 / (long)sizeof(T));
+    long blocks = (work + 255) / 256; if (blocks > 4096) blocks = 4096;
+    const int cpr = a.Cout / (16 / (int)sizeof(T));
+    // fused BN statistics: <= 256 blocks, every thread keeps its channel group (256 % cpr == 0, cpr <= 256)
+    const bool st_ok = a.stats && a.stats_rows && cpr <= 256 && 256 % cpr == 0 && a.Cout % (16 / (int)sizeof(T)) == 0;
+    if (st_ok) {
+        if (blocks > 256) blocks = 256;
+        if (blocks * 2 * a.Cout > a.stats_cap) blocks = a.stats_cap / (2 * a.Cout);
+        *a.stats_rows = (int)blocks;
+        splitk_finish_kernel<T, true><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
+                                                                        a.relu, a.post_scale, a.post_shift, (T*)a.out, a.stats);
+    } else {
+        splitk_finish_kernel<T, false><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
+                                                                         a.relu, a.post_scale, a.post_shift, (T*)a.out, nullptr);
+    }
+    return launch_ok();
+}
+
 template <typename T, int MODE, int BN, int BM, int WN, int WM>
 static int launch_glds_cfg(const ConvArgs& a_in, hipStream_t st) {
     using Cfg = GldsCfg<T, BN, BM>;
@@ -504,32 +526,352 @@ static int launch_glds_cfg(const ConvArgs& a_in, hipStream_t st) {
     a.ksplit = ks;
     kern<<<dim3((unsigned)tiles, ks), dim3(256), Cfg::SMEM, st>>>(a);
     int rc = launch_ok();
-    if (!rc && ks > 1) {
-        long work = M * a.Cout / (16 / (long)sizeof(T));
-        long blocks = (work + 255) / 256; if (blocks > 4096) blocks = 4096;
-        const int cpr = a.Cout / (16 / (int)sizeof(T));
-        // fused BN statistics: <= 256 blocks, every thread keeps its channel group (256 % cpr == 0, cpr <= 256)
-        const bool st_ok = a.stats && a.stats_rows && cpr <= 256 && 256 % cpr == 0 && a.Cout % (16 / (int)sizeof(T)) == 0;
-        if (st_ok) {
-            if (blocks > 256) blocks = 256;
-            if (blocks * 2 * a.Cout > a.stats_cap) blocks = a.stats_cap / (2 * a.Cout);
-            *a.stats_rows = (int)blocks;
-            splitk_finish_kernel<T, true><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
-                                                                            a.relu, a.post_scale, a.post_shift, (T*)a.out, a.stats);
-        } else {
-            splitk_finish_kernel<T, false><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
-                                                                             a.relu, a.post_scale, a.post_shift, (T*)a.out, nullptr);
-        }
-        rc = launch_ok();
-    }
+    if (!rc && ks > 1) rc = launch_splitk_finish<T>(a, ks, M, st);
     if (prof_on()) prof_end(st);
     return rc;
+}
+
+// ------------------------------------------------------------------------- //
+// conv_pipe_kernel (bf16): the same implicit GEMM for the DEEP U-Net levels (few pixels, long reductions, the
+// weights dominate the traffic), scheduled for ONE workgroup per CU:
+//   * 256-pixel x 128-channel tiles, 8 waves = 2 per SIMD (each a 64 x 64 sub-tile), so that the partner wave's
+//     MFMAs cover a wave's DMA issue and fragment waits; L2->LDS fill per K step = 48 KB per 1024 MFMA cycles
+//     (47 B/clk against the ~62 B/clk a CU can pull: the 128x128 / two-workgroup schedule sits AT that limit);
+//   * three 48-KB LDS stages, the DMA of K step t+2 issued at the start of step t (prefetch distance two steps,
+//     ~2000 cycles of cover instead of ~500: the 2-stage schedule is bound by the DMA round trip);
+//   * MFMA operand fragments double-buffered in registers: the ds_reads of k-step s+1 are issued before the
+//     MFMAs of k-step s, also across the stage boundary (one barrier per 16 MFMAs and wave, placed before the last
+//     k-step of a stage so that the next stage's first fragments are fetched under that k-step's MFMAs);
+//   * 1-D grid decoded m-tile fastest, then n-tile, then K slice, XCD-aware: the workgroups that share a slice of
+//     the weights run on one XCD, so the 19 MB of bottom-level weights are pulled from HBM once.
+// Split-K writes raw f32 partials (splitk_finish_kernel applies the epilogue); ksplit == 1 runs the same staged
+// epilogue as conv_glds_kernel.
+// ------------------------------------------------------------------------- //
+struct PipeCfg {
+    static constexpr int BN = 128, BM = 256, NS = 3;
+    static constexpr int STAGE = (BN + BM) * 128;
+    static constexpr int OROW = BN * 2 + 16;
+    static constexpr int EPI = BM * OROW + 3 * BN * 4;
+    static constexpr int SMEM = NS * STAGE > EPI ? NS * STAGE : EPI;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles_m, int tiles_n) {
+    typedef bf16_t T;
+    constexpr int BN = PipeCfg::BN, BM = PipeCfg::BM, NS = PipeCfg::NS, STAGE = PipeCfg::STAGE;
+    constexpr int EPC = 8, BKE = 64;
+    constexpr int NTAPS = GModeTraits<MODE>::NTAPS, KW = GModeTraits<MODE>::KW;
+    constexpr int GW = 2, GP = 4, NLD = GW + GP;         // 8-row DMA pieces per wave: weights, pixels
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;             // 2 x 4 waves of 64 channels x 64 pixels
+    const int logical = g_xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = logical % tiles_m, r1 = logical / tiles_m;
+    const int nt = r1 % tiles_n, kz = r1 / tiles_n;
+    const int n0 = nt * BN;
+    const long m0 = (long)mt * BM;
+    const int nch0 = (a.C0 + BKE - 1) / BKE, nch1 = (a.C1 + BKE - 1) / BKE;
+    const int nchunks = nch0 + nch1;
+    const int nit_all = NTAPS * nchunks;
+    const int ks = a.ksplit > 1 ? a.ksplit : 1;
+    const int it0 = (int)((long)kz * nit_all / ks);
+    const int nit = (int)((long)(kz + 1) * nit_all / ks) - it0;
+    const int Hi = g_in_h<MODE>(a.Ho), Wi = g_in_h<MODE>(a.Wo);
+    const long M = (long)a.B * a.Ho * a.Wo;
+    constexpr unsigned OOB = 0xfffffff0u;
+    const long npix = (long)a.B * Hi * Wi;
+    const i32x4 rs0 = make_rsrc(a.in0, npix * a.C0 * 2L);
+    const i32x4 rs1 = make_rsrc(a.in1 ? a.in1 : a.in0, a.in1 ? npix * a.C1 * 2L : 0);
+    const i32x4 rsw = make_rsrc(a.w, a.w_elems * 2L);
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+
+    const int lrow = lane >> 3, slot = lane & 7;
+    unsigned wlane[GW]; int wch[GW];
+#pragma unroll
+    for (int g = 0; g < GW; ++g) {
+        const int rl = wave * (BN / 8) + g * 8 + lrow;           // tile-local weight row
+        const int n = n0 + rl;
+        wch[g] = (slot ^ ((rl >> 1) & 7)) * EPC;
+        wlane[g] = n < a.Cout ? (unsigned)((long)n * a.w_row_stride * 2L) + (unsigned)(wch[g] * 2) : OOB;
+    }
+    int pb[GP], py[GP], px[GP], pch[GP];
+#pragma unroll
+    for (int g = 0; g < GP; ++g) {
+        const int rl = wave * (BM / 8) + g * 8 + lrow;           // tile-local pixel row
+        const int m = (int)m0 + rl;                              // (M < 2^31: checked by the launcher)
+        pch[g] = (slot ^ ((rl >> 1) & 7)) * EPC;
+        if (m < (int)M) {
+            const int ox = m % a.Wo, t = m / a.Wo;
+            const int oy = t % a.Ho, b = t / a.Ho;
+            pb[g] = b * Hi * Wi; py[g] = oy; px[g] = ox;
+        } else { pb[g] = -1; py[g] = 0; px[g] = 0; }
+    }
+    // One K step's DMA = 2 weight + 4 pixel pieces per wave, issued in two halves behind the MFMAs of two
+    // different k-steps (branch-free: the concat source is a scalar select of the descriptor, masked lanes get the
+    // out-of-range marker). begin_step() fixes the step's scalars and, on a tap change, the lanes' source pixels.
+    int ptap[GP], cur_tap = -1;
+    int tapN = it0 / nchunks, ccN = it0 % nchunks;
+    unsigned q_soff = 0, q_sbase = 0; int q_room = 0, q_cs = 0, q_cbase = 0; i32x4 q_rs = rs0;
+    auto begin_step = [&](int stage) {
+        const int tap = tapN, cc = ccN;
+        if (++ccN == nchunks) { ccN = 0; ++tapN; }
+        const bool s1 = cc >= nch0;
+        q_cbase = (s1 ? cc - nch0 : cc) * BKE;
+        q_cs = s1 ? a.C1 : a.C0;
+        q_room = q_cs - q_cbase;
+        q_soff = (unsigned)(((long)tap * a.w_tap_stride + (s1 ? a.C0 : 0) + q_cbase) * 2L);
+        q_sbase = lds0 + stage * STAGE;
+        q_rs.x = s1 ? rs1.x : rs0.x; q_rs.y = s1 ? rs1.y : rs0.y; q_rs.z = s1 ? rs1.z : rs0.z; q_rs.w = rs0.w;
+        if (tap != cur_tap) {
+            cur_tap = tap;
+            const int ky = tap / KW, kx = tap % KW;
+#pragma unroll
+            for (int g = 0; g < GP; ++g) {
+                int iy, ix;
+                const bool v = g_tap_src<MODE>(py[g], px[g], ky, kx, a.Ho, a.Wo, iy, ix) && pb[g] >= 0;
+                ptap[g] = v ? pb[g] + iy * Wi + ix : -1;
+            }
+        }
+    };
+    auto issue_w = [&]() {
+#pragma unroll
+        for (int g = 0; g < GW; ++g) {
+            const unsigned off = (wch[g] < q_room && wlane[g] != OOB) ? wlane[g] + q_soff : OOB;
+            dma16(rsw, off, q_sbase + (wave * (BN / 8) + g * 8) * 128);
+        }
+    };
+    auto issue_p = [&](int g) {
+        const unsigned off = (ptap[g] >= 0 && pch[g] < q_room)
+                                 ? (unsigned)((ptap[g] * q_cs + q_cbase + pch[g]) * 2) : OOB;
+        dma16(q_rs, off, q_sbase + BN * 128 + (wave * (BM / 8) + g * 8) * 128);
+    };
+    auto issue = [&](int stage) { begin_step(stage); issue_w(); issue_p(0); issue_p(1); issue_p(2); issue_p(3); };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fsw = ((lane & 31) >> 1) & 7, fh = lane >> 5;
+    const int wrow0 = (wn * 64 + (lane & 31)) * 128, prow0 = BN * 128 + (wm * 64 + (lane & 31)) * 128;
+    uint4 fa0[2], fb0[2], fa1[2], fb1[2];                        // two fragment sets (k-step parity)
+#define PIPE_LOAD(FA, FB, STG, S)                                                             \
+    do {                                                                                      \
+        const unsigned char* base_ = smem + (STG) * STAGE + (((2 * (S) + fh) ^ fsw) << 4);    \
+        FA[0] = *(const uint4*)(base_ + wrow0); FA[1] = *(const uint4*)(base_ + wrow0 + 32 * 128); \
+        FB[0] = *(const uint4*)(base_ + prow0); FB[1] = *(const uint4*)(base_ + prow0 + 32 * 128); \
+    } while (0)
+#define PIPE_MMA(FA, FB)                                                                      \
+    do {                                                                                      \
+        GMma<T>::run(FA[0], FB[0], acc[0][0]); GMma<T>::run(FA[0], FB[1], acc[0][1]);         \
+        GMma<T>::run(FA[1], FB[0], acc[1][0]); GMma<T>::run(FA[1], FB[1], acc[1][1]);         \
+    } while (0)
+
+    issue(0);
+    if (nit > 1) { issue(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    PIPE_LOAD(fa0, fb0, 0, 0);
+    int st = 0;                                                  // stage of K step `it`
+    for (int it = 0; it < nit; ++it) {
+        const int stn = st == NS - 1 ? 0 : st + 1;               // stage of step it+1
+        const int st2 = stn == NS - 1 ? 0 : stn + 1;             // stage of step it+2 == the one step it-1 used
+        const bool more = it + 2 < nit;
+        if (more) begin_step(st2);
+        PIPE_LOAD(fa1, fb1, st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        PIPE_MMA(fa0, fb0);
+        if (more) { issue_w(); issue_p(0); }                     // behind the MFMAs just issued (they run ~128 cycles)
+        __builtin_amdgcn_sched_barrier(0);
+        PIPE_LOAD(fa0, fb0, st, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        PIPE_MMA(fa1, fb1);
+        if (more) { issue_p(1); issue_p(2); issue_p(3); }
+        __builtin_amdgcn_sched_barrier(0);
+        PIPE_LOAD(fa1, fb1, st, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        PIPE_MMA(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < nit) {
+            // every read of stage `st` has returned; stage it+1 has landed (own pieces: vmcnt, all waves': barrier)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            PIPE_LOAD(fa0, fb0, stn, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        PIPE_MMA(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        st = stn;
+    }
+#undef PIPE_LOAD
+#undef PIPE_MMA
+
+    if (ks > 1) {        // split-K: raw f32 partial sums [kz][M][Cout]
+        float* P = a.partial + (long)kz * M * a.Cout;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long m = m0 + wm * 64 + j * 32 + (lane & 31);
+            if (m >= M) continue;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * (lane >> 5);
+                    if (n < a.Cout)
+                        *(float4*)(P + m * a.Cout + n) = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1],
+                                                                     acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                }
+        }
+        return;
+    }
+    // ksplit == 1: bias / ReLU / folded-BN affine, tile staged through LDS, coalesced 16-byte row stores
+    constexpr int OROW = PipeCfg::OROW;
+    __syncthreads();                                             // lagging waves still read the last stage
+    float* sbias = (float*)(smem + BM * OROW);
+    if (tid < BN) {
+        const bool nv = n0 + tid < a.Cout;
+        sbias[tid] = (a.bias && nv) ? a.bias[n0 + tid] : 0.f;
+        sbias[BN + tid] = (a.post_scale && nv) ? a.post_scale[n0 + tid] : 1.f;
+        sbias[2 * BN + tid] = (a.post_scale && nv) ? a.post_shift[n0 + tid] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ml = wm * 64 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = wn * 64 + i * 32 + 8 * q + 4 * (lane >> 5);
+                const float4 bq = *(const float4*)(sbias + nl);
+                float v[4] = {acc[i][j][4 * q] + bq.x, acc[i][j][4 * q + 1] + bq.y,
+                              acc[i][j][4 * q + 2] + bq.z, acc[i][j][4 * q + 3] + bq.w};
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (a.post_scale) {
+                    const float4 sq = *(const float4*)(sbias + BN + nl), hq = *(const float4*)(sbias + 2 * BN + nl);
+                    v[0] = v[0] * sq.x + hq.x; v[1] = v[1] * sq.y + hq.y;
+                    v[2] = v[2] * sq.z + hq.z; v[3] = v[3] * sq.w + hq.w;
+                }
+                uint2 pk;
+                pk.x = f32x2_to_bf16x2(v[0], v[1]);
+                pk.y = f32x2_to_bf16x2(v[2], v[3]);
+                *(uint2*)(smem + ml * OROW + nl * 2) = pk;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int CPRO = BN * 2 / 16;                        // 16-byte pieces per output row
+        T* out = (T*)a.out; const T* mask = (const T*)a.mask;
+        constexpr int NIT = BM * CPRO / 512;
+        uint4 mkv[NIT];
+        if (mask) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * 512, row = idx / CPRO, c = idx % CPRO;
+                const long m = m0 + row;
+                const int n = n0 + c * EPC;
+                mkv[it] = *(const uint4*)(mask + ((m < M && n < a.Cout) ? m * a.Cout + n : 0));
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 512;
+            const int row = idx / CPRO, c = idx % CPRO;
+            const long m = m0 + row;
+            const int n = n0 + c * EPC;
+            if (m >= M || n >= a.Cout) continue;
+            uint4 val = *(const uint4*)(smem + row * OROW + c * 16);
+            if (mask) {
+                const uint4 mk = mkv[it];
+                auto keep = [](uint32_t mw, uint32_t vw) {
+                    const uint32_t lo = ((mw & 0x8000u) == 0 && (mw & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
+                    const uint32_t hi = ((mw & 0x80000000u) == 0 && (mw & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+                    return vw & (lo | hi);
+                };
+                val.x = keep(mk.x, val.x); val.y = keep(mk.y, val.y);
+                val.z = keep(mk.z, val.z); val.w = keep(mk.w, val.w);
+            }
+            *(uint4*)(out + m * a.Cout + n) = val;
+        }
+    }
+}
+
+template <int MODE>
+static int launch_pipe(const ConvArgs& a_in, int ks, hipStream_t st) {
+    auto kern = conv_pipe_kernel<MODE>;
+    ConvArgs a = a_in;
+    constexpr int NT = GModeTraits<MODE>::NTAPS;
+    if (a.w_elems <= 0) a.w_elems = (NT - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg::SMEM));
+        attr_set = true;
+    }
+    const long M = (long)a.B * a.Ho * a.Wo;
+    const int tiles_m = cdiv(M, PipeCfg::BM), tiles_n = cdiv(a.Cout, PipeCfg::BN);
+    {
+        const long hi = MODE == UPCONV2 ? a.Ho / 2 : (MODE == CONV3S2 ? a.Ho * 2 : a.Ho);
+        const long wi = MODE == UPCONV2 ? a.Wo / 2 : (MODE == CONV3S2 ? a.Wo * 2 : a.Wo);
+        const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
+        if ((long)a.B * hi * wi * cmax * 2L >= (1L << 31) || a.w_elems * 2L >= (1L << 31))
+            return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
+    }
+    if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * NT * (a.C0 + a.C1), st);
+    a.ksplit = ks > 1 ? ks : 1;
+    kern<<<dim3((unsigned)((long)tiles_m * tiles_n * a.ksplit)), dim3(512), PipeCfg::SMEM, st>>>(a, tiles_m, tiles_n);
+    int rc = launch_ok();
+    if (!rc && a.ksplit > 1) rc = launch_splitk_finish<bf16_t>(a, a.ksplit, M, st);
+    if (prof_on()) prof_end(st);
+    return rc;
+}
+
+// 1 = launched by the one-workgroup-per-CU schedule, 0 = shape not suited, < 0 = error
+template <typename T, int MODE>
+static int try_pipe(const ConvArgs& a, hipStream_t st) {
+    if constexpr (sizeof(T) != 2 || MODE == CONV1) return 0;
+    else {
+        static int on = -1, min_steps = 12, wgs = 256;
+        if (on < 0) {
+            const char* e = getenv("MPU_CONV_PIPE"); on = (e && e[0] == '0') ? 0 : 1;
+            const char* s = getenv("MPU_PIPE_MIN_STEPS"); if (s) min_steps = atoi(s);
+            const char* w = getenv("MPU_PIPE_WGS"); if (w) wgs = atoi(w);
+        }
+        if (!on || a.Cout < 128) return 0;
+        const long M = (long)a.B * a.Ho * a.Wo;
+        const long tiles = (long)cdiv(M, PipeCfg::BM) * cdiv(a.Cout, PipeCfg::BN);
+        const int nit = GModeTraits<MODE>::NTAPS * (cdiv(a.C0, 64) + cdiv(a.C1, 64));
+        if (tiles > 2L * wgs || nit < min_steps) return 0;     // large grids: the two-workgroup schedules fill the chip
+        long ks = 1;
+        if (a.partial && tiles < wgs) {
+            ks = (wgs + tiles / 2) / tiles;                      // ~one workgroup per CU
+            if (ks > nit / 8) ks = nit / 8;
+            while (ks > 1 && ks * M * a.Cout > a.partial_cap) --ks;
+            if (ks < 1) ks = 1;
+        }
+        const int rc = launch_pipe<MODE>(a, (int)ks, st);
+        return rc ? rc : 1;
+    }
 }
 
 template <typename T, int MODE>
 static int launch_glds_mode(const ConvArgs& a_in, hipStream_t st) {
     ConvArgs a = a_in;
     a.ksplit = 1;
+    {
+        const int p = try_pipe<T, MODE>(a, st);
+        if (p != 0) return p < 0 ? p : MPU_OK;
+    }
     const long M = (long)a.B * a.Ho * a.Wo;
     const long t128 = (long)cdiv(a.Cout, 128) * cdiv(M, 128);
     const long t64x128 = (long)cdiv(a.Cout, 64) * cdiv(M, 128);

@@ -638,10 +638,10 @@ int mpu_conv2d_pack_weights(int32_t dtype, int32_t mode, const float* d_w, int32
     return launch_pack_weights(dtype, mode, d_w, Cin, Cout, d_w_fwd, d_w_dgrad, (hipStream_t)stream);
 }
 
-int mpu_conv2d_igemm(int32_t dtype, int32_t mode, const void* d_in0, int32_t C0, const void* d_in1, int32_t C1,
-                     const void* d_w_packed, int64_t w_tap_stride, int32_t w_row_stride, const float* d_bias,
-                     const void* d_mask, void* d_out, int32_t B, int32_t Ho, int32_t Wo, int32_t Cout, int32_t relu,
-                     void* stream) {
+static int conv2d_igemm_impl(int32_t dtype, int32_t mode, const void* d_in0, int32_t C0, const void* d_in1, int32_t C1,
+                             const void* d_w_packed, int64_t w_tap_stride, int32_t w_row_stride, const float* d_bias,
+                             const void* d_mask, void* d_out, int32_t B, int32_t Ho, int32_t Wo, int32_t Cout, int32_t relu,
+                             float* d_workspace, int64_t workspace_floats, void* stream) {
     MPU_REQUIRE(d_in0 && d_w_packed && d_out, "mpu_conv2d_igemm: null argument");
     MPU_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && Cout % 8 == 0 && C0 > 0, "mpu_conv2d_igemm: channels must be multiples of 8");
     MPU_REQUIRE((C1 == 0) == (d_in1 == nullptr), "mpu_conv2d_igemm: in1 / C1 mismatch");
@@ -649,10 +649,28 @@ int mpu_conv2d_igemm(int32_t dtype, int32_t mode, const void* d_in0, int32_t C0,
     ConvArgs a;
     a.in0 = d_in0; a.in1 = d_in1; a.C0 = C0; a.C1 = C1; a.w = d_w_packed; a.w_tap_stride = w_tap_stride;
     a.w_row_stride = w_row_stride; a.bias = d_bias; a.mask = d_mask; a.out = d_out;
-    a.B = B; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.relu = relu; a.flops = 0; a.w_elems = 0; a.partial = nullptr; a.partial_cap = 0; a.ksplit = 1;
+    a.B = B; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.relu = relu; a.flops = 0; a.w_elems = 0;
+    a.partial = d_workspace; a.partial_cap = d_workspace ? workspace_floats : 0; a.ksplit = 1;
     a.stats = nullptr; a.stats_rows = nullptr; a.stats_cap = 0;
     a.post_scale = nullptr; a.post_shift = nullptr;
     return launch_conv(dtype, mode, a, (hipStream_t)stream);
+}
+
+int mpu_conv2d_igemm(int32_t dtype, int32_t mode, const void* d_in0, int32_t C0, const void* d_in1, int32_t C1,
+                     const void* d_w_packed, int64_t w_tap_stride, int32_t w_row_stride, const float* d_bias,
+                     const void* d_mask, void* d_out, int32_t B, int32_t Ho, int32_t Wo, int32_t Cout, int32_t relu,
+                     void* stream) {
+    return conv2d_igemm_impl(dtype, mode, d_in0, C0, d_in1, C1, d_w_packed, w_tap_stride, w_row_stride, d_bias, d_mask,
+                             d_out, B, Ho, Wo, Cout, relu, nullptr, 0, stream);
+}
+
+int mpu_conv2d_igemm_ws(int32_t dtype, int32_t mode, const void* d_in0, int32_t C0, const void* d_in1, int32_t C1,
+                        const void* d_w_packed, int64_t w_tap_stride, int32_t w_row_stride, const float* d_bias,
+                        const void* d_mask, void* d_out, int32_t B, int32_t Ho, int32_t Wo, int32_t Cout, int32_t relu,
+                        float* d_workspace, int64_t workspace_floats, void* stream) {
+    MPU_REQUIRE(d_workspace && workspace_floats > 0, "mpu_conv2d_igemm_ws: null workspace");
+    return conv2d_igemm_impl(dtype, mode, d_in0, C0, d_in1, C1, d_w_packed, w_tap_stride, w_row_stride, d_bias, d_mask,
+                             d_out, B, Ho, Wo, Cout, relu, d_workspace, workspace_floats, stream);
 }
 
 int64_t mpu_conv2d_wgrad_workspace_floats(int32_t mode, int32_t Cin, int32_t Cout, int64_t M) {

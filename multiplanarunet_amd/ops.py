@@ -26,8 +26,9 @@ def pack_weights(w_hwio, mode, dtype):
 
 
 def conv2d(mode, x0, w_packed, cout, out_hw, bias=None, x1=None, mask=None, relu=False,
-           w_tap_stride=None, w_row_stride=None):
-    """x0 [B,Hi,Wi,C0] (+ x1 concatenated on channels) -> [B,Ho,Wo,cout]."""
+           w_tap_stride=None, w_row_stride=None, workspace=None):
+    """x0 [B,Hi,Wi,C0] (+ x1 concatenated on channels) -> [B,Ho,Wo,cout]. workspace: optional f32 scratch tensor
+    (split-K partial sums of the deep-level schedules; 8*B*Ho*Wo*cout floats always suffice)."""
     B = x0.shape[0]
     C0 = x0.shape[-1]
     C1 = 0 if x1 is None else x1.shape[-1]
@@ -37,9 +38,13 @@ def conv2d(mode, x0, w_packed, cout, out_hw, bias=None, x1=None, mask=None, relu
         w_row_stride = C0 + C1
     if w_tap_stride is None:
         w_tap_stride = cout * (C0 + C1)
-    _lib.call("mpu_conv2d_igemm", _dt(x0.dtype), mode, _lib.ptr(x0), C0, _lib.ptr(x1), C1,
-              _lib.ptr(w_packed), w_tap_stride, w_row_stride, _lib.ptr(bias), _lib.ptr(mask),
-              _lib.ptr(out), B, Ho, Wo, cout, int(relu), _lib.stream_ptr())
+    args = [_dt(x0.dtype), mode, _lib.ptr(x0), C0, _lib.ptr(x1), C1,
+            _lib.ptr(w_packed), w_tap_stride, w_row_stride, _lib.ptr(bias), _lib.ptr(mask),
+            _lib.ptr(out), B, Ho, Wo, cout, int(relu)]
+    if workspace is None:
+        _lib.call("mpu_conv2d_igemm", *args, _lib.stream_ptr())
+    else:
+        _lib.call("mpu_conv2d_igemm_ws", *args, _lib.ptr(workspace), workspace.numel(), _lib.stream_ptr())
     return out
 
 

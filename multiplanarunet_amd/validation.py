@@ -4,8 +4,8 @@ Epoch-end validation and the Keras callbacks that consume it (SURVEY.md 8f row N
   Validation ............ mpunet/callbacks/validation.py:59-306: predict `steps` validation batches, count
                           TP / relevant / selected per class (bincounts), per-class precision, recall, Dice,
                           logs val_dice / val_precision / val_recall = nanmean over classes (background NaN).
-                          The counting runs on the GPU (torch.bincount on the label tensors); under data
-                          parallelism the int64 counts are SUM all-reduced.
+                          argmax + counting run in one HIP kernel (mpu_validation_count, csrc/validation.hip);
+                          under data parallelism the int64 counts are SUM all-reduced.
                           NOTE the reference passes sel=relevant, rel=selected into _compute_dice
                           (validation.py:211-213), so its "precision" is TP/relevant and its "recall"
                           TP/selected; Dice is symmetric. The logs here carry the same (swapped) meaning.
@@ -20,14 +20,28 @@ import numpy as np
 import torch
 
 
-def count_cm_elements(pred_labels, true_labels, n_classes):
-    """TP, relevant, selected per class as int64 tensors (validation.py:115-125)."""
-    p = pred_labels.reshape(-1).long()
-    y = true_labels.reshape(-1).long()
-    tps = torch.bincount(torch.where(y == p, y, torch.full_like(y, n_classes)), minlength=n_classes + 1)[:n_classes]
-    rel = torch.bincount(y, minlength=n_classes)[:n_classes]
-    sel = torch.bincount(p, minlength=n_classes)[:n_classes]
-    return tps, rel, sel
+def count_cm_elements(pred, true, n_classes, counts=None):
+    """
+    validation.py:115-125 on the GPU: argmax of the class scores `pred` [..., K] (f32, device) fused with the
+    per-class TP / relevant / selected counting (mpu_validation_count, csrc/validation.hip). ADDS into
+    `counts` (int64 [3, K], device; created when None) and returns it.
+    """
+    from . import _lib
+    K = int(n_classes)
+    pred = pred.reshape(-1, K)
+    if pred.dtype != torch.float32 or not pred.is_contiguous():
+        pred = pred.to(torch.float32).contiguous()
+    y = true.reshape(-1)
+    if y.dtype != torch.uint8 or y.device != pred.device or not y.is_contiguous():
+        y = y.to(device=pred.device, dtype=torch.uint8).contiguous()
+    if y.shape[0] != pred.shape[0]:
+        raise ValueError("count_cm_elements: %d predictions for %d targets" % (pred.shape[0], y.shape[0]))
+    if pred.device.type != "cuda":
+        raise _lib.MpuError("count_cm_elements needs a HIP device (no CPU path)")
+    if counts is None:
+        counts = torch.zeros((3, K), dtype=torch.int64, device=pred.device)
+    _lib.call("mpu_validation_count", _lib.ptr(pred), _lib.ptr(y), pred.shape[0], K, _lib.ptr(counts), _lib.stream_ptr())
+    return counts
 
 
 def compute_dice(tp, rel, sel):
@@ -54,19 +68,14 @@ class Validation:
 
     def evaluate(self, model):
         K = self.n_classes
-        dev = model.device
-        TP = torch.zeros(K, dtype=torch.int64, device=dev)
-        REL = torch.zeros_like(TP); SEL = torch.zeros_like(TP)
+        cnt = torch.zeros((3, K), dtype=torch.int64, device=model.device)      # TP, relevant, selected
         for _ in range(self.steps):
             x, y, _w = self.sampler()
             pred = model.predict_on_batch(x)
-            lab = pred.reshape(-1, K).argmax(-1)
-            tps, rel, sel = count_cm_elements(lab, y.to(dev), K)
-            TP += tps; REL += rel; SEL += sel
+            count_cm_elements(pred, y, K, counts=cnt)
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            cnt = torch.stack([TP, REL, SEL])
             torch.distributed.all_reduce(cnt)
-            TP, REL, SEL = cnt[0], cnt[1], cnt[2]
+        TP, REL, SEL = cnt[0], cnt[1], cnt[2]
         # as the reference: sel=relevant, rel=selected
         precisions, recalls, dices = compute_dice(TP.cpu().numpy(), rel=SEL.cpu().numpy(), sel=REL.cpu().numpy())
         if self.ignore_bg:

@@ -59,10 +59,31 @@ CASES = [
     (CONV1,   2, 16, 16, 64, 0, 8),
 ]
 
+# BASELINE configs[1] deep-level layers at their real shapes (B=16): few pixels, long reductions. With a workspace
+# they take the one-workgroup-per-CU split-K schedule (conv_pipe_kernel) the train step uses.
+DEEP_CASES = [
+    # mode,   B, H,  W,  C0,  C1,  Cout
+    (CONV3,   16, 16, 16, 256, 0, 512),     # encoder_L3_conv1
+    (CONV3,   16, 8, 8, 1024, 0, 1024),     # bottom_conv2: K = 9216, 19 MB of weights
+    (CONV3,   16, 16, 16, 512, 512, 512),   # upsample_L0_conv2 (concat)
+    (UPCONV2, 16, 16, 16, 1024, 0, 512),    # upsample_L0_conv1 (+ its stride-2 data gradient)
+    (CONV3,   3, 8, 12, 136, 72, 200),      # ragged: M = 288 (tail tile), channel tails in both sources, N tail
+]
+
+
+@pytest.mark.parametrize("case", DEEP_CASES)
+def test_deep_level_layers_split_k_schedule(case):
+    """bf16, with the split-K workspace (the path mpu_unet_forward / backward take at the deep levels)."""
+    _run_case(case, torch.bfloat16, workspace=True)
+
 
 @pytest.mark.parametrize("dtype", (torch.float32, torch.bfloat16))
 @pytest.mark.parametrize("case", CASES)
 def test_conv_forward_dgrad_wgrad(case, dtype):
+    _run_case(case, dtype)
+
+
+def _run_case(case, dtype, workspace=False):
     from multiplanarunet_amd import ops
     mode, B, H, W, C0, C1, Cout = case
     g = torch.Generator().manual_seed(hash(case) % 2**31)
@@ -86,7 +107,10 @@ def test_conv_forward_dgrad_wgrad(case, dtype):
     x0 = xd[..., :C0].contiguous()
     x1 = xd[..., C0:].contiguous() if C1 else None
     wf, wd = ops.pack_weights(w.to(dev, torch.float32), mode, dtype)
-    y = ops.conv2d(mode, x0, wf, Cout, (H, W), bias=b.to(dev, torch.float32), x1=x1, relu=True)
+    ws = None
+    if workspace:
+        ws = torch.empty(8 * B * H * W * max(Cout, Cin), dtype=torch.float32, device=dev)
+    y = ops.conv2d(mode, x0, wf, Cout, (H, W), bias=b.to(dev, torch.float32), x1=x1, relu=True, workspace=ws)
     rt, at = tol(dtype, y_ref)
     np.testing.assert_allclose(y.cpu().double().numpy(), y_ref.detach().numpy(), rtol=rt, atol=at)
 
@@ -96,14 +120,15 @@ def test_conv_forward_dgrad_wgrad(case, dtype):
     wdg = wd if mode != CONV1 else w.to(dev, dtype).reshape(-1)
     mask = (torch.rand(B, Hi, Wi, Cin, generator=g) > 0.3).to(torch.float64)
     dx = ops.conv2d(dmode, dzd, wdg, Cin, (Hi, Wi), mask=mask.to(dev, dtype),
-                    w_tap_stride=Cin * Cout, w_row_stride=Cout)
+                    w_tap_stride=Cin * Cout, w_row_stride=Cout, workspace=ws)
     ref = dx_ref * mask
     rt, at = tol(dtype, ref)
     np.testing.assert_allclose(dx.cpu().double().numpy(), ref.numpy(), rtol=rt, atol=at)
     if C1:   # channel-sliced data gradient (how the concat gradient is split)
         import ctypes
         esz = 2 if dtype == torch.bfloat16 else 4
-        dx1 = ops.conv2d(dmode, dzd, wdg[C0 * Cout:], C1, (Hi, Wi), w_tap_stride=Cin * Cout, w_row_stride=Cout)
+        dx1 = ops.conv2d(dmode, dzd, wdg[C0 * Cout:], C1, (Hi, Wi), w_tap_stride=Cin * Cout, w_row_stride=Cout,
+                         workspace=ws)
         np.testing.assert_allclose(dx1.cpu().double().numpy(), dx_ref[..., C0:].numpy(), rtol=rt, atol=at)
 
     # weight gradient

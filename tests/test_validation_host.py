@@ -6,19 +6,44 @@ import torch
 from multiplanarunet_amd import validation as V
 
 
-def test_counts_match_numpy_bincount_and_dice_formula():
-    rng = np.random.RandomState(0)
-    K = 4
-    y = rng.randint(0, K, 5000); p = rng.randint(0, K, 5000)
-    p[:2000] = y[:2000]
-    tps, rel, sel = V.count_cm_elements(torch.tensor(p), torch.tensor(y), K)
-    np.testing.assert_array_equal(tps.numpy(), np.bincount(np.where(y == p, y, K), minlength=K + 1)[:-1])
-    np.testing.assert_array_equal(rel.numpy(), np.bincount(y, minlength=K))
-    np.testing.assert_array_equal(sel.numpy(), np.bincount(p, minlength=K))
-    pr, rc, dc = V.compute_dice(tps.numpy(), rel.numpy(), sel.numpy())
-    np.testing.assert_allclose(pr, tps.numpy() / sel.numpy(), rtol=1e-6)
-    np.testing.assert_allclose(rc, tps.numpy() / rel.numpy(), rtol=1e-6)
-    np.testing.assert_allclose(dc, 2 * tps.numpy() / (rel.numpy() + sel.numpy()), rtol=1e-5)   # 2PR/(P+R) == 2TP/(rel+sel)
+def _golden():
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "validation_golden.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_oracle_counts_and_metrics_match_reference_goldens():
+    """G8: the NumPy restatement (oracle/validation_ref.py) against outputs of the reference's own
+    _count_cm_elements_from_queue / _compute_dice (mpunet/callbacks/validation.py:59-131)."""
+    from oracle import validation_ref as R
+    g = _golden()
+    for ci, (K, steps, B, npx) in enumerate(g["g8_cases"]):
+        tp = np.zeros(K, np.uint64); rel = np.zeros(K, np.uint64); sel = np.zeros(K, np.uint64)
+        for s in range(steps):
+            a, b, c = R.count_cm_elements(g["g8_pred_%d" % ci][s], g["g8_true_%d" % ci][s], int(K))
+            tp += a; rel += b; sel += c
+        np.testing.assert_array_equal(tp, g["g8_tp_%d" % ci])
+        np.testing.assert_array_equal(rel, g["g8_rel_%d" % ci])
+        np.testing.assert_array_equal(sel, g["g8_sel_%d" % ci])
+        cw = R.class_wise_metrics(tp, rel, sel, ignore_bg=False)
+        for name in ("precision", "recall", "dice"):
+            np.testing.assert_array_equal(cw[name], g["g8_%s_%d" % (name, ci)])
+
+
+def test_product_compute_dice_matches_reference_goldens_incl_swapped_naming():
+    """The product's _compute_dice and its (swapped, as the reference) precision / recall naming."""
+    g = _golden()
+    for ci in range(len(g["g8_cases"])):
+        tp, rel, sel = (g["g8_%s_%d" % (n, ci)] for n in ("tp", "rel", "sel"))
+        # evalaute(): _compute_dice(tp=TPs, sel=relevant, rel=selected)  (validation.py:211-213)
+        pr, rc, dc = V.compute_dice(tp, rel=sel, sel=rel)
+        np.testing.assert_array_equal(pr, g["g8_precision_%d" % ci])
+        np.testing.assert_array_equal(rc, g["g8_recall_%d" % ci])
+        np.testing.assert_array_equal(dc, g["g8_dice_%d" % ci])
+        assert pr.dtype == np.float32 and dc.dtype == np.float32
+    # "precision" of the reference is TP / relevant
+    tp, rel, sel = g["g8_tp_0"].astype(float), g["g8_rel_0"].astype(float), g["g8_sel_0"].astype(float)
+    np.testing.assert_allclose(g["g8_precision_0"], tp / rel, rtol=1e-6)
+    np.testing.assert_allclose(g["g8_recall_0"], tp / sel, rtol=1e-6)
 
 
 def test_compute_dice_zero_denominators_give_zero():
@@ -60,24 +85,3 @@ def test_early_stopping_and_checkpoint_clean(tmp_path):
             break
     assert ep == 4 and es.stopped_epoch == 4                      # 3 epochs without beating 0.5 (equal is not better)
     assert os.listdir(tmp_path / "model") == ["@epoch_02_val_dice_0.50000.npz"]
-
-
-def test_validation_logs_swapped_names_and_background_nan():
-    K = 3
-    class S:
-        def __init__(self): self.i = 0
-        def __call__(self):
-            rng = np.random.RandomState(self.i); self.i += 1
-            y = torch.tensor(rng.randint(0, K, (2, 16, 1)).astype(np.uint8))
-            return y.float(), y, None
-    class Mdl(_M):
-        def predict_on_batch(self, x):                             # predicts the label, except class 2 -> 1 half the time
-            lab = x.long().reshape(-1)
-            flip = (torch.arange(lab.numel()) % 2 == 0) & (lab == 2)
-            lab = torch.where(flip, torch.ones_like(lab), lab)
-            return torch.nn.functional.one_hot(lab, K).float().reshape(2, 16, K)
-    logs = {}
-    cw = V.Validation(S(), steps=3, n_classes=K, verbose=False).on_epoch_end(Mdl(), 0, logs)
-    assert np.isnan(cw["dice"][0]) and set(logs) == {"val_dice", "val_precision", "val_recall"}
-    # class 2 is never over-predicted: TP/selected = 1, which the reference logs under "recall" (swapped names)
-    assert cw["recall"][2] == 1.0 and cw["precision"][2] < 1.0

@@ -13,7 +13,7 @@ LAYERS = [("enc0c1", 0, 128, 8, 0, 64), ("enc0c2", 0, 128, 64, 0, 64), ("enc1c1"
           ("botc1", 0, 8, 512, 0, 1024), ("botc2", 0, 8, 1024, 0, 1024),
           ("up0c1", 1, 16, 1024, 0, 512), ("up0c2", 0, 16, 512, 512, 512), ("up0c3", 0, 16, 512, 0, 512),
           ("up1c2", 0, 32, 256, 256, 256), ("up2c2", 0, 64, 128, 128, 128), ("up3c1", 1, 128, 128, 0, 64), ("up3c2", 0, 128, 64, 64, 64),
-          ("dg_up3", 2, 64, 64, 0, 128)]
+          ("dg_up3", 2, 64, 64, 0, 128), ("dg_up0", 2, 8, 512, 0, 1024), ("dg_botc1", 0, 8, 1024, 0, 512)]
 import os
 RELU = int(os.environ.get("RELU_BITS", "1"))
 what = sys.argv[1] if len(sys.argv) > 1 else "fwd"
@@ -36,9 +36,10 @@ for name, mode, H, C0, C1, Cout in LAYERS:
     else:
         wp, _ = ops.pack_weights(w, mode, dt)
     dz = torch.randn(B, H, H, Cout, device="cuda").to(dt)
+    ws = torch.empty(8 * B * H * H * Cout, dtype=torch.float32, device="cuda")     # split-K partials (as the U-Net passes)
     def run():
         if what == "fwd":
-            return ops.conv2d(mode, x0, wp, Cout, (H, H), bias=bias, x1=x1, relu=RELU)
+            return ops.conv2d(mode, x0, wp, Cout, (H, H), bias=bias, x1=x1, relu=RELU, workspace=ws)
         return ops.conv2d_wgrad(mode, x0, dz, x1=x1)
     if what == "wgrad" and mode == 2:
         continue
