@@ -58,8 +58,8 @@ def unet_forward_gflop(dim, n_channels=1, n_classes=3, depth=4, cf=1.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--dtype", default="bf16")
@@ -89,8 +89,18 @@ def main():
         D.DataParallelTrainer(model)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.randn(B, dim, dim, 1, generator=g).to(device)
-    y = torch.randint(0, 3, (B, dim * dim, 1), generator=g, dtype=torch.uint8).to(device)
+    # synthetic 3-class targets that depend on the image (thresholds of a smoothed copy), so that the correctness
+    # guard below can require the loss to fall over the timed steps
+    xs = torch.nn.functional.avg_pool2d(x.permute(0, 3, 1, 2), 5, 1, 2)[:, 0]
+    y = ((xs > 0.1).to(torch.uint8) + (xs > 0.45).to(torch.uint8)).reshape(B, dim * dim, 1).contiguous()
     sw = torch.ones(B, device=device)
+
+    def current_loss():
+        """mean per-pixel loss of the fixed batch under the current weights (train-mode forward; no update)."""
+        state = model.bn_state.clone()
+        _, l = model.forward_backward(x, y, sw, want_loss=True)
+        model.bn_state.copy_(state)
+        return float(l.mean().item())
 
     def step():
         model.train_step(x, y, sw, want_loss=False)
@@ -104,6 +114,7 @@ def main():
     for _ in range(args.warmup):
         step()
     lib = _lib.load()
+    loss_first = current_loss()
     events = not args.no_kernel_events
     # N=1: the whole step (fwd + bwd + Adam + repack, ~260 launches) is replayed from one HIP graph; the
     # per-launch HIP events of the roofline leg need eager launches, so they are taken over a second region
@@ -122,6 +133,25 @@ def main():
         run()
     barrier()
     dt = time.perf_counter() - t0
+    loss_last = current_loss()
+    # per-step times of a further K steps (events around each step): median next to the mean of the timed region
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a_, b_ in evs:
+        a_.record(); run(); b_.record()
+    torch.cuda.synchronize()
+    per_step = sorted(a_.elapsed_time(b_) for a_, b_ in evs)
+    sched = {}
+    if True:                                     # which kernel schedules one step dispatches to (tests assert the same);
+        import ctypes as C                       # every rank runs the step (it contains the all-reduce when N > 1)
+        lib.mpu_schedule_log_enable(1)
+        step()
+        n_ = lib.mpu_schedule_log_read(None, 0)
+        buf = C.create_string_buffer(int(n_) + 1)
+        lib.mpu_schedule_log_read(buf, n_ + 1)
+        lib.mpu_schedule_log_enable(0)
+        for line in buf.value.decode().splitlines():
+            k = " ".join(line.split()[:2])
+            sched[k] = sched.get(k, 0) + 1
     if events:                                   # roofline leg: same K steps again, eager, per-launch HIP events on
         barrier()
         lib.mpu_profile_enable(1)
@@ -160,7 +190,19 @@ def main():
                        "launch": "hip-graph replay" if graphed else "eager",
                        "algorithmic_gflop_per_slice": round(gf_slice, 2)},
             "step_tflops_algorithmic": round(gf_slice * B * world / 1e3 / (ms_step / 1e3), 1),
+            "ms_per_step_median": round(per_step[len(per_step) // 2], 4),
+            "ms_per_step_min": round(per_step[0], 4),
+            "guard": {"loss_before_timed_steps": round(loss_first, 5), "loss_after_timed_steps": round(loss_last, 5),
+                      "finite": bool(np.isfinite(loss_first) and np.isfinite(loss_last)),
+                      "decreasing": bool(loss_last < loss_first)},
+            "schedules": sched,
         }
+        if world > 1:
+            out["rccl_ranks"] = torch.distributed.get_world_size()
+            out["dist_backend"] = torch.distributed.get_backend()
+            out["config"]["dp_overlap"] = bool(getattr(model._grad_hook, "overlap", False))
+        if not out["guard"]["finite"] or loss_last > 1.05 * loss_first:      # NaN / diverging: the number is void
+            raise SystemExit("bench.py correctness guard failed: %r" % (out["guard"],))
         if dt_eager is not None:
             out["ms_per_step_eager_with_events"] = round(dt_eager / args.steps * 1e3, 4)
         traffic = {}
@@ -188,8 +230,16 @@ def main():
     # ---- secondary metric: 6-view predict+fuse on 256^3 (N=1) -------------------
     if rank == 0 and world == 1 and not args.no_predict:
         out["predict_fuse"] = bench_predict(device, quiet)
+    if rank == 0 and world == 1:
+        out["measured_peaks"] = measured_peaks(device)
+        if "roofline" in out:
+            for k in ("roofline", "wgrad"):
+                out[k]["peak_measured"] = out["measured_peaks"]["mfma_bf16_tflops"]
+                out[k]["frac_of_measured_peak"] = round(out[k]["achieved"] / out["measured_peaks"]["mfma_bf16_tflops"], 4)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B, dim)
+        if "predict_fuse" in out:
+            out["predict_fuse"]["cpu_baseline"] = cpu_baseline_predict()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -213,15 +263,18 @@ def bench_predict(device, quiet, D=256, V=6, K=3, reps=2, batch=None):
     batch = batch or (int(os.environ["MPU_BENCH_PREDICT_BATCH"]) if "MPU_BENCH_PREDICT_BATCH" in os.environ else None)
     multi_view_predict(model, vol, views, D, float(D), fm, batch_size=batch, want_probs=False)      # warm-up
     torch.cuda.synchronize()
-    best, tim = None, None
+    best, tim, labels = None, None, None
     for _ in range(reps):
         t = {}
         t0 = time.perf_counter()
-        multi_view_predict(model, vol, views, D, float(D), fm, batch_size=batch, want_probs=False, timings=t)
+        _, labels = multi_view_predict(model, vol, views, D, float(D), fm, batch_size=batch, want_probs=False, timings=t)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if best is None or el < best:
             best, tim = el, t
+    hist = torch.bincount(labels.reshape(-1).long(), minlength=K).tolist()          # correctness guard of the leg
+    if sum(hist) != D ** 3 or len(hist) != K or sum(1 for h in hist if h > 0) < 2:
+        raise SystemExit("bench.py predict guard failed: label histogram %r" % (hist,))
     P = D + 20
     fuse_bytes = D ** 3 * (V * K * 4 + 1)                        # labels only (73 B/voxel)
     samp_bytes = V * (4 * D ** 3 + 4 * P * D * D)
@@ -233,29 +286,95 @@ def bench_predict(device, quiet, D=256, V=6, K=3, reps=2, batch=None):
             "unet_tflops_algorithmic": round(gflop / tim["unet_ms"], 1),
             "sample_GBs_compulsory": round(samp_bytes / tim["sample_ms"] / 1e6, 1),
             "map_fuse_GBs_algorithmic": round(fuse_bytes / tim["map_fuse_ms"] / 1e6, 1),
-            "map_fuse_frac_of_hbm_peak": round(fuse_bytes / tim["map_fuse_ms"] / 1e6 / PEAK_HBM_GBS, 4)}
+            "map_fuse_frac_of_hbm_peak": round(fuse_bytes / tim["map_fuse_ms"] / 1e6 / PEAK_HBM_GBS, 4),
+            "roofline": {"bound": "hbm", "kernel": "map_fuse", "achieved": round(fuse_bytes / tim["map_fuse_ms"] / 1e6, 1),
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(fuse_bytes / tim["map_fuse_ms"] / 1e6 / PEAK_HBM_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": fuse_bytes},
+            "label_histogram": hist}
 
 
-def cpu_baseline(B, dim, budget_s=12.0):
-    """The oracle restatement of the reference train step (torch-CPU fp32) on the host cores."""
+def cpu_baseline(B, dim, budget_s=20.0):
+    """The oracle restatement of the reference train step (torch-CPU fp32) on the host cores, on the FULL batch of
+    the workload (B slices per step), repeated until ~budget_s of CPU work."""
     from oracle import unet_ref as U
     rng = np.random.RandomState(0)
     w = U.init_weights(3, 1, 4, 1, seed=0)
-    bs = min(B, 4)                                                # bounded sample: 4 slices per step
-    x = rng.randn(bs, dim, dim, 1).astype(np.float32)
-    y = rng.randint(0, 3, (bs, dim * dim, 1)).astype(np.uint8)
-    sw = np.ones(bs, np.float32)
-    U.train_step(w, x, y, sw)                                     # warm-up
+    x = rng.randn(B, dim, dim, 1).astype(np.float32)
+    y = rng.randint(0, 3, (B, dim * dim, 1)).astype(np.uint8)
+    sw = np.ones(B, np.float32)
     n, t0 = 0, time.perf_counter()
     while True:
         U.train_step(w, x, y, sw)
         n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 20:
+        if time.perf_counter() - t0 > budget_s or n >= 10:
             break
     el = time.perf_counter() - t0
-    return {"value": round(n * bs / el, 3), "unit": "slices/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d oracle train steps (torch-CPU fp32 autograd + NumPy Adam) on %d slices of %dx%d"
-                      % (n, bs, dim, dim)}
+    return {"value": round(n * B / el, 3), "unit": "slices/s", "cores": torch.get_num_threads(),
+            "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": "%d oracle train steps (torch-CPU fp32 autograd + NumPy Adam) on %d slices of %dx%d; the reference's "
+                      "TensorFlow-CPU path cannot run here (TF absent)" % (n, B, dim, dim)}
+
+
+def cpu_baseline_predict(D=64, V=6, K=3):
+    """The oracle 6-view predict+fuse pipeline (NumPy restatement of get_view_from / map_real_space_pred / FusionLayer,
+    pinned by the reference goldens, + the torch-CPU U-Net) on a bounded sample: one D^3 volume."""
+    from oracle import unet_ref as U
+    from oracle import geometry as G
+    rng = np.random.RandomState(0)
+    vol = rng.randn(D, D, D, 1).astype(np.float32)
+    views = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0], [0.5, 0.5, 0.707], [-0.6, 0.64, 0.48], [0.7, -0.5, 0.5]], float)[:V]
+    w = U.init_weights(K, 1, 4, 1, seed=0)
+    Wf, bf = np.ones((V, K), np.float32), np.zeros((1, K), np.float32)
+    tu = [0.0]
+
+    def pred(X):
+        t = time.perf_counter()
+        out = np.concatenate([U.predict(w, X[i:i + 28], depth=4) for i in range(0, X.shape[0], 28)])
+        tu[0] += time.perf_counter() - t
+        return out
+    t0 = time.perf_counter()
+    G.multi_view_predict(vol, np.eye(4), views, D, float(D), pred, Wf, bf, bg_value=[0.0], center=np.array([0.0]),
+                         scale=np.array([1.349]))
+    el = time.perf_counter() - t0
+    return {"value": round(D ** 3 / el, 1), "unit": "voxels/s", "cores": torch.get_num_threads(), "host_cpus": os.cpu_count(),
+            "kind": "port", "seconds": round(el, 2), "unet_seconds": round(tu[0], 2),
+            "sample": "one %d^3x1 volume, %d views x %d planes of %dx%d through the oracle pipeline (NumPy geometry "
+                      "restatement, threads as NumPy/torch choose; U-Net = torch-CPU fp32)" % (D, V, D + 20, D, D)}
+
+
+def measured_peaks(device):
+    """MFMA and HBM peaks measured on this box, quoted next to the spec values."""
+    import ctypes as C
+    from multiplanarunet_amd import _lib
+    lib = _lib.load()
+    st = _lib.stream_ptr()
+    sink = torch.zeros(16, device=device)
+    fl = C.c_double()
+    ncu = torch.cuda.get_device_properties(device).multi_processor_count
+    best = 0.0
+    for blocks in (ncu * 2, ncu * 4):
+        lib.mpu_probe_mfma_bf16(blocks, 2000, _lib.ptr(sink), C.byref(fl), st)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            lib.mpu_probe_mfma_bf16(blocks, 2000, _lib.ptr(sink), C.byref(fl), st)
+        e1.record(); torch.cuda.synchronize()
+        best = max(best, 3 * fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    n = 1 << 28                                                   # 3 x 1 GiB arrays: far beyond the 256 MB Infinity Cache
+    a = torch.empty(n, device=device); b = torch.ones(n, device=device); c = torch.ones(n, device=device)
+    lib.mpu_probe_stream_triad(_lib.ptr(a), _lib.ptr(b), _lib.ptr(c), n, st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        lib.mpu_probe_stream_triad(_lib.ptr(a), _lib.ptr(b), _lib.ptr(c), n, st)
+    e1.record(); torch.cuda.synchronize()
+    triad = 5 * 12.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b, c
+    return {"mfma_bf16_tflops": round(best, 1), "mfma_bf16_spec_tflops": PEAK_BF16_TFLOPS,
+            "stream_triad_GBs": round(triad, 1), "hbm_spec_GBs": PEAK_HBM_GBS, "compute_units": ncu}
 
 
 if __name__ == "__main__":

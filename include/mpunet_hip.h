@@ -341,6 +341,13 @@ int mpu_validation_count(const float* d_pred, const uint8_t* d_y, int64_t n, int
 int mpu_profile_enable(int32_t on);
 int mpu_profile_summary(int32_t kind, double* total_ms, double* total_flops, int64_t* launches);
 
+/* Measured machine peaks quoted next to the spec peaks in bench.py's roofline objects. The caller times
+ * the launches with events on `stream`. mpu_probe_mfma_bf16: `blocks` workgroups x 4 waves each issue iters x 8
+ * independent v_mfma_f32_32x32x16_bf16 (no memory traffic); *flops = FLOPs executed. mpu_probe_stream_triad:
+ * a = b + 1.5 c over n floats (n % 4 == 0), 12 * n bytes of HBM traffic. */
+int mpu_probe_mfma_bf16(int32_t blocks, int32_t iters, float* d_sink, double* flops, void* stream);
+int mpu_probe_stream_triad(float* d_a, const float* d_b, const float* d_c, int64_t n, void* stream);
+
 /* Test aid (no reference counterpart): when enabled, every convolution / weight-gradient launch appends one text
  * line naming the kernel schedule the dispatcher chose for the layer shape ("conv halo mode=0 B=.. H=.. W=.. Cin=..
  * Cout=.. dgrad=0", "wgrad taps ... ksplit=.."), so that parity tests at the BASELINE shapes can assert that the
