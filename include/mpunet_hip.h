@@ -341,6 +341,12 @@ int mpu_validation_count(const float* d_pred, const uint8_t* d_y, int64_t n, int
 int mpu_profile_enable(int32_t on);
 int mpu_profile_summary(int32_t kind, double* total_ms, double* total_flops, int64_t* launches);
 
+/* Test aid: the geometry kernels decide cells / nearest neighbours with a closed form on uniform axes wherever that
+ * is provably the exact answer (coordinate farther than 1e-6 index units from every decision boundary) and run the
+ * exact NumPy-order search otherwise. on = 0 forces the exact search for every sample (equality tests, A/B);
+ * the environment variable MPU_GEOM_FAST=0 sets the same at first use. */
+int mpu_geometry_set_fast_path(int32_t on);
+
 /* Measured machine peaks quoted next to the spec peaks in bench.py's roofline objects. The caller times
  * the launches with events on `stream`. mpu_probe_mfma_bf16: `blocks` workgroups x 4 waves each issue iters x 8
  * independent v_mfma_f32_32x32x16_bf16 (no memory traffic); *flops = FLOPs executed. mpu_probe_stream_triad:

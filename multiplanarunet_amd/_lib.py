@@ -125,6 +125,7 @@ _SIGS = {
     "mpu_profile_enable": (C.c_int, [i32]),
     "mpu_profile_summary": (C.c_int, [i32, C.POINTER(f64), C.POINTER(f64), C.POINTER(i64)]),
     "mpu_validation_count": (C.c_int, [c_p, c_p, i64, i32, c_p, c_p]),
+    "mpu_geometry_set_fast_path": (C.c_int, [i32]),
     "mpu_probe_mfma_bf16": (C.c_int, [i32, i32, c_p, C.POINTER(f64), c_p]),
     "mpu_probe_stream_triad": (C.c_int, [c_p, c_p, c_p, i64, c_p]),
     "mpu_schedule_log_enable": (C.c_int, [i32]),

@@ -647,7 +647,19 @@ __global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles
                                  ? (unsigned)((ptap[g] * q_cs + q_cbase + pch[g]) * 2) : OOB;
         dma16(q_rs, off, q_sbase + BN * 128 + (wave * (BM / 8) + g * 8) * 128);
     };
-    auto issue = [&](int stage) { begin_step(stage); issue_w(); issue_p(0); issue_p(1); issue_p(2); issue_p(3); };
+    const bool dbg_nodma = a.dbg & 4, dbg_nomma = a.dbg & 2, dbg_nolds = a.dbg & 8, dbg_nobar = a.dbg & 16;
+    // s_memtime stamps (MPU_PIPE_DEBUG & 32): workgroups 0 and 131, waves 0 and 5, 64 slots each
+    const bool stamping = (a.dbg & 32) && a.dbg_buf && (blockIdx.x == 0 || blockIdx.x == 131) && (wave == 0 || wave == 5) && lane == 0;
+    unsigned long long* sbuf = a.dbg_buf + ((blockIdx.x == 0 ? 0 : 2) + (wave == 0 ? 0 : 1)) * 64;
+    __shared__ unsigned long long s_stamps[2 * 64];              // kept in LDS during the run (a global store would
+    unsigned long long* sl = s_stamps + (wave == 0 ? 0 : 64);    //  disturb the vmcnt accounting of the DMA ring)
+    int nstamp = 0;
+    auto stamp = [&]() { if (stamping && nstamp < 63) sl[nstamp++] = __builtin_amdgcn_s_memtime(); };
+    auto flush_stamps = [&]() {
+        if (stamping) { for (int k = 0; k < nstamp; ++k) sbuf[k] = sl[k]; sbuf[63] = (unsigned long long)nstamp; }
+    };
+    stamp();
+    auto issue = [&](int stage) { begin_step(stage); if (dbg_nodma) return; issue_w(); issue_p(0); issue_p(1); issue_p(2); issue_p(3); };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -661,28 +673,34 @@ __global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles
     const int wrow0 = (wn * 64 + (lane & 31)) * 128, prow0 = BN * 128 + (wm * 64 + (lane & 31)) * 128;
     uint4 fa0[2], fb0[2], fa1[2], fb1[2];                        // two fragment sets (k-step parity)
 #define PIPE_LOAD(FA, FB, STG, S)                                                             \
-    do {                                                                                      \
+    if (!dbg_nolds) do {                                                                      \
         const unsigned char* base_ = smem + (STG) * STAGE + (((2 * (S) + fh) ^ fsw) << 4);    \
         FA[0] = *(const uint4*)(base_ + wrow0); FA[1] = *(const uint4*)(base_ + wrow0 + 32 * 128); \
         FB[0] = *(const uint4*)(base_ + prow0); FB[1] = *(const uint4*)(base_ + prow0 + 32 * 128); \
     } while (0)
 #define PIPE_MMA(FA, FB)                                                                      \
     do {                                                                                      \
+        if (!dbg_nomma) {                                                                     \
         GMma<T>::run(FA[0], FB[0], acc[0][0]); GMma<T>::run(FA[0], FB[1], acc[0][1]);         \
         GMma<T>::run(FA[1], FB[0], acc[1][0]); GMma<T>::run(FA[1], FB[1], acc[1][1]);         \
+        } else { acc[0][0][0] += __uint_as_float(FA[0].x ^ FB[0].x ^ FA[1].y ^ FB[1].y); }     \
     } while (0)
 
+    fa0[0] = fa0[1] = fb0[0] = fb0[1] = fa1[0] = fa1[1] = fb1[0] = fb1[1] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    stamp();
     issue(0);
     if (nit > 1) { issue(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();
     __builtin_amdgcn_s_barrier();
+    stamp();
     PIPE_LOAD(fa0, fb0, 0, 0);
     int st = 0;                                                  // stage of K step `it`
     for (int it = 0; it < nit; ++it) {
         const int stn = st == NS - 1 ? 0 : st + 1;               // stage of step it+1
         const int st2 = stn == NS - 1 ? 0 : stn + 1;             // stage of step it+2 == the one step it-1 used
-        const bool more = it + 2 < nit;
-        if (more) begin_step(st2);
+        const bool more = it + 2 < nit && !dbg_nodma;
+        if (it + 2 < nit) begin_step(st2);
         PIPE_LOAD(fa1, fb1, st, 1);
         __builtin_amdgcn_sched_barrier(0);
         PIPE_MMA(fa0, fb0);
@@ -700,9 +718,12 @@ __global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles
         if (it + 1 < nit) {
             // every read of stage `st` has returned; stage it+1 has landed (own pieces: vmcnt, all waves': barrier)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (it < 8) stamp();
             if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (it < 8) stamp();
+            if (!dbg_nobar) __builtin_amdgcn_s_barrier();
+            if (it < 8) stamp();
             PIPE_LOAD(fa0, fb0, stn, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -712,9 +733,11 @@ __global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles
     }
 #undef PIPE_LOAD
 #undef PIPE_MMA
+    stamp();
 
     if (ks > 1) {        // split-K: raw f32 partial sums [kz][M][Cout]
         float* P = a.partial + (long)kz * M * a.Cout;
+        if ((a.dbg & 1) && acc[0][0][0] != 12345.5f) { stamp(); flush_stamps(); return; }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const long m = m0 + wm * 64 + j * 32 + (lane & 31);
@@ -729,6 +752,7 @@ __global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles
                                                                      acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
                 }
         }
+        if (stamping) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); flush_stamps(); }
         return;
     }
     // ksplit == 1: bias / ReLU / folded-BN affine, tile staged through LDS, coalesced 16-byte row stores
@@ -841,8 +865,9 @@ template <typename T, int MODE>
 static int try_pipe(const ConvArgs& a, hipStream_t st) {
     if constexpr (sizeof(T) != 2 || MODE == CONV1) return 0;
     else {
-        static int on = -1, min_steps = 12, wgs = 256;
+        static int on = -1, min_steps = 12, wgs = 256, dbg = 0;
         if (on < 0) {
+            const char* d = getenv("MPU_PIPE_DEBUG"); if (d) dbg = atoi(d);
             const char* e = getenv("MPU_CONV_PIPE"); on = (e && e[0] == '0') ? 0 : 1;
             const char* s = getenv("MPU_PIPE_MIN_STEPS"); if (s) min_steps = atoi(s);
             const char* w = getenv("MPU_PIPE_WGS"); if (w) wgs = atoi(w);
@@ -859,7 +884,23 @@ static int try_pipe(const ConvArgs& a, hipStream_t st) {
             while (ks > 1 && ks * M * a.Cout > a.partial_cap) --ks;
             if (ks < 1) ks = 1;
         }
-        const int rc = launch_pipe<MODE>(a, (int)ks, st);
+        ConvArgs b = a; b.dbg = dbg;
+        static unsigned long long* dbuf = nullptr;
+        if ((dbg & 32) && !dbuf) { MPU_CHECK_HIP(hipMalloc(&dbuf, 4 * 64 * 8)); }
+        b.dbg_buf = dbuf;
+        if (dbg & 32) MPU_CHECK_HIP(hipMemsetAsync(dbuf, 0, 4 * 64 * 8, st));
+        const int rc = launch_pipe<MODE>(b, (int)ks, st);
+        if (!rc && (dbg & 32)) {                                   // dev aid: print the stamps of this launch
+            unsigned long long h[4 * 64];
+            MPU_CHECK_HIP(hipStreamSynchronize(st));
+            MPU_CHECK_HIP(hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost));
+            for (int w = 0; w < 4; ++w) {
+                const int n = (int)h[w * 64 + 63];
+                fprintf(stderr, "pipe stamps M=%ld N=%d ks=%ld wg%d wave%d:", M, a.Cout, ks, w < 2 ? 0 : 131, (w & 1) ? 5 : 0);
+                for (int k = 1; k < n && k < 63; ++k) fprintf(stderr, " %lld", (long long)(h[w * 64 + k] - h[w * 64 + k - 1]));
+                fprintf(stderr, "\n");
+            }
+        }
         return rc ? rc : 1;
     }
 }

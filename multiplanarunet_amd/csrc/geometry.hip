@@ -9,6 +9,7 @@
 // Reference: mpunet/interpolation/regular_grid_interpolator.py:152-270,
 // view_interpolator.py:54-133, sample_grid.py:101-130,192-244,
 // utils/fusion/fuse_and_predict.py:92-137, models/fusion_model.py:38-39.
+#include <stdlib.h>
 #include "common.h"
 
 namespace mpu {
@@ -26,7 +27,7 @@ __device__ __forceinline__ void mat3_apply(const Mat3& M, double x, double y, do
 
 // A coordinate axis: device array + (optionally) a closed form the host has verified to
 // reproduce that array bit for bit (mpu_axis), so values can be computed in registers.
-struct AxisDev { const double* g; int n, kind; double start, step, last, inv_h; };
+struct AxisDev { const double* g; int n, kind; double start, step, last, inv_h, g0; };
 
 __device__ __forceinline__ double axis_at(const AxisDev& a, int i) {
     if (a.kind == 1) return (i == a.n - 1) ? a.last : (double)i * a.step + a.start;   // np.linspace
@@ -55,10 +56,43 @@ __device__ __forceinline__ int find_cell_index(const AxisDev& a, double x, bool&
     }
     return c;
 }
+// ---- fast paths on uniform axes (closed-form kinds 1, 2) ---------------------------------------------
+// u = (x - g[0]) / h in index units carries an error < 1e-11 (|x|, |g| < 1e4: a few ulps of the operands), and the
+// actual axis nodes the exact search compares against lie within 1e-11 index units of the integers. So whenever
+// u is farther than TAU = 1e-6 from every value at which the exact procedure changes its answer -- an integer
+// (searchsorted / out-of-bounds limits g[0], g[n-1]) for the cell search, a half-integer (the y <= 0.5 tie) and
+// the two axis ends for the nearest search -- the closed form below IS the exact answer. The remaining samples
+// (a fraction ~6e-6) take the exact search. g_fast_geometry = 0 (MPU_GEOM_FAST=0) forces the exact search for
+// every sample (A/B and the equality test).
+__constant__ int g_fast_geometry_dev = 1;
+constexpr double GEOM_TAU = 1e-6;
+
+__device__ __forceinline__ bool cell_fast(const AxisDev& a, double x, int& c, bool& oob) {
+    if (a.kind == 0 || !g_fast_geometry_dev) return false;
+    const double u = (x - a.g0) * a.inv_h;
+    const double f = floor(u), nm1 = (double)(a.n - 1);
+    if (!(fabs(u) < 1e9) || (u - f) < GEOM_TAU || (f + 1.0 - u) < GEOM_TAU) return false;   // near a node (or NaN / huge)
+    oob = (u < 0.0) || (u > nm1);
+    const int ci = (int)f;
+    c = ci < 0 ? 0 : (ci > a.n - 2 ? a.n - 2 : ci);
+    return true;
+}
+__device__ __forceinline__ bool nearest_fast(const AxisDev& a, double x, int& n, bool& oob) {
+    if (a.kind == 0 || !g_fast_geometry_dev) return false;
+    const double u = (x - a.g0) * a.inv_h;
+    const double r = rint(u), nm1 = (double)(a.n - 1);
+    if (!(fabs(u) < 1e9) || fabs(fabs(u - r) - 0.5) < GEOM_TAU || fabs(u) < GEOM_TAU || fabs(u - nm1) < GEOM_TAU) return false;
+    oob = (u < 0.0) || (u > nm1);
+    n = (int)r;
+    return true;
+}
+
 // linear: also the normalised distance y = (x-g[i])/(g[i+1]-g[i]) (IEEE division as NumPy)
 __device__ __forceinline__ void find_cell(const AxisDev& a, double x, int& i, double& y, bool& oob) {
     double gc, gc1;
-    const int c = find_cell_index(a, x, oob, gc, gc1);
+    int c;
+    if (cell_fast(a, x, c, oob)) { gc = axis_at(a, c); gc1 = axis_at(a, c + 1); }
+    else c = find_cell_index(a, x, oob, gc, gc1);
     i = c;
     y = (x - gc) / (gc1 - gc);
 }
@@ -66,6 +100,8 @@ __device__ __forceinline__ void find_cell(const AxisDev& a, double x, int& i, do
 // correctly rounded quotient, fl(num/den) <= 0.5  <=>  2*num <= den (0.5 is a double, the next
 // double above den is den+ulp > den*(1+2^-53)), so no division is needed.
 __device__ __forceinline__ int find_nearest(const AxisDev& a, double x, bool& oob) {
+    int nf;
+    if (nearest_fast(a, x, nf, oob)) return nf;
     double gc, gc1;
     const int c = find_cell_index(a, x, oob, gc, gc1);
     const double num = x - gc, den = gc1 - gc;
@@ -111,6 +147,23 @@ __global__ __launch_bounds__(256) void sample_view_planes_kernel(SampleArgs a) {
         // itertools.product order of the 8 corners, weight = ((1*wx)*wy)*wz
         const double wx[2] = {1.0 - y0, y0}, wy[2] = {1.0 - y1, y1}, wz[2] = {1.0 - y2, y2};
         float* o = a.out + t * a.C;
+        // the two z-neighbours of a corner pair are contiguous in memory: one 8-byte (C == 1) or 16-byte (C == 2)
+        // load per (x, y) corner instead of two / four scalar gathers; all four issued before the first use
+        float cv[2][8];                                    // [channel][corner e]
+        const bool paired = a.C <= 2 && !oob;
+        if (paired) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long base = (((long)(i0 + (q >> 1)) * a.Y + (i1 + (q & 1))) * a.Z + i2) * a.C;
+                if (a.C == 1) {
+                    float2 v; __builtin_memcpy(&v, a.vol + base, 8);
+                    cv[0][2 * q] = v.x; cv[0][2 * q + 1] = v.y;
+                } else {
+                    float4 v; __builtin_memcpy(&v, a.vol + base, 16);
+                    cv[0][2 * q] = v.x; cv[1][2 * q] = v.y; cv[0][2 * q + 1] = v.z; cv[1][2 * q + 1] = v.w;
+                }
+            }
+        }
         for (int c = 0; c < a.C; ++c) {
             float v32;
             if (oob) {
@@ -122,7 +175,8 @@ __global__ __launch_bounds__(256) void sample_view_planes_kernel(SampleArgs a) {
                     const int ex = e >> 2, ey = (e >> 1) & 1, ez = e & 1;
                     const double w = ((1.0 * wx[ex]) * wy[ey]) * wz[ez];
                     const long idx = (((long)(i0 + ex) * a.Y + (i1 + ey)) * a.Z + (i2 + ez)) * a.C + c;
-                    acc = acc + (double)a.vol[idx] * w;
+                    const float val = paired ? cv[c & 1][e] : a.vol[idx];
+                    acc = acc + (double)val * w;
                 }
                 v32 = (float)acc;
             }
@@ -343,6 +397,8 @@ static AxisDev to_axis(const double* d_arr, int n, const mpu_axis& m) {
     a.kind = (m.kind == 1 || m.kind == 2) && m.n == n ? m.kind : 0;
     a.start = m.start; a.step = m.step; a.last = m.last;
     a.inv_h = m.step > 0 ? 1.0 / m.step : 1.0;
+    a.g0 = a.kind == 1 ? m.start : (a.kind == 2 ? (0.0 - m.start) * m.step : 0.0);     // == axis_at(a, 0)
+    if (!(m.step > 0)) a.kind = a.kind ? 0 : 0;
     return a;
 }
 static void to_view(const mpu_view_pred& v, ViewDev& d) {
@@ -393,9 +449,27 @@ static int grid_for(long total) {
 
 using namespace mpu;
 
+static int sync_fast_switch() {           // MPU_GEOM_FAST=0: exact search for every sample (read once per process)
+    static int done = 0;
+    if (done) return MPU_OK;
+    const char* e = getenv("MPU_GEOM_FAST");
+    const int v = (e && e[0] == '0') ? 0 : 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mpu::g_fast_geometry_dev), &v, sizeof(int)) != hipSuccess)
+        return mpu::fail(MPU_EHIP, "%s", "geometry: cannot set the fast-path switch");
+    done = 1;
+    return MPU_OK;
+}
+
 extern "C" {
 
 int mpu_abi_version(void) { return 1; }
+
+/* test aid: 1 = closed-form fast paths with exact fall-back (default), 0 = exact search everywhere */
+int mpu_geometry_set_fast_path(int32_t on) {
+    const int v = on ? 1 : 0;
+    MPU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(mpu::g_fast_geometry_dev), &v, sizeof(int)));
+    return MPU_OK;
+}
 const char* mpu_last_error(void) { return mpu::g_err; }
 
 int mpu_sample_view_planes(const float* d_vol, const uint8_t* d_labels, const int32_t vol_shape[4],
@@ -404,6 +478,7 @@ int mpu_sample_view_planes(const float* d_vol, const uint8_t* d_labels, const in
                            const float* d_bg, uint8_t bg_class,
                            const double* d_center, const double* d_scale,
                            float* d_out, uint8_t* d_out_lab, void* stream) {
+    { const int rc_ = sync_fast_switch(); if (rc_) return rc_; }
     MPU_REQUIRE(d_vol && vol_shape && d_ax && d_ay && d_az && geom && d_offsets && d_bg && d_out,
                 "mpu_sample_view_planes: null argument");
     MPU_REQUIRE(vol_shape[0] >= 2 && vol_shape[1] >= 2 && vol_shape[2] >= 2 && vol_shape[3] >= 1,
@@ -432,6 +507,7 @@ int mpu_sample_view_planes(const float* d_vol, const uint8_t* d_labels, const in
 
 int mpu_map_view_nearest(const mpu_voxel_grid* grid, const mpu_view_pred* view, int32_t n_classes,
                          float* d_mapped, void* stream) {
+    { const int rc_ = sync_fast_switch(); if (rc_) return rc_; }
     MPU_REQUIRE(grid && view && d_mapped && view->d_pred && view->d_g && view->d_offsets,
                 "mpu_map_view_nearest: null argument");
     MPU_REQUIRE(view->dim >= 2 && view->n_planes >= 2, "mpu_map_view_nearest: view needs dim>=2, planes>=2");
@@ -444,6 +520,7 @@ int mpu_map_view_nearest(const mpu_voxel_grid* grid, const mpu_view_pred* view, 
 int mpu_map_accumulate_view(const mpu_voxel_grid* grid, const mpu_view_pred* view, int32_t n_classes,
                             const float* d_Wv, int32_t p_lo, int32_t p_hi, int32_t owns_oob,
                             float* d_z, void* stream) {
+    { const int rc_ = sync_fast_switch(); if (rc_) return rc_; }
     MPU_REQUIRE(grid && view && d_z && d_Wv && view->d_pred && view->d_g && view->d_offsets,
                 "mpu_map_accumulate_view: null argument");
     MPU_REQUIRE(0 <= p_lo && p_lo < p_hi && p_hi <= view->n_planes, "mpu_map_accumulate_view: bad plane range");
@@ -456,6 +533,7 @@ int mpu_map_accumulate_view(const mpu_voxel_grid* grid, const mpu_view_pred* vie
 int mpu_map_fuse_views(const mpu_voxel_grid* grid, const mpu_view_pred* views, int32_t n_views,
                        int32_t n_classes, const float* d_W, const float* d_b, int32_t sum_fusion,
                        float* d_probs, uint8_t* d_labels, void* stream) {
+    { const int rc_ = sync_fast_switch(); if (rc_) return rc_; }
     MPU_REQUIRE(grid && views, "mpu_map_fuse_views: null argument");
     MPU_REQUIRE(n_views >= 1 && n_views <= MAX_VIEWS, "mpu_map_fuse_views: n_views must be in 1..16");
     MPU_REQUIRE(sum_fusion || (d_W && d_b), "mpu_map_fuse_views: W and b required unless sum_fusion");

@@ -23,6 +23,9 @@ struct ConvArgs {
     // *stats_rows to the number of rows
     // (0: the schedule chosen for this shape does not produce them; the caller runs the column reduction instead).
     float* stats; int* stats_rows; long stats_cap;              // capacity of `stats` in floats
+    int dbg = 0;                 // profiling switches of conv_pipe_kernel (MPU_PIPE_DEBUG: 1 no stores, 2 no MFMAs, 4 no DMA,
+                                 //   8 no fragment reads, 16 no barrier, 32 s_memtime stamps into dbg_buf)
+    unsigned long long* dbg_buf = nullptr;
 };
 struct WgradArgs {
     const void* x0; const void* x1; int C0, C1;

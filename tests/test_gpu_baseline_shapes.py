@@ -124,7 +124,7 @@ def test_cfg1_bf16_train_step_per_tensor_and_dispatch():
     gi = m.predict(xi, batch_size=4)
     di = np.abs(gi - li)
     print("cfg1 bf16 inference probs vs matched model: max %.3g mean %.3g" % (di.max(), di.mean()))
-    assert di.max() <= 1e-2 and di.mean() <= 5e-4
+    assert di.max() <= 1e-2 and di.mean() <= 3e-3            # ~one bf16 ulp of the last stored activation
 
     # --- training step: two evaluations of the matched-rounding model (f32 / f64 arithmetic, same rounding
     # points) give the noise floor of the storage mode per tensor; the kernels must sit within 2x of it

@@ -173,3 +173,47 @@ def test_train_sampler_planes_match_view_sampling_and_fg_balance():
         assert x.shape == (8, 48, 48, 1) and y.shape == (8, 48 * 48, 1) and w.shape == (8,)
         has_fg = (y.reshape(8, -1) > 0).any(1).sum().item()
         assert has_fg >= 4
+
+
+@pytest.mark.parametrize("aff", ("ident", "rot"))
+def test_fast_paths_equal_exact_search_at_scale(aff):
+    """The closed-form fast paths (uniform axes, samples farther than 1e-6 index units from a decision boundary)
+    against the exact NumPy-order search forced for every sample: sampled planes, labels, mapped volumes and fused
+    labels must be IDENTICAL, on volumes large enough to hit node / tie / out-of-bounds neighbourhoods (integer
+    spans put many samples exactly on nodes and half-way points)."""
+    from multiplanarunet_amd import _lib
+    from multiplanarunet_amd.interpolation import Volume, ViewGeometry, sample_view, map_and_fuse
+    lib = _lib.load()
+    rng = np.random.RandomState(3)
+    D, K = 96, 3
+    A = np.eye(4)
+    if aff == "rot":
+        th = np.deg2rad(25.0)
+        R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+        A[:3, :3] = R.dot(np.diag([1.0, 0.8, 1.5])); A[:3, 3] = [3.0, -2.0, 5.0]
+    vol_np = rng.randn(D, D - 8, D + 4, 2).astype(np.float32)
+    lab_np = rng.randint(0, K, (D, D - 8, D + 4)).astype(np.uint8)
+    views = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0], [0.3, 0.5, 0.8], [-0.6, 0.64, 0.48]], float)
+    W = torch.tensor(rng.uniform(.5, 1.5, (len(views), K)).astype(np.float32))
+    b = torch.tensor(rng.uniform(-.1, .1, (K,)).astype(np.float32))
+    outs = {}
+    for fast in (1, 0):
+        _lib.check(lib.mpu_geometry_set_fast_path(fast), "mpu_geometry_set_fast_path")
+        try:
+            vol = Volume(vol_np, lab_np, A, bg_value=[0.5, -1.0], scaler=(np.array([0.1, 0.2]), np.array([1.3, 0.7])))
+            res, preds = [], []
+            for vi, v in enumerate(views):
+                for dim, span in ((D, float(D)), (64, 70.0)):        # integer step (samples on nodes) and a ragged one
+                    g = ViewGeometry(v, dim, span, "same+20")
+                    X, y = sample_view(vol, g)
+                    res += [X.clone(), y.clone()]
+                    if dim == D:
+                        pr = torch.tensor(np.random.RandomState(10 + vi).rand(g.n_planes, dim, dim, K).astype(np.float32), device="cuda")
+                        preds.append((pr, (g.real_axis, g.real_axis, g.offsets), g.inv_basis))
+            probs, labels = map_and_fuse(vol, preds, W, b)
+            res += [probs.clone(), labels.clone()]
+            outs[fast] = res
+        finally:
+            _lib.check(lib.mpu_geometry_set_fast_path(1), "mpu_geometry_set_fast_path")
+    for a, b_ in zip(outs[1], outs[0]):
+        assert torch.equal(a, b_)
