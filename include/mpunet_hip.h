@@ -211,6 +211,9 @@ int mpu_unet_prepare_inference(const mpu_unet* m, const float* d_params, const f
  *   logits). training != 0: BatchNormalization uses batch statistics and updates
  *   the moving statistics in d_bn_state; activations stay in d_workspace for
  *   mpu_unet_backward. */
+/* d_out may be NULL in training mode: the probabilities then stay in the workspace only, at byte offset
+ * mpu_unet_workspace_probs_offset(m, batch) (f32 [B,H,W,n_classes]; valid until the next forward on that workspace). */
+int64_t mpu_unet_workspace_probs_offset(const mpu_unet* m, int32_t batch);
 int mpu_unet_forward(const mpu_unet* m, int32_t batch, const float* d_x, const float* d_params,
                      const void* d_packed, float* d_bn_state, void* d_workspace,
                      int32_t training, float* d_out, void* stream);

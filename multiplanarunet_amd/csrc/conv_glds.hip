@@ -14,6 +14,7 @@
 //
 // Pipeline: NSTAGE LDS stages; the loads of tile t+NSTAGE-1 are issued before the MFMAs of tile t.
 #include <stdlib.h>
+#include <type_traits>
 #include "kernels.h"
 
 namespace mpu {
@@ -534,44 +535,62 @@ static int launch_glds_cfg(const ConvArgs& a_in, hipStream_t st) {
 // ------------------------------------------------------------------------- //
 // conv_pipe_kernel (bf16): the same implicit GEMM for the DEEP U-Net levels (few pixels, long reductions, the
 // weights dominate the traffic), scheduled for ONE workgroup per CU:
-//   * 256-pixel x 128-channel tiles, 8 waves = 2 per SIMD (each a 64 x 64 sub-tile), so that the partner wave's
-//     MFMAs cover a wave's DMA issue and fragment waits; L2->LDS fill per K step = 48 KB per 1024 MFMA cycles
-//     (47 B/clk against the ~62 B/clk a CU can pull: the 128x128 / two-workgroup schedule sits AT that limit);
-//   * three 48-KB LDS stages, the DMA of K step t+2 issued at the start of step t (prefetch distance two steps,
-//     ~2000 cycles of cover instead of ~500: the 2-stage schedule is bound by the DMA round trip);
-//   * MFMA operand fragments double-buffered in registers: the ds_reads of k-step s+1 are issued before the
-//     MFMAs of k-step s, also across the stage boundary (one barrier per 16 MFMAs and wave, placed before the last
-//     k-step of a stage so that the next stage's first fragments are fetched under that k-step's MFMAs);
+//   * 256-pixel x 128-channel tiles, 8 waves = 2 per SIMD (each a 64 x 64 sub-tile); L2->LDS fill per K step =
+//     48 KB per 1024 MFMA cycles (47 B/clk against the ~62 B/clk a CU can pull);
+//   * three 48-KB LDS stages, the DMA of K step t+2 issued during step t (prefetch distance two steps);
+//   * a hand-placed instruction stream. In-kernel s_memtime stamps of the first version showed a wave spending
+//     ~2100 cycles on a step whose 16 MFMAs need 512: a wave issues in order, so everything between two of its
+//     MFMAs delays the second one, and ~200 address / select / branch instructions per step sat there. Now every
+//     per-lane DMA offset is precomputed (masked lanes carry a poison offset beyond the buffer's num_records:
+//     one v_add per piece), every fragment address lives in a register (none computed in the loop), the K loop is
+//     unrolled over the three stages (LDS destinations are immediates), and the stream alternates ONE MFMA with
+//     ONE ds_read and at most one DMA piece, so that the non-matrix work hides in the shadow of the wave's own MFMA
+//     and of its SIMD partner's;
+//   * MFMA operand fragments triple-buffered in registers: the reads of k-step s+1 (and s+2 at the stage end) are
+//     issued under the MFMAs of k-step s, also across the stage boundary; one barrier per 16 MFMAs and wave, with no
+//     LDS read outstanding at it;
 //   * 1-D grid decoded m-tile fastest, then n-tile, then K slice, XCD-aware: the workgroups that share a slice of
-//     the weights run on one XCD, so the 19 MB of bottom-level weights are pulled from HBM once.
-// Split-K writes raw f32 partials (splitk_finish_kernel applies the epilogue); ksplit == 1 runs the same staged
-// epilogue as conv_glds_kernel.
+//     the weights run on one XCD, so the 19 MB of bottom-level weights are pulled from HBM once;
+//   * split-K partials leave through wave-private LDS staging as 256-byte row runs (the direct accumulator stores
+//     were 32-byte pieces and took ~3 us of every launch).
+// ksplit == 1 runs the same staged epilogue as conv_glds_kernel. RAGGED = channel counts that are not multiples of
+// 64 (tail chunks mask lanes per step); DBG = s_memtime stamps (MPU_PIPE_DEBUG=32, dev aid).
 // ------------------------------------------------------------------------- //
 struct PipeCfg {
     static constexpr int BN = 128, BM = 256, NS = 3;
     static constexpr int STAGE = (BN + BM) * 128;
     static constexpr int OROW = BN * 2 + 16;
     static constexpr int EPI = BM * OROW + 3 * BN * 4;
-    static constexpr int SMEM = NS * STAGE > EPI ? NS * STAGE : EPI;
+    static constexpr int SROW = 64 * 4 + 16;                     // split-K staging: 64 f32 + pad per pixel row, per wave
+    static constexpr int STG = 8 * 64 * SROW;
+    static constexpr int S0 = NS * STAGE > EPI ? NS * STAGE : EPI;
+    static constexpr int SMEM = S0 > STG ? S0 : STG;
 };
+constexpr unsigned PIPE_POISON = 0x80001000u;                    // + any in-range byte offset stays >= num_records (< 2^31 - 8192)
 
-template <int MODE>
+// LDS-DMA piece with the LDS destination = scalar base + immediate (one SALU op)
+template <int IMM>
+__device__ __forceinline__ void dma16_at(const i32x4& rsrc, unsigned voff, unsigned lds_base) {
+    asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
+                 :: "v"(voff), "s"(lds_base), "s"(rsrc), "n"(IMM) : "memory", "scc");
+}
+
+template <int MODE, bool RAGGED, int DBG>
 __global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles_m, int tiles_n) {
     typedef bf16_t T;
-    constexpr int BN = PipeCfg::BN, BM = PipeCfg::BM, NS = PipeCfg::NS, STAGE = PipeCfg::STAGE;
+    constexpr int BN = PipeCfg::BN, BM = PipeCfg::BM, STAGE = PipeCfg::STAGE;
     constexpr int EPC = 8, BKE = 64;
     constexpr int NTAPS = GModeTraits<MODE>::NTAPS, KW = GModeTraits<MODE>::KW;
-    constexpr int GW = 2, GP = 4, NLD = GW + GP;         // 8-row DMA pieces per wave: weights, pixels
+    constexpr int GW = 2, GP = 4, NLD = GW + GP;                 // 8-row DMA pieces per wave: weights, pixels
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 1, wm = wave >> 1;             // 2 x 4 waves of 64 channels x 64 pixels
+    const int wn = wave & 1, wm = wave >> 1;                     // 2 x 4 waves of 64 channels x 64 pixels
     const int logical = g_xcd_remap(blockIdx.x, gridDim.x);
     const int mt = logical % tiles_m, r1 = logical / tiles_m;
     const int nt = r1 % tiles_n, kz = r1 / tiles_n;
-    const int n0 = nt * BN;
-    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN, m0 = mt * BM;
     const int nch0 = (a.C0 + BKE - 1) / BKE, nch1 = (a.C1 + BKE - 1) / BKE;
     const int nchunks = nch0 + nch1;
     const int nit_all = NTAPS * nchunks;
@@ -579,87 +598,93 @@ __global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles
     const int it0 = (int)((long)kz * nit_all / ks);
     const int nit = (int)((long)(kz + 1) * nit_all / ks) - it0;
     const int Hi = g_in_h<MODE>(a.Ho), Wi = g_in_h<MODE>(a.Wo);
-    const long M = (long)a.B * a.Ho * a.Wo;
-    constexpr unsigned OOB = 0xfffffff0u;
+    const int M = a.B * a.Ho * a.Wo;                             // (all operands < 2 GiB: checked by the launcher)
     const long npix = (long)a.B * Hi * Wi;
     const i32x4 rs0 = make_rsrc(a.in0, npix * a.C0 * 2L);
     const i32x4 rs1 = make_rsrc(a.in1 ? a.in1 : a.in0, a.in1 ? npix * a.C1 * 2L : 0);
     const i32x4 rsw = make_rsrc(a.w, a.w_elems * 2L);
     const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    const int wts = (int)a.w_tap_stride;
 
+    // s_memtime stamps (dev aid): workgroups 0 and 131, waves 0 and 5
+    const bool stamping = DBG && (a.dbg & 32) && a.dbg_buf && (blockIdx.x == 0 || blockIdx.x == 131) && (wave == 0 || wave == 5) && lane == 0;
+    __shared__ unsigned long long s_stamps[DBG ? 2 * 64 : 1];
+    unsigned long long* sl = s_stamps + (wave == 0 ? 0 : (DBG ? 64 : 0));
+    int nstamp = 0;
+    auto stamp = [&]() { if (DBG && stamping && nstamp < 63) sl[nstamp++] = __builtin_amdgcn_s_memtime(); };
+    auto flush_stamps = [&]() {
+        if (DBG && stamping) {
+            unsigned long long* sbuf = a.dbg_buf + ((blockIdx.x == 0 ? 0 : 2) + (wave == 0 ? 0 : 1)) * 64;
+            for (int k = 0; k < nstamp; ++k) sbuf[k] = sl[k];
+            sbuf[63] = (unsigned long long)nstamp;
+        }
+    };
+    stamp();
+
+    // ---- per-lane DMA roles: byte offsets computed once; invalid lanes carry the poison offset -----------------
     const int lrow = lane >> 3, slot = lane & 7;
-    unsigned wlane[GW]; int wch[GW];
+    unsigned wl[GW]; int wch[GW];
 #pragma unroll
     for (int g = 0; g < GW; ++g) {
         const int rl = wave * (BN / 8) + g * 8 + lrow;           // tile-local weight row
         const int n = n0 + rl;
         wch[g] = (slot ^ ((rl >> 1) & 7)) * EPC;
-        wlane[g] = n < a.Cout ? (unsigned)((long)n * a.w_row_stride * 2L) + (unsigned)(wch[g] * 2) : OOB;
+        wl[g] = n < a.Cout ? (unsigned)(n * a.w_row_stride * 2 + wch[g] * 2) : PIPE_POISON;
     }
     int pb[GP], py[GP], px[GP], pch[GP];
 #pragma unroll
     for (int g = 0; g < GP; ++g) {
         const int rl = wave * (BM / 8) + g * 8 + lrow;           // tile-local pixel row
-        const int m = (int)m0 + rl;                              // (M < 2^31: checked by the launcher)
+        const int m = m0 + rl;
         pch[g] = (slot ^ ((rl >> 1) & 7)) * EPC;
-        if (m < (int)M) {
+        if (m < M) {
             const int ox = m % a.Wo, t = m / a.Wo;
             const int oy = t % a.Ho, b = t / a.Ho;
             pb[g] = b * Hi * Wi; py[g] = oy; px[g] = ox;
         } else { pb[g] = -1; py[g] = 0; px[g] = 0; }
     }
-    // One K step's DMA = 2 weight + 4 pixel pieces per wave, issued in two halves behind the MFMAs of two
-    // different k-steps (branch-free: the concat source is a scalar select of the descriptor, masked lanes get the
-    // out-of-range marker). begin_step() fixes the step's scalars and, on a tap change, the lanes' source pixels.
-    int ptap[GP], cur_tap = -1;
-    int tapN = it0 / nchunks, ccN = it0 % nchunks;
-    unsigned q_soff = 0, q_sbase = 0; int q_room = 0, q_cs = 0, q_cbase = 0; i32x4 q_rs = rs0;
-    auto begin_step = [&](int stage) {
-        const int tap = tapN, cc = ccN;
-        if (++ccN == nchunks) { ccN = 0; ++tapN; }
-        const bool s1 = cc >= nch0;
-        q_cbase = (s1 ? cc - nch0 : cc) * BKE;
-        q_cs = s1 ? a.C1 : a.C0;
-        q_room = q_cs - q_cbase;
-        q_soff = (unsigned)(((long)tap * a.w_tap_stride + (s1 ? a.C0 : 0) + q_cbase) * 2L);
-        q_sbase = lds0 + stage * STAGE;
+    const unsigned wdst = lds0 + wave * (BN / 8) * 128;          // + g * 1024 + stage * STAGE (immediates)
+    const unsigned pdst = lds0 + BN * 128 + wave * (BM / 8) * 128;
+
+    // ---- request state: (r_tap, r_cc) = K step to request next; scalars of that step -----------------------------
+    int r_tap = it0 / nchunks, r_cc = it0 % nchunks;
+    int cur_tap = -1, cur_src = -1;
+    unsigned pbase[GP];                                          // per lane: (source pixel * Cs + chunk channel) * 2, or poison
+    unsigned q_wsoff = 0, q_pcoff = 0; int q_room = 0; i32x4 q_rs = rs0;
+    // valid = false (past the last K step of this workgroup): the step's scalar offsets become the poison, so the
+    // six DMA pieces of the stream stay unconditional (they fetch nothing useful into a stage nobody reads any
+    // more) and every step leaves exactly NLD requests in flight for the counted vmcnt wait
+    auto begin_step = [&](bool valid) {
+        const int tap = r_tap, cc = r_cc;
+        if (++r_cc == nchunks) { r_cc = 0; ++r_tap; }
+        const int s1 = cc >= nch0 ? 1 : 0;
+        const int cb = (s1 ? cc - nch0 : cc) * BKE;
+        const int Cs = s1 ? a.C1 : a.C0;
+        q_wsoff = valid ? (unsigned)((tap * wts + (s1 ? a.C0 : 0) + cb) * 2) : PIPE_POISON;
+        q_pcoff = valid ? (unsigned)(cb * 2) : PIPE_POISON;
+        q_room = Cs - cb;
         q_rs.x = s1 ? rs1.x : rs0.x; q_rs.y = s1 ? rs1.y : rs0.y; q_rs.z = s1 ? rs1.z : rs0.z; q_rs.w = rs0.w;
-        if (tap != cur_tap) {
-            cur_tap = tap;
+        if (valid && (tap != cur_tap || s1 != cur_src)) {        // rare: a new tap or the second concat source
+            cur_tap = tap; cur_src = s1;
             const int ky = tap / KW, kx = tap % KW;
 #pragma unroll
             for (int g = 0; g < GP; ++g) {
                 int iy, ix;
                 const bool v = g_tap_src<MODE>(py[g], px[g], ky, kx, a.Ho, a.Wo, iy, ix) && pb[g] >= 0;
-                ptap[g] = v ? pb[g] + iy * Wi + ix : -1;
+                pbase[g] = v ? (unsigned)(((pb[g] + iy * Wi + ix) * Cs + pch[g]) * 2) : PIPE_POISON;
             }
         }
     };
-    auto issue_w = [&]() {
-#pragma unroll
-        for (int g = 0; g < GW; ++g) {
-            const unsigned off = (wch[g] < q_room && wlane[g] != OOB) ? wlane[g] + q_soff : OOB;
-            dma16(rsw, off, q_sbase + (wave * (BN / 8) + g * 8) * 128);
-        }
+    auto w_off = [&](int g) -> unsigned {
+        const unsigned o = wl[g] + q_wsoff;
+        return (RAGGED && wch[g] >= q_room) ? PIPE_POISON : o;
     };
-    auto issue_p = [&](int g) {
-        const unsigned off = (ptap[g] >= 0 && pch[g] < q_room)
-                                 ? (unsigned)((ptap[g] * q_cs + q_cbase + pch[g]) * 2) : OOB;
-        dma16(q_rs, off, q_sbase + BN * 128 + (wave * (BM / 8) + g * 8) * 128);
+    auto p_off = [&](int g) -> unsigned {
+        const unsigned o = pbase[g] + q_pcoff;
+        return (RAGGED && pch[g] >= q_room) ? PIPE_POISON : o;
     };
-    const bool dbg_nodma = a.dbg & 4, dbg_nomma = a.dbg & 2, dbg_nolds = a.dbg & 8, dbg_nobar = a.dbg & 16;
-    // s_memtime stamps (MPU_PIPE_DEBUG & 32): workgroups 0 and 131, waves 0 and 5, 64 slots each
-    const bool stamping = (a.dbg & 32) && a.dbg_buf && (blockIdx.x == 0 || blockIdx.x == 131) && (wave == 0 || wave == 5) && lane == 0;
-    unsigned long long* sbuf = a.dbg_buf + ((blockIdx.x == 0 ? 0 : 2) + (wave == 0 ? 0 : 1)) * 64;
-    __shared__ unsigned long long s_stamps[2 * 64];              // kept in LDS during the run (a global store would
-    unsigned long long* sl = s_stamps + (wave == 0 ? 0 : 64);    //  disturb the vmcnt accounting of the DMA ring)
-    int nstamp = 0;
-    auto stamp = [&]() { if (stamping && nstamp < 63) sl[nstamp++] = __builtin_amdgcn_s_memtime(); };
-    auto flush_stamps = [&]() {
-        if (stamping) { for (int k = 0; k < nstamp; ++k) sbuf[k] = sl[k]; sbuf[63] = (unsigned long long)nstamp; }
-    };
-    stamp();
-    auto issue = [&](int stage) { begin_step(stage); if (dbg_nodma) return; issue_w(); issue_p(0); issue_p(1); issue_p(2); issue_p(3); };
+#define PIPE_DMA_W(G, ST_) dma16_at<(ST_) * STAGE + (G) * 1024>(rsw, w_off(G), wdst)
+#define PIPE_DMA_P(G, ST_) dma16_at<(ST_) * STAGE + (G) * 1024>(q_rs, p_off(G), pdst)
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -669,90 +694,112 @@ __global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // ---- fragment addresses: one register per (operand, k-step) for stages 0/1 (stage 1 = +STAGE as the
+    // instruction's immediate) and one for stage 2 (2 * STAGE does not fit the 16-bit immediate) -------------------
     const int fsw = ((lane & 31) >> 1) & 7, fh = lane >> 5;
-    const int wrow0 = (wn * 64 + (lane & 31)) * 128, prow0 = BN * 128 + (wm * 64 + (lane & 31)) * 128;
-    uint4 fa0[2], fb0[2], fa1[2], fb1[2];                        // two fragment sets (k-step parity)
-#define PIPE_LOAD(FA, FB, STG, S)                                                             \
-    if (!dbg_nolds) do {                                                                      \
-        const unsigned char* base_ = smem + (STG) * STAGE + (((2 * (S) + fh) ^ fsw) << 4);    \
-        FA[0] = *(const uint4*)(base_ + wrow0); FA[1] = *(const uint4*)(base_ + wrow0 + 32 * 128); \
-        FB[0] = *(const uint4*)(base_ + prow0); FB[1] = *(const uint4*)(base_ + prow0 + 32 * 128); \
-    } while (0)
-#define PIPE_MMA(FA, FB)                                                                      \
-    do {                                                                                      \
-        if (!dbg_nomma) {                                                                     \
-        GMma<T>::run(FA[0], FB[0], acc[0][0]); GMma<T>::run(FA[0], FB[1], acc[0][1]);         \
-        GMma<T>::run(FA[1], FB[0], acc[1][0]); GMma<T>::run(FA[1], FB[1], acc[1][1]);         \
-        } else { acc[0][0][0] += __uint_as_float(FA[0].x ^ FB[0].x ^ FA[1].y ^ FB[1].y); }     \
-    } while (0)
+    unsigned LA[4], LB[4], LA2[4], LB2[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+        const unsigned so = (unsigned)(((2 * s_ + fh) ^ fsw) << 4);
+        LA[s_] = lds0 + (wn * 64 + (lane & 31)) * 128 + so;
+        LB[s_] = lds0 + BN * 128 + (wm * 64 + (lane & 31)) * 128 + so;
+        LA2[s_] = LA[s_] + 2 * STAGE; LB2[s_] = LB[s_] + 2 * STAGE;
+    }
+    typedef __attribute__((address_space(3))) const uint4* lds_u4;
+#define PIPE_LD(DST, ARR, ARR2, ST_, S_, HALF)                                                         \
+    DST = *(lds_u4)(uintptr_t)(((ST_) == 2 ? ARR2[S_] : ARR[S_]) + ((ST_) == 1 ? STAGE : 0) + (HALF) * 4096)
+#define PIPE_SB() __builtin_amdgcn_sched_barrier(0)
+#define PIPE_MM(FA, FB, I, J) GMma<T>::run(FA[I], FB[J], acc[I][J])
 
-    fa0[0] = fa0[1] = fb0[0] = fb0[1] = fa1[0] = fa1[1] = fb1[0] = fb1[1] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    uint4 fa0[2], fb0[2], fa1[2], fb1[2], fa2[2], fb2[2];        // three fragment sets
+
+    // one K step on stage ST: 16 MFMAs, each followed by one fragment read and (12 of them) a share of the next DMA
+    auto kstep = [&](auto stc, int it) {
+        constexpr int ST = decltype(stc)::value, STN = (ST + 1) % 3, ST2 = (ST + 2) % 3;
+        begin_step(it + 2 < nit);                                // request K step it+2 into stage ST2 (free since step it-1)
+        PIPE_SB();
+        // k-step 0 on set 0; set 1 <- (ST, 1)
+        PIPE_MM(fa0, fb0, 0, 0); PIPE_LD(fa1[0], LA, LA2, ST, 1, 0); PIPE_DMA_W(0, ST2); PIPE_SB();
+        PIPE_MM(fa0, fb0, 0, 1); PIPE_LD(fb1[0], LB, LB2, ST, 1, 0); PIPE_DMA_W(1, ST2); PIPE_SB();
+        PIPE_MM(fa0, fb0, 1, 0); PIPE_LD(fa1[1], LA, LA2, ST, 1, 1); PIPE_SB();
+        PIPE_MM(fa0, fb0, 1, 1); PIPE_LD(fb1[1], LB, LB2, ST, 1, 1); PIPE_SB();
+        // k-step 1 on set 1; set 0 <- (ST, 2), set 2 <- (ST, 3)
+        PIPE_MM(fa1, fb1, 0, 0); PIPE_LD(fa0[0], LA, LA2, ST, 2, 0); PIPE_LD(fa2[0], LA, LA2, ST, 3, 0); PIPE_DMA_P(0, ST2); PIPE_SB();
+        PIPE_MM(fa1, fb1, 0, 1); PIPE_LD(fb0[0], LB, LB2, ST, 2, 0); PIPE_LD(fb2[0], LB, LB2, ST, 3, 0); PIPE_DMA_P(1, ST2); PIPE_SB();
+        PIPE_MM(fa1, fb1, 1, 0); PIPE_LD(fa0[1], LA, LA2, ST, 2, 1); PIPE_LD(fa2[1], LA, LA2, ST, 3, 1); PIPE_SB();
+        PIPE_MM(fa1, fb1, 1, 1); PIPE_LD(fb0[1], LB, LB2, ST, 2, 1); PIPE_LD(fb2[1], LB, LB2, ST, 3, 1); PIPE_SB();
+        // k-step 2 on set 0: no reads (every read of stage ST has been issued 4+ MFMAs before the barrier)
+        PIPE_MM(fa0, fb0, 0, 0); PIPE_DMA_P(2, ST2); PIPE_SB();
+        PIPE_MM(fa0, fb0, 0, 1); PIPE_DMA_P(3, ST2); PIPE_SB();
+        PIPE_MM(fa0, fb0, 1, 0); PIPE_SB();
+        PIPE_MM(fa0, fb0, 1, 1); PIPE_SB();
+        if (it + 1 < nit) {
+            // every read of stage ST has returned; stage it+1 has landed (own pieces: vmcnt, all waves': barrier)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (DBG && it < 8) stamp();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+            if (DBG && it < 8) stamp();
+            __builtin_amdgcn_s_barrier();
+            if (DBG && it < 8) stamp();
+        }
+        PIPE_SB();
+        // k-step 3 on set 2; set 0 <- (STN, 0) (after the last step: a harmless read of a stale stage)
+        PIPE_MM(fa2, fb2, 0, 0); PIPE_LD(fa0[0], LA, LA2, STN, 0, 0); PIPE_SB();
+        PIPE_MM(fa2, fb2, 0, 1); PIPE_LD(fb0[0], LB, LB2, STN, 0, 0); PIPE_SB();
+        PIPE_MM(fa2, fb2, 1, 0); PIPE_LD(fa0[1], LA, LA2, STN, 0, 1); PIPE_SB();
+        PIPE_MM(fa2, fb2, 1, 1); PIPE_LD(fb0[1], LB, LB2, STN, 0, 1); PIPE_SB();
+    };
+
     stamp();
-    issue(0);
-    if (nit > 1) { issue(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    begin_step(true);
+    PIPE_DMA_W(0, 0); PIPE_DMA_W(1, 0); PIPE_DMA_P(0, 0); PIPE_DMA_P(1, 0); PIPE_DMA_P(2, 0); PIPE_DMA_P(3, 0);
+    begin_step(nit > 1);
+    PIPE_DMA_W(0, 1); PIPE_DMA_W(1, 1); PIPE_DMA_P(0, 1); PIPE_DMA_P(1, 1); PIPE_DMA_P(2, 1); PIPE_DMA_P(3, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
     stamp();
     __builtin_amdgcn_s_barrier();
     stamp();
-    PIPE_LOAD(fa0, fb0, 0, 0);
-    int st = 0;                                                  // stage of K step `it`
-    for (int it = 0; it < nit; ++it) {
-        const int stn = st == NS - 1 ? 0 : st + 1;               // stage of step it+1
-        const int st2 = stn == NS - 1 ? 0 : stn + 1;             // stage of step it+2 == the one step it-1 used
-        const bool more = it + 2 < nit && !dbg_nodma;
-        if (it + 2 < nit) begin_step(st2);
-        PIPE_LOAD(fa1, fb1, st, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        PIPE_MMA(fa0, fb0);
-        if (more) { issue_w(); issue_p(0); }                     // behind the MFMAs just issued (they run ~128 cycles)
-        __builtin_amdgcn_sched_barrier(0);
-        PIPE_LOAD(fa0, fb0, st, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        PIPE_MMA(fa1, fb1);
-        if (more) { issue_p(1); issue_p(2); issue_p(3); }
-        __builtin_amdgcn_sched_barrier(0);
-        PIPE_LOAD(fa1, fb1, st, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        PIPE_MMA(fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (it + 1 < nit) {
-            // every read of stage `st` has returned; stage it+1 has landed (own pieces: vmcnt, all waves': barrier)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (it < 8) stamp();
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (it < 8) stamp();
-            if (!dbg_nobar) __builtin_amdgcn_s_barrier();
-            if (it < 8) stamp();
-            PIPE_LOAD(fa0, fb0, stn, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        PIPE_MMA(fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        st = stn;
+    PIPE_LD(fa0[0], LA, LA2, 0, 0, 0); PIPE_LD(fb0[0], LB, LB2, 0, 0, 0);
+    PIPE_LD(fa0[1], LA, LA2, 0, 0, 1); PIPE_LD(fb0[1], LB, LB2, 0, 0, 1);
+    for (int it = 0; it < nit; it += 3) {
+        kstep(std::integral_constant<int, 0>(), it);
+        if (it + 1 < nit) kstep(std::integral_constant<int, 1>(), it + 1);
+        if (it + 2 < nit) kstep(std::integral_constant<int, 2>(), it + 2);
     }
-#undef PIPE_LOAD
-#undef PIPE_MMA
+#undef PIPE_LD
+#undef PIPE_SB
+#undef PIPE_MM
+#undef PIPE_DMA_W
+#undef PIPE_DMA_P
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the trailing (poisoned) requests still write zeros into LDS
     stamp();
 
-    if (ks > 1) {        // split-K: raw f32 partial sums [kz][M][Cout]
+    if (ks > 1) {
+        // split-K: raw f32 partial sums [kz][M][Cout], staged through wave-private LDS rows so that each store
+        // instruction writes four 256-byte row runs
+        constexpr int SROW = PipeCfg::SROW;
         float* P = a.partial + (long)kz * M * a.Cout;
-        if ((a.dbg & 1) && acc[0][0][0] != 12345.5f) { stamp(); flush_stamps(); return; }
+        __syncthreads();                                         // lagging waves still read the last stage
+        unsigned char* sw = smem + wave * (64 * SROW);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const long m = m0 + wm * 64 + j * 32 + (lane & 31);
-            if (m >= M) continue;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * (lane >> 5);
-                    if (n < a.Cout)
-                        *(float4*)(P + m * a.Cout + n) = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1],
-                                                                     acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-                }
+                for (int q = 0; q < 4; ++q)
+                    *(float4*)(sw + (j * 32 + (lane & 31)) * SROW + (i * 32 + 8 * q + 4 * fh) * 4) =
+                        make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int nl = n0 + wn * 64 + (lane & 15) * 4;
+        float4 v[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) v[it] = *(const float4*)(sw + (it * 4 + (lane >> 4)) * SROW + (lane & 15) * 16);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int m = m0 + wm * 64 + it * 4 + (lane >> 4);
+            if (m < M && nl < a.Cout) *(float4*)(P + (long)m * a.Cout + nl) = v[it];
         }
-        if (stamping) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); flush_stamps(); }
+        if (DBG && stamping) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); flush_stamps(); }
         return;
     }
     // ksplit == 1: bias / ReLU / folded-BN affine, tile staged through LDS, coalesced 16-byte row stores
@@ -803,16 +850,16 @@ __global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int idx = tid + it * 512, row = idx / CPRO, c = idx % CPRO;
-                const long m = m0 + row;
+                const int m = m0 + row;
                 const int n = n0 + c * EPC;
-                mkv[it] = *(const uint4*)(mask + ((m < M && n < a.Cout) ? m * a.Cout + n : 0));
+                mkv[it] = *(const uint4*)(mask + ((m < M && n < a.Cout) ? (long)m * a.Cout + n : 0));
             }
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * 512;
             const int row = idx / CPRO, c = idx % CPRO;
-            const long m = m0 + row;
+            const int m = m0 + row;
             const int n = n0 + c * EPC;
             if (m >= M || n >= a.Cout) continue;
             uint4 val = *(const uint4*)(smem + row * OROW + c * 16);
@@ -826,14 +873,14 @@ __global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles
                 val.x = keep(mk.x, val.x); val.y = keep(mk.y, val.y);
                 val.z = keep(mk.z, val.z); val.w = keep(mk.w, val.w);
             }
-            *(uint4*)(out + m * a.Cout + n) = val;
+            *(uint4*)(out + (long)m * a.Cout + n) = val;
         }
     }
 }
 
-template <int MODE>
+template <int MODE, bool RAGGED, int DBG>
 static int launch_pipe(const ConvArgs& a_in, int ks, hipStream_t st) {
-    auto kern = conv_pipe_kernel<MODE>;
+    auto kern = conv_pipe_kernel<MODE, RAGGED, DBG>;
     ConvArgs a = a_in;
     constexpr int NT = GModeTraits<MODE>::NTAPS;
     if (a.w_elems <= 0) a.w_elems = (NT - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
@@ -844,13 +891,6 @@ static int launch_pipe(const ConvArgs& a_in, int ks, hipStream_t st) {
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const int tiles_m = cdiv(M, PipeCfg::BM), tiles_n = cdiv(a.Cout, PipeCfg::BN);
-    {
-        const long hi = MODE == UPCONV2 ? a.Ho / 2 : (MODE == CONV3S2 ? a.Ho * 2 : a.Ho);
-        const long wi = MODE == UPCONV2 ? a.Wo / 2 : (MODE == CONV3S2 ? a.Wo * 2 : a.Wo);
-        const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
-        if ((long)a.B * hi * wi * cmax * 2L >= (1L << 31) || a.w_elems * 2L >= (1L << 31))
-            return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
-    }
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * NT * (a.C0 + a.C1), st);
     a.ksplit = ks > 1 ? ks : 1;
     kern<<<dim3((unsigned)((long)tiles_m * tiles_n * a.ksplit)), dim3(512), PipeCfg::SMEM, st>>>(a, tiles_m, tiles_n);
@@ -877,6 +917,14 @@ static int try_pipe(const ConvArgs& a, hipStream_t st) {
         const long tiles = (long)cdiv(M, PipeCfg::BM) * cdiv(a.Cout, PipeCfg::BN);
         const int nit = GModeTraits<MODE>::NTAPS * (cdiv(a.C0, 64) + cdiv(a.C1, 64));
         if (tiles > 2L * wgs || nit < min_steps) return 0;     // large grids: the two-workgroup schedules fill the chip
+        {   // 32-bit offsets with a poison margin: every operand (and the f32 output rows) below 2 GiB - 8 KiB
+            const long hi = MODE == UPCONV2 ? a.Ho / 2 : (MODE == CONV3S2 ? a.Ho * 2 : a.Ho);
+            const long wi = MODE == UPCONV2 ? a.Wo / 2 : (MODE == CONV3S2 ? a.Wo * 2 : a.Wo);
+            const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
+            const long wel = a.w_elems > 0 ? a.w_elems : (GModeTraits<MODE>::NTAPS - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
+            const long lim = (1L << 31) - 8192;
+            if ((long)a.B * hi * wi * cmax * 2L >= lim || wel * 2L >= lim || M * a.Cout * 2L >= lim || M >= (1L << 30)) return 0;
+        }
         long ks = 1;
         if (a.partial && tiles < wgs) {
             ks = (wgs + tiles / 2) / tiles;                      // ~one workgroup per CU
@@ -885,21 +933,27 @@ static int try_pipe(const ConvArgs& a, hipStream_t st) {
             if (ks < 1) ks = 1;
         }
         ConvArgs b = a; b.dbg = dbg;
-        static unsigned long long* dbuf = nullptr;
-        if ((dbg & 32) && !dbuf) { MPU_CHECK_HIP(hipMalloc(&dbuf, 4 * 64 * 8)); }
-        b.dbg_buf = dbuf;
-        if (dbg & 32) MPU_CHECK_HIP(hipMemsetAsync(dbuf, 0, 4 * 64 * 8, st));
-        const int rc = launch_pipe<MODE>(b, (int)ks, st);
-        if (!rc && (dbg & 32)) {                                   // dev aid: print the stamps of this launch
-            unsigned long long h[4 * 64];
-            MPU_CHECK_HIP(hipStreamSynchronize(st));
-            MPU_CHECK_HIP(hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost));
-            for (int w = 0; w < 4; ++w) {
-                const int n = (int)h[w * 64 + 63];
-                fprintf(stderr, "pipe stamps M=%ld N=%d ks=%ld wg%d wave%d:", M, a.Cout, ks, w < 2 ? 0 : 131, (w & 1) ? 5 : 0);
-                for (int k = 1; k < n && k < 63; ++k) fprintf(stderr, " %lld", (long long)(h[w * 64 + k] - h[w * 64 + k - 1]));
-                fprintf(stderr, "\n");
+        const bool ragged = (a.C0 % 64) != 0 || (a.C1 % 64) != 0;
+        int rc;
+        if (dbg & 32) {
+            static unsigned long long* dbuf = nullptr;
+            if (!dbuf) { MPU_CHECK_HIP(hipMalloc(&dbuf, 4 * 64 * 8)); }
+            b.dbg_buf = dbuf;
+            MPU_CHECK_HIP(hipMemsetAsync(dbuf, 0, 4 * 64 * 8, st));
+            rc = ragged ? launch_pipe<MODE, true, 1>(b, (int)ks, st) : launch_pipe<MODE, false, 1>(b, (int)ks, st);
+            if (!rc) {                                           // dev aid: print the stamps of this launch
+                unsigned long long h[4 * 64];
+                MPU_CHECK_HIP(hipStreamSynchronize(st));
+                MPU_CHECK_HIP(hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost));
+                for (int w = 0; w < 4; ++w) {
+                    const int n = (int)h[w * 64 + 63];
+                    fprintf(stderr, "pipe stamps M=%ld N=%d ks=%ld wg%d wave%d:", M, a.Cout, ks, w < 2 ? 0 : 131, (w & 1) ? 5 : 0);
+                    for (int k = 1; k < n && k < 63; ++k) fprintf(stderr, " %lld", (long long)(h[w * 64 + k] - h[w * 64 + k - 1]));
+                    fprintf(stderr, "\n");
+                }
             }
+        } else {
+            rc = ragged ? launch_pipe<MODE, true, 0>(b, (int)ks, st) : launch_pipe<MODE, false, 0>(b, (int)ks, st);
         }
         return rc ? rc : 1;
     }

@@ -535,6 +535,10 @@ int64_t mpu_unet_workspace_bytes(const mpu_unet* m, int32_t batch) {
     if (!m || batch < 1) return 0;
     return make_plan(m, batch).total;
 }
+int64_t mpu_unet_workspace_probs_offset(const mpu_unet* m, int32_t batch) {
+    if (!m || batch < 1) return -1;
+    return make_plan(m, batch).probs;
+}
 
 int mpu_unet_pack_weights(const mpu_unet* m, const float* d_params, void* d_packed, void* stream) {
     MPU_REQUIRE(m && d_params && d_packed, "mpu_unet_pack_weights: null argument");

@@ -297,9 +297,18 @@ class UNet:
             _lib.call("mpu_unet_prepare_inference", self._h, _lib.ptr(self.params), _lib.ptr(self.bn_state),
                       _lib.ptr(self.packed), _lib.stream_ptr())
             self._infer_dirty = False
+        shape = (B, self.img_shape[0], self.img_shape[1], self.n_classes)
+        if training and out is None:
+            # train-mode forward: the probabilities stay in the workspace (the backward pass reads them there);
+            # the returned tensor is a VIEW of that region, valid until the next forward
+            off = int(_lib.load().mpu_unet_workspace_probs_offset(self._h, B))
+            n = 4 * B * shape[1] * shape[2] * shape[3]
+            view = ws[off:off + n].view(torch.float32).reshape(shape)
+            _lib.call("mpu_unet_forward", self._h, B, _lib.ptr(X), _lib.ptr(self.params), _lib.ptr(self.packed),
+                      _lib.ptr(self.bn_state), _lib.ptr(ws), 1, None, _lib.stream_ptr())
+            return view
         if out is None:
-            out = torch.empty((B, self.img_shape[0], self.img_shape[1], self.n_classes),
-                              dtype=torch.float32, device=self.device)
+            out = torch.empty(shape, dtype=torch.float32, device=self.device)
         _lib.call("mpu_unet_forward", self._h, B, _lib.ptr(X), _lib.ptr(self.params), _lib.ptr(self.packed),
                   _lib.ptr(self.bn_state), _lib.ptr(ws), 1 if training else 0, _lib.ptr(out), _lib.stream_ptr())
         return out
