@@ -705,13 +705,15 @@ __global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles
         LB[s_] = lds0 + BN * 128 + (wm * 64 + (lane & 31)) * 128 + so;
         LA2[s_] = LA[s_] + 2 * STAGE; LB2[s_] = LB[s_] + 2 * STAGE;
     }
-    typedef __attribute__((address_space(3))) const uint4* lds_u4;
+    typedef unsigned int pipe_u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const pipe_u32x4* lds_u4;
 #define PIPE_LD(DST, ARR, ARR2, ST_, S_, HALF)                                                         \
     DST = *(lds_u4)(uintptr_t)(((ST_) == 2 ? ARR2[S_] : ARR[S_]) + ((ST_) == 1 ? STAGE : 0) + (HALF) * 4096)
 #define PIPE_SB() __builtin_amdgcn_sched_barrier(0)
-#define PIPE_MM(FA, FB, I, J) GMma<T>::run(FA[I], FB[J], acc[I][J])
+#define PIPE_MM(FA, FB, I, J)                                                                          \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, FA[I]), __builtin_bit_cast(s16x8, FB[J]), acc[I][J], 0, 0, 0)
 
-    uint4 fa0[2], fb0[2], fa1[2], fb1[2], fa2[2], fb2[2];        // three fragment sets
+    pipe_u32x4 fa0[2], fb0[2], fa1[2], fb1[2], fa2[2], fb2[2];   // three fragment sets
 
     // one K step on stage ST: 16 MFMAs, each followed by one fragment read and (12 of them) a share of the next DMA
     auto kstep = [&](auto stc, int it) {
