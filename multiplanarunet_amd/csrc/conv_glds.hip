@@ -576,7 +576,7 @@ __device__ __forceinline__ void dma16_at(const i32x4& rsrc, unsigned voff, unsig
 }
 
 template <int MODE, bool RAGGED, int DBG>
-__global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles_m, int tiles_n, unsigned magic_w, unsigned magic_h) {
     typedef bf16_t T;
     constexpr int BN = PipeCfg::BN, BM = PipeCfg::BM, STAGE = PipeCfg::STAGE;
     constexpr int EPC = 8, BKE = 64;
@@ -637,9 +637,9 @@ __global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles
         const int rl = wave * (BM / 8) + g * 8 + lrow;           // tile-local pixel row
         const int m = m0 + rl;
         pch[g] = (slot ^ ((rl >> 1) & 7)) * EPC;
-        if (m < M) {
-            const int ox = m % a.Wo, t = m / a.Wo;
-            const int oy = t % a.Ho, b = t / a.Ho;
+        if (m < M) {                                             // exact multiply-high division (host-checked range)
+            const int t = (int)__umulhi((unsigned)m, magic_w), ox = m - t * a.Wo;
+            const int b = (int)__umulhi((unsigned)t, magic_h), oy = t - b * a.Ho;
             pb[g] = b * Hi * Wi; py[g] = oy; px[g] = ox;
         } else { pb[g] = -1; py[g] = 0; px[g] = 0; }
     }
@@ -685,6 +685,13 @@ __global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles
     };
 #define PIPE_DMA_W(G, ST_) dma16_at<(ST_) * STAGE + (G) * 1024>(rsw, w_off(G), wdst)
 #define PIPE_DMA_P(G, ST_) dma16_at<(ST_) * STAGE + (G) * 1024>(q_rs, p_off(G), pdst)
+
+    // the first two K steps are requested before anything else is set up (their round trip covers the rest)
+    stamp();
+    begin_step(true);
+    PIPE_DMA_W(0, 0); PIPE_DMA_W(1, 0); PIPE_DMA_P(0, 0); PIPE_DMA_P(1, 0); PIPE_DMA_P(2, 0); PIPE_DMA_P(3, 0);
+    begin_step(nit > 1);
+    PIPE_DMA_W(0, 1); PIPE_DMA_W(1, 1); PIPE_DMA_P(0, 1); PIPE_DMA_P(1, 1); PIPE_DMA_P(2, 1); PIPE_DMA_P(3, 1);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -752,11 +759,8 @@ __global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles
         PIPE_MM(fa2, fb2, 1, 1); PIPE_LD(fb0[1], LB, LB2, STN, 0, 1); PIPE_SB();
     };
 
-    stamp();
-    begin_step(true);
-    PIPE_DMA_W(0, 0); PIPE_DMA_W(1, 0); PIPE_DMA_P(0, 0); PIPE_DMA_P(1, 0); PIPE_DMA_P(2, 0); PIPE_DMA_P(3, 0);
-    begin_step(nit > 1);
-    PIPE_DMA_W(0, 1); PIPE_DMA_W(1, 1); PIPE_DMA_P(0, 1); PIPE_DMA_P(1, 1); PIPE_DMA_P(2, 1); PIPE_DMA_P(3, 1);
+    // waves 4-7 (the younger half: the arbitration loser on every segment) get static priority
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
     stamp();
     __builtin_amdgcn_s_barrier();
@@ -895,7 +899,8 @@ static int launch_pipe(const ConvArgs& a_in, int ks, hipStream_t st) {
     const int tiles_m = cdiv(M, PipeCfg::BM), tiles_n = cdiv(a.Cout, PipeCfg::BN);
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * NT * (a.C0 + a.C1), st);
     a.ksplit = ks > 1 ? ks : 1;
-    kern<<<dim3((unsigned)((long)tiles_m * tiles_n * a.ksplit)), dim3(512), PipeCfg::SMEM, st>>>(a, tiles_m, tiles_n);
+    const unsigned mw = (unsigned)(((1UL << 32) + a.Wo - 1) / a.Wo), mh = (unsigned)(((1UL << 32) + a.Ho - 1) / a.Ho);
+    kern<<<dim3((unsigned)((long)tiles_m * tiles_n * a.ksplit)), dim3(512), PipeCfg::SMEM, st>>>(a, tiles_m, tiles_n, mw, mh);
     int rc = launch_ok();
     if (!rc && a.ksplit > 1) rc = launch_splitk_finish<bf16_t>(a, a.ksplit, M, st);
     if (prof_on()) prof_end(st);
@@ -926,6 +931,7 @@ static int try_pipe(const ConvArgs& a, hipStream_t st) {
             const long wel = a.w_elems > 0 ? a.w_elems : (GModeTraits<MODE>::NTAPS - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
             const long lim = (1L << 31) - 8192;
             if ((long)a.B * hi * wi * cmax * 2L >= lim || wel * 2L >= lim || M * a.Cout * 2L >= lim || M >= (1L << 30)) return 0;
+            if ((M + 256) * (a.Wo > a.Ho ? a.Wo : a.Ho) >= (1L << 32)) return 0;      // multiply-high division is exact
         }
         long ks = 1;
         if (a.partial && tiles < wgs) {
@@ -959,6 +965,18 @@ static int try_pipe(const ConvArgs& a, hipStream_t st) {
         }
         return rc ? rc : 1;
     }
+}
+
+// experimental dispatch (MPU_PIPE_FIRST=1): 3x3 layers with ~256 tiles of 256 x 128 take this schedule before the
+// halo kernels (level 1 of configs[1])
+int try_conv_pipe_first(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MPU_PIPE_FIRST"); on = (e && e[0] == '1') ? 1 : 0; }
+    if (!on || dtype != MPU_BF16 || mode != CONV3 || a.Cout < 128) return 0;
+    const long M = (long)a.B * a.Ho * a.Wo;
+    const long tiles = (long)cdiv(M, PipeCfg::BM) * cdiv(a.Cout, PipeCfg::BN);
+    if (tiles < 192 || tiles > 512) return 0;
+    return try_pipe<bf16_t, CONV3>(a, st);
 }
 
 template <typename T, int MODE>

@@ -53,6 +53,7 @@ int  launch_conv_glds(int dtype, int mode, const ConvArgs& a, hipStream_t st);  
 int  try_conv_c8(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // <= 8 input channels: first layer (conv_c8.hip)
 int  try_conv_ws(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // register-stationary weights, persistent (conv_ws.hip)
 int  try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st);     // LDS-resident patch variant (conv_halo.hip)
+int  try_conv_pipe_first(int dtype, int mode, const ConvArgs& a, hipStream_t st);   // MPU_PIPE_FIRST=1 (conv_glds.hip)
 long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out);
 // all-taps weight gradient for the high-resolution 3x3 layers (wgrad_taps.hip)
 struct TapsPlan { int use, RH, sx, sy, nstrips; };
