@@ -384,17 +384,25 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
 // out = act(sum_z partial[z] + bias) (* ReLU mask), 16 bytes of output per thread (one 16-byte load of the mask, one
 // 16-byte store). STATS: also the fused BatchNorm statistics of the stored values - the grid is sized so that a
 // thread keeps its channel group over all its rows; per-block column sums go to stats[2][Cout][blocks].
-template <typename T, bool STATS>
+// STATS 2: the BatchNorm-backward sums (sum out, sum out * xhat of bn_x) instead of (sum, sum of squares)
+template <typename T, int STATS>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ partial, int ks, long M, int Cout,
                                                             const float* __restrict__ bias, const T* __restrict__ mask,
                                                             int relu, const float* __restrict__ ps,
                                                             const float* __restrict__ ph, T* __restrict__ out,
-                                                            float* __restrict__ stats) {
+                                                            float* __restrict__ stats, const T* __restrict__ bn_x,
+                                                            const float* __restrict__ bn_mean,
+                                                            const float* __restrict__ bn_invstd) {
     constexpr int EPC = 16 / sizeof(T);
     const long total = M * Cout / EPC, stride = M * Cout;
-    float ssum[EPC], ssq[EPC];
+    float ssum[EPC], ssq[EPC], bmu[EPC], bis[EPC];
 #pragma unroll
-    for (int k = 0; k < EPC; ++k) { ssum[k] = 0.f; ssq[k] = 0.f; }
+    for (int k = 0; k < EPC; ++k) { ssum[k] = 0.f; ssq[k] = 0.f; bmu[k] = 0.f; bis[k] = 0.f; }
+    if (STATS == 2) {                                 // the thread's channel group is the same for all its rows
+        const int n = (int)((((long)blockIdx.x * 256 + threadIdx.x) * EPC) % Cout);
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) { bmu[k] = bn_mean[n + k]; bis[k] = bn_invstd[n + k]; }
+    }
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int n = (int)((e * EPC) % Cout);
         float v[EPC];
@@ -405,6 +413,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
         }
         uint4 mk = make_uint4(0, 0, 0, 0);              // requested together with the first partials
         if (mask) mk = *(const uint4*)(mask + e * EPC);
+        uint4 xq = make_uint4(0, 0, 0, 0);
+        if (STATS == 2) xq = *(const uint4*)(bn_x + e * EPC);
         for (int z0 = 0; z0 < ks; z0 += 4) {            // four splits per round trip (clamped, unconditional loads;
             float4 p[4][EPC / 4];                       //  the adds keep the order z = 0, 1, 2, ...)
 #pragma unroll
@@ -450,17 +460,24 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
         }
         *(uint4*)(out + e * EPC) = o;
         if (STATS) {                                  // statistics of the STORED (rounded) values
+            const uint32_t xw[4] = {xq.x, xq.y, xq.z, xq.w};
             if (sizeof(T) == 2) {
                 const uint32_t wv[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float lo = __uint_as_float(wv[q] << 16), hi = __uint_as_float(wv[q] & 0xffff0000u);
-                    ssum[(2 * q) % EPC] += lo; ssq[(2 * q) % EPC] += lo * lo;
-                    ssum[(2 * q + 1) % EPC] += hi; ssq[(2 * q + 1) % EPC] += hi * hi;
+                    const int kl = (2 * q) % EPC, kh = (2 * q + 1) % EPC;
+                    const float fl = STATS == 2 ? (__uint_as_float(xw[q] << 16) - bmu[kl]) * bis[kl] : lo;
+                    const float fh = STATS == 2 ? (__uint_as_float(xw[q] & 0xffff0000u) - bmu[kh]) * bis[kh] : hi;
+                    ssum[kl] += lo; ssq[kl] += lo * fl;
+                    ssum[kh] += hi; ssq[kh] += hi * fh;
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < EPC; ++k) { ssum[k] += v[k]; ssq[k] += v[k] * v[k]; }
+                for (int k = 0; k < EPC; ++k) {
+                    const float f2 = STATS == 2 ? (__uint_as_float(xw[k % 4]) - bmu[k]) * bis[k] : v[k];
+                    ssum[k] += v[k]; ssq[k] += v[k] * f2;
+                }
             }
         }
     }
@@ -492,11 +509,18 @@ static int launch_splitk_finish(const ConvArgs& a, int ks, long M, hipStream_t s
         if (blocks > 256) blocks = 256;
         if (blocks * 2 * a.Cout > a.stats_cap) blocks = a.stats_cap / (2 * a.Cout);
         *a.stats_rows = (int)blocks;
-        splitk_finish_kernel<T, true><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
-                                                                        a.relu, a.post_scale, a.post_shift, (T*)a.out, a.stats);
+        if (a.bn_x)
+            splitk_finish_kernel<T, 2><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
+                                                                         a.relu, a.post_scale, a.post_shift, (T*)a.out, a.stats,
+                                                                         (const T*)a.bn_x, a.bn_mean, a.bn_invstd);
+        else
+            splitk_finish_kernel<T, 1><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
+                                                                         a.relu, a.post_scale, a.post_shift, (T*)a.out, a.stats,
+                                                                         nullptr, nullptr, nullptr);
     } else {
-        splitk_finish_kernel<T, false><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
-                                                                         a.relu, a.post_scale, a.post_shift, (T*)a.out, nullptr);
+        splitk_finish_kernel<T, 0><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
+                                                                     a.relu, a.post_scale, a.post_shift, (T*)a.out, nullptr,
+                                                                     nullptr, nullptr, nullptr);
     }
     return launch_ok();
 }

@@ -304,18 +304,27 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
         const unsigned char* srow = smem + r0 * OROW + c * 16;
         const bool n_ok = n < a.Cout;
         float ssum[EPC], ssq[EPC];                                                // fused BN statistics (a.stats)
+        float bmu[EPC], bis[EPC];                                                 // ... of the backward pass (a.bn_x)
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+        for (int e = 0; e < EPC; ++e) {
+            ssum[e] = 0.f; ssq[e] = 0.f;
+            const bool on = a.bn_x && n + e < a.Cout;
+            bmu[e] = on ? a.bn_mean[n + e] : 0.f; bis[e] = on ? a.bn_invstd[n + e] : 0.f;
+        }
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bn_x ? a.bn_x : a.out), 0,
+                                                                              (int)(npo * a.Cout * (long)sizeof(T)), 0x00020000);
         // ReLU masks of the data-gradient launches: every pass's 16 bytes requested up front (a load inside the
         // pass would be waited for on the spot, together with the previous pass's store: one round trip per pass).
         // Launches without a mask request nothing (out-of-range marker).
         constexpr int NIT = BM / RPI;
-        u32x4 mkv[NIT];
+        u32x4 mkv[NIT], bxv[NIT];                                                 // bxv: the BatchNorm input at the same positions
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int yy = it / XPI, xx = (it % XPI) * RPI;
-            const bool ok = a.mask && n_ok && (y0 + yy < H) && (x0 + xx + r0 < W);
-            mkv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsm, ok ? (unsigned)(obase + lane_off + (yy * W + xx) * pixB) : OOB, 0, 0);
+            const bool in = n_ok && (y0 + yy < H) && (x0 + xx + r0 < W);
+            const unsigned o = (unsigned)(obase + lane_off + (yy * W + xx) * pixB);
+            mkv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsm, (a.mask && in) ? o : OOB, 0, 0);
+            bxv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (a.bn_x && in) ? o : OOB, 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -323,17 +332,27 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
             const bool ok = n_ok && (y0 + yy < H) && (x0 + xx + r0 < W);
             u32x4 val = *(const u32x4*)(srow + it * RPI * OROW);
             if (a.stats && ok) {
+                // second factor: the value itself (forward: sum of squares) or xhat of the BatchNorm input (backward)
                 if (sizeof(T) == 2) {
                     const uint32_t wv[4] = {val.x, val.y, val.z, val.w};
+                    const uint32_t xw[4] = {bxv[it].x, bxv[it].y, bxv[it].z, bxv[it].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float lo = __uint_as_float(wv[e] << 16), hi = __uint_as_float(wv[e] & 0xffff0000u);
-                        ssum[2 * e] += lo; ssq[2 * e] += lo * lo; ssum[2 * e + 1] += hi; ssq[2 * e + 1] += hi * hi;
+                        const float xl = __uint_as_float(xw[e] << 16), xh = __uint_as_float(xw[e] & 0xffff0000u);
+                        const float fl = a.bn_x ? (xl - bmu[2 * e]) * bis[2 * e] : lo;
+                        const float fh = a.bn_x ? (xh - bmu[2 * e + 1]) * bis[2 * e + 1] : hi;
+                        ssum[2 * e] += lo; ssq[2 * e] += lo * fl; ssum[2 * e + 1] += hi; ssq[2 * e + 1] += hi * fh;
                     }
                 } else {
                     const float fv[4] = {__uint_as_float(val.x), __uint_as_float(val.y), __uint_as_float(val.z), __uint_as_float(val.w)};
+                    const float xf[4] = {__uint_as_float(bxv[it].x), __uint_as_float(bxv[it].y), __uint_as_float(bxv[it].z),
+                                         __uint_as_float(bxv[it].w)};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { ssum[e % EPC] += fv[e]; ssq[e % EPC] += fv[e] * fv[e]; }
+                    for (int e = 0; e < 4; ++e) {
+                        const float f2 = a.bn_x ? (xf[e] - bmu[e % EPC]) * bis[e % EPC] : fv[e];
+                        ssum[e % EPC] += fv[e]; ssq[e % EPC] += fv[e] * f2;
+                    }
                 }
             }
             // (no scalar offset operand: it is added after the range check of the vector offset, which would wrap

@@ -322,8 +322,8 @@ int launch_ws(const ConvArgs& a_in, hipStream_t st) {
     const long tx = cdiv(a.Wo, Cfg::TW), ty = cdiv(a.Ho, TH);
     if (tiles * (tx > ty ? tx : ty) >= (1L << 32)) return fail(MPU_EUNSUPPORTED, "%s", "conv: too many tiles");
     const unsigned mx = (unsigned)(((1UL << 32) + tx - 1) / tx), my = (unsigned)(((1UL << 32) + ty - 1) / ty);
-    if (a.stats && a.stats_rows && (long)grid * 2 * a.Cout <= a.stats_cap) *a.stats_rows = grid;
-    else a.stats = nullptr;
+    if (a.stats && a.stats_rows && !a.bn_x && (long)grid * 2 * a.Cout <= a.stats_cap) *a.stats_rows = grid;
+    else a.stats = nullptr;                                      // (forward statistics only: bn_x -> the caller reduces)
     kern<<<dim3((unsigned)grid), dim3(256), Cfg::SMEM, st>>>(a, (int)tiles, mx, my);
     if (prof_on()) prof_end(st);
     return launch_ok();

@@ -23,6 +23,10 @@ struct ConvArgs {
     // *stats_rows to the number of rows
     // (0: the schedule chosen for this shape does not produce them; the caller runs the column reduction instead).
     float* stats; int* stats_rows; long stats_cap;              // capacity of `stats` in floats
+    // With bn_x set the two sums are those of the BatchNorm BACKWARD pass of the layer that consumes this output as
+    // its dn: sum out, sum out * (bn_x - mean) * invstd (bn_x: the BatchNorm's input, same shape as out). Schedules that
+    // cannot produce them leave *stats_rows = 0.
+    const void* bn_x = nullptr; const float* bn_mean = nullptr; const float* bn_invstd = nullptr;
     int dbg = 0;                 // profiling switches of conv_pipe_kernel (MPU_PIPE_DEBUG: 1 no stores, 2 no MFMAs, 4 no DMA,
                                  //   8 no fragment reads, 16 no barrier, 32 s_memtime stamps into dbg_buf)
     unsigned long long* dbg_buf = nullptr;
@@ -102,7 +106,9 @@ int launch_bn_apply(int dtype, const void* x, int B, int H, int W, int C, const 
 int launch_bn_backward(int dtype, const void* dn, const void* x, long M, int C, float* partial,
                        const float* gamma, const float* mean, const float* invstd,
                        float* dgamma, float* dbeta, float* coeffs /*[3][C]*/, void* dz,
-                       int ready_rows /* > 0: partial already holds that many [2][C] rows */, hipStream_t st);
+                       int ready_rows /* > 0: partial already holds that many partial rows */,
+                       int ready_colmajor /* their layout: 0 = [rows][2][C], 1 = [2][C][rows] (conv epilogues) */,
+                       hipStream_t st);
 // dn = dskip + unpool(dp) (gradient of MaxPooling2D routed to the first max of each window)
 int launch_maxpool_bwd_add(int dtype, const void* n, const void* dskip, const void* dp,
                            int B, int H, int W, int C, void* dn, hipStream_t st);

@@ -194,6 +194,7 @@ int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* i
     if (fused_stats < 0) { const char* e = getenv("MPU_FUSED_BN_STATS"); fused_stats = (e && e[0] == '0') ? 0 : 1; }
     if (!fused_stats) stats_rows = nullptr;
     a.stats = stats_rows ? (float*)r.at(r.P.partial) : nullptr; a.stats_rows = stats_rows; a.stats_cap = r.P.partial_floats;
+    a.bn_x = nullptr; a.bn_mean = nullptr; a.bn_invstd = nullptr;
     a.flops = conv_flops(r, c, lvl); a.w_elems = 0;
     a.partial = r.overlap ? nullptr : (float*)r.at(r.P.wpartial); a.partial_cap = r.P.wpartial_floats; a.ksplit = 1;
     a.post_scale = post_scale; a.post_shift = post_shift;
@@ -205,10 +206,18 @@ int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* i
 }
 
 // data gradient of conv `c` w.r.t. input channels [n_off, n_off + n_cnt); out_lvl = resolution of the result
+// bn (optional): the output is the dn of that BatchNorm (input bn_x); the epilogue then also produces the partial sums
+// of its backward pass and *bn_rows (> 0) tells bn_bwd to skip the column reduction (column-major layout).
 int conv_dgrad(const Run& r, const Conv& c, const void* dz, const void* mask, void* out, int out_lvl,
-               int n_off, int n_cnt) {
+               int n_off, int n_cnt, const BN* bn = nullptr, const void* bn_x = nullptr, int* bn_rows = nullptr) {
     ConvArgs a;
-    a.stats = nullptr; a.stats_rows = nullptr; a.stats_cap = 0;
+    static int fused_bwd = -1;
+    if (fused_bwd < 0) { const char* e = getenv("MPU_FUSED_BN_BWD_CONV"); fused_bwd = (e && e[0] == '0') ? 0 : 1; }
+    if (bn_rows) *bn_rows = 0;
+    const bool want = fused_bwd && bn && bn_x && bn_rows && !mask;
+    a.stats = want ? (float*)r.at(r.P.partial) : nullptr; a.stats_rows = want ? bn_rows : nullptr;
+    a.stats_cap = want ? r.P.partial_floats : 0;
+    a.bn_x = want ? bn_x : nullptr; a.bn_mean = want ? r.stat(*bn, 0) : nullptr; a.bn_invstd = want ? r.stat(*bn, 1) : nullptr;
     a.in0 = dz; a.in1 = nullptr; a.C0 = c.Cout; a.C1 = 0; a.w_elems = 0;
     a.partial = r.overlap ? nullptr : (float*)r.at(r.P.wpartial); a.partial_cap = r.P.wpartial_floats; a.ksplit = 1;
     a.post_scale = nullptr; a.post_shift = nullptr;
@@ -272,10 +281,12 @@ int bn_fwd(const Run& r, const BN& b, const void* x, int lvl, int training, void
     return launch_bn_apply(r.m->cfg.dtype, x, r.B, H, W, b.C, r.stat(b, 2), r.stat(b, 3), y, pooled, r.st);
 }
 
-int bn_bwd(const Run& r, const BN& b, const void* dn, const void* x, int lvl, void* dz, int ready_rows = 0) {
+int bn_bwd(const Run& r, const BN& b, const void* dn, const void* x, int lvl, void* dz, int ready_rows = 0,
+           int ready_colmajor = 0) {
     const long M = (long)r.B * (r.m->cfg.H >> lvl) * (r.m->cfg.W >> lvl);
     return launch_bn_backward(r.m->cfg.dtype, dn, x, M, b.C, (float*)r.at(r.P.partial), r.params + b.g, r.stat(b, 0),
-                              r.stat(b, 1), r.grads + b.g, r.grads + b.b, (float*)r.at(r.P.coeffs), dz, ready_rows, r.st);
+                              r.stat(b, 1), r.grads + b.g, r.grads + b.b, (float*)r.at(r.P.coeffs), dz, ready_rows,
+                              ready_colmajor, r.st);
 }
 
 #define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
@@ -381,6 +392,7 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
     RC(mark_ready(r, point++));                                                            // head
     // Each weight gradient (side stream) runs next to the data gradient of the same layer (main stream);
     // wgrad_join() precedes the first main-stream kernel that overwrites the dz buffer it reads.
+    int rowsA = 0;       // partial rows of BN-backward sums already produced for the dn in gA (0: head_backward wrote it)
     for (int j = D - 1; j >= 0; --j) {
         const int lvl = D - 1 - j, f = m->F[lvl];
         const Conv& cu = m->conv[m->up_c(j, 0)]; const Conv& c2 = m->conv[m->up_c(j, 1)];
@@ -388,24 +400,28 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
         const void* prev = j > 0 ? r.at(P.n2[j - 1]) : r.at(P.nb);
         const int Cprev = j > 0 ? m->F[lvl + 1] : m->F[D];
         RC(wgrad_join(r));                                                                 // gB is about to be written
-        RC(bn_bwd(r, m->bn[m->up_bn(j, 1)], gA, r.at(P.c3u[j]), lvl, gB));                 // dz3 -> gB
+        RC(bn_bwd(r, m->bn[m->up_bn(j, 1)], gA, r.at(P.c3u[j]), lvl, gB, rowsA, 1));       // dz3 -> gB
         RC(conv_wgrad(r, c3, r.at(P.c2u[j]), f, nullptr, 0, gB, lvl));                     //   reads gB
         RC(conv_dgrad(r, c3, gB, r.at(P.c2u[j]), gA, lvl, 0, f));                          // dz2 -> gA
         RC(wgrad_join(r));
         RC(conv_wgrad(r, c2, r.at(P.n[lvl]), f, r.at(P.n1[j]), f, gA, lvl));               //   reads gA
         RC(conv_dgrad(r, c2, gA, nullptr, r.at(P.dskip[lvl]), lvl, 0, f));                 // d skip
-        RC(conv_dgrad(r, c2, gA, nullptr, gB, lvl, f, f));                                 // d n1 -> gB
-        RC(bn_bwd(r, m->bn[m->up_bn(j, 0)], gB, r.at(P.u1[j]), lvl, gC));                  // dz up-conv -> gC
+        int rowsB = 0;                                                                     // (BN-backward sums from the epilogue)
+        RC(conv_dgrad(r, c2, gA, nullptr, gB, lvl, f, f, &m->bn[m->up_bn(j, 0)], r.at(P.u1[j]), &rowsB));   // d n1 -> gB
+        RC(bn_bwd(r, m->bn[m->up_bn(j, 0)], gB, r.at(P.u1[j]), lvl, gC, rowsB, 1));        // dz up-conv -> gC
         RC(wgrad_join(r));                                                                 // gA is about to be written
         RC(conv_wgrad(r, cu, prev, Cprev, nullptr, 0, gC, lvl));                           //   reads gC
-        RC(conv_dgrad(r, cu, gC, nullptr, gA, lvl + 1, 0, Cprev));                         // d prev -> gA
+        // d prev -> gA: the dn of the previous block's second BatchNorm (or of the bottom one)
+        const BN& pbn = j > 0 ? m->bn[m->up_bn(j - 1, 1)] : m->bn[m->bot_bn()];
+        const void* pbx = j > 0 ? r.at(P.c3u[j - 1]) : r.at(P.c2b);
+        RC(conv_dgrad(r, cu, gC, nullptr, gA, lvl + 1, 0, Cprev, &pbn, pbx, &rowsA));
         RC(mark_ready(r, point++));                                                        // up block j
     }
     {   // bottom
         const Conv& c1 = m->conv[m->bot_c1()]; const Conv& c2 = m->conv[m->bot_c2()];
         const void* xin = D > 0 ? r.at(P.p[D - 1]) : r.at(P.xin);
         const int Cx = D > 0 ? m->F[D - 1] : m->cin_pad;
-        RC(bn_bwd(r, m->bn[m->bot_bn()], gA, r.at(P.c2b), D, gB));                         // gC reader may still run: gB is free
+        RC(bn_bwd(r, m->bn[m->bot_bn()], gA, r.at(P.c2b), D, gB, D > 0 ? rowsA : 0, 1));   // gC reader may still run: gB is free
         RC(conv_wgrad_after_join(r, c2, r.at(P.c1b), m->F[D], nullptr, 0, gB, D));
         RC(conv_dgrad(r, c2, gB, r.at(P.c1b), gA, D, 0, m->F[D]));
         RC(conv_wgrad_after_join(r, c1, xin, Cx, nullptr, 0, gA, D));
@@ -656,6 +672,7 @@ static int conv2d_igemm_impl(int32_t dtype, int32_t mode, const void* d_in0, int
     a.B = B; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.relu = relu; a.flops = 0; a.w_elems = 0;
     a.partial = d_workspace; a.partial_cap = d_workspace ? workspace_floats : 0; a.ksplit = 1;
     a.stats = nullptr; a.stats_rows = nullptr; a.stats_cap = 0;
+    a.bn_x = nullptr; a.bn_mean = nullptr; a.bn_invstd = nullptr;
     a.post_scale = nullptr; a.post_shift = nullptr;
     return launch_conv(dtype, mode, a, (hipStream_t)stream);
 }

@@ -561,14 +561,21 @@ int launch_bn_apply(int dtype, const void* x, int B, int H, int W, int C, const 
 
 // BN backward finalize: dgamma, dbeta and the per-channel coefficients of
 // dx = k1*dn + k2*x + k3  (dx = scale*(dn - mean(dn) - xhat*mean(dn*xhat)))
+// COLMAJOR: partial is [2][C][nblk] (written by a conv epilogue), else [nblk][2][C] (colreduce, maxpool_bwd_add)
+template <bool COLMAJOR>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
                                        const float* gamma, const float* mean, const float* invstd,
                                        float* dgamma, float* dbeta, float* coeffs) {
     __shared__ double red[256];
-    const int c = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
+    const int c = blockIdx.x * FIN_COLS + (COLMAJOR ? threadIdx.x / FIN_KL : threadIdx.x % FIN_COLS);
     double st[2];
-    partial_sums<2>(partial, nblk, 2L * C, C, c, c < C, red, st);
-    if (c >= C || threadIdx.x >= FIN_COLS) return;
+    if (COLMAJOR) {
+        partial_sums_colmajor<2>(partial, nblk, C, c, c < C, red, st);
+        if (c >= C || threadIdx.x % FIN_KL) return;
+    } else {
+        partial_sums<2>(partial, nblk, 2L * C, C, c, c < C, red, st);
+        if (c >= C || threadIdx.x >= FIN_COLS) return;
+    }
     const double s = st[0], sx = st[1];
     dgamma[c] = (float)sx; dbeta[c] = (float)s;
     const double sc = (double)gamma[c] * (double)invstd[c];
@@ -612,12 +619,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 int launch_bn_backward(int dtype, const void* dn, const void* x, long M, int C, float* partial, const float* gamma,
                        const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coeffs, void* dz,
-                       int ready_rows, hipStream_t st) {
-    int nblk = ready_rows;                       // > 0: the producer of dn already wrote that many [2][C] partial rows
+                       int ready_rows, int ready_colmajor, hipStream_t st) {
+    int nblk = ready_rows;                       // > 0: the producer of dn already wrote that many partial rows
     int rc = 0;
-    if (nblk <= 0) rc = launch_colreduce<1>(dtype, dn, x, M, C, mean, invstd, partial, &nblk, st);
+    if (nblk <= 0) { ready_colmajor = 0; rc = launch_colreduce<1>(dtype, dn, x, M, C, mean, invstd, partial, &nblk, st); }
     if (rc) return rc;
-    bn_bwd_finalize_kernel<<<cdiv(C, FIN_COLS), 256, 0, st>>>(partial, nblk, C, M, gamma, mean, invstd, dgamma, dbeta, coeffs);
+    if (ready_colmajor)
+        bn_bwd_finalize_kernel<true><<<cdiv(C, FIN_COLS), 256, 0, st>>>(partial, nblk, C, M, gamma, mean, invstd, dgamma, dbeta, coeffs);
+    else
+        bn_bwd_finalize_kernel<false><<<cdiv(C, FIN_COLS), 256, 0, st>>>(partial, nblk, C, M, gamma, mean, invstd, dgamma, dbeta, coeffs);
     rc = launch_ok();
     if (rc) return rc;
     const long work = M * C / 8 / 2;

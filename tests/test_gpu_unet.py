@@ -280,3 +280,16 @@ def test_l2_kernel_regulariser_vs_oracle():
     step(); got.train_step(xd, yd, swd, want_loss=False)
     torch.cuda.synchronize()
     assert torch.equal(a.params, got.params)
+
+
+def test_bn_backward_sums_switch_off_subprocess():
+    """The data-gradient epilogues (conv_halo, split-K finish) produce the BatchNorm-backward sums by default;
+    MPU_FUSED_BN_BWD_CONV=0 (read once at library load, hence a fresh interpreter) restores the separate column
+    reduction. The f32 and bf16 train-step parity tests must pass either way."""
+    import os, subprocess, sys
+    env = dict(os.environ, MPU_FUSED_BN_BWD_CONV="0")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_unet.py"), "-x", "-q", "-k",
+                        "f32_train_step or bf16_forward_and_step or graphed"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(here))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
