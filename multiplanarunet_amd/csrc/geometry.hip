@@ -99,9 +99,13 @@ __device__ __forceinline__ void find_cell(const AxisDev& a, double x, int& i, do
 // nearest: index of np.where(y <= .5, i, i+1). With num = fl(x-g[i]), den = fl(g[i+1]-g[i]) > 0 and a
 // correctly rounded quotient, fl(num/den) <= 0.5  <=>  2*num <= den (0.5 is a double, the next
 // double above den is den+ulp > den*(1+2^-53)), so no division is needed.
+__device__ __forceinline__ int find_nearest_exact(const AxisDev& a, double x, bool& oob);
 __device__ __forceinline__ int find_nearest(const AxisDev& a, double x, bool& oob) {
     int nf;
     if (nearest_fast(a, x, nf, oob)) return nf;
+    return find_nearest_exact(a, x, oob);
+}
+__device__ __forceinline__ int find_nearest_exact(const AxisDev& a, double x, bool& oob) {
     double gc, gc1;
     const int c = find_cell_index(a, x, oob, gc, gc1);
     const double num = x - gc, den = gc1 - gc;
@@ -212,9 +216,13 @@ __device__ __forceinline__ long view_lookup(const ViewDev& v, double rx, double 
     double qx, qy, qz;
     mat3_apply(v.invb, rx, ry, rz, qx, qy, qz);
     bool o0, o1, o2;
-    const int n0 = find_nearest(v.g, qx, o0);
-    const int n1 = find_nearest(v.g, qy, o1);
-    const int n2 = find_nearest(v.offs, qz, o2);
+    int n0, n1, n2;
+    const bool f0 = nearest_fast(v.g, qx, n0, o0), f1 = nearest_fast(v.g, qy, n1, o1), f2 = nearest_fast(v.offs, qz, n2, o2);
+    if (__builtin_expect(!(f0 && f1 && f2), 0)) {            // ~1e-5 of the lookups: near a tie / an axis end
+        n0 = find_nearest_exact(v.g, qx, o0);
+        n1 = find_nearest_exact(v.g, qy, o1);
+        n2 = find_nearest_exact(v.offs, qz, o2);
+    }
     if (o0 || o1 || o2) { pl = -1; return -1; }
     pl = n2;
     return (((long)n2 * v.dim + n0) * v.dim + n1) * K;
@@ -297,9 +305,30 @@ __global__ __launch_bounds__(256) void map_fuse_kernel(FuseArgs a) {
     }
     for (int v = 0; v < a.V; ++v) {
         const ViewDev& vw = a.views[v];
+        // closed-form nearest lookups of the four voxels (branch-free); the rare lookups near a tie or an axis end are
+        // redone by ONE copy of the exact search (a rolled loop: the exact search is large, and four inlined copies
+        // per view made the kernel's code larger than the instruction cache)
         long off[FZ];
+        unsigned risky = 0;
 #pragma unroll
-        for (int u = 0; u < FZ; ++u) { int pl; off[u] = view_lookup(vw, rx[u], ry[u], rz[u], K, pl); }
+        for (int u = 0; u < FZ; ++u) {
+            double qx, qy, qz;
+            mat3_apply(vw.invb, rx[u], ry[u], rz[u], qx, qy, qz);
+            int n0, n1, n2; bool o0, o1, o2;
+            const bool f0 = nearest_fast(vw.g, qx, n0, o0), f1 = nearest_fast(vw.g, qy, n1, o1), f2 = nearest_fast(vw.offs, qz, n2, o2);
+            if (!(f0 && f1 && f2)) risky |= 1u << u;
+            off[u] = (o0 || o1 || o2) ? -1 : (((long)n2 * vw.dim + n0) * vw.dim + n1) * K;
+        }
+        if (__builtin_expect(risky != 0, 0)) {
+#pragma unroll 1
+            for (int u = 0; u < FZ; ++u) {
+                if (!((risky >> u) & 1u)) continue;
+                int pl;
+                const long o = view_lookup(vw, rx[u], ry[u], rz[u], K, pl);
+#pragma unroll
+                for (int t = 0; t < FZ; ++t) if (t == u) off[t] = o;
+            }
+        }
         float w[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) w[k] = a.sum_fusion ? 1.f : a.W[v * K + k];
