@@ -36,15 +36,9 @@ def get_argparser():
 
 
 def best_model_path(model_dir):
-    """get_best_model (mpunet/utils/utils.py:88-110): highest val_dice checkpoint, else the final weights."""
-    best, score = None, -1.0
-    for f in os.listdir(model_dir):
-        if f.startswith("@epoch") and "val_dice_" in f:
-            s = float(f.split("val_dice_")[1].rsplit(".", 1)[0])
-            if s > score:
-                best, score = f, s
-    best = best or "model_weights.npz"
-    return os.path.join(model_dir, best)
+    """get_best_model (mpunet/utils/utils.py:88-110) over this build's .npz and the reference's .h5 checkpoints."""
+    from ..formats import get_best_model
+    return get_best_model(model_dir)
 
 
 def run(args):

@@ -105,7 +105,7 @@ struct Plan {
     std::vector<long> c1, c2, n, p, dskip;          // encoder levels
     long c1b, c2b, nb;
     std::vector<long> u1, n1, c2u, c3u, n2;         // up levels
-    long probs, gA, gB, gC, partial, partial_floats, partial2, wpartial, wpartial_floats, coeffs, stats, total;
+    long probs, gA, gB, gC, partial, partial_floats, partial2, wpartial, wpartial_floats, cpartial, cpartial_floats, coeffs, stats, total;
 };
 
 Plan make_plan(const mpu_unet* m, int B) {
@@ -151,14 +151,19 @@ Plan make_plan(const mpu_unet* m, int B) {
             if (e > we) we = e;
         }
     }
-    {   // the same scratch serves split-K forward / data-gradient convs: [ks<=8][M][Cout] at the deep levels
-        for (int l = 0; l <= D; ++l) {
-            const long M = (long)B * (m->cfg.H >> l) * (m->cfg.W >> l);
-            if ((long)cdiv(M, 128) * cdiv(m->F[l], 128) < 256) { const long e = 8 * M * m->F[l]; if (e > we) we = e; }
-        }
-    }
     P.wpartial = take(we * 4);
     P.wpartial_floats = we;
+    long ce = 0;        // split-K scratch of the forward / data-gradient convs (its own region: the weight gradient of the
+    {                   // same layer may run next to the data gradient on the side stream): [ks <= 16][M][Cout] at the deep levels
+        for (int l = 0; l <= D; ++l) {
+            const long M = (long)B * (m->cfg.H >> l) * (m->cfg.W >> l);
+            const int fmax = l > 0 && m->F[l - 1] > m->F[l] ? m->F[l - 1] : m->F[l];
+            if ((long)cdiv(M, 128) * cdiv(m->F[l], 128) < 256) { const long e = 16 * M * (long)fmax; if (e > ce) ce = e; }
+        }
+        if (ce > (96L << 20)) ce = 96L << 20;          // 384 MB is plenty: larger layers fill the chip without a K split
+    }
+    P.cpartial = take(ce * 4);
+    P.cpartial_floats = ce;
     P.coeffs = take(3L * m->cmax * 4);
     P.stats = take(m->n_stats * 4);
     P.total = off;
@@ -196,7 +201,7 @@ int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* i
     a.stats = stats_rows ? (float*)r.at(r.P.partial) : nullptr; a.stats_rows = stats_rows; a.stats_cap = r.P.partial_floats;
     a.bn_x = nullptr; a.bn_mean = nullptr; a.bn_invstd = nullptr;
     a.flops = conv_flops(r, c, lvl); a.w_elems = 0;
-    a.partial = r.overlap ? nullptr : (float*)r.at(r.P.wpartial); a.partial_cap = r.P.wpartial_floats; a.ksplit = 1;
+    a.partial = r.P.cpartial_floats ? (float*)r.at(r.P.cpartial) : nullptr; a.partial_cap = r.P.cpartial_floats; a.ksplit = 1;
     a.post_scale = post_scale; a.post_shift = post_shift;
     a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1;
     a.w = r.wf(c); a.w_tap_stride = (long)c.Cin * c.Cout; a.w_row_stride = c.Cin;
@@ -219,7 +224,7 @@ int conv_dgrad(const Run& r, const Conv& c, const void* dz, const void* mask, vo
     a.stats_cap = want ? r.P.partial_floats : 0;
     a.bn_x = want ? bn_x : nullptr; a.bn_mean = want ? r.stat(*bn, 0) : nullptr; a.bn_invstd = want ? r.stat(*bn, 1) : nullptr;
     a.in0 = dz; a.in1 = nullptr; a.C0 = c.Cout; a.C1 = 0; a.w_elems = 0;
-    a.partial = r.overlap ? nullptr : (float*)r.at(r.P.wpartial); a.partial_cap = r.P.wpartial_floats; a.ksplit = 1;
+    a.partial = r.P.cpartial_floats ? (float*)r.at(r.P.cpartial) : nullptr; a.partial_cap = r.P.cpartial_floats; a.ksplit = 1;
     a.post_scale = nullptr; a.post_shift = nullptr;
     a.w = (const unsigned char*)r.wd(c) + (long)n_off * c.Cout * r.esz;
     a.w_tap_stride = (long)c.Cin * c.Cout; a.w_row_stride = c.Cout;

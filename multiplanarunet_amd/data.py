@@ -20,8 +20,9 @@ from .interpolation import Volume, ViewGeometry, sample_view
 
 def load_volume_file(path):
     if path.endswith((".nii", ".nii.gz")):
-        raise NotImplementedError("NIfTI input needs nibabel, which is outside the accelerated path and "
-                                  "not installed here; convert to .npz (image, labels, affine)")
+        from .formats import load_nifti                      # needs nibabel (import-guarded adapter)
+        img, aff = load_nifti(path)
+        return img, None, aff
     with np.load(path) as z:
         d = {k: z[k] for k in z.files}
     img = d.get("image", d.get("arr_0"))
@@ -36,7 +37,7 @@ def list_volume_files(base_dir, img_subdir="images"):
     d = os.path.join(base_dir, img_subdir)
     if not os.path.isdir(d):
         return []
-    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".npz"))
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".npz", ".nii", ".nii.gz")))
 
 
 def make_toy_volume(size=64, seed=0):

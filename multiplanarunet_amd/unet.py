@@ -248,14 +248,24 @@ class UNet:
         self.set_weights_dict(dict(zip(names, weights)), strict=True)
 
     def save_weights(self, path):
-        """.npz keyed by Keras layer/variable names (h5py is not available here)."""
+        """Name-keyed weights: .npz (native; keys "<layer>__<var>") or, with h5py installed, a tf.keras
+        `save_weights` .h5 file (mpunet/callbacks/mcp_clean.py:57, multiplanarunet_amd/formats.py)."""
         d = self.get_weights_dict()
+        if str(path).endswith((".h5", ".hdf5")):
+            from .formats import save_keras_h5
+            save_keras_h5(path, d, depth=self.depth)
+            return
         with open(path, "wb") as f:
             np.savez(f, **{k.replace("/", "__"): v for k, v in d.items()})
 
     def load_weights(self, path, by_name=True):
-        with np.load(path) as z:
-            d = {k.replace("__", "/"): z[k] for k in z.files}
+        """load_weights(by_name=True) (mpunet/models/model_init.py:31,56): .npz or a reference Keras .h5 checkpoint."""
+        if str(path).endswith((".h5", ".hdf5")):
+            from .formats import load_keras_h5
+            d = load_keras_h5(path)
+        else:
+            with np.load(path) as z:
+                d = {k.replace("__", "/"): z[k] for k in z.files}
         self.set_weights_dict(d, strict=not by_name)
 
     def count_params(self):
