@@ -155,7 +155,7 @@ def test_cfg1_bf16_train_step_per_tensor_and_dispatch():
 
 
 def test_bf16_six_view_pipeline_dice_delta_vs_f64_oracle():
-    """North-star end-to-end tolerance in the benchmarked dtype: train a toy net (~120 Adam steps on sampled planes),
+    """North-star end-to-end tolerance in the benchmarked dtype: train a toy net (200 Adam steps on sampled planes),
     6-view predict+fuse of a 64^3 volume with the bf16 kernels, and the same weights through the f64 oracle
     pipeline (oracle geometry + oracle U-Net + FusionLayer): per-class Dice against the ground truth differs by
     <= 1e-3, every class present in both (mpunet/evaluate/metrics.py:26-52, mpunet/bin/predict.py:294-366)."""
@@ -167,15 +167,17 @@ def test_bf16_six_view_pipeline_dice_delta_vs_f64_oracle():
     from oracle import unet_ref as U
     from oracle import geometry as G
     K, D, depth, cf = 3, 64, 3, 0.0625
-    vols = []
-    for s in range(3):
-        img, lab, aff = make_toy_volume(D, 40 + s)
-        vols.append((img, lab, as_volume(img, lab, aff, "1pct", "RobustScaler", "cuda", "toy%d" % s)))
+    vols, seed = [], 40
+    while len(vols) < 3:                                        # volumes whose three classes are all sizeable: a Dice
+        img, lab, aff = make_toy_volume(D, seed); seed += 1    # delta of 1e-3 should mean a real disagreement, not a
+        if np.bincount(lab.ravel(), minlength=K).min() < 8000:  # handful of boundary voxels of a tiny structure
+            continue
+        vols.append((img, lab, as_volume(img, lab, aff, "1pct", "RobustScaler", "cuda", "toy%d" % seed)))
     m = UNet(n_classes=K, dim=D, depth=depth, complexity_factor=cf, flatten_output=True, dtype="bf16", logger=quiet, seed=0)
     m.compile("Adam", "SparseCategoricalCrossentropy", optimizer_kwargs=dict(lr=2e-3))
     tr = TrainSampler([v for _, _, v in vols[:2]], VIEWS6, D, float(D), 8, K, noise_sd=0.1, seed=1)
     first = last = None
-    for it in range(120):
+    for it in range(200):
         x, y, w = tr()
         l = float(m.train_step(x, y, w).mean().item())
         first = l if first is None else first
