@@ -356,131 +356,6 @@ __global__ __launch_bounds__(256) void map_fuse_kernel(FuseArgs a) {
     }
 }
 
-// ---- two-pass fused map + fuse ---------------------------------------------------------------------------
-// Pass 1 (map_fuse_fast_kernel) decides every nearest lookup with the closed form and FLAGS the voxels for which one
-// of its lookups was not provably exact (coordinate within 1e-6 index units of a tie or an axis end; a non-uniform
-// axis): label 255, or a NaN in probs[.., 0] when no label map is requested. It holds no exact-search code: the view
-// parameters it needs (inverse basis, two (g0, 1/h, n-1) triples) stay in scalar registers, where the one-pass kernel
-// re-fetched its ~50 parameters from the argument segment several times per view and waited for each fetch.
-// Pass 2 (map_fuse_fixup_kernel) scans the flags and recomputes the flagged voxels (~1e-5 of them) with the exact
-// NumPy-order search for every view. The result is exactly that of the one-pass kernel.
-struct ViewFast { double m[9]; double g0, gih, gnm1, o0, oih, onm1; const float* pred; int dim, ok; };
-struct FuseFastArgs {
-    GridDev grid; ViewFast views[MAX_VIEWS]; int V;
-    const float* W; const float* b; int sum_fusion;
-    float* probs; uint8_t* labels;
-};
-
-template <int K>
-__global__ __launch_bounds__(256) void map_fuse_fast_kernel(FuseFastArgs a) {
-    const GridDev& g = a.grid;
-    const int nz = (g.Z + BRZ * FZ - 1) / (BRZ * FZ), ny = (g.Y + BRY - 1) / BRY;
-    const long blk = blockIdx.x;
-    const int bz = (int)(blk % nz), by = (int)((blk / nz) % ny), bx = (int)(blk / ((long)nz * ny));
-    const int vx = bx * BRX + (threadIdx.x >> 6);
-    const int vy = by * BRY + ((threadIdx.x >> 4) & 3);
-    const int vz0 = bz * BRZ * FZ + (threadIdx.x & 15);
-    if (vx >= g.X || vy >= g.Y) return;
-    double rx[FZ], ry[FZ], rz[FZ];
-    float z[FZ][K];
-    unsigned risky = 0;
-#pragma unroll
-    for (int u = 0; u < FZ; ++u) {
-        voxel_real(g, vx, vy, vz0 + 16 * u, rx[u], ry[u], rz[u]);
-#pragma unroll
-        for (int k = 0; k < K; ++k) z[u][k] = 0.f;
-    }
-    for (int v = 0; v < a.V; ++v) {
-        const ViewFast& f = a.views[v];
-        const double m0 = f.m[0], m1 = f.m[1], m2 = f.m[2], m3 = f.m[3], m4 = f.m[4], m5 = f.m[5], m6 = f.m[6], m7 = f.m[7], m8 = f.m[8];
-        const double g0 = f.g0, gih = f.gih, gnm1 = f.gnm1, o0 = f.o0, oih = f.oih, onm1 = f.onm1;
-        const float* pred = f.pred;
-        const int dim = f.dim;
-        if (!f.ok) risky = 0xfu;
-        long off[FZ];
-#pragma unroll
-        for (int u = 0; u < FZ; ++u) {
-            const double qx = fma(m2, rz[u], fma(m1, ry[u], m0 * rx[u]));
-            const double qy = fma(m5, rz[u], fma(m4, ry[u], m3 * rx[u]));
-            const double qz = fma(m8, rz[u], fma(m7, ry[u], m6 * rx[u]));
-            const double u0 = (qx - g0) * gih, u1 = (qy - g0) * gih, u2 = (qz - o0) * oih;
-            const double r0 = rint(u0), r1 = rint(u1), r2 = rint(u2);
-            // not provably exact: within TAU of a half-way point or of either end of the axis (or NaN / huge)
-            const bool bad = !(fabs(u0) < 1e9 && fabs(u1) < 1e9 && fabs(u2) < 1e9) ||
-                             fabs(fabs(u0 - r0) - 0.5) < GEOM_TAU || fabs(u0) < GEOM_TAU || fabs(u0 - gnm1) < GEOM_TAU ||
-                             fabs(fabs(u1 - r1) - 0.5) < GEOM_TAU || fabs(u1) < GEOM_TAU || fabs(u1 - gnm1) < GEOM_TAU ||
-                             fabs(fabs(u2 - r2) - 0.5) < GEOM_TAU || fabs(u2) < GEOM_TAU || fabs(u2 - onm1) < GEOM_TAU;
-            if (bad) risky |= 1u << u;
-            const bool oob = u0 < 0.0 || u0 > gnm1 || u1 < 0.0 || u1 > gnm1 || u2 < 0.0 || u2 > onm1;
-            off[u] = (oob || bad) ? -1 : (((long)(int)r2 * dim + (int)r0) * dim + (int)r1) * K;
-        }
-        float w[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) w[k] = a.sum_fusion ? 1.f : a.W[v * K + k];
-#pragma unroll
-        for (int u = 0; u < FZ; ++u) {
-            float x[K];
-            __builtin_memcpy(x, pred + (off[u] >= 0 ? off[u] : 0), K * sizeof(float));
-            if (off[u] < 0) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) x[k] = k == 0 ? 1.f : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < K; ++k) z[u][k] = a.sum_fusion ? (z[u][k] + x[k]) : (z[u][k] + w[k] * x[k]);
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < FZ; ++u) {
-        const int vz = vz0 + 16 * u;
-        if (vz >= g.Z) continue;
-        const long t = ((long)vx * g.Y + vy) * g.Z + vz;
-        if ((risky >> u) & 1u) {                       // flag for pass 2
-            if (a.labels) a.labels[t] = 255;
-            else a.probs[t * K] = __uint_as_float(0x7fc00001u);
-            continue;
-        }
-        if (!a.sum_fusion) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) z[u][k] = z[u][k] + a.b[k];
-        }
-        softmax_argmax_store<K>(z[u], !a.sum_fusion, t, a.probs, a.labels);
-    }
-}
-
-template <int K>
-__global__ __launch_bounds__(256) void map_fuse_fixup_kernel(FuseArgs a) {
-    const GridDev& g = a.grid;
-    const long n = (long)g.X * g.Y * g.Z;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
-        const bool flagged = a.labels ? a.labels[t] == 255 : (__float_as_uint(a.probs[t * K]) == 0x7fc00001u);
-        if (!flagged) continue;
-        const int vz = (int)(t % g.Z), vy = (int)((t / g.Z) % g.Y), vx = (int)(t / ((long)g.Z * g.Y));
-        double rx, ry, rz;
-        voxel_real(g, vx, vy, vz, rx, ry, rz);
-        float z[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) z[k] = 0.f;
-        for (int v = 0; v < a.V; ++v) {
-            const ViewDev& vw = a.views[v];
-            double qx, qy, qz;
-            mat3_apply(vw.invb, rx, ry, rz, qx, qy, qz);
-            bool o0, o1, o2;
-            const int n0 = find_nearest_exact(vw.g, qx, o0), n1 = find_nearest_exact(vw.g, qy, o1), n2 = find_nearest_exact(vw.offs, qz, o2);
-            const long off = (o0 || o1 || o2) ? -1 : (((long)n2 * vw.dim + n0) * vw.dim + n1) * K;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const float x = off >= 0 ? vw.pred[off + k] : (k == 0 ? 1.f : 0.f);
-                z[k] = a.sum_fusion ? (z[k] + x) : (z[k] + a.W[v * K + k] * x);
-            }
-        }
-        if (!a.sum_fusion) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) z[k] = z[k] + a.b[k];
-        }
-        softmax_argmax_store<K>(z, !a.sum_fusion, t, a.probs, a.labels);
-    }
-}
-
 struct MapArgs {
     GridDev grid; ViewDev view; const float* Wv; int p_lo, p_hi, owns_oob; float* out;
 };
@@ -704,21 +579,7 @@ int mpu_map_fuse_views(const mpu_voxel_grid* grid, const mpu_view_pred* views, i
         to_view(views[v], a.views[v]);
     }
     a.V = n_views; a.W = d_W; a.b = d_b; a.sum_fusion = sum_fusion; a.probs = d_probs; a.labels = d_labels;
-    if (!fast_path_host()) {          // MPU_GEOM_FAST=0 / mpu_geometry_set_fast_path(0): the one-pass exact kernel
-        MPU_DISPATCH_K(n_classes, (map_fuse_kernel<KK><<<dim3(fuse_grid(a.grid)), dim3(256), 0, (hipStream_t)stream>>>(a)));
-        return launch_ok();
-    }
-    FuseFastArgs f; f.grid = a.grid; f.V = n_views; f.W = d_W; f.b = d_b; f.sum_fusion = sum_fusion; f.probs = d_probs; f.labels = d_labels;
-    for (int v = 0; v < n_views; ++v) {
-        const ViewDev& d = a.views[v]; ViewFast& q = f.views[v];
-        memcpy(q.m, d.invb.m, sizeof(q.m));
-        q.g0 = d.g.g0; q.gih = d.g.inv_h; q.gnm1 = (double)(d.g.n - 1);
-        q.o0 = d.offs.g0; q.oih = d.offs.inv_h; q.onm1 = (double)(d.offs.n - 1);
-        q.pred = d.pred; q.dim = d.dim; q.ok = (d.g.kind != 0 && d.offs.kind != 0) ? 1 : 0;
-    }
-    MPU_DISPATCH_K(n_classes, (map_fuse_fast_kernel<KK><<<dim3(fuse_grid(a.grid)), dim3(256), 0, (hipStream_t)stream>>>(f)));
-    { const int rc_ = launch_ok(); if (rc_) return rc_; }
-    MPU_DISPATCH_K(n_classes, (map_fuse_fixup_kernel<KK><<<dim3(grid_for((long)a.grid.X * a.grid.Y * a.grid.Z)), dim3(256), 0, (hipStream_t)stream>>>(a)));
+    MPU_DISPATCH_K(n_classes, (map_fuse_kernel<KK><<<dim3(fuse_grid(a.grid)), dim3(256), 0, (hipStream_t)stream>>>(a)));
     return launch_ok();
 }
 

@@ -155,7 +155,7 @@ def test_cfg1_bf16_train_step_per_tensor_and_dispatch():
 
 
 def test_bf16_six_view_pipeline_dice_delta_vs_f64_oracle():
-    """North-star end-to-end tolerance in the benchmarked dtype: train a toy net (200 Adam steps on sampled planes),
+    """North-star end-to-end tolerance in the benchmarked dtype: train a toy net (300 Adam steps on sampled planes),
     6-view predict+fuse of a 64^3 volume with the bf16 kernels, and the same weights through the f64 oracle
     pipeline (oracle geometry + oracle U-Net + FusionLayer): per-class Dice against the ground truth differs by
     <= 1e-3, every class present in both (mpunet/evaluate/metrics.py:26-52, mpunet/bin/predict.py:294-366)."""
@@ -167,17 +167,29 @@ def test_bf16_six_view_pipeline_dice_delta_vs_f64_oracle():
     from oracle import unet_ref as U
     from oracle import geometry as G
     K, D, depth, cf = 3, 64, 3, 0.0625
-    vols, seed = [], 40
-    while len(vols) < 3:                                        # volumes whose three classes are all sizeable: a Dice
-        img, lab, aff = make_toy_volume(D, seed); seed += 1    # delta of 1e-3 should mean a real disagreement, not a
-        if np.bincount(lab.ravel(), minlength=K).min() < 8000:  # handful of boundary voxels of a tiny structure
-            continue
-        vols.append((img, lab, as_volume(img, lab, aff, "1pct", "RobustScaler", "cuda", "toy%d" % seed)))
+    def toy(seed):
+        """background / ellipsoid / box with SIZEABLE structures (>= 8000 voxels each): a Dice delta of 1e-3 then
+        means a real disagreement, not a handful of boundary voxels of a tiny object."""
+        rng = np.random.RandomState(seed)
+        g = np.mgrid[:D, :D, :D].astype(np.float32)
+        c1 = D * (0.30 + 0.08 * rng.rand(3)); r1 = D * (0.19 + 0.04 * rng.rand(3))
+        c2 = D * (0.66 + 0.06 * rng.rand(3)); h2 = D * (0.15 + 0.03 * rng.rand(3))
+        lab = np.zeros((D, D, D), np.uint8)
+        lab[(((g[0] - c1[0]) / r1[0]) ** 2 + ((g[1] - c1[1]) / r1[1]) ** 2 + ((g[2] - c1[2]) / r1[2]) ** 2) <= 1] = 1
+        lab[(abs(g[0] - c2[0]) < h2[0]) & (abs(g[1] - c2[1]) < h2[1]) & (abs(g[2] - c2[2]) < h2[2])] = 2
+        img = 0.3 * np.sin(g[0] / D * 3) + 0.2 * np.cos(g[1] / D * 5) + 0.05 * rng.randn(D, D, D)
+        img = (img + 0.8 * (lab == 1) + 1.5 * (lab == 2))[..., None].astype(np.float32)
+        assert np.bincount(lab.ravel(), minlength=K).min() >= 8000
+        return img, lab, np.eye(4)
+    vols = []
+    for s in range(3):
+        img, lab, aff = toy(40 + s)
+        vols.append((img, lab, as_volume(img, lab, aff, "1pct", "RobustScaler", "cuda", "toy%d" % s)))
     m = UNet(n_classes=K, dim=D, depth=depth, complexity_factor=cf, flatten_output=True, dtype="bf16", logger=quiet, seed=0)
     m.compile("Adam", "SparseCategoricalCrossentropy", optimizer_kwargs=dict(lr=2e-3))
     tr = TrainSampler([v for _, _, v in vols[:2]], VIEWS6, D, float(D), 8, K, noise_sd=0.1, seed=1)
     first = last = None
-    for it in range(200):
+    for it in range(300):
         x, y, w = tr()
         l = float(m.train_step(x, y, w).mean().item())
         first = l if first is None else first
