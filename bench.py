@@ -168,10 +168,15 @@ def main():
             _lib.check(lib.mpu_profile_summary(kind, C.byref(ms), C.byref(fl), C.byref(n)), "mpu_profile_summary")
             roof[name] = (ms.value, fl.value, n.value)
         lib.mpu_profile_enable(0)
+    guard_bad = 0.0 if (np.isfinite(loss_first) and np.isfinite(loss_last) and loss_last <= 1.05 * loss_first) else 1.0
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt, guard_bad], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, guard_bad = float(t[0].item()), float(t[1].item())
+    if guard_bad:                                # NaN / diverging on some rank: every rank stops (no half-dead job)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        raise SystemExit("bench.py correctness guard failed on rank %d view: loss %r -> %r" % (rank, loss_first, loss_last))
 
     out = None
     if rank == 0:
@@ -201,8 +206,6 @@ def main():
             out["rccl_ranks"] = torch.distributed.get_world_size()
             out["dist_backend"] = torch.distributed.get_backend()
             out["config"]["dp_overlap"] = bool(getattr(model._grad_hook, "overlap", False))
-        if not out["guard"]["finite"] or loss_last > 1.05 * loss_first:      # NaN / diverging: the number is void
-            raise SystemExit("bench.py correctness guard failed: %r" % (out["guard"],))
         if dt_eager is not None:
             out["ms_per_step_eager_with_events"] = round(dt_eager / args.steps * 1e3, 4)
         traffic = {}
