@@ -526,6 +526,89 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kl4_kernel(const float* __re
     }
 }
 
+// every recorded reduction in one launch: block -> job by the table's block ranges; bodies as above
+struct ReduceTable { int njobs, _pad; ReduceJob job[REDUCE_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(ReduceTable t) {
+    int j = 0;
+#pragma unroll 1
+    for (int k = 1; k < t.njobs; ++k) if ((int)blockIdx.x >= t.job[k].blk_begin) j = k;
+    const ReduceJob& q = t.job[j];
+    const int b = (int)blockIdx.x - q.blk_begin;
+    if (b >= q.main_blocks) {
+        __shared__ double dred[256];
+        colsum_finalize_block(b - q.main_blocks, q.db_partial, q.nshare, q.C, q.db, dred);
+        return;
+    }
+    const long n4 = q.n >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(q.partial);
+    const int ksplit = q.ksplit;
+    if (!q.kl4) {
+        for (long e = (long)b * 256 + threadIdx.x; e < n4; e += (long)q.main_blocks * 256) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            int k = 0;
+            for (; k + 4 <= ksplit; k += 4) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = p4[(long)(k + u) * n4 + e];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+            }
+            if (k < ksplit) {
+                float4 v[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) v[u] = p4[(long)(k + u < ksplit ? k + u : k) * n4 + e];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const bool on = k + u < ksplit;
+                    s.x += on ? v[u].x : 0.f; s.y += on ? v[u].y : 0.f; s.z += on ? v[u].z : 0.f; s.w += on ? v[u].w : 0.f;
+                }
+            }
+            reinterpret_cast<float4*>(q.dW)[e] = s;
+        }
+        return;
+    }
+    __shared__ float4 red[256];
+    const int col = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const long e = (long)b * 64 + col;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < n4) {
+        int k = kl;
+        for (; k + 12 < ksplit; k += 16) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = p4[(long)(k + 4 * u) * n4 + e];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        if (k < ksplit) {
+            float4 v[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) v[u] = p4[(long)(k + 4 * u < ksplit ? k + 4 * u : k) * n4 + e];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const bool on = k + 4 * u < ksplit;
+                s.x += on ? v[u].x : 0.f; s.y += on ? v[u].y : 0.f; s.z += on ? v[u].z : 0.f; s.w += on ? v[u].w : 0.f;
+            }
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (kl == 0 && e < n4) {
+#pragma unroll
+        for (int jj = 1; jj < 4; ++jj) { const float4 v = red[jj * 64 + col]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        reinterpret_cast<float4*>(q.dW)[e] = s;
+    }
+}
+
+int flush_wgrad_reduces(ReduceQueue& q, hipStream_t st) {
+    if (q.njobs == 0) return MPU_OK;
+    ReduceTable t; t.njobs = q.njobs; t._pad = 0;
+    for (int k = 0; k < q.njobs; ++k) t.job[k] = q.job[k];
+    wgrad_reduce_all_kernel<<<dim3((unsigned)q.nblocks), dim3(256), 0, st>>>(t);
+    q.njobs = 0; q.nblocks = 0;
+    return launch_ok();
+}
+
 // MPU_CONV_IMPL=regs selects the register-staged kernel of this file; default is the LDS-DMA
 // kernel of conv_glds.hip (same tiling, same results).
 static int conv_impl() {
@@ -655,7 +738,7 @@ long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, i
 }
 
 template <typename T, int MODE>
-static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
+static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue* rq) {
     const int Cin = a.C0 + a.C1;
     const int dt_ = sizeof(T) == 2 ? MPU_BF16 : MPU_F32;
     if (conv_impl() == 1) {                      // first layer: 1-2 image channels in 8-channel records
@@ -712,27 +795,49 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st) {
         f.partial = a.db_partial; f.db = a.db; f.C = a.Cout;
         f.nshare = taps.use ? a.ksplit : a.ksplit * ntaps * cdiv(Cin, big128 ? 128 : 64);
         db_blocks = cdiv(a.Cout, FIN_COLS);
-        if (a.ksplit == 1) return launch_colsum_finalize(a.db_partial, f.nshare, a.Cout, a.db, st);
     }
-    if (a.ksplit == 1) return MPU_OK;
     const long n4 = n / 4;
-    if (a.ksplit >= 8 && n4 <= 64L * 8192) {
-        f.main_blocks = (int)((n4 + 63) / 64);
-        wgrad_reduce_kl4_kernel<<<dim3((unsigned)(f.main_blocks + db_blocks)), dim3(256), 0, st>>>(a.partial, a.ksplit, n, dW, f);
-    } else {
-        long blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096;
-        f.main_blocks = (int)blocks;
-        wgrad_reduce_kernel<<<dim3((unsigned)(f.main_blocks + db_blocks)), dim3(256), 0, st>>>(a.partial, a.ksplit, n, dW, f);
+    const bool kl4 = a.ksplit >= 8 && n4 <= 64L * 8192;
+    if (a.ksplit > 1) {
+        if (kl4) f.main_blocks = (int)((n4 + 63) / 64);
+        else { long blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096; f.main_blocks = (int)blocks; }
     }
+    if (rq && (a.ksplit > 1 || db_blocks) && rq->njobs < REDUCE_MAX_JOBS) {      // deferred: one launch for many layers
+        ReduceJob& j = rq->job[rq->njobs++];
+        j.partial = a.partial; j.dW = dW; j.n = a.ksplit > 1 ? n : 0; j.ksplit = a.ksplit; j.kl4 = kl4 ? 1 : 0;
+        j.db_partial = f.partial; j.db = f.db; j.nshare = f.nshare; j.C = f.C;
+        j.blk_begin = rq->nblocks; j.main_blocks = a.ksplit > 1 ? f.main_blocks : 0; j.db_blocks = db_blocks; j._pad = 0;
+        rq->nblocks += j.main_blocks + j.db_blocks;
+        return MPU_OK;
+    }
+    if (a.ksplit == 1) return db_blocks ? launch_colsum_finalize(a.db_partial, f.nshare, a.Cout, a.db, st) : MPU_OK;
+    if (kl4)
+        wgrad_reduce_kl4_kernel<<<dim3((unsigned)(f.main_blocks + db_blocks)), dim3(256), 0, st>>>(a.partial, a.ksplit, n, dW, f);
+    else
+        wgrad_reduce_kernel<<<dim3((unsigned)(f.main_blocks + db_blocks)), dim3(256), 0, st>>>(a.partial, a.ksplit, n, dW, f);
     return launch_ok();
 }
 
-int launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st) {
+// exact scratch of one layer (mirrors the split / schedule decisions of launch_wgrad_mode)
+long wgrad_scratch_need(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout) {
+    const int Cin = C0 + C1;
+    const int ntaps = mode == UPCONV2 ? 4 : (mode == CONV1 ? 1 : 9);
+    const long M = (long)B * H * W, n = (long)ntaps * Cin * Cout;
+    int ks = 1, mchunk = 0;
+    wgrad_partial_elems(mode, Cin, Cout, M, &ks, &mchunk);
+    TapsPlan taps; taps.use = 0;
+    if (conv_impl() == 1) taps = wgrad_taps_plan(dtype, mode, B, H, W, C0, C1, Cout);
+    if (taps.use) ks = (taps.nstrips + 1) / 2;
+    const long nshare = taps.use ? ks : (long)ks * ntaps * cdiv(Cin, 64);
+    return ((long)ks * n + nshare * Cout + 63) / 64 * 64 + 64;
+}
+
+int launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st, ReduceQueue* rq) {
 #define MPU_WG_CASE(TT)                                                            \
     switch (mode) {                                                                \
-        case CONV3: return launch_wgrad_mode<TT, CONV3>(a, dW, st);                \
-        case UPCONV2: return launch_wgrad_mode<TT, UPCONV2>(a, dW, st);            \
-        case CONV1: return launch_wgrad_mode<TT, CONV1>(a, dW, st);                \
+        case CONV3: return launch_wgrad_mode<TT, CONV3>(a, dW, st, rq);            \
+        case UPCONV2: return launch_wgrad_mode<TT, UPCONV2>(a, dW, st, rq);        \
+        case CONV1: return launch_wgrad_mode<TT, CONV1>(a, dW, st, rq);            \
         default: return fail(MPU_EINVAL, "%s", "wgrad: bad mode");                 \
     }
     if (dtype == MPU_BF16) { MPU_WG_CASE(bf16_t) }

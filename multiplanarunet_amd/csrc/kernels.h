@@ -66,7 +66,20 @@ constexpr int TAPS_MAX_WGS = 1024;             // strips * 64x64 tiles; bounds t
                                                // dW per strip): <= 1024 * 9 * 4096 floats = 151 MB for any layer
 TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout);
 int  launch_wgrad_taps(int mode, const WgradArgs& a, const TapsPlan& p, hipStream_t st);
-int  launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st);
+// Deferred second stage of the weight gradients: launch_wgrad(.., q) records its reduction (fixed-order sum of the
+// K-split partials into dW, bias-gradient finalize) in q instead of launching it; flush_wgrad_reduces() runs every
+// recorded job in ONE launch. The partial buffers of the recorded layers must stay untouched until the flush.
+struct ReduceJob {
+    const float* partial; float* dW; long n; int ksplit, kl4;    // main part (n = 0: none)
+    const float* db_partial; float* db; int nshare, C;           // bias gradient (db = nullptr: none)
+    int blk_begin, main_blocks, db_blocks, _pad;
+};
+constexpr int REDUCE_MAX_JOBS = 32;
+struct ReduceQueue { int njobs = 0, nblocks = 0; ReduceJob job[REDUCE_MAX_JOBS]; };
+int  flush_wgrad_reduces(ReduceQueue& q, hipStream_t st);
+// exact scratch need (floats) of one layer's weight gradient: K-split partials + bias-gradient partials
+long wgrad_scratch_need(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout);
+int  launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st, ReduceQueue* q = nullptr);
 int  try_wgrad_c8(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st);   // first layer (wgrad_c8.hip)
 int  try_wgrad_glds(int dtype, int mode, const WgradArgs& a, hipStream_t st);   // 1 launched, 0 unsupported shape
 bool wgrad_glds_supported(int dtype, int mode, const WgradArgs& a);

@@ -106,6 +106,7 @@ struct Plan {
     long c1b, c2b, nb;
     std::vector<long> u1, n1, c2u, c3u, n2;         // up levels
     long probs, gA, gB, gC, partial, partial_floats, partial2, wpartial, wpartial_floats, cpartial, cpartial_floats, coeffs, stats, total;
+    std::vector<long> wscratch;                     // per conv: float offset of its weight-gradient scratch inside wpartial
 };
 
 Plan make_plan(const mpu_unet* m, int B) {
@@ -140,15 +141,26 @@ Plan make_plan(const mpu_unet* m, int B) {
     P.partial = take(pe * 4);
     P.partial_floats = pe;
     P.partial2 = take((long)RED_MAX_BLOCKS * m->cmax * 4);
+    // Weight-gradient scratch: every layer has its OWN region (K-split partials + bias-gradient partials), because the
+    // second-stage reductions are deferred and run batched (flush_wgrad_reduces); sized exactly per layer.
     long we = 0;
-    for (size_t i = 0; i < m->conv.size(); ++i) {
-        const Conv& c = m->conv[i];
-        if (c.mode == CONV1) continue;
-        // the layer's output resolution: find from the tables below (upper bound: try all levels)
-        for (int l = 0; l <= D; ++l) {
-            const long M = (long)B * (m->cfg.H >> l) * (m->cfg.W >> l);
-            const long e = wgrad_partial_elems(c.mode, c.Cin, c.Cout, M, nullptr, nullptr);
-            if (e > we) we = e;
+    {
+        auto level_of = [&](size_t i) -> int {          // output resolution level of conv i (creation order)
+            const int nenc = 2 * D;
+            if ((int)i < nenc) return (int)i / 2;
+            if ((int)i < nenc + 2) return D;
+            const int j = ((int)i - nenc - 2) / 3;
+            return j < D ? D - 1 - j : 0;
+        };
+        P.wscratch.assign(m->conv.size(), 0);
+        for (size_t i = 0; i < m->conv.size(); ++i) {
+            const Conv& c = m->conv[i];
+            if (c.mode == CONV1) continue;
+            const int l = level_of(i);
+            const bool concat = c.mode == CONV3 && (int)i >= 2 * D + 2 && ((int)i - 2 * D - 2) % 3 == 1;
+            const int C0 = concat ? c.Cin / 2 : c.Cin, C1 = concat ? c.Cin / 2 : 0;
+            P.wscratch[i] = we;
+            we += wgrad_scratch_need(m->cfg.dtype, c.mode, B, m->cfg.H >> l, m->cfg.W >> l, C0, C1, c.Cout);
         }
     }
     P.wpartial = take(we * 4);
@@ -176,6 +188,7 @@ struct Run {
     mutable bool pending = false;  // a weight gradient is in flight on the side stream
     const float* params; const unsigned char* packed; float* state; float* grads;
     void* const* ready_events = nullptr; int n_ready = 0;        // gradient-ready points (mpu_unet_backward_events)
+    mutable ReduceQueue rq;                                      // deferred weight-gradient reductions (one launch per flush)
     int esz;
     void* at(long off) const { return ws + off; }
     const void* wf(const Conv& c) const { return packed + c.wf * esz; }
@@ -238,18 +251,21 @@ int conv_dgrad(const Run& r, const Conv& c, const void* dz, const void* mask, vo
 int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* x1, int C1, const void* dz, int lvl) {
     WgradArgs a;
     a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.dz = dz; a.Cout = c.Cout;
-    a.partial = (float*)r.at(r.P.wpartial);
+    a.partial = (float*)r.at(r.P.wpartial) + r.P.wscratch[&c - &r.m->conv[0]];      // this layer's own scratch
     a.B = r.B; a.Ho = r.m->cfg.H >> lvl; a.Wo = r.m->cfg.W >> lvl;
     a.flops = conv_flops(r, c, lvl);
     const long M = (long)a.B * a.Ho * a.Wo;
     wgrad_partial_elems(c.mode, c.Cin, c.Cout, M, &a.ksplit, &a.mchunk);
     a.db = r.grads + c.b; a.db_partial = nullptr; a.colsum_scratch = (float*)r.at(r.P.partial2); a.fuse_db = 0;
     a.c0_logical = (C1 == 0 && C0 == c.Cin) ? c.lCin : 0;
-    if (!r.overlap) return launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st);
+    static int defer = -1;         // MPU_WGRAD_BATCHED_REDUCE=0: reduce right behind every weight-gradient kernel (A/B)
+    if (defer < 0) { const char* e = getenv("MPU_WGRAD_BATCHED_REDUCE"); defer = (e && e[0] == '0') ? 0 : 1; }
+    ReduceQueue* q = defer ? &r.rq : nullptr;
+    if (!r.overlap) return launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st, q);
     // fork: the side stream waits until dz (and everything before it) is produced on the main stream
     MPU_CHECK_HIP(hipEventRecord(r.m->ev_ready, r.st));
     MPU_CHECK_HIP(hipStreamWaitEvent(r.m->side, r.m->ev_ready, 0));
-    int rc = launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.m->side);
+    int rc = launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.m->side, q);
     if (rc) return rc;
     MPU_CHECK_HIP(hipEventRecord(r.m->ev_done, r.m->side));
     r.pending = true;
@@ -380,6 +396,8 @@ int mark_ready(const Run& r, int k) {
     if (!r.ready_events || k >= r.n_ready || !r.ready_events[k]) return MPU_OK;
     int rc = wgrad_join(r);
     if (rc) return rc;
+    rc = flush_wgrad_reduces(r.rq, r.st);          // the gradients above this point must be final before the event
+    if (rc) return rc;
     MPU_CHECK_HIP(hipEventRecord((hipEvent_t)r.ready_events[k], r.st));
     return MPU_OK;
 }
@@ -452,7 +470,8 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
         if (i > 0) RC(conv_dgrad(r, c1, gA, nullptr, gB, i, 0, Cx));
         RC(mark_ready(r, point++));                                                        // encoder level i
     }
-    return wgrad_join(r);            // the gradient buffer is complete when the main stream continues
+    RC(wgrad_join(r));               // the gradient buffer is complete when the main stream continues
+    return flush_wgrad_reduces(r.rq, r.st);
 }
 
 int make_run(Run& r, const mpu_unet* m, int batch, const float* params, const void* packed, float* state,
