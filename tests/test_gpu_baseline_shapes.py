@@ -155,7 +155,7 @@ def test_cfg1_bf16_train_step_per_tensor_and_dispatch():
 
 
 def test_bf16_six_view_pipeline_dice_delta_vs_f64_oracle():
-    """North-star end-to-end tolerance in the benchmarked dtype: train a toy net (300 Adam steps on sampled planes),
+    """North-star end-to-end tolerance in the benchmarked dtype: train a toy net (800 Adam steps on sampled planes),
     6-view predict+fuse of a 64^3 volume with the bf16 kernels, and the same weights through the f64 oracle
     pipeline (oracle geometry + oracle U-Net + FusionLayer): per-class Dice against the ground truth differs by
     <= 1e-3, every class present in both (mpunet/evaluate/metrics.py:26-52, mpunet/bin/predict.py:294-366)."""
@@ -189,8 +189,8 @@ def test_bf16_six_view_pipeline_dice_delta_vs_f64_oracle():
     m.compile("Adam", "SparseCategoricalCrossentropy", optimizer_kwargs=dict(lr=2e-3))
     tr = TrainSampler([v for _, _, v in vols[:2]], VIEWS6, D, float(D), 8, K, noise_sd=0.1, seed=1)
     first = last = None
-    for it in range(300):
-        x, y, w = tr()
+    for it in range(800):                                       # (BatchNorm momentum 0.99: the moving statistics need
+        x, y, w = tr()                                          #  several hundred steps to catch up with the weights)
         l = float(m.train_step(x, y, w).mean().item())
         first = l if first is None else first
         last = l
@@ -216,7 +216,7 @@ def test_bf16_six_view_pipeline_dice_delta_vs_f64_oracle():
           % (np.round(d_hip, 5), np.round(d_ref, 5), np.round(d_x, 5), (got != ref_l).mean()))
     for arr in (lab, got, ref_l):
         assert set(np.unique(arr)) == set(range(K))             # every class present everywhere: no NaN Dice
-    assert np.all(d_ref[1:] > 0.6), d_ref                       # the net has learned the task (a real decision surface)
+    assert np.all(d_ref[1:] > 0.85), d_ref                      # the net has learned the task (a crisp decision surface)
     assert np.abs(d_hip - d_ref).max() <= 1e-3, (d_hip, d_ref)
 
 
