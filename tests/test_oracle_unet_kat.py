@@ -198,3 +198,82 @@ def test_l2_kernel_regulariser_known_answer():
         else:
             assert np.abs(d).max() <= 1e-13, name
     np.testing.assert_allclose(r1["reg_loss"], l2 * tot, rtol=1e-12)
+
+
+def test_encoder_block_backward_independent_numpy_derivation():
+    """An independent BACKWARD of one whole encoder block (conv-ReLU-conv-ReLU-BatchNorm(train)-MaxPool, skip tap
+    included; mpunet/models/unet.py:114-134) written out with NumPy loops from the textbook formulas -- conv
+    gradients as explicit correlations over the SAME-padded window, the batch-statistics BatchNorm gradient
+    dx = g*invstd*(dn - mean(dn) - xhat*mean(dn*xhat)), max-pool gradient routed to the FIRST maximum of each
+    window -- against autograd through the oracle's own layer functions. Anchors the part of the oracle the
+    reference's tests (and TensorFlow's absence) leave unpinned a second, independently derived way."""
+    import torch.nn.functional as F
+    rng = np.random.RandomState(11)
+    B, H, W, C0, C1 = 2, 6, 4, 2, 3
+    x = rng.randn(B, H, W, C0)
+    k1 = rng.randn(3, 3, C0, C1) * 0.5; b1 = rng.randn(C1) * 0.2
+    k2 = rng.randn(3, 3, C1, C1) * 0.5; b2 = rng.randn(C1) * 0.2
+    gam = rng.uniform(0.5, 1.5, C1); gam[0] = -0.7                 # a negative gamma: pooling follows the affine
+    bet = rng.randn(C1) * 0.3
+    R_skip = rng.randn(B, H, W, C1)                                # cotangents of the two outputs of the block
+    R_pool = rng.randn(B, H // 2, W // 2, C1)
+    eps = 1e-3
+
+    # ---- oracle side: torch autograd through unet_ref's layer functions ------------------------------------------
+    t = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    tx, tk1, tb1, tk2, tb2, tg, tbt = t(x), t(k1), t(b1), t(k2), t(b2), t(gam), t(bet)
+    p = {"bn/gamma": tg, "bn/beta": tbt}
+    c1 = U._conv(tx.permute(0, 3, 1, 2), tk1, tb1)
+    c2 = U._conv(c1, tk2, tb2)
+    n = U._bn(c2, p, "bn", True, None)
+    pool = F.max_pool2d(n, 2, 2)
+    loss = (n.permute(0, 2, 3, 1) * torch.tensor(R_skip)).sum() + (pool.permute(0, 2, 3, 1) * torch.tensor(R_pool)).sum()
+    loss.backward()
+
+    # ---- independent side: forward and backward in explicit loops -------------------------------------------------
+    def conv_fwd(inp, k, b):
+        out = np.zeros(inp.shape[:3] + (k.shape[3],))
+        for bb in range(B):
+            out[bb] = naive_conv_same(inp[bb], k, b, relu=False)
+        return out
+
+    def conv_bwd(inp, k, dz):
+        """dz = gradient at the pre-activation; returns d inp, dk, db."""
+        dinp, dk = np.zeros_like(inp), np.zeros_like(k)
+        for bb in range(B):
+            for i in range(H):
+                for j in range(W):
+                    for a in range(3):
+                        for c in range(3):
+                            ii, jj = i + a - 1, j + c - 1
+                            if 0 <= ii < H and 0 <= jj < W:
+                                dk[a, c] += np.outer(inp[bb, ii, jj], dz[bb, i, j])
+                                dinp[bb, ii, jj] += k[a, c] @ dz[bb, i, j]
+        return dinp, dk, dz.sum((0, 1, 2))
+
+    z1 = conv_fwd(x, k1, b1); a1 = np.maximum(z1, 0)
+    z2 = conv_fwd(a1, k2, b2); a2 = np.maximum(z2, 0)
+    mean, var = a2.mean((0, 1, 2)), a2.var((0, 1, 2))
+    invstd = 1.0 / np.sqrt(var + eps)
+    xhat = (a2 - mean) * invstd
+    nn_ = xhat * gam + bet
+    # max-pool backward: the first maximum in row-major window order receives the gradient
+    dn = R_skip.copy()
+    for bb in range(B):
+        for i in range(H // 2):
+            for j in range(W // 2):
+                for ch in range(C1):
+                    win = nn_[bb, 2 * i:2 * i + 2, 2 * j:2 * j + 2, ch]
+                    a, c = np.unravel_index(np.argmax(win), (2, 2))
+                    dn[bb, 2 * i + a, 2 * j + c, ch] += R_pool[bb, i, j, ch]
+    dgam, dbet = (dn * xhat).sum((0, 1, 2)), dn.sum((0, 1, 2))
+    N = B * H * W
+    da2 = gam * invstd * (dn - dbet / N - xhat * dgam / N)
+    dz2 = da2 * (z2 > 0)
+    da1, dk2, db2 = conv_bwd(a1, k2, dz2)
+    dz1 = da1 * (z1 > 0)
+    dx, dk1, db1 = conv_bwd(x, k1, dz1)
+
+    for name, got, ref in (("gamma", dgam, tg.grad), ("beta", dbet, tbt.grad), ("k2", dk2, tk2.grad), ("b2", db2, tb2.grad),
+                           ("k1", dk1, tk1.grad), ("b1", db1, tb1.grad), ("x", dx, tx.grad)):
+        np.testing.assert_allclose(got, ref.numpy(), rtol=1e-9, atol=1e-10, err_msg=name)

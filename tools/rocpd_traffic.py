@@ -4,7 +4,7 @@ bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: gfx950 FETCH_SIZE counts 128-B reque
 import sqlite3, sys, re, json
 
 CLASSES = {
-    "conv_igemm": (("conv_glds", "conv_halo", "conv_ws", "conv_c8", "conv_igemm"), ("splitk_finish",)),
+    "conv_igemm": (("conv_glds", "conv_halo", "conv_ws", "conv_c8", "conv_igemm", "conv_pipe"), ("splitk_finish",)),
     "wgrad_igemm": (("wgrad_glds", "wgrad_taps", "wgrad_c8_kernel", "wgrad_igemm"), ("wgrad_reduce", "colsum_finalize", "wgrad_c8_finalize")),
 }
 
