@@ -60,7 +60,7 @@ int  try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st);     
 int  try_conv_pipe_first(int dtype, int mode, const ConvArgs& a, hipStream_t st);   // MPU_PIPE_FIRST=1 (conv_glds.hip)
 long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out);
 // all-taps weight gradient for the high-resolution 3x3 layers (wgrad_taps.hip)
-struct TapsPlan { int use, RH, sx, sy, nstrips; };
+struct TapsPlan { int use, RH, sx, sy, nstrips, split; };
 constexpr long TAPS_MAX_CICO = 512L * 512;     // eligible layers: Cin * Cout up to this
 constexpr int TAPS_MAX_WGS = 1024;             // strips * 64x64 tiles; bounds the fp32 partial workspace (one copy of
                                                // dW per strip): <= 1024 * 9 * 4096 floats = 151 MB for any layer

@@ -65,11 +65,16 @@ constexpr int TAPS_SMEM = XCH_A + XCH_B > 2 * GROUP_LDS ? XCH_A + XCH_B : 2 * GR
 // MODE CONV3: nine taps, X rows y-1..y+1 at full resolution. MODE UPCONV2 (nearest-upsample x2 + 2x2 conv): four
 // taps; staged "X row r" is the low-resolution row (y0 + r) >> 1 (each low-res row is staged for both upsampled rows
 // it feeds), 17 low-res pixels wide, and tap (ky, kx) reads staged row t + ky at pixel (px + kx) >> 1.
-template <int MODE>
-__global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPlan p) {
-    constexpr int NT = MODE == UPCONV2 ? 4 : 9, KW = MODE == UPCONV2 ? 2 : 3;
+// The body handles the taps [T0, T1) of one (strip pair, channel tile): all of them, or -- TapsPlan.split -- one half
+// (the two halves are neighbouring workgroups on one XCD: they stage the same X / dZ rows, the second one from L2).
+// Splitting the taps halves the workgroup's share of the fp32 partial copy, and with the workgroup count kept at ~one
+// per CU every workgroup covers twice the pixels: half as many partial copies, half the partial write + re-read.
+template <int MODE, int T0, int T1>
+__device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPlan& p, unsigned char* smem_all,
+                                                const int tile, const int pair) {
+    constexpr int NT = T1 - T0, KW = MODE == UPCONV2 ? 2 : 3;
+    constexpr int NTALL = MODE == UPCONV2 ? 4 : 9;
     constexpr int NXP = MODE == UPCONV2 ? 3 : 5;                 // DMA pieces (8 pixels) per staged X row
-    extern __shared__ __attribute__((aligned(128))) unsigned char smem_all[];
     constexpr unsigned OOB = 0xfffffff0u;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -78,12 +83,6 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPla
     const int H = a.Ho, W = a.Wo;
     const int Cin = a.C0 + a.C1;
     const int tiles_co = (a.Cout + 63) / 64;
-    const int ntile = tiles_co * ((Cin + 63) / 64);
-    // XCD-aware decode: the tiles of one strip run on one XCD (shared X / dZ in its L2)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int npairs = (p.nstrips + 1) / 2;
-    const int tile = slot % ntile, pair = (slot / ntile) * 8 + xcd;
-    if (pair >= npairs) return;
     const int strip = pair * 2 + grp;
     const bool valid = strip < p.nstrips;
     const int xs = strip % p.sx; int t_ = strip / p.sx;
@@ -213,12 +212,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPla
         const unsigned char* xr[KW];
 #pragma unroll
         for (int ky = 0; ky < KW; ++ky) xr[ky] = smem + ((t + ky) % NXR) * XROWB;
-        s16x8 af = t_frag(xr[0] + offA[0][0], xr[0] + offA[0][1]);
+        s16x8 af = t_frag(xr[T0 / KW] + offA[T0 % KW][0], xr[T0 / KW] + offA[T0 % KW][1]);
 #pragma unroll
         for (int tp = 0; tp < NT; ++tp) {
             s16x8 an = af;
             if (tp + 1 < NT) {
-                const int ky = (tp + 1) / KW, kx = (tp + 1) % KW;
+                const int ky = (T0 + tp + 1) / KW, kx = (T0 + tp + 1) % KW;
                 an = t_frag(xr[ky] + offA[kx][0], xr[ky] + offA[kx][1]);
             }
 #pragma unroll
@@ -226,7 +225,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPla
                 acc[tp][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bz[cb], acc[tp][cb], 0, 0, 0);
             af = an;
         }
-        if (a.fuse_db) {
+        if (a.fuse_db && T0 == 0) {                              // (the half that holds tap 0 also sums dZ)
             s16x8 bw = bz[0];
             if (wave == 1) bw = bz[1]; else if (wave == 2) bw = bz[2]; else if (wave == 3) bw = bz[3];
             accdb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bw, accdb, 0, 0, 0);
@@ -280,7 +279,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPla
         }
     }
     // ---- partial sums: [pair][tap][ci][co] ---------------------------------------------------------------
-    float* P = a.partial + (long)pair * NT * Cin * a.Cout;
+    float* P = a.partial + (long)pair * NTALL * Cin * a.Cout;
 #pragma unroll
     for (int tp = 0; tp < NT; ++tp) {
         if ((tp < (NT + 1) / 2) != (grp == 0)) continue;
@@ -290,14 +289,31 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPla
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = ci0 + wave * 16 + 4 * g + r;
-                if (ci < Cin && co < a.Cout) P[((long)tp * Cin + ci) * a.Cout + co] = acc[tp][cb][r];
+                if (ci < Cin && co < a.Cout) P[((long)(T0 + tp) * Cin + ci) * a.Cout + co] = acc[tp][cb][r];
             }
         }
     }
-    if (a.fuse_db && grp == 0 && ci0 == 0 && g == 0) {          // every row of accdb holds the column sums: take row 0
+    if (a.fuse_db && T0 == 0 && grp == 0 && ci0 == 0 && g == 0) {          // every row of accdb holds the column sums: take row 0
         const int co = co0 + wave * 16 + i;
         if (co < a.Cout) a.db_partial[(long)pair * a.Cout + co] = accdb[0];
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPlan p) {
+    constexpr int NTALL = MODE == UPCONV2 ? 4 : 9, NH = (NTALL + 1) / 2;
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem_all[];
+    const int Cin = a.C0 + a.C1;
+    const int ntile = ((a.Cout + 63) / 64) * ((Cin + 63) / 64);
+    // XCD-aware decode: the tiles (and tap halves) of one strip pair run on one XCD (shared X / dZ in its L2)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int npairs = (p.nstrips + 1) / 2;
+    const int nsub = p.split ? ntile * 2 : ntile;
+    const int sub = slot % nsub, pair = (slot / nsub) * 8 + xcd;
+    if (pair >= npairs) return;
+    if (!p.split) wgrad_taps_body<MODE, 0, NTALL>(a, p, smem_all, sub, pair);
+    else if ((sub & 1) == 0) wgrad_taps_body<MODE, 0, NH>(a, p, smem_all, sub >> 1, pair);
+    else wgrad_taps_body<MODE, NH, NTALL>(a, p, smem_all, sub >> 1, pair);
 }
 
 }  // namespace
@@ -305,7 +321,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPla
 // Strip decomposition: 32-pixel-wide column strips of RH rows; aims at ~2 workgroups per CU while keeping
 // the number of fp32 partial copies (one per strip) small: their write + re-read is the kernel's HBM traffic.
 TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout) {
-    TapsPlan p; p.use = 0; p.RH = 0; p.sx = 0; p.sy = 0; p.nstrips = 0;
+    TapsPlan p; p.use = 0; p.RH = 0; p.sx = 0; p.sy = 0; p.nstrips = 0; p.split = 0;
     static int on = -1, target = 0; static long max_cico = 0;
     if (on < 0) {
         const char* e = getenv("MPU_WGRAD_TAPS"); on = (e && e[0] == '0') ? 0 : 1;
@@ -320,7 +336,10 @@ TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C
     if ((long)Cin * Cout > max_cico) return p;
     const long M = (long)B * H * W;
     if (M * (C0 > C1 ? C0 : C1) * 2L >= (1L << 31) || M * Cout * 2L >= (1L << 31)) return p;
-    const int ntile = cdiv(Cin, 64) * cdiv(Cout, 64);
+    static int split_on = -1;
+    if (split_on < 0) { const char* e = getenv("MPU_WGRAD_TAPS_SPLIT"); split_on = (e && e[0] == '0') ? 0 : 1; }
+    p.split = split_on;
+    const int ntile = cdiv(Cin, 64) * cdiv(Cout, 64) * (p.split ? 2 : 1);       // workgroups per strip pair
     const int sx = cdiv(W, 32);
     int best = 0; long bestd = 1L << 60;
     for (int rh = 8; rh <= 256; rh *= 2) {
@@ -340,7 +359,7 @@ TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C
 
 int launch_wgrad_taps(int mode, const WgradArgs& a, const TapsPlan& p, hipStream_t st) {
     const int Cin = a.C0 + a.C1;
-    const int ntile = cdiv(Cin, 64) * cdiv(a.Cout, 64);
+    const int ntile = cdiv(Cin, 64) * cdiv(a.Cout, 64) * (p.split ? 2 : 1);
     const int npairs = (p.nstrips + 1) / 2;
     const int grid = cdiv(npairs, 8) * 8 * ntile;
     static bool attr_set = false;
