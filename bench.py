@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--predict-only", action="store_true", help="only the 6-view predict+fuse leg (profiling aid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-peaks", action="store_true", help="skip the MFMA / stream-triad peak probes (profiling runs)")
     ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a HIP graph")
     args = ap.parse_args()
 
@@ -233,7 +234,7 @@ def main():
     # ---- secondary metric: 6-view predict+fuse on 256^3 (N=1) -------------------
     if rank == 0 and world == 1 and not args.no_predict:
         out["predict_fuse"] = bench_predict(device, quiet)
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_peaks:
         out["measured_peaks"] = measured_peaks(device)
         if "roofline" in out:
             for k in ("roofline", "wgrad"):

@@ -337,7 +337,9 @@ TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C
     const long M = (long)B * H * W;
     if (M * (C0 > C1 ? C0 : C1) * 2L >= (1L << 31) || M * Cout * 2L >= (1L << 31)) return p;
     static int split_on = -1;
-    if (split_on < 0) { const char* e = getenv("MPU_WGRAD_TAPS_SPLIT"); split_on = (e && e[0] == '0') ? 0 : 1; }
+    // measured on configs[1] (r2k): the split halves the partial traffic but doubles the K steps of every workgroup and
+    // comes out 8-25 % SLOWER per layer (3.16 vs 3.12 ms per train step): off unless MPU_WGRAD_TAPS_SPLIT=1
+    if (split_on < 0) { const char* e = getenv("MPU_WGRAD_TAPS_SPLIT"); split_on = (e && e[0] == '1') ? 1 : 0; }
     p.split = split_on;
     const int ntile = cdiv(Cin, 64) * cdiv(Cout, 64) * (p.split ? 2 : 1);       // workgroups per strip pair
     const int sx = cdiv(W, 32);
