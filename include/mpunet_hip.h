@@ -350,6 +350,11 @@ int mpu_profile_summary(int32_t kind, double* total_ms, double* total_flops, int
  * the environment variable MPU_GEOM_FAST=0 sets the same at first use. */
 int mpu_geometry_set_fast_path(int32_t on);
 
+/* Test aid for the plane sampler's cell division (csrc/geometry.hip cell_div): evaluates `count` pseudo-random
+ * quotients (x - g[c]) / (g[c+1] - g[c]) on the closed-form axis both ways and returns in *n_bad how many differ
+ * from the IEEE `/` (must be 0). Synchronous; default stream. */
+int mpu_geometry_check_cell_division(const mpu_axis* axis, int64_t count, uint64_t seed, uint64_t* n_bad);
+
 /* Measured machine peaks quoted next to the spec peaks in bench.py's roofline objects. The caller times
  * the launches with events on `stream`. mpu_probe_mfma_bf16: `blocks` workgroups x 4 waves each issue iters x 8
  * independent v_mfma_f32_32x32x16_bf16 (no memory traffic); *flops = FLOPs executed. mpu_probe_stream_triad:

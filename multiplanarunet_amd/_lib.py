@@ -44,10 +44,12 @@ def make_axis(values):
             return a
         half = (n - 1) / 2.0                                       # voxel axes: (arange(n) - (n-1)/2) * pixdim
         pd = (v[-1] - v[0]) / float(n - 1)
-        for cand in (pd, float(v[1] - v[0]), float(v[-1] / half) if half else pd):
-            if np.array_equal((i - half) * cand, v):
-                a.kind, a.start, a.step, a.last = 2, float(half), float(cand), float(v[-1])
-                return a
+        bases = (pd, float(v[1] - v[0]), float(v[-1] / half) if half else pd, float(v[0] / -half) if half else pd)
+        for base in bases:                                         # the quotients can miss pixdim by an ulp: try the neighbours too
+            for cand in (base, float(np.nextafter(base, np.inf)), float(np.nextafter(base, -np.inf))):
+                if np.array_equal((i - half) * cand, v):
+                    a.kind, a.start, a.step, a.last = 2, float(half), float(cand), float(v[-1])
+                    return a
     return a
 
 
@@ -127,6 +129,7 @@ _SIGS = {
     "mpu_profile_summary": (C.c_int, [i32, C.POINTER(f64), C.POINTER(f64), C.POINTER(i64)]),
     "mpu_validation_count": (C.c_int, [c_p, c_p, i64, i32, c_p, c_p]),
     "mpu_geometry_set_fast_path": (C.c_int, [i32]),
+    "mpu_geometry_check_cell_division": (C.c_int, [C.POINTER(Axis), i64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "mpu_probe_mfma_bf16": (C.c_int, [i32, i32, c_p, C.POINTER(f64), c_p]),
     "mpu_probe_stream_triad": (C.c_int, [c_p, c_p, c_p, i64, c_p]),
     "mpu_schedule_log_enable": (C.c_int, [i32]),

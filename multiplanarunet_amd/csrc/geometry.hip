@@ -10,7 +10,11 @@
 // view_interpolator.py:54-133, sample_grid.py:101-130,192-244,
 // utils/fusion/fuse_and_predict.py:92-137, models/fusion_model.py:38-39.
 #include <stdlib.h>
+#include <math.h>
+#include <mutex>
+#include <vector>
 #include "common.h"
+#include "kernels.h"
 
 namespace mpu {
 
@@ -123,7 +127,60 @@ struct SampleArgs {
     float* out; uint8_t* out_lab;
 };
 
-// one workgroup = one 16x16 patch of one plane (compact footprint in the volume for any view)
+// One sample of get_view_from: the exact NumPy-order evaluation (any axis kind, any channel count).
+__device__ __forceinline__ void sample_one(const SampleArgs& a, int p, int i, int j) {
+    const long t = ((long)p * a.dim + i) * a.dim + j;
+    const double gx = (double)i * a.g_step + a.g_start;
+    const double gy = (double)j * a.g_step + a.g_start;
+    const double off = a.offsets[p];
+    double rx, ry, rz;
+    mat3_apply(a.basis, gx, gy, off, rx, ry, rz);
+    if (a.has_rot) {
+        double qx, qy, qz;
+        mat3_apply(a.rot, rx, ry, rz, qx, qy, qz);
+        rx = qx; ry = qy; rz = qz;
+    }
+    int i0, i1, i2; double y0, y1, y2; bool o0, o1, o2;
+    find_cell(a.ax, rx, i0, y0, o0);
+    find_cell(a.ay, ry, i1, y1, o1);
+    find_cell(a.az, rz, i2, y2, o2);
+    const bool oob = o0 || o1 || o2;
+    // itertools.product order of the 8 corners, weight = ((1*wx)*wy)*wz
+    const double wx[2] = {1.0 - y0, y0}, wy[2] = {1.0 - y1, y1}, wz[2] = {1.0 - y2, y2};
+    float* o = a.out + t * a.C;
+    for (int c = 0; c < a.C; ++c) {
+        float v32;
+        if (oob) {
+            v32 = a.bg[c];
+        } else {
+            double acc = 0.0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ex = e >> 2, ey = (e >> 1) & 1, ez = e & 1;
+                const double w = ((1.0 * wx[ex]) * wy[ey]) * wz[ez];
+                const long idx = (((long)(i0 + ex) * a.Y + (i1 + ey)) * a.Z + (i2 + ez)) * a.C + c;
+                acc = acc + (double)a.vol[idx] * w;
+            }
+            v32 = (float)acc;
+        }
+        if (a.center) {    // sklearn: X -= center_; X /= scale_ (f64 op, f32 store)
+            v32 = (float)((double)v32 - a.center[c]);
+            v32 = (float)((double)v32 / a.scale[c]);
+        }
+        o[c] = v32;
+    }
+    if (a.out_lab) {
+        uint8_t l = a.bg_class;
+        if (!oob) {
+            const int n0 = (y0 <= .5) ? i0 : i0 + 1;
+            const int n1 = (y1 <= .5) ? i1 : i1 + 1;
+            const int n2 = (y2 <= .5) ? i2 : i2 + 1;
+            l = a.labels[((long)n0 * a.Y + n1) * a.Z + n2];
+        }
+        a.out_lab[t] = l;
+    }
+}
+// Generic kernel (any axis kind / channel count): one workgroup = one 16x16 patch of one plane.
 __global__ __launch_bounds__(256) void sample_view_planes_kernel(SampleArgs a) {
     const int tpd = (a.dim + 15) / 16;
     const long nblk = (long)a.P * tpd * tpd;
@@ -132,75 +189,155 @@ __global__ __launch_bounds__(256) void sample_view_planes_kernel(SampleArgs a) {
         const int ti = (int)((blk / tpd) % tpd), tj = (int)(blk % tpd);
         const int i = ti * 16 + (threadIdx.x >> 4), j = tj * 16 + (threadIdx.x & 15);
         if (i >= a.dim || j >= a.dim) continue;
-        const long t = ((long)p * a.dim + i) * a.dim + j;
-        const double gx = (double)i * a.g_step + a.g_start;
-        const double gy = (double)j * a.g_step + a.g_start;
-        const double off = a.offsets[p];
-        double rx, ry, rz;
-        mat3_apply(a.basis, gx, gy, off, rx, ry, rz);
-        if (a.has_rot) {
-            double qx, qy, qz;
-            mat3_apply(a.rot, rx, ry, rz, qx, qy, qz);
-            rx = qx; ry = qy; rz = qz;
-        }
-        int i0, i1, i2; double y0, y1, y2; bool o0, o1, o2;
-        find_cell(a.ax, rx, i0, y0, o0);
-        find_cell(a.ay, ry, i1, y1, o1);
-        find_cell(a.az, rz, i2, y2, o2);
-        const bool oob = o0 || o1 || o2;
-        // itertools.product order of the 8 corners, weight = ((1*wx)*wy)*wz
-        const double wx[2] = {1.0 - y0, y0}, wy[2] = {1.0 - y1, y1}, wz[2] = {1.0 - y2, y2};
-        float* o = a.out + t * a.C;
-        // the two z-neighbours of a corner pair are contiguous in memory: one 8-byte (C == 1) or 16-byte (C == 2)
-        // load per (x, y) corner instead of two / four scalar gathers; all four issued before the first use
-        float cv[2][8];                                    // [channel][corner e]
-        const bool paired = a.C <= 2 && !oob;
-        if (paired) {
+        sample_one(a, p, i, j);
+    }
+}
+
+// exact recomputation of the samples on the straight-line kernel's work list (all samples if the list overflowed)
+__global__ __launch_bounds__(256) void sample_fixup_kernel(SampleArgs a, const unsigned* list, const unsigned* count, unsigned cap,
+                                                           unsigned* next_count) {
+    const unsigned n = *count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;
+    const long total = (long)a.P * a.dim * a.dim;
+    const bool all = n > cap;
+    const long m = all ? total : (long)n;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < m; k += (long)gridDim.x * 256) {
+        const long t = all ? k : (long)list[k];
+        sample_one(a, (int)(t / ((long)a.dim * a.dim)), (int)((t / a.dim) % a.dim), (int)(t % a.dim));
+    }
+}
+
+// ---- straight-line sampler for three voxel axes of one closed-form kind (1 or 2), C = 1 or 2 ------------
+// The point coordinates follow the exact chain (they feed the interpolation weights). Per axis the cell is
+// c = floor(u), u = (x - g[0]) / h: exact whenever u is farther than GEOM_TAU from an integer (see cell_fast); the
+// other samples (~6e-6 of them) go to a work list and are redone by sample_fixup_kernel. Everything else is the reference's arithmetic
+// op for op, written without branches: out-of-bounds samples load from a clamped cell and select the fill value.
+// num / den for a cell width den = g[c+1] - g[c] of a uniform axis, bit for bit the IEEE quotient, without the
+// generic division's scaling / fix-up instructions: rh = fl(1/h) is within ~n * 2^-52 (relative) of 1/den, one
+// Newton step makes it a reciprocal good to an ulp, and the quotient is then refined through the exact remainder --
+// the same final steps as the compiler's own f64 division expansion (v_rcp + 2 Newton steps, q = num * r,
+// rem = fma(-den, q, num), q' = fma(rem, r, q)), whose operands here are far from the overflow / denormal ranges that
+// the skipped v_div_scale / v_div_fixup handle. tests/test_gpu_geometry.py::test_cell_division_is_ieee compares 2^28
+// quotients per axis step with the `/` operator; MPU_GEOM_FAST=0 keeps `/` everywhere.
+__device__ __forceinline__ double cell_div(double num, double den, double rh) {
+    const double e = fma(-den, rh, 1.0);
+    const double r = fma(rh, e, rh);
+    const double q = num * r;
+    const double rem = fma(-den, q, num);
+    return fma(rem, r, q);
+}
+struct CellF { int c; double num, den; };
+template <int KIND>
+__device__ __forceinline__ CellF cell_uniform(const AxisDev& a, double x, bool& oob, bool& risky) {
+    const double u = (x - a.g0) * a.inv_h;
+    const double f = floor(u);
+    const double nm1 = (double)(a.n - 1);
+    risky |= !(fabs((u - f) - 0.5) < 0.5 - GEOM_TAU);                // within TAU of a node, or NaN
+    oob |= (u < 0.0) | (u > nm1);
+    const double fc = fmin(fmax(f, 0.0), nm1 - 1.0);                 // in-bounds samples: fc == f
+    double gc, gc1;                                                  // axis_at(c), axis_at(c + 1)
+    if (KIND == 2) { gc = (fc - a.start) * a.step; gc1 = ((fc + 1.0) - a.start) * a.step; }
+    else { gc = fc * a.step + a.start; gc1 = (fc + 1.0 == nm1) ? a.last : (fc + 1.0) * a.step + a.start; }
+    CellF r;
+    r.c = (int)fc;
+    r.num = x - gc; r.den = gc1 - gc;
+    return r;
+}
+
+// test aid: count the lanes whose cell_div differs from `/` on pseudo-random (num, den) with den = a cell width of
+// the axis (start, step, n), num = x - g[c] for x inside or just outside the cell
+__global__ __launch_bounds__(256) void cell_div_check_kernel(double start, double step, int n, int kind, long count,
+                                                             unsigned long long seed, unsigned long long* bad) {
+    const double rh = 1.0 / step;
+    unsigned long long local = 0;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += (long)gridDim.x * blockDim.x) {
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(t + 1);      // splitmix64
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        const int c = (int)((z >> 40) % (unsigned long long)(n - 1));
+        const double frac = (double)(z & 0xFFFFFFFFFFull) * (1.0 / 1099511627776.0) * 1.25 - 0.125;   // [-0.125, 1.125)
+        const double fc = (double)c;
+        double gc, gc1;
+        if (kind == 2) { gc = (fc - start) * step; gc1 = ((fc + 1.0) - start) * step; }
+        else { gc = fc * step + start; gc1 = (fc + 1.0) * step + start; }
+        const double x = gc + frac * step;
+        const double num = x - gc, den = gc1 - gc;
+        if (cell_div(num, den, rh) != num / den) ++local;
+    }
+    if (local) atomicAdd(bad, local);
+}
+
+template <int KIND, int C, bool LAB>
+__global__ __launch_bounds__(256) void sample_fast_kernel(SampleArgs a, unsigned* list, unsigned* count, unsigned cap) {
+    // one workgroup = 8 rows x 32 columns of one plane (128-byte rows of output, compact footprint in the volume)
+    const int p = blockIdx.z;
+    const int i = blockIdx.y * 8 + (threadIdx.x >> 5), j = blockIdx.x * 32 + (threadIdx.x & 31);
+    if (i >= a.dim || j >= a.dim) return;
+    const double gx = (double)i * a.g_step + a.g_start;
+    const double gy = (double)j * a.g_step + a.g_start;
+    const double off = a.offsets[p];
+    double rx, ry, rz;
+    mat3_apply(a.basis, gx, gy, off, rx, ry, rz);
+    if (a.has_rot) {
+        double qx, qy, qz;
+        mat3_apply(a.rot, rx, ry, rz, qx, qy, qz);
+        rx = qx; ry = qy; rz = qz;
+    }
+    bool oob = false, risky = false;
+    const CellF c0 = cell_uniform<KIND>(a.ax, rx, oob, risky);
+    const CellF c1 = cell_uniform<KIND>(a.ay, ry, oob, risky);
+    const CellF c2 = cell_uniform<KIND>(a.az, rz, oob, risky);
+    const long t = ((long)p * a.dim + i) * a.dim + j;
+    if (__builtin_expect(risky, 0)) {                  // redone (and stored) by sample_fixup_kernel
+        const unsigned idx = atomicAdd(count, 1u);
+        if (idx < cap) list[idx] = (unsigned)t;
+        return;
+    }
+    // the two z-neighbours of an (x, y) corner are contiguous: one 8-byte (C == 1) / 16-byte (C == 2) load per corner,
+    // all four issued before the divisions below
+    const unsigned sy = (unsigned)a.Z * C, sx = (unsigned)a.Y * sy;
+    const unsigned base = (unsigned)c0.c * sx + (unsigned)c1.c * sy + (unsigned)c2.c * C;
+    float cv[C][8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const long base = (((long)(i0 + (q >> 1)) * a.Y + (i1 + (q & 1))) * a.Z + i2) * a.C;
-                if (a.C == 1) {
-                    float2 v; __builtin_memcpy(&v, a.vol + base, 8);
-                    cv[0][2 * q] = v.x; cv[0][2 * q + 1] = v.y;
-                } else {
-                    float4 v; __builtin_memcpy(&v, a.vol + base, 16);
-                    cv[0][2 * q] = v.x; cv[1][2 * q] = v.y; cv[0][2 * q + 1] = v.z; cv[1][2 * q + 1] = v.w;
-                }
-            }
-        }
-        for (int c = 0; c < a.C; ++c) {
-            float v32;
-            if (oob) {
-                v32 = a.bg[c];
-            } else {
-                double acc = 0.0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int ex = e >> 2, ey = (e >> 1) & 1, ez = e & 1;
-                    const double w = ((1.0 * wx[ex]) * wy[ey]) * wz[ez];
-                    const long idx = (((long)(i0 + ex) * a.Y + (i1 + ey)) * a.Z + (i2 + ez)) * a.C + c;
-                    const float val = paired ? cv[c & 1][e] : a.vol[idx];
-                    acc = acc + (double)val * w;
-                }
-                v32 = (float)acc;
-            }
-            if (a.center) {    // sklearn: X -= center_; X /= scale_ (f64 op, f32 store)
-                v32 = (float)((double)v32 - a.center[c]);
-                v32 = (float)((double)v32 / a.scale[c]);
-            }
-            o[c] = v32;
-        }
-        if (a.out_lab) {
-            uint8_t l = a.bg_class;
-            if (!oob) {
-                const int n0 = (y0 <= .5) ? i0 : i0 + 1;
-                const int n1 = (y1 <= .5) ? i1 : i1 + 1;
-                const int n2 = (y2 <= .5) ? i2 : i2 + 1;
-                l = a.labels[((long)n0 * a.Y + n1) * a.Z + n2];
-            }
-            a.out_lab[t] = l;
+    for (int q = 0; q < 4; ++q) {
+        const float* src = a.vol + (base + (q >> 1) * sx + (q & 1) * sy);
+        if (C == 1) {
+            float2 v; __builtin_memcpy(&v, src, 8);
+            cv[0][2 * q] = v.x; cv[0][2 * q + 1] = v.y;
+        } else {
+            float4 v; __builtin_memcpy(&v, src, 16);
+            cv[0][2 * q] = v.x; cv[C - 1][2 * q] = v.y; cv[0][2 * q + 1] = v.z; cv[C - 1][2 * q + 1] = v.w;
         }
     }
+    const double y0 = cell_div(c0.num, c0.den, a.ax.inv_h), y1 = cell_div(c1.num, c1.den, a.ay.inv_h),
+                 y2 = cell_div(c2.num, c2.den, a.az.inv_h);
+    uint8_t lab = a.bg_class;
+    if (LAB) {
+        const unsigned n0 = (unsigned)c0.c + (y0 <= .5 ? 0u : 1u), n1 = (unsigned)c1.c + (y1 <= .5 ? 0u : 1u),
+                       n2 = (unsigned)c2.c + (y2 <= .5 ? 0u : 1u);
+        const uint8_t l = a.labels[(n0 * (unsigned)a.Y + n1) * (unsigned)a.Z + n2];
+        lab = oob ? a.bg_class : l;
+    }
+    // itertools.product order of the 8 corners, weight = ((1*wx)*wy)*wz (1*wx is exact)
+    const double wx[2] = {1.0 - y0, y0}, wy[2] = {1.0 - y1, y1}, wz[2] = {1.0 - y2, y2};
+    double w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = (wx[e >> 2] * wy[(e >> 1) & 1]) * wz[e & 1];
+    float res[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        double acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = acc + (double)cv[c][e] * w[e];
+        float v32 = oob ? a.bg[c] : (float)acc;
+        if (a.center) {    // sklearn: X -= center_; X /= scale_ (f64 op, f32 store)
+            v32 = (float)((double)v32 - a.center[c]);
+            v32 = (float)((double)v32 / a.scale[c]);
+        }
+        res[c] = v32;
+    }
+    if (C == 1) a.out[t] = res[0];
+    else { float2 v; v.x = res[0]; v.y = res[C - 1]; __builtin_memcpy(a.out + t * 2, &v, 8); }
+    if (LAB) a.out_lab[t] = lab;
 }
 
 // ------------------------------------------------------------------------- //
@@ -356,6 +493,183 @@ __global__ __launch_bounds__(256) void map_fuse_kernel(FuseArgs a) {
     }
 }
 
+// ---- straight-line fused kernel on composed affine maps -------------------------------------------------
+// For a view whose in-plane axis and offsets are uniform (kinds 1, 2) the three nearest searches of a voxel depend
+// only on the index-space coordinates u = diag(1/h) (invb (A v - c) - g0) = M v + t of the voxel v = (x, y, z). The
+// host composes M and t once per view (compose_view); the kernel evaluates u with one FMA chain per axis, rounds,
+// and flags a lookup as RISKY when u is within GEOM_TAU of a value where the exact procedure changes its answer (a
+// half-integer tie, an axis end). |u - u_exact| is bounded by compose_view's err (it must be < GEOM_TAU / 4, else
+// the view is not eligible), so a lookup that is not risky equals the exact one. Risky voxels (~1e-5 of them) are
+// appended to a work list and recomputed from scratch by map_fuse_fixup_kernel with the exact search.
+struct AffView { double M[9], t[3]; const float* pred; int dim, P; };
+struct FuseFastArgs {
+    AffView v[MAX_VIEWS]; int V, X, Y, Z;
+    const float* W; const float* b; int sum_fusion;
+    float* probs; uint8_t* labels;
+    unsigned* list; unsigned* count; unsigned cap, nblk8;
+};
+
+template <int K, int CFG>
+__global__ __launch_bounds__(256) void map_fuse_fast_kernel(FuseFastArgs a) {
+    // lanes: 16 along z, LY along y, the rest along x; a thread owns FZ voxels strided along z (CFG 0: brick
+    // 4x4x64) or along x (CFG 1: brick 8x8x16)
+    // CFG 2: a WAVE covers a 4x4x16 block, lane (tx, ty, tz) owns the 4 consecutive voxels z = 4 tz .. 4 tz + 3; the 4
+    //        waves tile a 8x8x16 brick. Each of a view's 4 gather instructions then has a compact 4x4x(4 strided) footprint and
+    //        the four together touch the lines of a 4x4x16 block once (fewest L2 requests per voxel for an arbitrary view).
+    constexpr int LY = CFG == 1 ? 8 : 4, BX = CFG ? 8 : 4, BY = CFG ? 8 : 4, BZ = CFG ? 16 : 64, OWN = CFG == 1 ? 0 : 2,
+                  STRIDE = CFG == 1 ? 2 : (CFG == 2 ? 1 : 16);
+    const int nz = (a.Z + BZ - 1) / BZ, ny = (a.Y + BY - 1) / BY, nx = (a.X + BX - 1) / BX;
+    // workgroups with equal blockIdx % 8 share an XCD (one L2): each XCD walks its own contiguous run of bricks
+    const unsigned L = (blockIdx.x & 7u) * a.nblk8 + (blockIdx.x >> 3);
+    if (L >= (unsigned)nz * (unsigned)ny * (unsigned)nx) return;
+    const int bz = (int)(L % (unsigned)nz), by = (int)((L / (unsigned)nz) % (unsigned)ny), bx = (int)(L / ((unsigned)nz * (unsigned)ny));
+    int vx0, vy, vz0;
+    if (CFG == 2) {
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        vx0 = bx * BX + (wv & 1) * 4 + (ln >> 4);
+        vy = by * BY + (wv >> 1) * 4 + ((ln >> 2) & 3);
+        vz0 = bz * BZ + (ln & 3) * 4;
+    } else {
+        vx0 = bx * BX + (int)(threadIdx.x / (16 * LY));
+        vy = by * BY + (int)((threadIdx.x >> 4) % LY);
+        vz0 = bz * BZ + (int)(threadIdx.x & 15);
+    }
+    if (vx0 >= a.X || vy >= a.Y || vz0 >= a.Z) return;
+    const double cf0 = OWN == 0 ? (double)vz0 : (double)vx0, cy = (double)vy;      // the two coordinates all owned voxels share
+    const int own0 = OWN == 0 ? vx0 : vz0;
+    double co[FZ];
+    float z[FZ][K];
+#pragma unroll
+    for (int u = 0; u < FZ; ++u) {
+        co[u] = (double)(own0 + STRIDE * u);
+#pragma unroll
+        for (int k = 0; k < K; ++k) z[u][k] = 0.f;
+    }
+    unsigned risky = 0;
+    for (int v = 0; v < a.V; ++v) {
+        const AffView& w = a.v[v];
+        const double hg = 0.5 * (double)(w.dim - 1), ho = 0.5 * (double)(w.P - 1);
+        double base[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) base[r] = fma(w.M[3 * r + 1], cy, fma(w.M[3 * r + (OWN == 0 ? 2 : 0)], cf0, w.t[r]));
+        float wk[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) wk[k] = a.sum_fusion ? 1.f : a.W[v * K + k];
+        unsigned off[FZ]; bool out[FZ];
+#pragma unroll
+        for (int u = 0; u < FZ; ++u) {
+            int n[3]; bool o = false, rk = false;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double uu = fma(w.M[3 * r + OWN], co[u], base[r]);
+                const double h = r == 2 ? ho : hg;
+                const double rr = rint(uu);
+                rk |= !(fabs(fabs(uu - rr) - 0.5) > GEOM_TAU);                 // tie (or NaN)
+                const double e = fabs(uu - h);
+                const bool in = e < h - GEOM_TAU, sure_out = e > h + GEOM_TAU;
+                o |= sure_out; rk |= !(in | sure_out);
+                n[r] = (int)rr;
+            }
+            out[u] = o;
+            risky |= rk ? (1u << u) : 0u;
+            off[u] = (o | rk) ? 0u : (((unsigned)n[2] * (unsigned)w.dim + (unsigned)n[0]) * (unsigned)w.dim + (unsigned)n[1]) * K;
+        }
+#pragma unroll
+        for (int u = 0; u < FZ; ++u) {
+            float x[K];
+            __builtin_memcpy(x, w.pred + off[u], K * sizeof(float));
+            if (out[u]) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) x[k] = k == 0 ? 1.f : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) z[u][k] = a.sum_fusion ? (z[u][k] + x[k]) : (z[u][k] + wk[k] * x[k]);
+        }
+    }
+    // labels of the 4 consecutive voxels of a CFG-2 lane as one 32-bit store (risky ones are overwritten by the fix-up,
+    // which runs after this kernel)
+    const bool packed = CFG == 2 && a.labels && !a.probs && (a.Z & 3) == 0;
+    unsigned pack = 0;
+#pragma unroll
+    for (int u = 0; u < FZ; ++u) {
+        const int vx = OWN == 0 ? own0 + STRIDE * u : vx0, vz = OWN == 0 ? vz0 : own0 + STRIDE * u;
+        if (vx >= a.X || vz >= a.Z) continue;
+        const long t = ((long)vx * a.Y + vy) * a.Z + vz;
+        if ((risky >> u) & 1u) {                       // redone by the fix-up kernel (which also stores it)
+            const unsigned idx = atomicAdd(a.count, 1u);
+            if (idx < a.cap) a.list[idx] = (unsigned)t;
+            continue;
+        }
+        if (!a.sum_fusion) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) z[u][k] = z[u][k] + a.b[k];
+        }
+        if (packed) {
+            int best = 0; float bv = z[u][0];           // argmax is invariant under the softmax
+#pragma unroll
+            for (int k = 1; k < K; ++k) if (z[u][k] > bv) { bv = z[u][k]; best = k; }
+            pack |= (unsigned)best << (8 * u);
+        } else {
+            softmax_argmax_store<K>(z[u], !a.sum_fusion, t, a.probs, a.labels);
+        }
+    }
+    if (packed) *(unsigned*)(a.labels + (((long)vx0 * a.Y + vy) * a.Z + vz0)) = pack;
+}
+
+// exact recomputation of the voxels on the work list (all voxels if the list overflowed). 8 lanes share a voxel and
+// look up the views v = lane, lane + 8, ... in parallel (the exact search is long and the list short: the kernel's
+// time is the latency of one voxel); lane 0 of the group then accumulates the views in order, as the fused kernels do.
+template <int K>
+__global__ __launch_bounds__(256) void map_fuse_fixup_kernel(FuseArgs a, const unsigned* list, const unsigned* count, unsigned cap,
+                                                             unsigned* next_count) {
+    __shared__ float xs[32][MAX_VIEWS][K];
+    const GridDev& g = a.grid;
+    const unsigned n = *count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;
+    const long total = (long)g.X * g.Y * g.Z;
+    const bool all = n > cap;
+    const long m = all ? total : (long)n;
+    const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    for (long i0 = (long)blockIdx.x * 32; i0 < m; i0 += (long)gridDim.x * 32) {       // uniform trip count per workgroup
+        const long i = i0 + grp;
+        const bool live = i < m;
+        long t = 0;
+        if (live) {
+            t = all ? i : (long)list[i];
+            const int vz = (int)(t % g.Z), vy = (int)((t / g.Z) % g.Y), vx = (int)(t / ((long)g.Z * g.Y));
+            double rx, ry, rz;
+            voxel_real(g, vx, vy, vz, rx, ry, rz);
+            for (int v = sub; v < a.V; v += 8) {
+                const ViewDev& vw = a.views[v];
+                int pl;
+                const long o = view_lookup(vw, rx, ry, rz, K, pl);
+#pragma unroll
+                for (int k = 0; k < K; ++k) xs[grp][v][k] = o >= 0 ? vw.pred[o + k] : (k == 0 ? 1.f : 0.f);
+            }
+        }
+        __syncthreads();
+        if (live && sub == 0) {
+            float z[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) z[k] = 0.f;
+            for (int v = 0; v < a.V; ++v) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float x = xs[grp][v][k];
+                    const float wv = a.sum_fusion ? 1.f : a.W[v * K + k];
+                    z[k] = a.sum_fusion ? (z[k] + x) : (z[k] + wv * x);
+                }
+            }
+            if (!a.sum_fusion) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) z[k] = z[k] + a.b[k];
+            }
+            softmax_argmax_store<K>(z, !a.sum_fusion, t, a.probs, a.labels);
+        }
+        __syncthreads();
+    }
+}
+
 struct MapArgs {
     GridDev grid; ViewDev view; const float* Wv; int p_lo, p_hi, owns_oob; float* out;
 };
@@ -492,6 +806,68 @@ static int sync_fast_switch() {           // MPU_GEOM_FAST=0: exact search for e
     return MPU_OK;
 }
 
+// Compose u = M v + t (index units of the view's three axes) for the straight-line fused kernel; false when the view
+// is not eligible: a non-uniform axis, offsets beyond 32 bits, or an error bound that is not far below GEOM_TAU.
+static bool compose_view(const GridDev& g, const ViewDev& v, int K, AffView& o) {
+    if (v.g.kind == 0 || v.offs.kind == 0) return false;
+    if ((long)v.P * v.dim * v.dim * K >= (1L << 31)) return false;
+    const AxisDev* ax[3] = {&v.g, &v.g, &v.offs};
+    const double vmax[3] = {(double)(g.X - 1), (double)(g.Y - 1), (double)(g.Z - 1)};
+    for (int r = 0; r < 3; ++r) {
+        const long double ih = 1.0L / (long double)ax[r]->step;
+        long double tr = 0.0L, mag = 0.0L;
+        for (int j = 0; j < 3; ++j) {
+            long double m = 0.0L;
+            for (int k = 0; k < 3; ++k) m += (long double)v.invb.m[3 * r + k] * (long double)g.A.m[3 * k + j];
+            o.M[3 * r + j] = (double)(m * ih);
+        }
+        for (int k = 0; k < 3; ++k) {
+            tr += (long double)v.invb.m[3 * r + k] * (long double)g.c[k];
+            long double rk = fabsl((long double)g.c[k]);
+            for (int j = 0; j < 3; ++j) rk += fabsl((long double)g.A.m[3 * k + j]) * vmax[j];
+            mag += fabsl((long double)v.invb.m[3 * r + k]) * rk;
+        }
+        o.t[r] = (double)(-(tr + (long double)ax[r]->g0) * ih);
+        // magnitude (index units) of every intermediate of both evaluations; each of their <= ~20 roundings
+        // contributes at most 2^-53 of it
+        const long double span = (long double)(ax[r]->n - 1) / ih;
+        mag = (mag + fabsl((long double)ax[r]->g0) + fabsl((long double)ax[r]->g0 + span)) * ih;
+        const long double err = 64.0L * 1.1102230246251565e-16L * mag;
+        if (!(err < GEOM_TAU / 4) || !isfinite((double)mag)) return false;
+        if (!isfinite(o.t[r]) || !isfinite(o.M[3 * r]) || !isfinite(o.M[3 * r + 1]) || !isfinite(o.M[3 * r + 2])) return false;
+    }
+    o.pred = v.pred; o.dim = v.dim; o.P = v.P;
+    return true;
+}
+
+// Work list of the straight-line kernels: [0], [1] = two counters, [16 ..] = sample / voxel indices. One buffer per
+// (device, stream), allocated on first use and kept: calls on one stream are ordered, calls on different streams use
+// different buffers. Call k of a stream counts in counter k & 1, and its fix-up kernel -- the last thing the call
+// launches -- zeroes the other counter for call k + 1 (no memset launch per call).
+constexpr unsigned FUSE_LIST_CAP = 1u << 20;
+struct FuseScratch { int dev; hipStream_t st; unsigned* buf; unsigned seq; };
+static int fuse_scratch(hipStream_t st, unsigned** count, unsigned** next_count, unsigned** list) {
+    static std::mutex mu;
+    static std::vector<FuseScratch> slots;
+    int dev = 0;
+    MPU_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    FuseScratch* hit = nullptr;
+    for (FuseScratch& s : slots) if (s.dev == dev && s.st == st) hit = &s;
+    if (!hit) {
+        unsigned* p = nullptr;
+        MPU_CHECK_HIP(hipMalloc((void**)&p, (size_t)(FUSE_LIST_CAP + 16) * sizeof(unsigned)));
+        MPU_CHECK_HIP(hipMemset(p, 0, 16 * sizeof(unsigned)));
+        slots.push_back({dev, st, p, 0u});
+        hit = &slots.back();
+    }
+    *count = hit->buf + (hit->seq & 1u);
+    *next_count = hit->buf + ((hit->seq + 1u) & 1u);
+    *list = hit->buf + 16;
+    ++hit->seq;
+    return MPU_OK;
+}
+
 extern "C" {
 
 int mpu_abi_version(void) { return 1; }
@@ -505,6 +881,24 @@ int mpu_geometry_set_fast_path(int32_t on) {
     return MPU_OK;
 }
 const char* mpu_last_error(void) { return mpu::g_err; }
+
+/* test aid: number of pseudo-random (num, den) pairs, den a cell width of the axis, for which the sampler's division
+ * differs from the IEEE quotient (must be 0) */
+int mpu_geometry_check_cell_division(const mpu_axis* axis, int64_t count, uint64_t seed, uint64_t* n_bad) {
+    MPU_REQUIRE(axis && n_bad && count >= 0, "mpu_geometry_check_cell_division: bad argument");
+    MPU_REQUIRE((axis->kind == 1 || axis->kind == 2) && axis->n >= 2 && axis->step > 0, "mpu_geometry_check_cell_division: need a closed-form axis");
+    unsigned long long* d = nullptr;
+    MPU_CHECK_HIP(hipMalloc((void**)&d, sizeof(unsigned long long)));
+    MPU_CHECK_HIP(hipMemset(d, 0, sizeof(unsigned long long)));
+    cell_div_check_kernel<<<dim3(2048), dim3(256)>>>(axis->start, axis->step, axis->n, axis->kind, (long)count,
+                                                     (unsigned long long)seed, d);
+    unsigned long long h = 0;
+    const hipError_t e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    MPU_CHECK_HIP(e);
+    *n_bad = (uint64_t)h;
+    return MPU_OK;
+}
 
 int mpu_sample_view_planes(const float* d_vol, const uint8_t* d_labels, const int32_t vol_shape[4],
                            const double* d_ax, const double* d_ay, const double* d_az,
@@ -532,6 +926,25 @@ int mpu_sample_view_planes(const float* d_vol, const uint8_t* d_labels, const in
     a.dim = geom->dim; a.P = geom->n_planes; a.g_start = geom->g_start; a.g_step = geom->g_step;
     a.bg = d_bg; a.bg_class = bg_class; a.center = d_center; a.scale = d_scale;
     a.out = d_out; a.out_lab = d_out_lab;
+    // straight-line kernel: ImagePair voxel axes (kind 2), 1 or 2 channels, 32-bit element offsets
+    const bool fast = fast_path_host() && a.ax.kind != 0 && a.ay.kind == a.ax.kind && a.az.kind == a.ax.kind && (a.C == 1 || a.C == 2) &&
+                      (long)a.X * a.Y * a.Z * a.C < (1L << 31) && a.P < 65536 && (long)a.P * a.dim * a.dim < (1L << 32);
+    if (fast) {
+        const dim3 g((unsigned)((a.dim + 31) / 32), (unsigned)((a.dim + 7) / 8), (unsigned)a.P), b(256);
+        hipStream_t st = (hipStream_t)stream;
+        unsigned *cnt = nullptr, *nxt = nullptr, *lst = nullptr;
+        { const int rc_ = fuse_scratch(st, &cnt, &nxt, &lst); if (rc_) return rc_; }
+#define MPU_SAMPLE_FAST(KIND_) \
+        if (a.C == 1) { if (a.out_lab) sample_fast_kernel<KIND_, 1, true><<<g, b, 0, st>>>(a, lst, cnt, FUSE_LIST_CAP); else sample_fast_kernel<KIND_, 1, false><<<g, b, 0, st>>>(a, lst, cnt, FUSE_LIST_CAP); } \
+        else          { if (a.out_lab) sample_fast_kernel<KIND_, 2, true><<<g, b, 0, st>>>(a, lst, cnt, FUSE_LIST_CAP); else sample_fast_kernel<KIND_, 2, false><<<g, b, 0, st>>>(a, lst, cnt, FUSE_LIST_CAP); }
+        if (a.ax.kind == 1) { MPU_SAMPLE_FAST(1) } else { MPU_SAMPLE_FAST(2) }
+#undef MPU_SAMPLE_FAST
+        { const int rc_ = launch_ok(); if (rc_) return rc_; }
+        sample_fixup_kernel<<<dim3(64), dim3(256), 0, st>>>(a, lst, cnt, FUSE_LIST_CAP, nxt);
+        if (sched_log_on()) sched_note("sample fast kind=%d C=%d labels=%d", a.ax.kind, a.C, a.out_lab ? 1 : 0);
+        return launch_ok();
+    }
+    if (sched_log_on()) sched_note("sample generic kinds=%d%d%d C=%d labels=%d", a.ax.kind, a.ay.kind, a.az.kind, a.C, a.out_lab ? 1 : 0);
     const long tpd = (a.dim + 15) / 16;
     long nblk = (long)a.P * tpd * tpd;
     if (nblk > (1L << 20)) nblk = 1L << 20;
@@ -579,6 +992,30 @@ int mpu_map_fuse_views(const mpu_voxel_grid* grid, const mpu_view_pred* views, i
         to_view(views[v], a.views[v]);
     }
     a.V = n_views; a.W = d_W; a.b = d_b; a.sum_fusion = sum_fusion; a.probs = d_probs; a.labels = d_labels;
+    // straight-line kernel on composed affine maps + exact fix-up of the flagged voxels, when every view is eligible
+    bool fast = fast_path_host() && n_classes >= 1 && n_classes <= 16 && (long)a.grid.X * a.grid.Y * a.grid.Z < (1L << 32);
+    FuseFastArgs f;
+    for (int v = 0; fast && v < n_views; ++v) fast = compose_view(a.grid, a.views[v], n_classes, f.v[v]);
+    if (fast) {
+        hipStream_t st = (hipStream_t)stream;
+        unsigned* nxt = nullptr;
+        { const int rc_ = fuse_scratch(st, &f.count, &nxt, &f.list); if (rc_) return rc_; }
+        static const int cfg = getenv("MPU_FUSE_BRICK") ? atoi(getenv("MPU_FUSE_BRICK")) : 2;
+        f.V = n_views; f.X = a.grid.X; f.Y = a.grid.Y; f.Z = a.grid.Z;
+        f.W = d_W; f.b = d_b; f.sum_fusion = sum_fusion; f.probs = d_probs; f.labels = d_labels;
+        f.cap = FUSE_LIST_CAP;
+        const long nblk = cfg ? (long)cdiv(f.X, 8) * cdiv(f.Y, 8) * cdiv(f.Z, 16) : (long)cdiv(f.X, 4) * cdiv(f.Y, 4) * cdiv(f.Z, 64);    // bricks
+        f.nblk8 = (unsigned)((nblk + 7) / 8);
+        const dim3 g(f.nblk8 * 8u), b(256);
+        if (cfg == 2)      { MPU_DISPATCH_K(n_classes, (map_fuse_fast_kernel<KK, 2><<<g, b, 0, st>>>(f))); }
+        else if (cfg == 1) { MPU_DISPATCH_K(n_classes, (map_fuse_fast_kernel<KK, 1><<<g, b, 0, st>>>(f))); }
+        else               { MPU_DISPATCH_K(n_classes, (map_fuse_fast_kernel<KK, 0><<<g, b, 0, st>>>(f))); }
+        { const int rc_ = launch_ok(); if (rc_) return rc_; }
+        MPU_DISPATCH_K(n_classes, (map_fuse_fixup_kernel<KK><<<dim3(128), dim3(256), 0, st>>>(a, f.list, f.count, f.cap, nxt)));
+        if (sched_log_on()) sched_note("map_fuse fast views=%d K=%d brick=%d", n_views, n_classes, cfg);
+        return launch_ok();
+    }
+    if (sched_log_on()) sched_note("map_fuse generic views=%d K=%d", n_views, n_classes);
     MPU_DISPATCH_K(n_classes, (map_fuse_kernel<KK><<<dim3(fuse_grid(a.grid)), dim3(256), 0, (hipStream_t)stream>>>(a)));
     return launch_ok();
 }

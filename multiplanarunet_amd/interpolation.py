@@ -87,6 +87,18 @@ class ViewGeometry:
         bounds = (real_space_span + (extra * sample_res)) / 2
         self.offsets = np.linspace(-bounds, bounds, P)
         self.n_planes = P
+        self._dev_axes = {}
+
+    def device_axes(self, device):
+        """(real_axis, offsets) as device f64 tensors: ONE upload per view and device, shared by the sampler and the
+        back-mapping (small synchronous host-to-device copies are what the geometry kernels would otherwise wait on)."""
+        key = str(device)
+        hit = self._dev_axes.get(key)
+        if hit is None or hit[0] is not self.offsets or hit[1] is not self.real_axis:      # (re)assigned arrays: upload again
+            both = torch.tensor(np.concatenate([self.real_axis, self.offsets]), device=device)
+            hit = (self.offsets, self.real_axis, both[:len(self.real_axis)], both[len(self.real_axis):])
+            self._dev_axes[key] = hit
+        return hit[2], hit[3]
 
     def struct(self, rot_mat, axes=None):
         g = _lib.ViewGeom()
@@ -199,7 +211,7 @@ def sample_view(volume, geom, want_labels=True, out=None):
     y = None
     if want_labels and volume.labels is not None:
         y = torch.empty((P, d, d), dtype=torch.uint8, device=dev)
-    offs = torch.tensor(geom.offsets, device=dev)
+    offs = geom.device_axes(dev)[1] if hasattr(geom, "device_axes") else torch.tensor(geom.offsets, device=dev)
     shape = (C.c_int32 * 4)(*[int(v) for v in volume.image.shape])
     gs = geom.struct(volume.rot_mat, volume.axes)
     _lib.call("mpu_sample_view_planes", _lib.ptr(volume.image),
@@ -246,12 +258,15 @@ class ViewSampler:
 class _ViewPredHolder:
     """Keeps the device buffers a mpu_view_pred points at alive."""
 
-    def __init__(self, pred, grid, inv_basis, device):
+    def __init__(self, pred, grid, inv_basis, device, dev_axes=None):
         if pred.ndim != 4:
             raise ValueError("pred must be [P,dim,dim,K]")
         self.pred = pred.to(dtype=torch.float32).contiguous()
-        self.g = torch.tensor(np.asarray(grid[0], np.float64), device=device)
-        self.offs = torch.tensor(np.asarray(grid[2], np.float64), device=device)
+        if dev_axes is not None:            # ViewGeometry.device_axes: already resident
+            self.g, self.offs = dev_axes
+        else:
+            self.g = torch.tensor(np.asarray(grid[0], np.float64), device=device)
+            self.offs = torch.tensor(np.asarray(grid[2], np.float64), device=device)
         s = _lib.ViewPred()
         s.inv_basis[:] = np.asarray(inv_basis, np.float64).ravel().tolist()
         s.d_pred = self.pred.data_ptr()
@@ -294,11 +309,11 @@ def map_and_fuse(volume, view_preds, W=None, b=None, sum_fusion=False,
                  want_probs=True, want_labels=True):
     """
     Fused _multi_view_predict_on + merge_multi_view_preds. view_preds: list of
-    (pred [P,dim,dim,K] device f32, grid=(g,g,offsets), inv_basis). Returns
+    (pred [P,dim,dim,K] device f32, grid=(g,g,offsets), inv_basis[, ViewGeometry.device_axes]). Returns
     (merged f32 [X,Y,Z,K] or None, merged_map u8 [X,Y,Z] or None).
     """
     dev = volume.device
-    holders = [_ViewPredHolder(p, g, ib, dev) for p, g, ib in view_preds]
+    holders = [_ViewPredHolder(vp[0], vp[1], vp[2], dev, vp[3] if len(vp) > 3 else None) for vp in view_preds]
     V = len(holders)
     K = int(holders[0].pred.shape[-1])
     arr = (_lib.ViewPred * V)(*[h.struct for h in holders])

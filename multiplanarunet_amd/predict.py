@@ -37,7 +37,8 @@ def multi_view_predict(model, volume, views, dim, real_space_span, fusion_model=
         if timings is not None:
             e2.record()
             ev.append((e0, e1, e2))
-        view_preds.append((pred, (geom.real_axis, geom.real_axis, geom.offsets), geom.inv_basis))
+        view_preds.append((pred, (geom.real_axis, geom.real_axis, geom.offsets), geom.inv_basis,
+                           geom.device_axes(volume.device)))
     if timings is not None:
         f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         f0.record()

@@ -175,7 +175,20 @@ def test_train_sampler_planes_match_view_sampling_and_fg_balance():
         assert has_fg >= 4
 
 
-@pytest.mark.parametrize("aff", ("ident", "rot"))
+def _schedule_log(lib, fn):
+    import ctypes as C
+    lib.mpu_schedule_log_enable(1)
+    try:
+        out = fn()
+        n = lib.mpu_schedule_log_read(None, 0)
+        buf = C.create_string_buffer(int(n) + 1)
+        lib.mpu_schedule_log_read(buf, n + 1)
+    finally:
+        lib.mpu_schedule_log_enable(0)
+    return out, buf.value.decode().splitlines()
+
+
+@pytest.mark.parametrize("aff", ("ident", "rot", "aniso", "aniso1"))
 def test_fast_paths_equal_exact_search_at_scale(aff):
     """The closed-form fast paths (uniform axes, samples farther than 1e-6 index units from a decision boundary)
     against the exact NumPy-order search forced for every sample: sampled planes, labels, mapped volumes and fused
@@ -191,7 +204,10 @@ def test_fast_paths_equal_exact_search_at_scale(aff):
         th = np.deg2rad(25.0)
         R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
         A[:3, :3] = R.dot(np.diag([1.0, 0.8, 1.5])); A[:3, 3] = [3.0, -2.0, 5.0]
-    vol_np = rng.randn(D, D - 8, D + 4, 2).astype(np.float32)
+    if aff.startswith("aniso"):       # pixdims whose voxel axes are NOT reproduced by the linspace form: closed-form kind 2
+        A[:3, :3] = np.diag([0.8, 0.7, 1.3]); A[:3, 3] = [1.0, 2.0, -3.0]
+    nch = 1 if aff == "aniso1" else 2
+    vol_np = rng.randn(D, D - 8, D + 4, nch).astype(np.float32)
     lab_np = rng.randint(0, K, (D, D - 8, D + 4)).astype(np.uint8)
     views = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0], [0.3, 0.5, 0.8], [-0.6, 0.64, 0.48]], float)
     W = torch.tensor(rng.uniform(.5, 1.5, (len(views), K)).astype(np.float32))
@@ -200,20 +216,53 @@ def test_fast_paths_equal_exact_search_at_scale(aff):
     for fast in (1, 0):
         _lib.check(lib.mpu_geometry_set_fast_path(fast), "mpu_geometry_set_fast_path")
         try:
-            vol = Volume(vol_np, lab_np, A, bg_value=[0.5, -1.0], scaler=(np.array([0.1, 0.2]), np.array([1.3, 0.7])))
-            res, preds = [], []
-            for vi, v in enumerate(views):
-                for dim, span in ((D, float(D)), (64, 70.0)):        # integer step (samples on nodes) and a ragged one
-                    g = ViewGeometry(v, dim, span, "same+20")
-                    X, y = sample_view(vol, g)
-                    res += [X.clone(), y.clone()]
-                    if dim == D:
-                        pr = torch.tensor(np.random.RandomState(10 + vi).rand(g.n_planes, dim, dim, K).astype(np.float32), device="cuda")
-                        preds.append((pr, (g.real_axis, g.real_axis, g.offsets), g.inv_basis))
-            probs, labels = map_and_fuse(vol, preds, W, b)
-            res += [probs.clone(), labels.clone()]
-            outs[fast] = res
+            vol = Volume(vol_np, lab_np, A, bg_value=[0.5, -1.0][:nch], scaler=(np.array([0.1, 0.2][:nch]), np.array([1.3, 0.7][:nch])))
+
+            def run():
+                res, preds = [], []
+                for vi, v in enumerate(views):
+                    for dim, span in ((D, float(D)), (64, 70.0)):        # integer step (samples on nodes) and a ragged one
+                        g = ViewGeometry(v, dim, span, "same+20")
+                        X, y = sample_view(vol, g, want_labels=(vi % 2 == 0))
+                        res += [X.clone()] + ([y.clone()] if y is not None else [])
+                        if dim == D:
+                            pr = torch.tensor(np.random.RandomState(10 + vi).rand(g.n_planes, dim, dim, K).astype(np.float32), device="cuda")
+                            preds.append((pr, (g.real_axis, g.real_axis, g.offsets), g.inv_basis))
+                probs, labels = map_and_fuse(vol, preds, W, b)
+                return res + [probs.clone(), labels.clone()]
+
+            outs[fast], log = _schedule_log(lib, run)
+            if fast:                      # the straight-line kernels are the ones under test
+                kinds = {"ident": "kind=1", "aniso": "kind=2", "aniso1": "kind=2"}
+                if aff in kinds:
+                    assert sum(1 for l in log if l.startswith("sample fast " + kinds[aff])) == 2 * len(views), log
+                assert any(l.startswith("map_fuse fast") for l in log), log
+            else:
+                assert not any(" fast" in l for l in log), log
         finally:
             _lib.check(lib.mpu_geometry_set_fast_path(1), "mpu_geometry_set_fast_path")
     for a, b_ in zip(outs[1], outs[0]):
         assert torch.equal(a, b_)
+
+
+def test_cell_division_is_ieee():
+    """The straight-line sampler divides by a cell width through a Newton-refined reciprocal of the axis step
+    (csrc/geometry.hip cell_div); it must give the IEEE quotient the reference's NumPy division gives. 2^28
+    pseudo-random quotients per axis, on linspace axes (kind 1) and voxel axes (kind 2) of several spacings."""
+    import ctypes as C
+    from multiplanarunet_amd import _lib
+    lib = _lib.load()
+    axes = [np.linspace(-128, 128, 256), np.linspace(-35.0, 35.0, 64), np.linspace(-140.04, 140.04, 276)]
+    for n, pd in ((256, 1.0), (96, 0.8), (88, 0.7), (100, 1.3), (512, 0.123456789), (600, 2.9999)):
+        a32 = np.arange(n, dtype=np.float32) - np.float32((n - 1) / 2)
+        axes.append(a32.astype(np.float64) * np.float64(pd))
+    kinds = set()
+    for i, ax in enumerate(axes):
+        m = _lib.make_axis(ax)
+        assert m.kind in (1, 2)
+        kinds.add(m.kind)
+        bad = C.c_uint64(123)
+        _lib.check(lib.mpu_geometry_check_cell_division(C.byref(m), 1 << 28, 1000 + i, C.byref(bad)),
+                   "mpu_geometry_check_cell_division")
+        assert bad.value == 0, (i, m.kind, m.step, bad.value)
+    assert kinds == {1, 2}
