@@ -377,6 +377,27 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
             }
             __builtin_amdgcn_raw_buffer_store_b128(val, rso, off, 0, 0);
         }
+        if (a.pooled) {  // second output: 2x2 max pooling of the tile (TH and TW even, tile origin even), from the staging tile
+            constexpr int PW2 = TW / 2, PPIX = BM / 4;
+            const int Hp = H >> 1, Wp = W >> 1;
+            const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(a.pooled, 0, (int)((npo >> 2) * a.Cout * (long)sizeof(T)), 0x00020000);
+            for (int v = tid; v < PPIX * CPRO; v += 256) {
+                const int pc = v % CPRO, pp = v / CPRO;
+                const int py = pp / PW2, px = pp % PW2;
+                const unsigned char* s0 = smem + ((2 * py) * TW + 2 * px) * OROW + pc * 16;
+                const u32x4 q0 = *(const u32x4*)s0, q1 = *(const u32x4*)(s0 + OROW), q2 = *(const u32x4*)(s0 + TW * OROW),
+                            q3 = *(const u32x4*)(s0 + TW * OROW + OROW);
+                u32x4 m;
+                m.x = piece_max<T>(piece_max<T>(q0.x, q1.x), piece_max<T>(q2.x, q3.x));
+                m.y = piece_max<T>(piece_max<T>(q0.y, q1.y), piece_max<T>(q2.y, q3.y));
+                m.z = piece_max<T>(piece_max<T>(q0.z, q1.z), piece_max<T>(q2.z, q3.z));
+                m.w = piece_max<T>(piece_max<T>(q0.w, q1.w), piece_max<T>(q2.w, q3.w));
+                const int gy = (y0 >> 1) + py, gx = (x0 >> 1) + px, nn = n0 + pc * EPC;
+                const bool okp = gy < Hp && gx < Wp && nn < a.Cout;
+                const unsigned offp = okp ? (unsigned)((((b * Hp + gy) * Wp + gx) * a.Cout + nn) * (int)sizeof(T)) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(m, rsp, offp, 0, 0);
+            }
+        }
         if (a.stats) {   // block reduction over the RPI row-lanes of each column (fixed order), one partial row per pixel tile
             __syncthreads();                                                      // the staging tile has been read
             float* red = (float*)smem;                                            // [RPI][BN][2]
@@ -421,6 +442,8 @@ int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
         if (ptiles * 2 * a.Cout <= a.stats_cap) *a.stats_rows = (int)ptiles;
         else { a.stats = nullptr; *a.stats_rows = 0; }
     } else a.stats = nullptr;
+    if (a.pooled && a.pooled_done && MODE == CONV3 && !a.mask && !(a.Ho & 1) && !(a.Wo & 1) && TH % 2 == 0) *a.pooled_done = 1;
+    else a.pooled = nullptr;
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);
     kern<<<dim3((unsigned)tiles), dim3(256), Cfg::SMEM, st>>>(a);
     if (prof_on()) prof_end(st);

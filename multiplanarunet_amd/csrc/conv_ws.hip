@@ -269,6 +269,27 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
                     }
                 }
             }
+            if (a.pooled) {    // second output: 2x2 max pooling of this wave's TM x 32 pixels x 32 channels (staging rows)
+                static_assert(TM % 2 == 0, "pooling windows stay inside a wave's rows");
+                const int Hp = H >> 1, Wp = W >> 1;
+                const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(a.pooled, 0, (int)((npix >> 2) * a.Cout * 2L), 0x00020000);
+#pragma unroll
+                for (int jp = 0; jp < TM / 2; ++jp) {                // lane -> pooled pixel (lane >> 2) of 16, 16-byte piece (lane & 3)
+                    const unsigned char* s0 = wstage + ((2 * jp) * 32 + 2 * (lane >> 2)) * OROW + (lane & 3) * 16;
+                    const u32x4 q0 = *(const u32x4*)s0, q1 = *(const u32x4*)(s0 + OROW), q2 = *(const u32x4*)(s0 + 32 * OROW),
+                                q3 = *(const u32x4*)(s0 + 32 * OROW + OROW);
+                    u32x4 m;
+                    m.x = bf16x2_max(bf16x2_max(q0.x, q1.x), bf16x2_max(q2.x, q3.x));
+                    m.y = bf16x2_max(bf16x2_max(q0.y, q1.y), bf16x2_max(q2.y, q3.y));
+                    m.z = bf16x2_max(bf16x2_max(q0.z, q1.z), bf16x2_max(q2.z, q3.z));
+                    m.w = bf16x2_max(bf16x2_max(q0.w, q1.w), bf16x2_max(q2.w, q3.w));
+                    const int gy = ((y0 + wm * TM) >> 1) + jp, gx = (x0 >> 1) + (lane >> 2);
+                    const bool okp = n_ok && gy < Hp && gx < Wp;
+                    const unsigned offp = okp ? (unsigned)((((b * Hp + gy) * Wp + gx) * a.Cout + wn * 32 + (lane & 3) * 8) * 2) : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(m, rsp, offp, 0, 0);
+                }
+                if (!a.stats) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // before the next tile's staging writes
+            }
             if (a.stats) {     // transpose-reduce over the 16 pixel-lanes through the wave's own staging rows (now free)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 float* tb = (float*)wstage;                          // [16 pixel-lanes][64 values]
@@ -324,6 +345,8 @@ int launch_ws(const ConvArgs& a_in, hipStream_t st) {
     const unsigned mx = (unsigned)(((1UL << 32) + tx - 1) / tx), my = (unsigned)(((1UL << 32) + ty - 1) / ty);
     if (a.stats && a.stats_rows && !a.bn_x && (long)grid * 2 * a.Cout <= a.stats_cap) *a.stats_rows = grid;
     else a.stats = nullptr;                                      // (forward statistics only: bn_x -> the caller reduces)
+    if (a.pooled && a.pooled_done && !a.mask && !(a.Ho & 1) && !(a.Wo & 1)) *a.pooled_done = 1;
+    else a.pooled = nullptr;
     kern<<<dim3((unsigned)grid), dim3(256), Cfg::SMEM, st>>>(a, (int)tiles, mx, my);
     if (prof_on()) prof_end(st);
     return launch_ok();

@@ -27,6 +27,10 @@ struct ConvArgs {
     // its dn: sum out, sum out * (bn_x - mean) * invstd (bn_x: the BatchNorm's input, same shape as out). Schedules that
     // cannot produce them leave *stats_rows = 0.
     const void* bn_x = nullptr; const float* bn_mean = nullptr; const float* bn_invstd = nullptr;
+    // Optional second output (inference forward of an encoder block): the 2x2 / stride-2 max pooling of the stored
+    // output [B][Ho/2][Wo/2][Cout] (Ho, Wo even), taken from the epilogue's staging tile. The launcher sets
+    // *pooled_done = 1 when the schedule it chose wrote it (else the caller runs launch_maxpool).
+    void* pooled = nullptr; int* pooled_done = nullptr;
     int dbg = 0;                 // profiling switches of conv_pipe_kernel (MPU_PIPE_DEBUG: 1 no stores, 2 no MFMAs, 4 no DMA,
                                  //   8 no fragment reads, 16 no barrier, 32 s_memtime stamps into dbg_buf)
     unsigned long long* dbg_buf = nullptr;
@@ -43,6 +47,17 @@ struct WgradArgs {
     int fuse_db;                 // set by the launcher: the wgrad kernel also produces the db partials
     int c0_logical;              // image channels actually present in an 8-channel x0 (first layer); 0 = unknown
 };
+
+// element-wise maximum of two 16-byte pieces of T (8 bf16 or 4 f32)
+__device__ __forceinline__ uint32_t bf16x2_max(uint32_t a, uint32_t b) {
+    const float ml = fmaxf(__uint_as_float(a << 16), __uint_as_float(b << 16));
+    const float mh = fmaxf(__uint_as_float(a & 0xffff0000u), __uint_as_float(b & 0xffff0000u));
+    return (__float_as_uint(mh) & 0xffff0000u) | (__float_as_uint(ml) >> 16);
+}
+template <typename T> __device__ __forceinline__ uint32_t piece_max(uint32_t a, uint32_t b) {
+    if (sizeof(T) == 2) return bf16x2_max(a, b);
+    return __float_as_uint(fmaxf(__uint_as_float(a), __uint_as_float(b)));
+}
 
 // ---- profile.hip: optional per-launch HIP-event timing of the MFMA kernels ----
 enum { PROF_CONV = 0, PROF_WGRAD = 1, PROF_KINDS = 2 };

@@ -205,8 +205,13 @@ double conv_flops(const Run& r, const Conv& c, int lvl, int n_cnt_logical = -1) 
 }
 
 int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* in1, int C1, void* out, int lvl,
-             const float* post_scale = nullptr, const float* post_shift = nullptr, int* stats_rows = nullptr) {
+             const float* post_scale = nullptr, const float* post_shift = nullptr, int* stats_rows = nullptr,
+             void* pooled = nullptr, int* pooled_done = nullptr) {
     ConvArgs a;
+    static int fused_pool = -1;              // inference: 2x2 max pooling as a second output of the conv epilogue
+    if (fused_pool < 0) { const char* e = getenv("MPU_FUSED_POOL"); fused_pool = (e && e[0] == '0') ? 0 : 1; }
+    if (pooled_done) *pooled_done = 0;
+    a.pooled = (fused_pool && pooled_done) ? pooled : nullptr; a.pooled_done = a.pooled ? pooled_done : nullptr;
     // training: the conv in front of a BatchNormalization also produces the per-tile column sums of its output
     static int fused_stats = -1;
     if (fused_stats < 0) { const char* e = getenv("MPU_FUSED_BN_STATS"); fused_stats = (e && e[0] == '0') ? 0 : 1; }
@@ -326,8 +331,10 @@ int run_forward_infer(const Run& r, const float* d_x, float* d_out) {
     for (int i = 0; i < D; ++i) {
         const BN& b = m->bn[m->enc_bn(i)];
         RC(conv_fwd(r, m->conv[m->enc_c1(i)], cur, Ccur, nullptr, 0, r.at(P.c1[i]), i));
-        RC(conv_fwd(r, m->conv[m->enc_c2(i)], r.at(P.c1[i]), m->F[i], nullptr, 0, r.at(P.n[i]), i, sc(b), sh(b)));
-        RC(launch_maxpool(dt, r.at(P.n[i]), r.B, m->cfg.H >> i, m->cfg.W >> i, m->F[i], r.at(P.p[i]), r.st));
+        int pooled_done = 0;
+        RC(conv_fwd(r, m->conv[m->enc_c2(i)], r.at(P.c1[i]), m->F[i], nullptr, 0, r.at(P.n[i]), i, sc(b), sh(b), nullptr,
+                    r.at(P.p[i]), &pooled_done));
+        if (!pooled_done) RC(launch_maxpool(dt, r.at(P.n[i]), r.B, m->cfg.H >> i, m->cfg.W >> i, m->F[i], r.at(P.p[i]), r.st));
         cur = r.at(P.p[i]); Ccur = m->F[i];
     }
     {

@@ -293,3 +293,38 @@ def test_bn_backward_sums_switch_off_subprocess():
                         "f32_train_step or bf16_forward_and_step or graphed"], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(here))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_fused_pool_equals_separate_maxpool_subprocess(tmp_path):
+    """Inference forward: the encoder blocks' 2x2 max pooling is a second output of the conv epilogue (conv_ws /
+    conv_halo staging tile). MPU_FUSED_POOL=0 (read once per process, hence a fresh interpreter) runs the separate
+    max-pool kernel instead; the probabilities must be IDENTICAL, f32 and bf16, on shapes that take the
+    weight-stationary (level 0, bf16) and the halo schedules (negative gammas: the pool follows the affine)."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from multiplanarunet_amd.unet import UNet
+from oracle import unet_ref as U
+sys.path.insert(0, %r)
+from test_gpu_unet import rand_weights, quiet
+out = {}
+for dt, (K, C, D, cf, H, W, B) in (("f32", (3, 1, 2, 1, 64, 96, 2)), ("bf16", (3, 1, 4, 1, 128, 128, 16))):
+    w = rand_weights(U, K, C, D, cf, seed=5)
+    x = np.random.RandomState(1).randn(B, H, W, C).astype(np.float32)
+    m = UNet(n_classes=K, img_rows=H, img_cols=W, n_channels=C, depth=D, complexity_factor=cf, dtype=dt, logger=quiet)
+    m.set_weights_dict(w)
+    out[dt] = m._forward(m._as_input(x), training=False).cpu().numpy()
+np.savez(sys.argv[1], **out)
+''' % (os.path.dirname(here), here)
+    res = {}
+    for flag in ("1", "0"):
+        path = str(tmp_path / ("pool%s.npz" % flag))
+        r = subprocess.run([sys.executable, "-c", script, path], env=dict(os.environ, MPU_FUSED_POOL=flag),
+                           capture_output=True, text=True, cwd=os.path.dirname(here))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res[flag] = np.load(path)
+    for dt in ("f32", "bf16"):
+        assert np.isfinite(res["1"][dt]).all()
+        assert np.array_equal(res["1"][dt], res["0"][dt]), (dt, np.abs(res["1"][dt] - res["0"][dt]).max())
