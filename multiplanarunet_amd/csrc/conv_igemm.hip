@@ -676,8 +676,9 @@ int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
     if (a.stats_rows) *a.stats_rows = 0;          // set by the schedules that produce the fused BN statistics
     auto note = [&](const char* sched) {
         if (sched_log_on())
-            sched_note("conv %s mode=%d B=%d H=%d W=%d Cin=%d Cout=%d dgrad=%d", sched, mode, a.B, a.Ho, a.Wo,
-                       a.C0 + a.C1, a.Cout, a.bias ? 0 : 1);
+            sched_note("conv %s mode=%d B=%d H=%d W=%d Cin=%d Cout=%d dgrad=%d pool=%d head=%d", sched, mode, a.B, a.Ho, a.Wo,
+                       a.C0 + a.C1, a.Cout, a.bias ? 0 : 1, (a.pooled_done && *a.pooled_done) ? 1 : 0,
+                       (a.head_done && *a.head_done) ? 1 : 0);
     };
     if (conv_impl() == 1) {
         if (halo_on()) {

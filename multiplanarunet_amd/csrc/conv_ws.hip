@@ -46,7 +46,8 @@ struct WsCfg {
     static constexpr int WPX = BM / 2;                           // pixels per wave (2 x 2 waves: channels x rows)
     static constexpr int OROW = 32 * 2 + 16;                     // per-wave staging row: 32 channels + pad
     static constexpr int WBYTES = 9 * 64 * 128;
-    static constexpr int STAGE_MIN = 4 * WPX * OROW + 3 * 64 * 4;
+    static constexpr int HEADW = 64 * 8 * 4;                     // head weights [64 channels][8 classes] f32 (fused head)
+    static constexpr int STAGE_MIN = 4 * WPX * OROW + 3 * 64 * 4 + HEADW;
     // LDS: [per-wave staging tiles + bias tables][patch 1][patch 0]; the whole weight tensor is staged
     // through the same bytes once, before the first patch is requested
     static constexpr int STAGE0 = (STAGE_MIN + 1023) / 1024 * 1024;
@@ -55,7 +56,7 @@ struct WsCfg {
     static_assert(STAGE % 1024 == 0 && SMEM >= WBYTES, "LDS plan");
 };
 
-template <int TH>
+template <int TH, bool HEAD>
 __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles, unsigned magic_x, unsigned magic_y) {
     using Cfg = WsCfg<TH>;
     constexpr int TW = Cfg::TW, PW = Cfg::PW, PROWS = Cfg::PROWS;
@@ -124,6 +125,18 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     float* stab = (float*)(smem + 4 * Cfg::WPX * OROW);         // bias; folded-BN affine (inference): scale, shift
+    // fused head: the head weights of classes 0..7 as two bf16 parts (w = hi + lo, |error| <= 2^-18 |w|), rows of 64
+    // channels: hwt[part][class][channel] -- the A operand of a 32x32x16 MFMA whose rows 8..31 are zero
+    bf16_t* hwt = (bf16_t*)(stab + 3 * 64);
+    if (HEAD) {
+        for (int i = tid; i < 8 * 64; i += 256) {
+            const int k = i >> 6, c = i & 63;
+            const float w = (c < a.Cout && k < a.head_k) ? a.head_w[(long)c * a.head_ldw + k] : 0.f;
+            const bf16_t hi = f32_to_bf16(w);
+            hwt[i] = hi;
+            hwt[8 * 64 + i] = f32_to_bf16(w - bf16_to_f32(hi));
+        }
+    }
     if (tid < 64) {
         const bool nv = tid < a.Cout;
         stab[128 + tid] = (a.bias && nv) ? a.bias[tid] : 0.f;
@@ -227,7 +240,39 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        {
+        if (HEAD) {
+            // fused 1x1 head as 4 * TM MFMAs: logits[class][pixel] = sum_c w[class][c] * y[pixel][c] over this wave's 32
+            // channels (two 16-channel k-steps, two weight parts), B fragments = the staged (rounded) pixels. The
+            // accumulator of lane l holds classes 4 * (l >> 5) + 0..3 of pixel l & 31; the output tensor is not stored.
+            int b, y0, x0; tile_coords(tile, b, y0, x0);
+            const bool arow = (lane & 31) < 8;
+            uint4 ah[2], al[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16_t* src = hwt + (lane & 7) * 64 + wn * 32 + s2 * 16 + 8 * fh;
+                ah[s2] = *(const uint4*)src; al[s2] = *(const uint4*)(src + 8 * 64);
+                if (!arow) { ah[s2] = make_uint4(0, 0, 0, 0); al[s2] = make_uint4(0, 0, 0, 0); }
+            }
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                f32x16 hacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const uint4 bfr = *(const uint4*)(wstage + (j * 32 + (lane & 31)) * OROW + (2 * s2 + fh) * 16);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, ah[s2]), __builtin_bit_cast(s16x8, bfr), hacc, 0, 0, 0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, al[s2]), __builtin_bit_cast(s16x8, bfr), hacc, 0, 0, 0);
+                }
+                const int py = y0 + wm * TM + j, px = x0 + (lane & 31);
+                if (py < H && px < W) {
+                    float* hp = a.head_partial + ((long)wn * npix + ((long)b * H + py) * W + px) * a.head_k + 4 * fh;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (4 * fh + e < a.head_k) hp[e] = hacc[e];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // before the next tile's staging writes
+        } else {
             int b, y0, x0; tile_coords(tile, b, y0, x0);
             const int obase = ((b * H + y0) * W + x0) * a.Cout * 2;          // scalar part of the output offset
             const bool xok0 = x0 + (lane >> 2) < W, xok1 = x0 + 16 + (lane >> 2) < W;
@@ -320,10 +365,10 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
     }
 }
 
-template <int TH>
+template <int TH, bool HEAD>
 int launch_ws(const ConvArgs& a_in, hipStream_t st) {
     using Cfg = WsCfg<TH>;
-    auto kern = conv_ws_kernel<TH>;
+    auto kern = conv_ws_kernel<TH, HEAD>;
     ConvArgs a = a_in;
     if (a.w_elems <= 0) a.w_elems = 8 * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
     static int ncu = 0;
@@ -347,6 +392,8 @@ int launch_ws(const ConvArgs& a_in, hipStream_t st) {
     else a.stats = nullptr;                                      // (forward statistics only: bn_x -> the caller reduces)
     if (a.pooled && a.pooled_done && !a.mask && !(a.Ho & 1) && !(a.Wo & 1)) *a.pooled_done = 1;
     else a.pooled = nullptr;
+    if (HEAD) *a.head_done = 1;
+    else a.head_partial = nullptr;
     kern<<<dim3((unsigned)grid), dim3(256), Cfg::SMEM, st>>>(a, (int)tiles, mx, my);
     if (prof_on()) prof_end(st);
     return launch_ok();
@@ -362,7 +409,8 @@ int try_conv_ws(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
     if (a.ksplit > 1) return 0;
     const long tiles4 = (long)a.B * cdiv(a.Ho, 4) * cdiv(a.Wo, 32);
     if (a.Wo < 32 || a.Ho < 4 || tiles4 < 1024) return 0;    // needs >= 2 tiles per workgroup to amortise the weight load
-    const int rc = launch_ws<4>(a, st);
+    const bool head = a.head_partial && a.head_done && a.head_w && a.head_k >= 1 && a.head_k <= 8 && !a.mask && !a.stats && !a.pooled;
+    const int rc = head ? launch_ws<4, true>(a, st) : launch_ws<4, false>(a, st);
     return rc ? rc : 1;
 }
 

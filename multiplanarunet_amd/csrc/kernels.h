@@ -31,6 +31,12 @@ struct ConvArgs {
     // output [B][Ho/2][Wo/2][Cout] (Ho, Wo even), taken from the epilogue's staging tile. The launcher sets
     // *pooled_done = 1 when the schedule it chose wrote it (else the caller runs launch_maxpool).
     void* pooled = nullptr; int* pooled_done = nullptr;
+    // Optional fused 1x1 head (inference; the last conv of the up path on the conv_ws schedule): the output tensor is NOT
+    // stored; every wave multiplies its 32-channel half of the staged (rounded) pixels with the head weights
+    // head_w[c * head_ldw + k] and stores the partial logits head_partial[half][M][head_k] (f32). The launcher sets
+    // *head_done = 1 when the schedule did so; launch_head_combine then adds the halves and the bias and applies the
+    // softmax. Otherwise the caller runs launch_head_forward on the stored output.
+    const float* head_w = nullptr; int head_k = 0, head_ldw = 0; float* head_partial = nullptr; int* head_done = nullptr;
     int dbg = 0;                 // profiling switches of conv_pipe_kernel (MPU_PIPE_DEBUG: 1 no stores, 2 no MFMAs, 4 no DMA,
                                  //   8 no fragment reads, 16 no barrier, 32 s_memtime stamps into dbg_buf)
     unsigned long long* dbg_buf = nullptr;
@@ -152,6 +158,8 @@ int launch_colsum_finalize(const float* partial, int nblk, int C, float* out, hi
 // 1x1 head: logits = n @ Wh + bh ; probs = softmax (or linear)
 int launch_head_forward(int dtype, const void* n, long M, int C, int K, const float* Wh, int ldw,
                         const float* bh, int softmax, float* out, hipStream_t st);
+// second stage of the head fused into the last conv (ConvArgs.head_partial [2][M][K]): logits = p0 + p1 + bh, softmax / linear
+int launch_head_combine(const float* partial, long M, int K, const float* bh, int softmax, float* out, hipStream_t st);
 // Keras sparse CE (clipped probabilities, see oracle/unet_ref.py keras_sparse_ce), sum-gradient:
 // dn = dlogits @ Wh^T, dWh, dbh, per-pixel loss
 int launch_head_backward(int dtype, const void* n, const float* probs, const uint8_t* y,

@@ -204,10 +204,19 @@ double conv_flops(const Run& r, const Conv& c, int lvl, int n_cnt_logical = -1) 
     return 2.0 * M * taps * c.lCin * c.lCout;
 }
 
+// fused head request of the last conv (inference): weights, class count, scratch for the partial logits [2][M][k]
+struct HeadFuse { const float* w; int k, ldw; float* partial; int* done; };
+
 int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* in1, int C1, void* out, int lvl,
              const float* post_scale = nullptr, const float* post_shift = nullptr, int* stats_rows = nullptr,
-             void* pooled = nullptr, int* pooled_done = nullptr) {
+             void* pooled = nullptr, int* pooled_done = nullptr, const HeadFuse* head = nullptr) {
     ConvArgs a;
+    static int fused_head = -1;              // inference: 1x1 head out of the last conv's epilogue (partial logits)
+    if (fused_head < 0) { const char* e = getenv("MPU_FUSED_HEAD"); fused_head = (e && e[0] == '0') ? 0 : 1; }
+    if (head && head->done) *head->done = 0;
+    if (head && fused_head && head->done) {
+        a.head_w = head->w; a.head_k = head->k; a.head_ldw = head->ldw; a.head_partial = head->partial; a.head_done = head->done;
+    }
     static int fused_pool = -1;              // inference: 2x2 max pooling as a second output of the conv epilogue
     if (fused_pool < 0) { const char* e = getenv("MPU_FUSED_POOL"); fused_pool = (e && e[0] == '0') ? 0 : 1; }
     if (pooled_done) *pooled_done = 0;
@@ -348,8 +357,18 @@ int run_forward_infer(const Run& r, const float* d_x, float* d_out) {
         const BN& b1 = m->bn[m->up_bn(j, 0)]; const BN& b2 = m->bn[m->up_bn(j, 1)];
         RC(conv_fwd(r, m->conv[m->up_c(j, 0)], prev, Cprev, nullptr, 0, r.at(P.n1[j]), lvl, sc(b1), sh(b1)));
         RC(conv_fwd(r, m->conv[m->up_c(j, 1)], r.at(P.n[lvl]), f, r.at(P.n1[j]), f, r.at(P.c2u[j]), lvl));
-        RC(conv_fwd(r, m->conv[m->up_c(j, 2)], r.at(P.c2u[j]), f, nullptr, 0, r.at(P.n2[j]), lvl, sc(b2), sh(b2)));
+        // the last conv of the up path: the 1x1 head rides in its epilogue when the schedule can (conv_ws); the partial
+        // logits [2][M][K] f32 go to the level-0 conv1 buffer, which is dead by now (128 B per pixel >= 8 K bytes)
+        int head_done = 0;
+        HeadFuse hf{r.params + m->head_w, m->cfg.n_classes, m->cfg.n_classes, (float*)r.at(P.c1[0]), &head_done};
+        const bool last = j == D - 1 && D > 0 && m->head_C == f && (long)m->cfg.n_classes * 8 <= (long)m->F[0] * r.esz;
+        RC(conv_fwd(r, m->conv[m->up_c(j, 2)], r.at(P.c2u[j]), f, nullptr, 0, r.at(P.n2[j]), lvl, sc(b2), sh(b2), nullptr,
+                    nullptr, nullptr, last ? &hf : nullptr));
         prev = r.at(P.n2[j]); Cprev = f;
+        if (head_done) {
+            float* out = d_out ? d_out : (float*)r.at(P.probs);
+            return launch_head_combine(hf.partial, M0, m->cfg.n_classes, r.params + m->head_b, m->cfg.softmax, out, r.st);
+        }
     }
     float* out = d_out ? d_out : (float*)r.at(P.probs);
     return launch_head_forward(dt, prev, M0, m->head_C, m->cfg.n_classes, r.params + m->head_w, m->cfg.n_classes,

@@ -974,6 +974,38 @@ int launch_head_forward(int dtype, const void* n, long M, int C, int K, const fl
     return launch_ok();
 }
 
+// Second stage of the head fused into the last conv's epilogue (conv_ws, ConvArgs.head_partial): the two channel halves of
+// the logits, + bias, softmax (or linear). 12-36 bytes per pixel in, K floats out.
+template <int K>
+__global__ __launch_bounds__(256) void head_combine_kernel(const float* __restrict__ partial, long M, const float* __restrict__ bh,
+                                                           int softmax, float* __restrict__ out) {
+    float bias[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) bias[k] = bh[k];
+    for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
+        float z[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) z[k] = (partial[m * K + k] + partial[(M + m) * K + k]) + bias[k];
+        if (softmax) {
+            float mx = z[0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
+            float ssum = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) { z[k] = expf(z[k] - mx); ssum += z[k]; }
+#pragma unroll
+            for (int k = 0; k < K; ++k) z[k] = z[k] / ssum;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[m * K + k] = z[k];
+    }
+}
+int launch_head_combine(const float* partial, long M, int K, const float* bh, int softmax, float* out, hipStream_t st) {
+    long rb = (M + 255) / 256; if (rb > 8192) rb = 8192;
+    MPU_HEAD_DISPATCH_K(K, (head_combine_kernel<KK><<<(unsigned)rb, 256, 0, st>>>(partial, M, bh, softmax, out)))
+    return launch_ok();
+}
+
 // Gradient of the Keras sparse CE on clipped probabilities through the softmax
 // (oracle/unet_ref.py keras_sparse_ce). Per pixel:
 //   q = clip(p, eps, 1-eps); S = sum q; L = (-log q_y + log S) * w

@@ -299,7 +299,8 @@ def test_fused_pool_equals_separate_maxpool_subprocess(tmp_path):
     """Inference forward: the encoder blocks' 2x2 max pooling is a second output of the conv epilogue (conv_ws /
     conv_halo staging tile). MPU_FUSED_POOL=0 (read once per process, hence a fresh interpreter) runs the separate
     max-pool kernel instead; the probabilities must be IDENTICAL, f32 and bf16, on shapes that take the
-    weight-stationary (level 0, bf16) and the halo schedules (negative gammas: the pool follows the affine)."""
+    weight-stationary (level 0, bf16) and the halo schedules (negative gammas: the pool follows the affine).
+    Same for the 1x1 head fused into the last conv_ws epilogue (MPU_FUSED_HEAD=0 = the separate head kernel)."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     script = r'''
@@ -319,12 +320,19 @@ for dt, (K, C, D, cf, H, W, B) in (("f32", (3, 1, 2, 1, 64, 96, 2)), ("bf16", (3
 np.savez(sys.argv[1], **out)
 ''' % (os.path.dirname(here), here)
     res = {}
-    for flag in ("1", "0"):
+    for flag in ("1", "0", "nohead"):
         path = str(tmp_path / ("pool%s.npz" % flag))
-        r = subprocess.run([sys.executable, "-c", script, path], env=dict(os.environ, MPU_FUSED_POOL=flag),
-                           capture_output=True, text=True, cwd=os.path.dirname(here))
+        env = dict(os.environ, MPU_FUSED_POOL="0" if flag == "0" else "1", MPU_FUSED_HEAD="0" if flag != "1" else "1")
+        r = subprocess.run([sys.executable, "-c", script, path], env=env, capture_output=True, text=True,
+                           cwd=os.path.dirname(here))
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         res[flag] = np.load(path)
     for dt in ("f32", "bf16"):
         assert np.isfinite(res["1"][dt]).all()
-        assert np.array_equal(res["1"][dt], res["0"][dt]), (dt, np.abs(res["1"][dt] - res["0"][dt]).max())
+        # pooling from the staging tile == pooling the stored tensor, bit for bit (head unfused in both)
+        assert np.array_equal(res["nohead"][dt], res["0"][dt]), (dt, np.abs(res["nohead"][dt] - res["0"][dt]).max())
+    # 1x1 head out of the last conv's epilogue (bf16 level 0 on conv_ws): same products, the 64 channels summed as two
+    # halves of 32 -> f32 rounding differences only; f32 models do not take that schedule: identical
+    assert np.array_equal(res["1"]["f32"], res["nohead"]["f32"])
+    d = np.abs(res["1"]["bf16"] - res["nohead"]["bf16"]).max()
+    assert 0 < d <= 2e-5, d
