@@ -283,6 +283,15 @@ def bench_predict(device, quiet, D=256, V=6, K=3, reps=2, batch=None):
     fuse_bytes = D ** 3 * (V * K * 4 + 1)                        # labels only (73 B/voxel)
     samp_bytes = V * (4 * D ** 3 + 4 * P * D * D)
     gflop = V * P * unet_forward_gflop(D)
+    fuse_traffic = fuse_traffic_src = None       # HBM bytes per launch of the fused back-mapping from the round's PMC passes
+    if D == 256 and V == 6 and K == 3:
+        try:
+            gf = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_geometry_pmc.json"))[-1]
+            with open(os.path.join(ROOT, "profiles", gf)) as fh:
+                fuse_traffic = int(json.load(fh)["kernels"]["map_fuse_fast_kernel<3,2>"]["hbm_bytes_per_launch"])
+            fuse_traffic_src = "profiles/" + gf
+        except (IndexError, KeyError, OSError, ValueError):
+            pass
     return {"metric": "voxels/sec (6-view predict+fuse)", "value": round(D ** 3 / best, 1), "unit": "voxels/s",
             "volume": "%d^3x1" % D, "views": V, "planes_per_view": P, "seconds": round(best, 4),
             "sample_ms": round(tim["sample_ms"], 2), "unet_ms": round(tim["unet_ms"], 2),
@@ -293,7 +302,8 @@ def bench_predict(device, quiet, D=256, V=6, K=3, reps=2, batch=None):
             "map_fuse_frac_of_hbm_peak": round(fuse_bytes / tim["map_fuse_ms"] / 1e6 / PEAK_HBM_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": "map_fuse", "achieved": round(fuse_bytes / tim["map_fuse_ms"] / 1e6, 1),
                          "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": round(fuse_bytes / tim["map_fuse_ms"] / 1e6 / PEAK_HBM_GBS, 4), "traffic": None,
+                         "frac": round(fuse_bytes / tim["map_fuse_ms"] / 1e6 / PEAK_HBM_GBS, 4), "traffic": fuse_traffic,
+                         "traffic_source": fuse_traffic_src,
                          "algorithmic_bytes_per_launch": fuse_bytes},
             "label_histogram": hist}
 

@@ -507,6 +507,7 @@ struct FuseFastArgs {
     const float* W; const float* b; int sum_fusion;
     float* probs; uint8_t* labels;
     unsigned* list; unsigned* count; unsigned cap, nblk8;
+    int morton, px2, py2;        // brick columns (x, y) in Morton order (log2 of the padded column grid), z fastest
 };
 
 template <int K, int CFG>
@@ -521,8 +522,24 @@ __global__ __launch_bounds__(256) void map_fuse_fast_kernel(FuseFastArgs a) {
     const int nz = (a.Z + BZ - 1) / BZ, ny = (a.Y + BY - 1) / BY, nx = (a.X + BX - 1) / BX;
     // workgroups with equal blockIdx % 8 share an XCD (one L2): each XCD walks its own contiguous run of bricks
     const unsigned L = (blockIdx.x & 7u) * a.nblk8 + (blockIdx.x >> 3);
-    if (L >= (unsigned)nz * (unsigned)ny * (unsigned)nx) return;
-    const int bz = (int)(L % (unsigned)nz), by = (int)((L / (unsigned)nz) % (unsigned)ny), bx = (int)(L / ((unsigned)nz * (unsigned)ny));
+    int bx, by, bz;
+    if (a.morton) {
+        // a 128-byte line of a view's predictions (10.7 voxels) straddles neighbouring bricks: walk the brick columns in
+        // Morton order so that x- and y-neighbours follow within a few columns (while the line is still in this XCD's L2)
+        auto compact = [](unsigned v) { v &= 0x55555555u; v = (v | (v >> 1)) & 0x33333333u; v = (v | (v >> 2)) & 0x0f0f0f0fu;
+                                        v = (v | (v >> 4)) & 0x00ff00ffu; v = (v | (v >> 8)) & 0x0000ffffu; return v; };
+        const unsigned col = L / (unsigned)nz;
+        bz = (int)(L % (unsigned)nz);
+        const int mb = a.px2 < a.py2 ? a.px2 : a.py2;
+        const unsigned lo = col & ((1u << (2 * mb)) - 1u), hi = col >> (2 * mb);
+        unsigned cx = compact(lo), cy = compact(lo >> 1);
+        if (a.px2 > a.py2) cx |= hi << mb; else cy |= hi << mb;
+        if (cx >= (unsigned)nx || cy >= (unsigned)ny) return;
+        bx = (int)cx; by = (int)cy;
+    } else {
+        if (L >= (unsigned)nz * (unsigned)ny * (unsigned)nx) return;
+        bz = (int)(L % (unsigned)nz); by = (int)((L / (unsigned)nz) % (unsigned)ny); bx = (int)(L / ((unsigned)nz * (unsigned)ny));
+    }
     int vx0, vy, vz0;
     if (CFG == 2) {
         const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
@@ -1004,7 +1021,16 @@ int mpu_map_fuse_views(const mpu_voxel_grid* grid, const mpu_view_pred* views, i
         f.V = n_views; f.X = a.grid.X; f.Y = a.grid.Y; f.Z = a.grid.Z;
         f.W = d_W; f.b = d_b; f.sum_fusion = sum_fusion; f.probs = d_probs; f.labels = d_labels;
         f.cap = FUSE_LIST_CAP;
-        const long nblk = cfg ? (long)cdiv(f.X, 8) * cdiv(f.Y, 8) * cdiv(f.Z, 16) : (long)cdiv(f.X, 4) * cdiv(f.Y, 4) * cdiv(f.Z, 64);    // bricks
+        long nblk = cfg ? (long)cdiv(f.X, 8) * cdiv(f.Y, 8) * cdiv(f.Z, 16) : (long)cdiv(f.X, 4) * cdiv(f.Y, 4) * cdiv(f.Z, 64);    // bricks
+        static const int morton = getenv("MPU_FUSE_MORTON") ? atoi(getenv("MPU_FUSE_MORTON")) : 1;
+        f.morton = 0; f.px2 = f.py2 = 0;
+        if (morton) {
+            const int nxb = cdiv(f.X, cfg ? 8 : 4), nyb = cdiv(f.Y, cfg ? 8 : 4), nzb = cdiv(f.Z, cfg ? 16 : 64);
+            while ((1 << f.px2) < nxb) ++f.px2;
+            while ((1 << f.py2) < nyb) ++f.py2;
+            const long padded = (1L << f.px2) * (1L << f.py2) * nzb;
+            if (padded < (1L << 31)) { f.morton = 1; nblk = padded; }
+        }
         f.nblk8 = (unsigned)((nblk + 7) / 8);
         const dim3 g(f.nblk8 * 8u), b(256);
         if (cfg == 2)      { MPU_DISPATCH_K(n_classes, (map_fuse_fast_kernel<KK, 2><<<g, b, 0, st>>>(f))); }
