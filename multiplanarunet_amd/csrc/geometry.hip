@@ -944,7 +944,11 @@ int mpu_sample_view_planes(const float* d_vol, const uint8_t* d_labels, const in
     a.bg = d_bg; a.bg_class = bg_class; a.center = d_center; a.scale = d_scale;
     a.out = d_out; a.out_lab = d_out_lab;
     // straight-line kernel: ImagePair voxel axes (kind 2), 1 or 2 channels, 32-bit element offsets
-    const bool fast = fast_path_host() && a.ax.kind != 0 && a.ay.kind == a.ax.kind && a.az.kind == a.ax.kind && (a.C == 1 || a.C == 2) &&
+    // (single planes -- the train-time sampler cuts one candidate plane per call -- stay on the one-launch kernel: the
+    // straight-line kernel needs a second launch for its work list)
+    static const long fast_min = getenv("MPU_SAMPLE_FAST_MIN") ? atol(getenv("MPU_SAMPLE_FAST_MIN")) : 262144;
+    const bool fast = fast_path_host() && (long)a.P * a.dim * a.dim >= fast_min &&
+                      a.ax.kind != 0 && a.ay.kind == a.ax.kind && a.az.kind == a.ax.kind && (a.C == 1 || a.C == 2) &&
                       (long)a.X * a.Y * a.Z * a.C < (1L << 31) && a.P < 65536 && (long)a.P * a.dim * a.dim < (1L << 32);
     if (fast) {
         const dim3 g((unsigned)((a.dim + 31) / 32), (unsigned)((a.dim + 7) / 8), (unsigned)a.P), b(256);
