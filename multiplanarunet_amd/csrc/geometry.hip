@@ -61,15 +61,16 @@ __device__ __forceinline__ int find_cell_index(const AxisDev& a, double x, bool&
     return c;
 }
 // ---- fast paths on uniform axes (closed-form kinds 1, 2) ---------------------------------------------
-// u = (x - g[0]) / h in index units carries an error < 1e-11 (|x|, |g| < 1e4: a few ulps of the operands), and the
-// actual axis nodes the exact search compares against lie within 1e-11 index units of the integers. So whenever
-// u is farther than TAU = 1e-6 from every value at which the exact procedure changes its answer -- an integer
-// (searchsorted / out-of-bounds limits g[0], g[n-1]) for the cell search, a half-integer (the y <= 0.5 tie) and
-// the two axis ends for the nearest search -- the closed form below IS the exact answer. The remaining samples
-// (a fraction ~6e-6) take the exact search. g_fast_geometry = 0 (MPU_GEOM_FAST=0) forces the exact search for
-// every sample (A/B and the equality test).
+// u = (x - g[0]) / h in index units carries an error of a few ulps of (|g[0]| / h + n), and the actual axis nodes the
+// exact search compares against lie within the same distance of the integers; to_axis() keeps an axis closed-form
+// only while 64 * 2^-53 * (|g[0]| / h + n) < TAU / 4 (typical: 2e-12). So whenever u is farther than TAU = 1e-8 from
+// every value at which the exact procedure changes its answer -- an integer (searchsorted / out-of-bounds limits
+// g[0], g[n-1]) for the cell search, a half-integer (the y <= 0.5 tie) and the two axis ends for the nearest search
+// -- the closed form below IS the exact answer. The remaining samples (a fraction ~1e-7; integer spans put more of
+// them exactly ON nodes and ties) take the exact search. g_fast_geometry = 0 (MPU_GEOM_FAST=0) forces the exact
+// search for every sample (A/B and the equality test).
 __constant__ int g_fast_geometry_dev = 1;
-constexpr double GEOM_TAU = 1e-6;
+constexpr double GEOM_TAU = 1e-8;
 
 __device__ __forceinline__ bool cell_fast(const AxisDev& a, double x, int& c, bool& oob) {
     if (a.kind == 0 || !g_fast_geometry_dev) return false;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void sample_fixup_kernel(SampleArgs a, const u
 // ---- straight-line sampler for three voxel axes of one closed-form kind (1 or 2), C = 1 or 2 ------------
 // The point coordinates follow the exact chain (they feed the interpolation weights). Per axis the cell is
 // c = floor(u), u = (x - g[0]) / h: exact whenever u is farther than GEOM_TAU from an integer (see cell_fast); the
-// other samples (~6e-6 of them) go to a work list and are redone by sample_fixup_kernel. Everything else is the reference's arithmetic
+// other samples (~1e-7 of them) go to a work list and are redone by sample_fixup_kernel. Everything else is the reference's arithmetic
 // op for op, written without branches: out-of-bounds samples load from a clamped cell and select the fill value.
 // num / den for a cell width den = g[c+1] - g[c] of a uniform axis, bit for bit the IEEE quotient, without the
 // generic division's scaling / fix-up instructions: rh = fl(1/h) is within ~n * 2^-52 (relative) of 1/den, one
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(256) void map_fuse_kernel(FuseArgs a) {
 // host composes M and t once per view (compose_view); the kernel evaluates u with one FMA chain per axis, rounds,
 // and flags a lookup as RISKY when u is within GEOM_TAU of a value where the exact procedure changes its answer (a
 // half-integer tie, an axis end). |u - u_exact| is bounded by compose_view's err (it must be < GEOM_TAU / 4, else
-// the view is not eligible), so a lookup that is not risky equals the exact one. Risky voxels (~1e-5 of them) are
+// the view is not eligible), so a lookup that is not risky equals the exact one. Risky voxels (~1e-7 of them) are
 // appended to a work list and recomputed from scratch by map_fuse_fixup_kernel with the exact search.
 struct AffView { double M[9], t[3]; const float* pred; int dim, P; };
 struct FuseFastArgs {
@@ -633,46 +634,44 @@ __global__ __launch_bounds__(256) void map_fuse_fast_kernel(FuseFastArgs a) {
     if (packed) *(unsigned*)(a.labels + (((long)vx0 * a.Y + vy) * a.Z + vz0)) = pack;
 }
 
-// exact recomputation of the voxels on the work list (all voxels if the list overflowed). 8 lanes share a voxel and
-// look up the views v = lane, lane + 8, ... in parallel (the exact search is long and the list short: the kernel's
-// time is the latency of one voxel); lane 0 of the group then accumulates the views in order, as the fused kernels do.
+// exact recomputation of the voxels on the work list (all voxels if the list overflowed). The list is short and the exact
+// search long, so the kernel's time is the latency of ONE voxel: a workgroup takes 64 voxels (lane = voxel), its four
+// waves look up the views w, w + 4, ... (a wave-uniform view: its parameters stay scalar loads), and wave 0 then
+// accumulates the views in order, as the fused kernels do.
 template <int K>
 __global__ __launch_bounds__(256) void map_fuse_fixup_kernel(FuseArgs a, const unsigned* list, const unsigned* count, unsigned cap,
                                                              unsigned* next_count) {
-    __shared__ float xs[32][MAX_VIEWS][K];
+    __shared__ float xs[MAX_VIEWS][K][64];
     const GridDev& g = a.grid;
     const unsigned n = *count;
     if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;
     const long total = (long)g.X * g.Y * g.Z;
     const bool all = n > cap;
     const long m = all ? total : (long)n;
-    const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
-    for (long i0 = (long)blockIdx.x * 32; i0 < m; i0 += (long)gridDim.x * 32) {       // uniform trip count per workgroup
-        const long i = i0 + grp;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    for (long i0 = (long)blockIdx.x * 64; i0 < m; i0 += (long)gridDim.x * 64) {       // uniform trip count per workgroup
+        const long i = i0 + lane;
         const bool live = i < m;
-        long t = 0;
-        if (live) {
-            t = all ? i : (long)list[i];
-            const int vz = (int)(t % g.Z), vy = (int)((t / g.Z) % g.Y), vx = (int)(t / ((long)g.Z * g.Y));
-            double rx, ry, rz;
-            voxel_real(g, vx, vy, vz, rx, ry, rz);
-            for (int v = sub; v < a.V; v += 8) {
-                const ViewDev& vw = a.views[v];
-                int pl;
-                const long o = view_lookup(vw, rx, ry, rz, K, pl);
+        const long t = live ? (all ? i : (long)list[i]) : 0;
+        const int vz = (int)(t % g.Z), vy = (int)((t / g.Z) % g.Y), vx = (int)(t / ((long)g.Z * g.Y));
+        double rx, ry, rz;
+        voxel_real(g, vx, vy, vz, rx, ry, rz);
+        for (int v = wave; v < a.V; v += 4) {
+            const ViewDev& vw = a.views[v];
+            int pl;
+            const long o = live ? view_lookup(vw, rx, ry, rz, K, pl) : -1;
 #pragma unroll
-                for (int k = 0; k < K; ++k) xs[grp][v][k] = o >= 0 ? vw.pred[o + k] : (k == 0 ? 1.f : 0.f);
-            }
+            for (int k = 0; k < K; ++k) xs[v][k][lane] = o >= 0 ? vw.pred[o + k] : (k == 0 ? 1.f : 0.f);
         }
         __syncthreads();
-        if (live && sub == 0) {
+        if (wave == 0 && live) {
             float z[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) z[k] = 0.f;
             for (int v = 0; v < a.V; ++v) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const float x = xs[grp][v][k];
+                    const float x = xs[v][k][lane];
                     const float wv = a.sum_fusion ? 1.f : a.W[v * K + k];
                     z[k] = a.sum_fusion ? (z[k] + x) : (z[k] + wv * x);
                 }
@@ -758,7 +757,9 @@ static AxisDev to_axis(const double* d_arr, int n, const mpu_axis& m) {
     a.start = m.start; a.step = m.step; a.last = m.last;
     a.inv_h = m.step > 0 ? 1.0 / m.step : 1.0;
     a.g0 = a.kind == 1 ? m.start : (a.kind == 2 ? (0.0 - m.start) * m.step : 0.0);     // == axis_at(a, 0)
-    if (!(m.step > 0)) a.kind = a.kind ? 0 : 0;
+    if (!(m.step > 0)) a.kind = 0;
+    // error bound of the closed-form index coordinate against the fast paths' margin (see GEOM_TAU)
+    if (a.kind && !(64.0 * 1.1102230246251565e-16 * (fabs(a.g0) * a.inv_h + (double)n) < 1e-8 / 4)) a.kind = 0;
     return a;
 }
 static void to_view(const mpu_view_pred& v, ViewDev& d) {
@@ -1041,7 +1042,7 @@ int mpu_map_fuse_views(const mpu_voxel_grid* grid, const mpu_view_pred* views, i
         else if (cfg == 1) { MPU_DISPATCH_K(n_classes, (map_fuse_fast_kernel<KK, 1><<<g, b, 0, st>>>(f))); }
         else               { MPU_DISPATCH_K(n_classes, (map_fuse_fast_kernel<KK, 0><<<g, b, 0, st>>>(f))); }
         { const int rc_ = launch_ok(); if (rc_) return rc_; }
-        MPU_DISPATCH_K(n_classes, (map_fuse_fixup_kernel<KK><<<dim3(128), dim3(256), 0, st>>>(a, f.list, f.count, f.cap, nxt)));
+        MPU_DISPATCH_K(n_classes, (map_fuse_fixup_kernel<KK><<<dim3(256), dim3(256), 0, st>>>(a, f.list, f.count, f.cap, nxt)));
         if (sched_log_on()) sched_note("map_fuse fast views=%d K=%d brick=%d", n_views, n_classes, cfg);
         return launch_ok();
     }

@@ -1,0 +1,11 @@
+#!/bin/bash
+# round-2 call X: GEOM_TAU 1e-6 -> 1e-8 (fewer fix-ups): equality tests + timing
+R="$GRAFT_REPO_ROOT"; O=$R/gpurun_out/r2x; mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_gpu_geometry.py -q 2>&1 | tail -2
+timeout 300 python tools/bench_geometry.py 2>&1 | grep -v amdgpu.ids | tail -3
+C=2 K=5 D=192 timeout 300 python tools/bench_geometry.py 2>&1 | grep -v amdgpu.ids | tail -3
+cd /tmp; CHECK=0 REPS=3 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof -o g -- python $R/tools/bench_geometry.py > /dev/null 2>&1
+python $R/tools/rocpd_stats.py $(ls $O/prof/*/*.db $O/prof/*.db 2>/dev/null | head -1) 2>/dev/null | grep "sample_\|map_fuse" | cut -c1-150
+
