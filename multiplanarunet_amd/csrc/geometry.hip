@@ -720,6 +720,41 @@ __global__ __launch_bounds__(256) void map_view_kernel(MapArgs a) {
     }
 }
 
+// exact map / accumulate of the voxels on the work list of map_view_fast_kernel (all voxels if the list overflowed)
+template <int K, bool ACCUM>
+__global__ __launch_bounds__(256) void map_view_fixup_kernel(MapArgs a, const unsigned* list, const unsigned* count, unsigned cap,
+                                                             unsigned* next_count) {
+    const GridDev& g = a.grid;
+    const unsigned n = *count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;
+    const long total = (long)g.X * g.Y * g.Z;
+    const bool all = n > cap;
+    const long m = all ? total : (long)n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < m; i += (long)gridDim.x * 256) {
+        const long t = all ? i : (long)list[i];
+        const int vz = (int)(t % g.Z), vy = (int)((t / g.Z) % g.Y), vx = (int)(t / ((long)g.Z * g.Y));
+        double rx, ry, rz;
+        voxel_real(g, vx, vy, vz, rx, ry, rz);
+        int pl;
+        const long off = view_lookup(a.view, rx, ry, rz, K, pl);
+        if (!ACCUM) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                a.out[t * K + k] = (off >= 0) ? a.view.pred[off + k] : (k == 0 ? 1.f : 0.f);
+        } else {
+            if (off >= 0) {
+                if (pl >= a.p_lo && pl < a.p_hi) {
+                    const long o2 = off - (long)a.p_lo * a.view.dim * a.view.dim * K;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) a.out[t * K + k] += a.Wv[k] * a.view.pred[o2 + k];
+                }
+            } else if (a.owns_oob) {
+                a.out[t * K] += a.Wv[0];
+            }
+        }
+    }
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void fusion_forward_kernel(const float* __restrict__ x, long n, int V,
                                                              const float* W, const float* b,
@@ -746,6 +781,108 @@ __global__ __launch_bounds__(256) void fusion_finalize_kernel(const float* __res
 #pragma unroll
         for (int k = 0; k < K; ++k) z[k] = zin[t * K + k] + (sum_fusion ? 0.f : b[k]);
         softmax_argmax_store<K>(z, !sum_fusion, t, probs, labels);
+    }
+}
+
+// ---- straight-line single-view kernels (map_real_space_pred / the sharded accumulate) ---------------------
+// Same scheme as map_fuse_fast_kernel for ONE view: composed affine index map, a wave = a 4x4x16 block of voxels with 4
+// consecutive z per lane, 8x8x16 bricks walked in Morton order per XCD; voxels within GEOM_TAU of a decision boundary are
+// skipped here and handled by map_view_fixup_kernel with the exact search (for the accumulate: exactly once).
+struct MapFastArgs {
+    AffView v; int X, Y, Z;
+    const float* Wv; int p_lo, p_hi, owns_oob; float* out;
+    unsigned* list; unsigned* count; unsigned cap, nblk8; int px2, py2;
+};
+template <int K, bool ACCUM>
+__global__ __launch_bounds__(256) void map_view_fast_kernel(MapFastArgs a) {
+    const int nz = (a.Z + 15) / 16, ny = (a.Y + 7) / 8, nx = (a.X + 7) / 8;
+    const unsigned L = (blockIdx.x & 7u) * a.nblk8 + (blockIdx.x >> 3);
+    auto compact = [](unsigned v) { v &= 0x55555555u; v = (v | (v >> 1)) & 0x33333333u; v = (v | (v >> 2)) & 0x0f0f0f0fu;
+                                    v = (v | (v >> 4)) & 0x00ff00ffu; v = (v | (v >> 8)) & 0x0000ffffu; return v; };
+    const unsigned col = L / (unsigned)nz;
+    const int bz = (int)(L % (unsigned)nz);
+    const int mb = a.px2 < a.py2 ? a.px2 : a.py2;
+    const unsigned lo = col & ((1u << (2 * mb)) - 1u), hi = col >> (2 * mb);
+    unsigned cx = compact(lo), cy = compact(lo >> 1);
+    if (a.px2 > a.py2) cx |= hi << mb; else cy |= hi << mb;
+    if (cx >= (unsigned)nx || cy >= (unsigned)ny) return;
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int vx = (int)cx * 8 + (wv & 1) * 4 + (ln >> 4);
+    const int vy = (int)cy * 8 + (wv >> 1) * 4 + ((ln >> 2) & 3);
+    const int vz0 = bz * 16 + (ln & 3) * 4;
+    if (vx >= a.X || vy >= a.Y || vz0 >= a.Z) return;
+    const AffView& w = a.v;
+    const double hg = 0.5 * (double)(w.dim - 1), ho = 0.5 * (double)(w.P - 1);
+    double base[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) base[r] = fma(w.M[3 * r + 1], (double)vy, fma(w.M[3 * r], (double)vx, w.t[r]));
+    // the lane's 4 voxels are 4 K contiguous floats of the output: one 16-byte-vector read-modify-write per lane (four
+    // separate 12-byte accesses per lane cost more than the exact kernel's whole run)
+    const long t0 = ((long)vx * a.Y + vy) * a.Z + vz0;
+    const bool vec = (a.Z & 3) == 0;                              // then vz0 + 3 < Z and t0 * K floats are 16-byte aligned
+    float val[FZ][K];
+    float4* dst4 = (float4*)(a.out + t0 * K);
+    if (ACCUM && vec) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const float4 v4 = dst4[q];
+            (&val[0][0])[4 * q] = v4.x; (&val[0][0])[4 * q + 1] = v4.y; (&val[0][0])[4 * q + 2] = v4.z; (&val[0][0])[4 * q + 3] = v4.w;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < FZ; ++u) {
+        const int vz = vz0 + u;
+        if (vz >= a.Z) continue;
+        int n[3]; bool o = false, rk = false;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double uu = fma(w.M[3 * r + 2], (double)vz, base[r]);
+            const double h = r == 2 ? ho : hg;
+            const double rr = rint(uu);
+            rk |= !(fabs(fabs(uu - rr) - 0.5) > GEOM_TAU);                     // tie (or NaN)
+            const double e = fabs(uu - h);
+            const bool in = e < h - GEOM_TAU, sure_out = e > h + GEOM_TAU;
+            o |= sure_out; rk |= !(in | sure_out);
+            n[r] = (int)rr;
+        }
+        const long t = t0 + u;
+        if (rk) {                                                // left as it is here; map_view_fixup_kernel handles it
+            const unsigned idx = atomicAdd(a.count, 1u);
+            if (idx < a.cap) a.list[idx] = (unsigned)t;
+            if (!ACCUM && vec) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) val[u][k] = 0.f;
+            }
+            continue;
+        }
+        float* dst = a.out + t * K;
+        if (!ACCUM) {
+            float x[K];
+            const unsigned off = o ? 0u : (((unsigned)n[2] * (unsigned)w.dim + (unsigned)n[0]) * (unsigned)w.dim + (unsigned)n[1]) * K;
+            __builtin_memcpy(x, w.pred + off, K * sizeof(float));
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float r_ = o ? (k == 0 ? 1.f : 0.f) : x[k];
+                if (vec) val[u][k] = r_; else dst[k] = r_;
+            }
+        } else if (!o) {
+            if (n[2] >= a.p_lo && n[2] < a.p_hi) {            // (w.pred points at plane p_lo of the view)
+                const unsigned off = (((unsigned)(n[2] - a.p_lo) * (unsigned)w.dim + (unsigned)n[0]) * (unsigned)w.dim + (unsigned)n[1]) * K;
+                float x[K];
+                __builtin_memcpy(x, w.pred + off, K * sizeof(float));
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if (vec) val[u][k] = val[u][k] + a.Wv[k] * x[k]; else dst[k] += a.Wv[k] * x[k];
+                }
+            }
+        } else if (a.owns_oob) {
+            if (vec) val[u][0] = val[u][0] + a.Wv[0]; else dst[0] += a.Wv[0];
+        }
+    }
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+            dst4[q] = make_float4((&val[0][0])[4 * q], (&val[0][0])[4 * q + 1], (&val[0][0])[4 * q + 2], (&val[0][0])[4 * q + 3]);
     }
 }
 
@@ -886,6 +1023,42 @@ static int fuse_scratch(hipStream_t st, unsigned** count, unsigned** next_count,
     return MPU_OK;
 }
 
+// map_real_space_pred / sharded accumulate of one view: straight-line kernel + exact fix-up when the view is eligible
+static int launch_map_view(const MapArgs& a, int n_classes, bool accum, hipStream_t st) {
+    MapFastArgs f;
+    const bool fast = fast_path_host() && n_classes >= 1 && n_classes <= 16 && (long)a.grid.X * a.grid.Y * a.grid.Z < (1L << 32) &&
+                      compose_view(a.grid, a.view, n_classes, f.v);
+    if (fast) {
+        unsigned* nxt = nullptr;
+        { const int rc_ = fuse_scratch(st, &f.count, &nxt, &f.list); if (rc_) return rc_; }
+        f.cap = FUSE_LIST_CAP;
+        f.X = a.grid.X; f.Y = a.grid.Y; f.Z = a.grid.Z;
+        f.Wv = a.Wv; f.p_lo = a.p_lo; f.p_hi = a.p_hi; f.owns_oob = a.owns_oob; f.out = a.out;
+        const int nxb = cdiv(f.X, 8), nyb = cdiv(f.Y, 8), nzb = cdiv(f.Z, 16);
+        f.px2 = f.py2 = 0;
+        while ((1 << f.px2) < nxb) ++f.px2;
+        while ((1 << f.py2) < nyb) ++f.py2;
+        const long padded = (1L << f.px2) * (1L << f.py2) * nzb;
+        if (padded < (1L << 31)) {
+            f.nblk8 = (unsigned)((padded + 7) / 8);
+            const dim3 g(f.nblk8 * 8u), b(256);
+            if (accum) { MPU_DISPATCH_K(n_classes, (map_view_fast_kernel<KK, true><<<g, b, 0, st>>>(f))); }
+            else       { MPU_DISPATCH_K(n_classes, (map_view_fast_kernel<KK, false><<<g, b, 0, st>>>(f))); }
+            { const int rc_ = launch_ok(); if (rc_) return rc_; }
+            if (accum) { MPU_DISPATCH_K(n_classes, (map_view_fixup_kernel<KK, true><<<dim3(64), dim3(256), 0, st>>>(a, f.list, f.count, f.cap, nxt))); }
+            else       { MPU_DISPATCH_K(n_classes, (map_view_fixup_kernel<KK, false><<<dim3(64), dim3(256), 0, st>>>(a, f.list, f.count, f.cap, nxt))); }
+            if (sched_log_on()) sched_note("map_view fast accum=%d K=%d", accum ? 1 : 0, n_classes);
+            return launch_ok();
+        }
+        // (unreachable in practice: the scratch sequence number advanced without a launch; zero the next counter by hand)
+        MPU_CHECK_HIP(hipMemsetAsync(nxt, 0, sizeof(unsigned), st));
+    }
+    if (sched_log_on()) sched_note("map_view generic accum=%d K=%d", accum ? 1 : 0, n_classes);
+    if (accum) { MPU_DISPATCH_K(n_classes, (map_view_kernel<KK, true><<<dim3(brick_grid(a.grid)), dim3(256), 0, st>>>(a))); }
+    else       { MPU_DISPATCH_K(n_classes, (map_view_kernel<KK, false><<<dim3(brick_grid(a.grid)), dim3(256), 0, st>>>(a))); }
+    return launch_ok();
+}
+
 extern "C" {
 
 int mpu_abi_version(void) { return 1; }
@@ -982,8 +1155,7 @@ int mpu_map_view_nearest(const mpu_voxel_grid* grid, const mpu_view_pred* view, 
     MPU_REQUIRE(view->dim >= 2 && view->n_planes >= 2, "mpu_map_view_nearest: view needs dim>=2, planes>=2");
     MapArgs a; to_grid(*grid, a.grid); to_view(*view, a.view);
     a.Wv = nullptr; a.p_lo = 0; a.p_hi = view->n_planes; a.owns_oob = 1; a.out = d_mapped;
-    MPU_DISPATCH_K(n_classes, (map_view_kernel<KK, false><<<dim3(brick_grid(a.grid)), dim3(256), 0, (hipStream_t)stream>>>(a)));
-    return launch_ok();
+    return launch_map_view(a, n_classes, false, (hipStream_t)stream);
 }
 
 int mpu_map_accumulate_view(const mpu_voxel_grid* grid, const mpu_view_pred* view, int32_t n_classes,
@@ -995,8 +1167,7 @@ int mpu_map_accumulate_view(const mpu_voxel_grid* grid, const mpu_view_pred* vie
     MPU_REQUIRE(0 <= p_lo && p_lo < p_hi && p_hi <= view->n_planes, "mpu_map_accumulate_view: bad plane range");
     MapArgs a; to_grid(*grid, a.grid); to_view(*view, a.view);
     a.Wv = d_Wv; a.p_lo = p_lo; a.p_hi = p_hi; a.owns_oob = owns_oob; a.out = d_z;
-    MPU_DISPATCH_K(n_classes, (map_view_kernel<KK, true><<<dim3(brick_grid(a.grid)), dim3(256), 0, (hipStream_t)stream>>>(a)));
-    return launch_ok();
+    return launch_map_view(a, n_classes, true, (hipStream_t)stream);
 }
 
 int mpu_map_fuse_views(const mpu_voxel_grid* grid, const mpu_view_pred* views, int32_t n_views,

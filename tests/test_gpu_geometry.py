@@ -195,7 +195,7 @@ def test_fast_paths_equal_exact_search_at_scale(aff):
     labels must be IDENTICAL, on volumes large enough to hit node / tie / out-of-bounds neighbourhoods (integer
     spans put many samples exactly on nodes and half-way points)."""
     from multiplanarunet_amd import _lib
-    from multiplanarunet_amd.interpolation import Volume, ViewGeometry, sample_view, map_and_fuse
+    from multiplanarunet_amd.interpolation import Volume, ViewGeometry, sample_view, map_and_fuse, map_real_space_pred, map_accumulate
     lib = _lib.load()
     rng = np.random.RandomState(3)
     D, K = 96, 3
@@ -229,7 +229,14 @@ def test_fast_paths_equal_exact_search_at_scale(aff):
                             pr = torch.tensor(np.random.RandomState(10 + vi).rand(g.n_planes, dim, dim, K).astype(np.float32), device="cuda")
                             preds.append((pr, (g.real_axis, g.real_axis, g.offsets), g.inv_basis))
                 probs, labels = map_and_fuse(vol, preds, W, b)
-                return res + [probs.clone(), labels.clone()]
+                # single-view kernels: map_real_space_pred of one view, and the sharded accumulate in two plane chunks
+                pr, grid, ib = preds[3]
+                mapped = map_real_space_pred(pr.permute(1, 2, 0, 3), grid, ib, vol)
+                z = torch.zeros(tuple(vol.image.shape[:3]) + (K,), dtype=torch.float32, device="cuda")
+                P = pr.shape[0]
+                for lo, hi in ((0, P // 3), (P // 3, P)):
+                    map_accumulate(vol, pr[lo:hi].contiguous(), grid, ib, W[3].cuda(), lo, hi, owns_oob=(lo == 0), z=z)
+                return res + [probs.clone(), labels.clone(), mapped.clone(), z.clone()]
 
             outs[fast], log = _schedule_log(lib, run)
             if fast:                      # the straight-line kernels are the ones under test
@@ -237,6 +244,7 @@ def test_fast_paths_equal_exact_search_at_scale(aff):
                 if aff in kinds:
                     assert sum(1 for l in log if l.startswith("sample fast " + kinds[aff])) == 2 * len(views), log
                 assert any(l.startswith("map_fuse fast") for l in log), log
+                assert sum(1 for l in log if l.startswith("map_view fast")) == 3, log
             else:
                 assert not any(" fast" in l for l in log), log
         finally:

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from multiplanarunet_amd import _lib
-from multiplanarunet_amd.interpolation import Volume, ViewGeometry, sample_view, map_and_fuse
+from multiplanarunet_amd.interpolation import Volume, ViewGeometry, sample_view, map_and_fuse, map_accumulate
 
 D = int(os.environ.get("D", 256)); K = int(os.environ.get("K", 3)); C = int(os.environ.get("C", 1))
 check = int(os.environ.get("CHECK", 1)); reps = int(os.environ.get("REPS", 5))
@@ -47,10 +47,13 @@ for fast in (1, 0) if check else (1,):
     ts, _ = timed(run_sample)
     tf, r = timed(run_fuse)
     res[fast] = ([o.clone() for o in outs], r[1].clone())
+    zacc = torch.zeros((D, D, D, K), device="cuda")
+    ta, _ = timed(lambda: map_accumulate(vol, preds[3][0], preds[3][1], preds[3][2], W[3], 0, P, True, zacc))
     samp_bytes = len(views) * (4 * D ** 3 * C + 4 * P * D * D * C)
     fuse_bytes = D ** 3 * (len(views) * K * 4 + 1)
     print("fast=%d  sample %.3f ms (%.0f GB/s compulsory)   map_fuse %.3f ms (%.0f GB/s algorithmic, %.3f of 8 TB/s)"
           % (fast, ts, samp_bytes / ts / 1e6, tf, fuse_bytes / tf / 1e6, fuse_bytes / tf / 1e6 / 8000), flush=True)
+    print("        map_accumulate of one oblique view: %.3f ms" % ta, flush=True)
 _lib.check(lib.mpu_geometry_set_fast_path(1), "set_fast")
 if check:
     ok = all(torch.equal(a, b_) for a, b_ in zip(res[1][0], res[0][0])) and torch.equal(res[1][1], res[0][1])
