@@ -298,15 +298,18 @@ __global__ __launch_bounds__(256) void sample_fast_kernel(SampleArgs a, unsigned
     const unsigned sy = (unsigned)a.Z * C, sx = (unsigned)a.Y * sy;
     const unsigned base = (unsigned)c0.c * sx + (unsigned)c1.c * sy + (unsigned)c2.c * C;
     float cv[C][8];
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.vol, 0, (int)((long)a.X * sx * 4L), 0x00020000);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float* src = a.vol + (base + (q >> 1) * sx + (q & 1) * sy);
         if (C == 1) {
             float2 v; __builtin_memcpy(&v, src, 8);
             cv[0][2 * q] = v.x; cv[0][2 * q + 1] = v.y;
-        } else {
-            float4 v; __builtin_memcpy(&v, src, 16);
-            cv[0][2 * q] = v.x; cv[C - 1][2 * q] = v.y; cv[0][2 * q + 1] = v.z; cv[C - 1][2 * q + 1] = v.w;
+        } else {                                                 // two channels: one 16-byte buffer load per corner pair (a 16-byte
+            typedef unsigned int geo_u32x4 __attribute__((ext_vector_type(4)));      // memcpy of unknown alignment became 4 dword loads)
+            const geo_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(vrs, (base + (q >> 1) * sx + (q & 1) * sy) * 4u, 0, 0);
+            cv[0][2 * q] = __uint_as_float(v.x); cv[C - 1][2 * q] = __uint_as_float(v.y);
+            cv[0][2 * q + 1] = __uint_as_float(v.z); cv[C - 1][2 * q + 1] = __uint_as_float(v.w);
         }
     }
     const double y0 = cell_div(c0.num, c0.den, a.ax.inv_h), y1 = cell_div(c1.num, c1.den, a.ay.inv_h),
@@ -1123,7 +1126,7 @@ int mpu_sample_view_planes(const float* d_vol, const uint8_t* d_labels, const in
     static const long fast_min = getenv("MPU_SAMPLE_FAST_MIN") ? atol(getenv("MPU_SAMPLE_FAST_MIN")) : 262144;
     const bool fast = fast_path_host() && (long)a.P * a.dim * a.dim >= fast_min &&
                       a.ax.kind != 0 && a.ay.kind == a.ax.kind && a.az.kind == a.ax.kind && (a.C == 1 || a.C == 2) &&
-                      (long)a.X * a.Y * a.Z * a.C < (1L << 31) && a.P < 65536 && (long)a.P * a.dim * a.dim < (1L << 32);
+                      (long)a.X * a.Y * a.Z * a.C < (1L << 29) && a.P < 65536 && (long)a.P * a.dim * a.dim < (1L << 32);
     if (fast) {
         const dim3 g((unsigned)((a.dim + 31) / 32), (unsigned)((a.dim + 7) / 8), (unsigned)a.P), b(256);
         hipStream_t st = (hipStream_t)stream;
