@@ -188,7 +188,7 @@ def _schedule_log(lib, fn):
     return out, buf.value.decode().splitlines()
 
 
-@pytest.mark.parametrize("aff", ("ident", "rot", "aniso", "aniso1"))
+@pytest.mark.parametrize("aff", ("ident", "rot", "aniso", "aniso1", "odd"))
 def test_fast_paths_equal_exact_search_at_scale(aff):
     """The closed-form fast paths (uniform axes, samples farther than 1e-6 index units from a decision boundary)
     against the exact NumPy-order search forced for every sample: sampled planes, labels, mapped volumes and fused
@@ -207,8 +207,11 @@ def test_fast_paths_equal_exact_search_at_scale(aff):
     if aff.startswith("aniso"):       # pixdims whose voxel axes are NOT reproduced by the linspace form: closed-form kind 2
         A[:3, :3] = np.diag([0.8, 0.7, 1.3]); A[:3, 3] = [1.0, 2.0, -3.0]
     nch = 1 if aff == "aniso1" else 2
-    vol_np = rng.randn(D, D - 8, D + 4, nch).astype(np.float32)
-    lab_np = rng.randint(0, K, (D, D - 8, D + 4)).astype(np.uint8)
+    shape = (D, D - 8, D + 4)
+    if aff == "odd":                  # odd extents: partial bricks, Z % 4 != 0 (unpacked label stores, scalar accumulate), 5 classes
+        A[:3, :3] = np.diag([1.7, 1.9, 1.1]); shape = (50, 47, 61); K = 5
+    vol_np = rng.randn(*shape, nch).astype(np.float32)
+    lab_np = rng.randint(0, K, shape).astype(np.uint8)
     views = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0], [0.3, 0.5, 0.8], [-0.6, 0.64, 0.48]], float)
     W = torch.tensor(rng.uniform(.5, 1.5, (len(views), K)).astype(np.float32))
     b = torch.tensor(rng.uniform(-.1, .1, (K,)).astype(np.float32))
@@ -243,6 +246,8 @@ def test_fast_paths_equal_exact_search_at_scale(aff):
                 kinds = {"ident": "kind=1", "aniso": "kind=2", "aniso1": "kind=2"}
                 if aff in kinds:
                     assert sum(1 for l in log if l.startswith("sample fast " + kinds[aff])) == 2 * len(views), log
+                if aff == "odd":
+                    assert any(l.startswith("sample fast") for l in log), log
                 assert any(l.startswith("map_fuse fast") for l in log), log
                 assert sum(1 for l in log if l.startswith("map_view fast")) == 3, log
             else:
