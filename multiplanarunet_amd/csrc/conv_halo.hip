@@ -460,7 +460,14 @@ int try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
         static int up_on = -1;
         if (up_on < 0) { const char* e = getenv("MPU_HALO_UPCONV"); up_on = (e && e[0] == '0') ? 0 : 1; }
         if (!up_on || dtype != MPU_BF16 || (a.Ho & 3) || (a.Wo & 1)) return 0;
-        rc = a.Cout > 64 ? launch_halo_cfg<bf16_t, 128, 4, 3, UPCONV2>(a, st) : launch_halo_cfg<bf16_t, 64, 4, 3, UPCONV2>(a, st);
+        // 8-row tiles on large grids (predict batches): twice the work per workgroup for the same patch / weight prologue
+        static long up8_min = -1;
+        if (up8_min < 0) { const char* e = getenv("MPU_HALO_UP8_MIN"); up8_min = e ? atol(e) : 2048; }
+        const long t8 = (long)a.B * cdiv(a.Ho, 8) * cdiv(a.Wo, 32) * cdiv(a.Cout, a.Cout > 64 ? 128 : 64);
+        if (!(a.Ho & 7) && t8 >= up8_min)
+            rc = a.Cout > 64 ? launch_halo_cfg<bf16_t, 128, 8, 3, UPCONV2>(a, st) : launch_halo_cfg<bf16_t, 64, 8, 3, UPCONV2>(a, st);
+        else
+            rc = a.Cout > 64 ? launch_halo_cfg<bf16_t, 128, 4, 3, UPCONV2>(a, st) : launch_halo_cfg<bf16_t, 64, 4, 3, UPCONV2>(a, st);
         return rc ? rc : 1;
     }
     static int variant = -1;                      // MPU_HALO_VARIANT: tuning aid
