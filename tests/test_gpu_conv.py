@@ -225,3 +225,15 @@ def test_first_layer_weight_gradient(case):
     # the general-purpose entry point agrees (it has no channel-count hint and runs the MFMA kernels)
     dWg = ops.conv2d_wgrad(CONV3, x.cuda(), dz.cuda()).cpu().double()
     assert float((dWg - ref).abs().max()) <= 2e-3 * s
+
+
+def test_upconv_8row_tiles_subprocess():
+    """The up-conv halo kernels switch to 8-row pixel tiles on large grids (predict batches). MPU_HALO_UP8_MIN=1 (read
+    once per process, hence a fresh interpreter) selects them for every eligible shape: the layer parity tests of this
+    file must pass with them too (both the 64- and the 128-channel tile variants)."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_conv.py"), "-x", "-q", "-k",
+                        "deep_level or forward_dgrad_wgrad"], env=dict(os.environ, MPU_HALO_UP8_MIN="1"),
+                       capture_output=True, text=True, cwd=os.path.dirname(here))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
