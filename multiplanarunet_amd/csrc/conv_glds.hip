@@ -1015,13 +1015,17 @@ int try_conv_pipe_first(int dtype, int mode, const ConvArgs& a, hipStream_t st) 
     return try_pipe<bf16_t, CONV3>(a, st);
 }
 
+static thread_local const char* g_glds_sched = "glds";       // which schedule the last launch_conv_glds took (schedule log)
+const char* last_glds_schedule() { return g_glds_sched; }
+
 template <typename T, int MODE>
 static int launch_glds_mode(const ConvArgs& a_in, hipStream_t st) {
     ConvArgs a = a_in;
     a.ksplit = 1;
+    g_glds_sched = "glds";
     {
         const int p = try_pipe<T, MODE>(a, st);
-        if (p != 0) return p < 0 ? p : MPU_OK;
+        if (p != 0) { g_glds_sched = "pipe"; return p < 0 ? p : MPU_OK; }
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const long t128 = (long)cdiv(a.Cout, 128) * cdiv(M, 128);

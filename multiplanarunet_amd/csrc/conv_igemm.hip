@@ -691,8 +691,9 @@ int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
             const int h = try_conv_halo(dtype, mode, a, st);
             if (h != 0) { note("halo"); return h < 0 ? h : MPU_OK; }
         }
-        note("glds");
-        return launch_conv_glds(dtype, mode, a, st);
+        const int rc = launch_conv_glds(dtype, mode, a, st);
+        note(last_glds_schedule());
+        return rc;
     }
     note("regs");
 #define MPU_CONV_CASE(TT)                                                          \

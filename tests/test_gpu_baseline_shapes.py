@@ -115,7 +115,8 @@ def test_cfg1_bf16_train_step_per_tensor_and_dispatch():
     assert len(conv) == 47 and len(wg) == 22, (len(conv), len(wg))     # 22 forward + 25 data-gradient launches; 22 wgrads
     assert "regs" not in scheds(conv) and "regs" not in scheds(wg)      # no register-staged fallback on the bench path
     assert scheds(conv).get("c8") == 1 and scheds(wg).get("c8") == 1    # first layer kernels
-    assert set(scheds(conv)) >= {"c8", "halo", "glds"} and set(scheds(wg)) >= {"c8", "taps", "glds"}
+    assert set(scheds(conv)) >= {"c8", "ws", "halo", "pipe"} and set(scheds(wg)) >= {"c8", "taps", "glds"}
+    assert scheds(conv).get("pipe", 0) >= 14, scheds(conv)              # the deep levels run on conv_pipe (16 of the 47 launches)
 
     # --- inference mode (well conditioned: BatchNorm with moving statistics): tight bound against the matched model
     m.flatten_output = False
