@@ -98,28 +98,59 @@ def fill_build_from_data(hp, volumes, n_classes=None):
 AUDITED_KEYS = (("build", "dim"), ("build", "n_channels"), ("build", "n_classes"), ("fit", "real_space_span"))
 
 
+def _patch_yaml_value(text, sec, key, val):
+    """Set `sec.key` in the YAML TEXT, touching only that line (comments, anchors and layout of the rest survive, as
+    with the reference's YAMLHParams.set_value, mpunet/hyperparameters/hparams.py:161-221). Works on the block style
+    the project YAMLs use (top-level `sec:` line, indented `key: value` lines)."""
+    import re
+    lines = text.split("\n")
+    start = next((i for i, l in enumerate(lines) if re.match(r"^%s\s*:" % re.escape(sec), l)), None)
+    if start is None:                                   # section missing: append it
+        return text.rstrip("\n") + "\n\n%s:\n  %s: %s\n" % (sec, key, val)
+    end = start + 1
+    while end < len(lines) and (not lines[end].strip() or lines[end][:1] in " \t#"):
+        end += 1
+    pat = re.compile(r"^(\s+)%s\s*:\s*([^#]*?)(\s*#.*)?$" % re.escape(key))
+    for i in range(start + 1, end):
+        mt = pat.match(lines[i])
+        if mt:
+            lines[i] = "%s%s: %s%s" % (mt.group(1), key, val, mt.group(3) or "")
+            return "\n".join(lines)
+    last = end - 1                                      # key missing: add it behind the section's last entry
+    while last > start and not lines[last].strip():
+        last -= 1
+    lines.insert(last + 1, "  %s: %s" % (key, val))
+    return "\n".join(lines)
+
+
 def save_audited_hparams(project_dir, hp):
     """Write the audited values back into train_hparams.yaml (the reference's Auditor.fill +
     YAMLHParams.save_current, mpunet/bin/train.py:210-228), so that `mp predict` / `mp train_fusion` use the
-    geometry the model was trained with instead of re-auditing whatever volumes they are given."""
+    geometry the model was trained with instead of re-auditing whatever volumes they are given. Only the audited
+    lines are patched in the text: the user's comments and formatting are kept."""
     path = os.path.join(project_dir, "train_hparams.yaml")
     with open(path) as f:
-        raw = yaml.safe_load(f) or {}
+        text = f.read()
+    raw = yaml.safe_load(text) or {}
     changed = False
     for sec, key in AUDITED_KEYS:
         val = hp[sec].get(key)
         if val is None:
             continue
         val = float(val) if key == "real_space_span" else int(val)
-        if not isinstance(raw.get(sec), dict):
-            raw[sec] = {}
-        if raw[sec].get(key) != val:
-            raw[sec][key] = val
+        cur = raw.get(sec) if isinstance(raw.get(sec), dict) else {}
+        if cur.get(key) != val:
+            text = _patch_yaml_value(text, sec, key, repr(val))
             changed = True
     if changed:
+        check = yaml.safe_load(text) or {}
+        for sec, key in AUDITED_KEYS:                   # the patched text must parse back to the audited values
+            val = hp[sec].get(key)
+            if val is not None and float((check.get(sec) or {}).get(key, float("nan"))) != float(val):
+                raise RuntimeError("could not patch %s.%s in %s" % (sec, key, path))
         tmp = path + ".tmp"
         with open(tmp, "w") as f:
-            yaml.safe_dump(raw, f, sort_keys=False)
+            f.write(text)
         os.replace(tmp, path)
     return changed
 

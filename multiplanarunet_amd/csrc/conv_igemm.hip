@@ -821,7 +821,7 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue
 }
 
 // exact scratch of one layer (mirrors the split / schedule decisions of launch_wgrad_mode)
-long wgrad_scratch_need(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout) {
+long wgrad_scratch_need(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout, int c0_logical) {
     const int Cin = C0 + C1;
     const int ntaps = mode == UPCONV2 ? 4 : (mode == CONV1 ? 1 : 9);
     const long M = (long)B * H * W, n = (long)ntaps * Cin * Cout;
@@ -831,7 +831,11 @@ long wgrad_scratch_need(int dtype, int mode, int B, int H, int W, int C0, int C1
     if (conv_impl() == 1) taps = wgrad_taps_plan(dtype, mode, B, H, W, C0, C1, Cout);
     if (taps.use) ks = (taps.nstrips + 1) / 2;
     const long nshare = taps.use ? ks : (long)ks * ntaps * cdiv(Cin, 64);
-    return ((long)ks * n + nshare * Cout + 63) / 64 * 64 + 64;
+    long need = (long)ks * n + nshare * Cout;
+    // the first-layer schedule (tried first) keeps one compact row per strip of image rows: its own layout and size
+    const long c8 = conv_impl() == 1 ? wgrad_c8_scratch_floats(dtype, mode, B, H, W, C0, C1, c0_logical, Cout) : 0;
+    if (c8 > need) need = c8;
+    return (need + 63) / 64 * 64 + 64;
 }
 
 int launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st, ReduceQueue* rq) {

@@ -1026,6 +1026,14 @@ static int fuse_scratch(hipStream_t st, unsigned** count, unsigned** next_count,
     return MPU_OK;
 }
 
+// The two counters only stay consistent when BOTH launches of a call (fast kernel, fix-up) were issued: an early
+// return in between (launch error, unsupported class count) would leave the next call a stale non-zero count and
+// replay list entries of an older, possibly larger volume. The guard zeroes both counters on such a path.
+struct FuseCounterGuard {
+    hipStream_t st; unsigned* list; bool done = false;
+    ~FuseCounterGuard() { if (!done && list) (void)hipMemsetAsync(list - 16, 0, 16 * sizeof(unsigned), st); }
+};
+
 // map_real_space_pred / sharded accumulate of one view: straight-line kernel + exact fix-up when the view is eligible
 static int launch_map_view(const MapArgs& a, int n_classes, bool accum, hipStream_t st) {
     MapFastArgs f;
@@ -1034,6 +1042,7 @@ static int launch_map_view(const MapArgs& a, int n_classes, bool accum, hipStrea
     if (fast) {
         unsigned* nxt = nullptr;
         { const int rc_ = fuse_scratch(st, &f.count, &nxt, &f.list); if (rc_) return rc_; }
+        FuseCounterGuard guard{st, f.list};
         f.cap = FUSE_LIST_CAP;
         f.X = a.grid.X; f.Y = a.grid.Y; f.Z = a.grid.Z;
         f.Wv = a.Wv; f.p_lo = a.p_lo; f.p_hi = a.p_hi; f.owns_oob = a.owns_oob; f.out = a.out;
@@ -1051,10 +1060,11 @@ static int launch_map_view(const MapArgs& a, int n_classes, bool accum, hipStrea
             if (accum) { MPU_DISPATCH_K(n_classes, (map_view_fixup_kernel<KK, true><<<dim3(64), dim3(256), 0, st>>>(a, f.list, f.count, f.cap, nxt))); }
             else       { MPU_DISPATCH_K(n_classes, (map_view_fixup_kernel<KK, false><<<dim3(64), dim3(256), 0, st>>>(a, f.list, f.count, f.cap, nxt))); }
             if (sched_log_on()) sched_note("map_view fast accum=%d K=%d", accum ? 1 : 0, n_classes);
-            return launch_ok();
+            const int rc_ = launch_ok();
+            guard.done = rc_ == MPU_OK;
+            return rc_;
         }
-        // (unreachable in practice: the scratch sequence number advanced without a launch; zero the next counter by hand)
-        MPU_CHECK_HIP(hipMemsetAsync(nxt, 0, sizeof(unsigned), st));
+        // (unreachable in practice: the scratch sequence number advanced without a launch; the guard zeroes the counters)
     }
     if (sched_log_on()) sched_note("map_view generic accum=%d K=%d", accum ? 1 : 0, n_classes);
     if (accum) { MPU_DISPATCH_K(n_classes, (map_view_kernel<KK, true><<<dim3(brick_grid(a.grid)), dim3(256), 0, st>>>(a))); }
@@ -1132,6 +1142,7 @@ int mpu_sample_view_planes(const float* d_vol, const uint8_t* d_labels, const in
         hipStream_t st = (hipStream_t)stream;
         unsigned *cnt = nullptr, *nxt = nullptr, *lst = nullptr;
         { const int rc_ = fuse_scratch(st, &cnt, &nxt, &lst); if (rc_) return rc_; }
+        FuseCounterGuard guard{st, lst};
 #define MPU_SAMPLE_FAST(KIND_) \
         if (a.C == 1) { if (a.out_lab) sample_fast_kernel<KIND_, 1, true><<<g, b, 0, st>>>(a, lst, cnt, FUSE_LIST_CAP); else sample_fast_kernel<KIND_, 1, false><<<g, b, 0, st>>>(a, lst, cnt, FUSE_LIST_CAP); } \
         else          { if (a.out_lab) sample_fast_kernel<KIND_, 2, true><<<g, b, 0, st>>>(a, lst, cnt, FUSE_LIST_CAP); else sample_fast_kernel<KIND_, 2, false><<<g, b, 0, st>>>(a, lst, cnt, FUSE_LIST_CAP); }
@@ -1140,7 +1151,9 @@ int mpu_sample_view_planes(const float* d_vol, const uint8_t* d_labels, const in
         { const int rc_ = launch_ok(); if (rc_) return rc_; }
         sample_fixup_kernel<<<dim3(64), dim3(256), 0, st>>>(a, lst, cnt, FUSE_LIST_CAP, nxt);
         if (sched_log_on()) sched_note("sample fast kind=%d C=%d labels=%d", a.ax.kind, a.C, a.out_lab ? 1 : 0);
-        return launch_ok();
+        const int rc_ = launch_ok();
+        guard.done = rc_ == MPU_OK;
+        return rc_;
     }
     if (sched_log_on()) sched_note("sample generic kinds=%d%d%d C=%d labels=%d", a.ax.kind, a.ay.kind, a.az.kind, a.C, a.out_lab ? 1 : 0);
     const long tpd = (a.dim + 15) / 16;
@@ -1196,6 +1209,7 @@ int mpu_map_fuse_views(const mpu_voxel_grid* grid, const mpu_view_pred* views, i
         hipStream_t st = (hipStream_t)stream;
         unsigned* nxt = nullptr;
         { const int rc_ = fuse_scratch(st, &f.count, &nxt, &f.list); if (rc_) return rc_; }
+        FuseCounterGuard guard{st, f.list};
         static const int cfg = getenv("MPU_FUSE_BRICK") ? atoi(getenv("MPU_FUSE_BRICK")) : 2;
         f.V = n_views; f.X = a.grid.X; f.Y = a.grid.Y; f.Z = a.grid.Z;
         f.W = d_W; f.b = d_b; f.sum_fusion = sum_fusion; f.probs = d_probs; f.labels = d_labels;
@@ -1218,7 +1232,9 @@ int mpu_map_fuse_views(const mpu_voxel_grid* grid, const mpu_view_pred* views, i
         { const int rc_ = launch_ok(); if (rc_) return rc_; }
         MPU_DISPATCH_K(n_classes, (map_fuse_fixup_kernel<KK><<<dim3(256), dim3(256), 0, st>>>(a, f.list, f.count, f.cap, nxt)));
         if (sched_log_on()) sched_note("map_fuse fast views=%d K=%d brick=%d", n_views, n_classes, cfg);
-        return launch_ok();
+        const int rc_ = launch_ok();
+        guard.done = rc_ == MPU_OK;
+        return rc_;
     }
     if (sched_log_on()) sched_note("map_fuse generic views=%d K=%d", n_views, n_classes);
     MPU_DISPATCH_K(n_classes, (map_fuse_kernel<KK><<<dim3(fuse_grid(a.grid)), dim3(256), 0, (hipStream_t)stream>>>(a)));

@@ -52,6 +52,7 @@ struct WgradArgs {
     float* colsum_scratch;       // [RED_MAX_BLOCKS][Cout] scratch for the unfused bias-gradient path
     int fuse_db;                 // set by the launcher: the wgrad kernel also produces the db partials
     int c0_logical;              // image channels actually present in an 8-channel x0 (first layer); 0 = unknown
+    long partial_cap = 0;        // floats available at `partial` (0 = unknown: schedules with their own layout refuse)
 };
 
 // element-wise maximum of two 16-byte pieces of T (8 bf16 or 4 f32)
@@ -100,7 +101,9 @@ constexpr int REDUCE_MAX_JOBS = 32;
 struct ReduceQueue { int njobs = 0, nblocks = 0; ReduceJob job[REDUCE_MAX_JOBS]; };
 int  flush_wgrad_reduces(ReduceQueue& q, hipStream_t st);
 // exact scratch need (floats) of one layer's weight gradient: K-split partials + bias-gradient partials
-long wgrad_scratch_need(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout);
+// c0_logical: image channels of an 8-channel first layer (selects the wgrad_c8 schedule, which has its own layout)
+long wgrad_scratch_need(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout, int c0_logical = 0);
+long wgrad_c8_scratch_floats(int dtype, int mode, int B, int H, int W, int C0, int C1, int c0_logical, int Cout);   // 0 = not eligible
 int  launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st, ReduceQueue* q = nullptr);
 int  try_wgrad_c8(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st);   // first layer (wgrad_c8.hip)
 int  try_wgrad_glds(int dtype, int mode, const WgradArgs& a, hipStream_t st);   // 1 launched, 0 unsupported shape

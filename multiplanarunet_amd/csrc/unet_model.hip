@@ -160,7 +160,8 @@ Plan make_plan(const mpu_unet* m, int B) {
             const bool concat = c.mode == CONV3 && (int)i >= 2 * D + 2 && ((int)i - 2 * D - 2) % 3 == 1;
             const int C0 = concat ? c.Cin / 2 : c.Cin, C1 = concat ? c.Cin / 2 : 0;
             P.wscratch[i] = we;
-            we += wgrad_scratch_need(m->cfg.dtype, c.mode, B, m->cfg.H >> l, m->cfg.W >> l, C0, C1, c.Cout);
+            we += wgrad_scratch_need(m->cfg.dtype, c.mode, B, m->cfg.H >> l, m->cfg.W >> l, C0, C1, c.Cout,
+                                     i == 0 ? c.lCin : 0);
         }
     }
     P.wpartial = take(we * 4);
@@ -265,7 +266,9 @@ int conv_dgrad(const Run& r, const Conv& c, const void* dz, const void* mask, vo
 int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* x1, int C1, const void* dz, int lvl) {
     WgradArgs a;
     a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.dz = dz; a.Cout = c.Cout;
-    a.partial = (float*)r.at(r.P.wpartial) + r.P.wscratch[&c - &r.m->conv[0]];      // this layer's own scratch
+    const size_t ci_ = &c - &r.m->conv[0];
+    a.partial = (float*)r.at(r.P.wpartial) + r.P.wscratch[ci_];                     // this layer's own scratch
+    a.partial_cap = (ci_ + 1 < r.P.wscratch.size() ? r.P.wscratch[ci_ + 1] : r.P.wpartial_floats) - r.P.wscratch[ci_];
     a.B = r.B; a.Ho = r.m->cfg.H >> lvl; a.Wo = r.m->cfg.W >> lvl;
     a.flops = conv_flops(r, c, lvl);
     const long M = (long)a.B * a.Ho * a.Wo;
@@ -756,7 +759,7 @@ int mpu_conv2d_wgrad(int32_t dtype, int32_t mode, const void* d_x0, int32_t C0, 
     WgradArgs a;
     a.x0 = d_x0; a.x1 = d_x1; a.C0 = C0; a.C1 = C1; a.dz = d_dz; a.Cout = Cout; a.partial = d_workspace;
     a.B = B; a.Ho = Ho; a.Wo = Wo; a.flops = 0; a.db = nullptr; a.db_partial = nullptr; a.colsum_scratch = nullptr; a.fuse_db = 0;
-    a.c0_logical = 0;
+    a.c0_logical = 0; a.partial_cap = 0;
     wgrad_partial_elems(mode, C0 + C1, Cout, (long)B * Ho * Wo, &a.ksplit, &a.mchunk);
     return launch_wgrad(dtype, mode, a, d_dW, (hipStream_t)stream);
 }
@@ -773,12 +776,16 @@ int mpu_conv2d_wgrad_first_layer(int32_t dtype, const void* d_x, int32_t n_image
     a.B = B; a.Ho = H; a.Wo = W; a.flops = 0; a.db = d_db; a.db_partial = nullptr; a.fuse_db = 0;
     a.c0_logical = n_image_channels;
     const long M = (long)B * H * W;
-    const long we = wgrad_partial_elems(CONV3, 8, Cout, M, &a.ksplit, &a.mchunk);
+    long we = wgrad_partial_elems(CONV3, 8, Cout, M, &a.ksplit, &a.mchunk);
+    if (we < 2048L * 19 * Cout) we = 2048L * 19 * Cout;
+    a.partial_cap = we;                              // what mpu_conv2d_wgrad_first_layer_workspace_floats promised
     a.colsum_scratch = d_workspace + we;             // (the workspace query below includes this tail)
     return launch_wgrad(dtype, CONV3, a, d_dW, (hipStream_t)stream);
 }
 int64_t mpu_conv2d_wgrad_first_layer_workspace_floats(int32_t Cout, int64_t M) {
-    return wgrad_partial_elems(CONV3, 8, Cout, M, nullptr, nullptr) + (int64_t)RED_MAX_BLOCKS * Cout;
+    long we = wgrad_partial_elems(CONV3, 8, Cout, M, nullptr, nullptr);
+    if (we < 2048L * 19 * Cout) we = 2048L * 19 * Cout;       // wgrad_c8: <= 2048 strips x (9 * 2 * Cout + Cout) floats
+    return we + (int64_t)RED_MAX_BLOCKS * Cout;
 }
 
 }  // extern "C"

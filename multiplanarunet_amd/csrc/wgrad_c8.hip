@@ -156,19 +156,40 @@ __global__ __launch_bounds__(256) void wgrad_c8_finalize_kernel(const float* __r
 
 }  // namespace
 
-// 1 = handled (dW and, if wanted, db written), 0 = shape not suited, < 0 = error
-int try_wgrad_c8(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st) {
+// Shape test of the schedule, shared by the launcher and by the workspace plan (wgrad_scratch_need): returns the
+// number of strips (= partial rows, one per workgroup) or 0 when the shape is not suited.
+static long c8_strips(int dtype, int mode, int B, int H, int W, int C0, int C1, int c0_logical, int Cout, int* R_out,
+                      int* strips_out) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("MPU_WGRAD_C8"); on = (e && e[0] == '0') ? 0 : 1; }
-    if (!on || dtype != MPU_BF16 || mode != CONV3 || a.C1 != 0 || a.x1 || a.C0 != 8) return 0;
-    if (a.c0_logical < 1 || a.c0_logical > 2) return 0;
-    const int groups = a.Cout / 8;
-    if (a.Cout % 8 || groups < 1 || groups > 16 || (groups & (groups - 1))) return 0;
-    const long rows_all = (long)a.B * a.Ho;
+    if (!on || dtype != MPU_BF16 || mode != CONV3 || C1 != 0 || C0 != 8) return 0;
+    if (c0_logical < 1 || c0_logical > 2) return 0;
+    const int groups = Cout / 8;
+    if (Cout % 8 || groups < 1 || groups > 16 || (groups & (groups - 1))) return 0;
+    const long rows_all = (long)B * H;
     const int R = (int)((rows_all + 1023) / 1024);
-    const int strips = cdiv(a.Ho, R);
-    const long wgs = (long)a.B * strips;
-    if (wgs > 2048 || a.Wo < 1) return 0;                        // partial rows bounded by the all-taps workspace plan
+    const int strips = cdiv(H, R);
+    const long wgs = (long)B * strips;
+    if (wgs > 2048 || W < 1) return 0;
+    if (R_out) *R_out = R;
+    if (strips_out) *strips_out = strips;
+    return wgs;
+}
+
+long wgrad_c8_scratch_floats(int dtype, int mode, int B, int H, int W, int C0, int C1, int c0_logical, int Cout) {
+    const long wgs = c8_strips(dtype, mode, B, H, W, C0, C1, c0_logical, Cout, nullptr, nullptr);
+    return wgs * (9L * c0_logical * Cout + Cout);
+}
+
+// 1 = handled (dW and, if wanted, db written), 0 = shape not suited, < 0 = error
+int try_wgrad_c8(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st) {
+    if (a.x1) return 0;
+    int R = 0, strips = 0;
+    const long wgs = c8_strips(dtype, mode, a.B, a.Ho, a.Wo, a.C0, a.C1, a.c0_logical, a.Cout, &R, &strips);
+    if (wgs == 0) return 0;
+    // one compact partial row per workgroup: the caller's region must hold them (the plan sizes it with
+    // wgrad_c8_scratch_floats; an op-level caller states its capacity)
+    if (a.partial_cap < wgs * (9L * a.c0_logical * a.Cout + a.Cout)) return 0;
     const long M = (long)a.B * a.Ho * a.Wo;
     if (M * 16L >= (1L << 31) || M * a.Cout * 2L >= (1L << 31)) return 0;   // 32-bit buffer offsets
     if (prof_on()) prof_begin(PROF_WGRAD, a.flops > 0 ? a.flops : 2.0 * M * 9 * a.C0 * a.Cout, st);

@@ -259,13 +259,33 @@ class UNet:
             np.savez(f, **{k.replace("/", "__"): v for k, v in d.items()})
 
     def load_weights(self, path, by_name=True):
-        """load_weights(by_name=True) (mpunet/models/model_init.py:31,56): .npz or a reference Keras .h5 checkpoint."""
+        """load_weights(by_name=True) (mpunet/models/model_init.py:31,56): .npz or a reference Keras .h5 checkpoint.
+        The 1x1 head is unnamed in the reference (unet.py:211), so a checkpoint written by a process that had built
+        other models calls it conv2d_<N>: a lone 1x1 `conv2d(_N)` layer of the file is mapped onto the head. Model
+        tensors the file does not supply are reported (Keras by_name loading skips them silently; here that almost
+        always means a naming problem) -- `self.missing_on_load` lists them."""
+        import re
         if str(path).endswith((".h5", ".hdf5")):
             from .formats import load_keras_h5
             d = load_keras_h5(path)
         else:
             with np.load(path) as z:
                 d = {k.replace("__", "/"): z[k] for k in z.files}
+        if "conv2d/kernel" not in d:
+            auto = sorted({k.split("/")[0] for k, v in d.items()
+                           if re.fullmatch(r"conv2d_\d+/kernel", k) and tuple(np.shape(v)[:2]) == (1, 1)})
+            if len(auto) == 1:
+                for v in ("kernel", "bias"):
+                    if auto[0] + "/" + v in d:
+                        d["conv2d/" + v] = d.pop(auto[0] + "/" + v)
+        self.missing_on_load = sorted(n for n in self._tensors if n not in d)
+        if self.missing_on_load:
+            msg = "load_weights(%s): %d model tensors not in the file (kept as they are): %s" % (
+                path, len(self.missing_on_load), ", ".join(self.missing_on_load[:6]) +
+                (" ..." if len(self.missing_on_load) > 6 else ""))
+            if not by_name:
+                raise KeyError(msg)
+            self.logger(msg)
         self.set_weights_dict(d, strict=not by_name)
 
     def count_params(self):

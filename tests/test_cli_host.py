@@ -98,3 +98,31 @@ def test_fusion_weights_belong_to_one_checkpoint(tmp_path):
     p = C.fusion_weights_path(m, os.path.join(m, "@epoch_07_val_dice_0.80011.npz"))
     assert p == os.path.join(m, "fusion_weights", "@epoch_07_val_dice_0.80011_fusion_weights.npz")
     assert C.fusion_weights_path(m, os.path.join(m, "model_weights.npz")).endswith("model_weights_fusion_weights.npz")
+
+
+def test_audited_hparams_patch_keeps_comments_and_layout(tmp_path):
+    """the write-back patches only the audited lines (the reference's YAMLHParams edits its string
+    representation in place, mpunet/hyperparameters/hparams.py:161-221): comments, `Null` placeholders with
+    trailing comments, blank lines and unrelated sections survive byte for byte."""
+    text = ("# project file\nbuild:\n  #\n  # Hyperparameters passed to the Model.build\n  #\n  model_class_name: \"UNet\"\n"
+            "  dim: Null  # audited\n  n_classes: Null\n  n_channels: Null\n  complexity_factor: 2\n\n"
+            "fit:\n  # training\n  batch_size: 16\n  real_space_span: Null\n\n__VERSION__: Null\n")
+    (tmp_path / "train_hparams.yaml").write_text(text)
+    hp = C.load_hparams(str(tmp_path))
+    hp["build"].update(dim=128, n_channels=2, n_classes=5)
+    hp["fit"]["real_space_span"] = 200.25
+    assert C.save_audited_hparams(str(tmp_path), hp)
+    out = (tmp_path / "train_hparams.yaml").read_text()
+    expect = (text.replace("dim: Null  # audited", "dim: 128  # audited").replace("n_classes: Null", "n_classes: 5")
+              .replace("n_channels: Null", "n_channels: 2").replace("real_space_span: Null", "real_space_span: 200.25"))
+    assert out == expect
+    # a key that is missing from its section is added at the end of that section only
+    (tmp_path / "train_hparams.yaml").write_text("build:\n  complexity_factor: 1  # keep\n\nfit:\n  batch_size: 8\n")
+    hp = C.load_hparams(str(tmp_path))
+    hp["build"].update(dim=64, n_channels=1, n_classes=3)
+    hp["fit"]["real_space_span"] = 63.5
+    assert C.save_audited_hparams(str(tmp_path), hp)
+    out = (tmp_path / "train_hparams.yaml").read_text()
+    assert "complexity_factor: 1  # keep" in out and out.index("dim: 64") < out.index("fit:")
+    hp2 = C.load_hparams(str(tmp_path))
+    assert hp2["build"]["dim"] == 64 and hp2["fit"]["real_space_span"] == 63.5 and hp2["fit"]["batch_size"] == 8

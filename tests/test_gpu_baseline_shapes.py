@@ -306,3 +306,36 @@ def test_cfg3_train_step_batch32_256_properties():
         m2.train_step(x, y, w, want_loss=False)
     assert torch.equal(m2.params, ms[1][0].params) and torch.equal(m2.bn_state, ms[1][0].bn_state)
     assert ms[1][1] == losses[:2]
+
+
+@pytest.mark.parametrize("n_channels,cf", [(2, 1), (1, 2)])
+def test_first_layer_wgrad_scratch_does_not_overrun_the_next_layer(n_channels, cf):
+    """the first-layer weight-gradient schedule (wgrad_c8: one compact partial row per strip of image
+    rows) used to be sized by the generic K-split plan and overran into the not-yet-reduced partials of
+    encoder_L0_conv2 with 2 image channels at F0=64 (B=16, 128x128) and with F0>=128 for any channel count. A
+    shallow net at exactly those shapes, every gradient tensor against the matched-rounding model (depth 1: the
+    graph is well conditioned, so a fixed bound holds)."""
+    from multiplanarunet_amd.unet import UNet
+    from oracle import unet_ref as U
+    B, K, D = 16, 3, 1
+    w = U.init_weights(K, n_channels, D, cf, seed=21)
+    rng = np.random.RandomState(6)
+    for k in w:
+        if k.endswith("/bias"):
+            w[k] = rng.uniform(-.1, .1, w[k].shape).astype(np.float32)
+    x = rng.randn(B, 128, 128, n_channels).astype(np.float32)
+    y = rng.randint(0, K, (B, 128 * 128, 1)).astype(np.uint8)
+    sw = np.ones(B, np.float32)
+    m = UNet(n_classes=K, dim=128, n_channels=n_channels, depth=D, complexity_factor=cf, flatten_output=True,
+             dtype="bf16", logger=quiet)
+    m.set_weights_dict(w)
+    (probs, loss), log = _schedule_log(lambda: m.forward_backward(x, y, sw))
+    wg = [l for l in log if l[0] == "wgrad"]
+    print("first-layer case n_channels=%d cf=%g: wgrad schedules %s" % (n_channels, cf, [l[1] for l in wg]))
+    g = m.grads.cpu().numpy()
+    assert np.isfinite(g).all()
+    r64 = U.bf16_matched_step(w, x, y, sw, depth=D, dtype=torch.float64)
+    rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+    for name, g64 in r64["grads"].items():
+        e = rel(_grad(m, g, name).astype(np.float64), g64)
+        assert e <= 3e-2, (name, e)

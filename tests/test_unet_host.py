@@ -100,3 +100,23 @@ def test_flat_layout_follows_keras_creation_order_and_ready_points():
         order = [nm for _, nm in sorted(off_sorted)]
         keras = [nm for nm in m._keras_order() if not nm.endswith(("moving_mean", "moving_variance"))]
         assert order == keras
+
+
+def test_load_weights_reports_missing_tensors_and_maps_auto_named_head(tmp_path):
+    """Keras names the unnamed 1x1 head conv2d_<N> when the process built other models first
+    (mpunet/models/unet.py:211); such a file must still load the head, and tensors a file does not supply are
+    reported instead of silently staying at their initial values."""
+    from multiplanarunet_amd.unet import UNet
+    msgs = []
+    m = UNet(n_classes=3, dim=32, depth=2, complexity_factor=0.25, device="cpu", logger=msgs.append, seed=0)
+    d = m.get_weights_dict()
+    d["conv2d/kernel"] = d["conv2d/kernel"] + 1.5
+    f = {k.replace("conv2d/", "conv2d_7/").replace("/", "__"): v for k, v in d.items() if not k.startswith("bottom_BN")}
+    np.savez(tmp_path / "w.npz", **f)
+    m2 = UNet(n_classes=3, dim=32, depth=2, complexity_factor=0.25, device="cpu", logger=msgs.append, seed=1)
+    m2.load_weights(str(tmp_path / "w.npz"))
+    np.testing.assert_array_equal(m2.get_weights_dict()["conv2d/kernel"], d["conv2d/kernel"])
+    assert m2.missing_on_load == sorted("bottom_BN/" + v for v in ("gamma", "beta", "moving_mean", "moving_variance"))
+    assert any("bottom_BN" in s and "not in the file" in s for s in msgs)
+    with pytest.raises(KeyError):
+        m2.load_weights(str(tmp_path / "w.npz"), by_name=False)
