@@ -17,8 +17,17 @@ Added objects:
   wgrad        : same for the weight-gradient kernel.
   cpu_baseline : the oracle (torch-CPU fp32 restatement of the reference train
                  step) on the host cores, bounded sample (rank 0, N=1 only).
-  predict_fuse : secondary metric of BASELINE.json -- voxels/s of the 6-view
-                 predict+fuse pipeline on one 256^3 volume (N=1 only; --no-predict skips).
+  predict_fuse : secondary metric of BASELINE.json -- voxels/s (whole node) of the 6-view
+                 predict+fuse pipeline on one 256^3 volume; N>1: the sharded pipeline
+                 (plane-chunk work items, reduce-scatter of the partial fusion sums + label
+                 all-gather, and the literal all-gather-of-per-view-volumes variant), exchange
+                 time reported separately (--no-predict skips).
+  comm         : N>1 -- per-step gradient all-reduce time on the communication stream, the part of
+                 it Adam waits for, and the overlap fraction (HIP events).
+
+--config selects the BASELINE.json configuration: 1 (default; the line above), 2 (predict leg only),
+3 (train, GLOBAL batch 32 of 256x256 split 32/N per GPU: strong scaling), 4 (predict of a 512^3 x 2
+volume, 5 classes, sharded over the N ranks).
 """
 import argparse
 import json
@@ -69,6 +78,11 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-peaks", action="store_true", help="skip the MFMA / stream-triad peak probes (profiling runs)")
     ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a HIP graph")
+    ap.add_argument("--config", type=int, default=1, choices=(1, 2, 3, 4), help="BASELINE.json configs[] index (see the module docstring)")
+    ap.add_argument("--exchange", default="both", choices=("reduce_scatter", "all_gather", "both"),
+                    help="N>1 predict leg: which exchange(s) to time")
+    ap.add_argument("--predict-dim", type=int, default=0, help="override the predict volume edge (tests)")
+    ap.add_argument("--cf", type=float, default=1.0, help="complexity_factor of the train-leg network (2 = the default project YAML)")
     args = ap.parse_args()
 
     from multiplanarunet_amd import distributed as D
@@ -79,15 +93,42 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     quiet = lambda *a, **k: None
     B, dim = args.batch, args.dim
-    if args.predict_only:
-        print(json.dumps({"predict_fuse": bench_predict(device, quiet)}), flush=True)
+    scaling = "weak"
+    if args.config == 3:                       # configs[3]: GLOBAL batch 32 of 256x256, split over the ranks
+        if 32 % world:
+            raise SystemExit("--config 3 needs a world size that divides 32")
+        B, dim, scaling = 32 // world, 256, "strong"
+    pD, pC, pK = (512, 2, 5) if args.config == 4 else (256, 1, 3)
+    if args.predict_dim:
+        pD = args.predict_dim
+    if args.predict_only or args.config in (2, 4):
+        if world == 1:
+            res = bench_predict(device, quiet, D=pD, K=pK, C=pC)
+        else:
+            res = bench_predict_sharded(device, quiet, rank, world, args.exchange, D=pD, K=pK, C=pC)
+        if rank == 0:
+            if args.predict_only:
+                print(json.dumps({"predict_fuse": res}), flush=True)
+            else:
+                line = {"metric": "voxels/sec whole-node (6-view predict+fuse)", "value": res["value"], "unit": "voxels/s",
+                        "n_gpus": world, "steps": res.get("reps", 1), "warmup": 1, "ms_per_step": round(res["seconds"] * 1e3, 3),
+                        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+                        "data": "synthetic",
+                        "config": {"workload": "6-view predict+fuse of one %s volume, %d classes (BASELINE.json configs[%d])"
+                                               % (res["volume"], pK, args.config), "parallelism": "plane-chunk x%d" % world},
+                        "predict_fuse": res}
+                if "roofline" in res:
+                    line["roofline"] = res["roofline"]
+                print(json.dumps(line), flush=True)
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
         return
 
-    model = UNet(n_classes=3, dim=dim, n_channels=1, depth=4, complexity_factor=1,
+    model = UNet(n_classes=3, dim=dim, n_channels=1, depth=4, complexity_factor=args.cf,
                  flatten_output=True, dtype=args.dtype, logger=quiet, seed=0, device=device)
     model.compile("Adam", "SparseCategoricalCrossentropy")
-    if world > 1:
-        D.DataParallelTrainer(model)
+    trainer = D.DataParallelTrainer(model) if world > 1 else None
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.randn(B, dim, dim, 1, generator=g).to(device)
     # synthetic 3-class targets that depend on the image (thresholds of a smoothed copy), so that the correctness
@@ -153,6 +194,18 @@ def main():
         for line in buf.value.decode().splitlines():
             k = " ".join(line.split()[:2])
             sched[k] = sched.get(k, 0) + 1
+    comm = None
+    if trainer is not None:                      # N>1: the all-reduce on the communication stream, timed by events
+        barrier()                                # over a further K steps (outside the timed region)
+        trainer.start_timing()
+        for _ in range(args.steps):
+            step()
+        comm = trainer.stop_timing()
+        if comm is not None:                     # the slowest rank's view
+            t = torch.tensor([comm["comm_ms_per_step"], comm["exposed_ms_per_step"]], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            comm["comm_ms_per_step_max_rank"], comm["exposed_ms_per_step_max_rank"] = round(float(t[0]), 4), round(float(t[1]), 4)
+            comm["allreduce_bytes"] = int(model.grads.numel() * 4)
     if events:                                   # roofline leg: same K steps again, eager, per-launch HIP events on
         barrier()
         lib.mpu_profile_enable(1)
@@ -183,16 +236,19 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = world * B * args.steps / dt
-        gf_slice = 3.0 * unet_forward_gflop(dim)
+        gf_slice = 3.0 * unet_forward_gflop(dim, cf=args.cf)
+        cfg_name = {1: "configs[1]", 3: "configs[3]"}.get(args.config, "configs[1]")
+        if args.cf != 1.0:
+            cfg_name += ", complexity_factor=%g as the default project YAML" % args.cf
         out = {
             "metric": "2D slices/sec (train), whole job", "value": round(value, 2), "unit": "slices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "2-D U-Net train step, depth 4, 64 base filters (complexity_factor=1), "
-                                   "%d slices of %dx%dx1 per GPU, 3 classes, Adam + sparse CE (BASELINE.json configs[1])"
-                                   % (B, dim, dim),
-                       "slices_per_gpu": B, "parallelism": "dp%d" % world,
+            "config": {"workload": "2-D U-Net train step, depth 4, %d base filters (complexity_factor=%g), "
+                                   "%d slices of %dx%dx1 per GPU, 3 classes, Adam + sparse CE (BASELINE.json %s)"
+                                   % (model.filters[0] if hasattr(model, "filters") else int(64 * np.sqrt(args.cf)), args.cf, B, dim, dim, cfg_name),
+                       "slices_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "launch": "hip-graph replay" if graphed else "eager",
                        "algorithmic_gflop_per_slice": round(gf_slice, 2)},
             "step_tflops_algorithmic": round(gf_slice * B * world / 1e3 / (ms_step / 1e3), 1),
@@ -207,6 +263,8 @@ def main():
             out["rccl_ranks"] = torch.distributed.get_world_size()
             out["dist_backend"] = torch.distributed.get_backend()
             out["config"]["dp_overlap"] = bool(getattr(model._grad_hook, "overlap", False))
+            if comm is not None:
+                out["comm"] = comm
         if dt_eager is not None:
             out["ms_per_step_eager_with_events"] = round(dt_eager / args.steps * 1e3, 4)
         traffic = {}
@@ -214,7 +272,7 @@ def main():
             tfile = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic_pmc.json"))[-1]
             with open(os.path.join(ROOT, "profiles", tfile)) as f:
                 traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["classes"].items()}
-            out["config"]["traffic_source"] = "profiles/" + tfile
+            out["config"]["traffic_source"] = "from_file:profiles/" + tfile      # a separate rocprofv3 --pmc pass, not this run
         except Exception:
             pass
         if events:
@@ -231,9 +289,16 @@ def main():
             out["roofline"] = leg("conv_igemm")
             out["wgrad"] = leg("wgrad_igemm")
 
-    # ---- secondary metric: 6-view predict+fuse on 256^3 (N=1) -------------------
-    if rank == 0 and world == 1 and not args.no_predict:
-        out["predict_fuse"] = bench_predict(device, quiet)
+    # ---- secondary metric: 6-view predict+fuse on 256^3 (N>1: sharded over the ranks, whole-node voxels/s) ---
+    if not args.no_predict and args.config == 1:
+        if world == 1:
+            out["predict_fuse"] = bench_predict(device, quiet, D=pD)
+        else:
+            del model                                            # (the train-leg network is not needed any more)
+            torch.cuda.empty_cache()
+            pf = bench_predict_sharded(device, quiet, rank, world, args.exchange, D=pD)
+            if rank == 0:
+                out["predict_fuse"] = pf
     if rank == 0 and world == 1 and not args.no_peaks:
         out["measured_peaks"] = measured_peaks(device)
         if "roofline" in out:
@@ -251,52 +316,66 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def bench_predict(device, quiet, D=256, V=6, K=3, reps=2, batch=None):
-    """BASELINE.json configs[2]: 6-view predict+fuse on one 256^3x1 synthetic volume."""
+VIEWS6 = [[0, 0, 1], [1, 0, 0], [0, 1, 0], [0.5, 0.5, 0.707], [-0.6, 0.64, 0.48], [0.7, -0.5, 0.5]]
+
+
+def _predict_setup(device, quiet, D, V, K, C):
     from multiplanarunet_amd.unet import UNet
     from multiplanarunet_amd.fusion_model import FusionModel
     from multiplanarunet_amd.interpolation import Volume
-    from multiplanarunet_amd.predict import multi_view_predict
     rng = np.random.RandomState(0)
-    vol_np = rng.randn(D, D, D, 1).astype(np.float32)
-    vol = Volume(vol_np, None, np.eye(4), bg_value=0.0, scaler=(np.array([0.0]), np.array([1.349])), device=device)
-    views = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0], [0.5, 0.5, 0.707], [-0.6, 0.64, 0.48], [0.7, -0.5, 0.5]], float)[:V]
-    model = UNet(n_classes=K, dim=D, n_channels=1, depth=4, complexity_factor=1, dtype="bf16", logger=quiet,
+    vol_np = rng.randn(D, D, D, C).astype(np.float32)
+    vol = Volume(vol_np, None, np.eye(4), bg_value=0.0, scaler=(np.zeros(C), np.full(C, 1.349)), device=device)
+    views = np.array(VIEWS6, float)[:V]
+    model = UNet(n_classes=K, dim=D, n_channels=C, depth=4, complexity_factor=1, dtype="bf16", logger=quiet,
                  seed=0, device=device)
     fm = FusionModel(V, K, verbose=False, device=device)
+    if K > 2:          # a biased head / fusion bias so that every class appears in the synthetic output (guard below)
+        with torch.no_grad():
+            fm.b.copy_(torch.linspace(-0.02, 0.02, K, device=device).reshape(1, K))
+    return vol, views, model, fm
+
+
+def bench_predict(device, quiet, D=256, V=6, K=3, reps=5, batch=None, C=1):
+    """BASELINE.json configs[2] (D=256, C=1, K=3) / configs[4] (D=512, C=2, K=5): 6-view predict+fuse on one synthetic
+    volume, one GPU. Median of `reps` runs (the per-stage times are those of the median run)."""
+    from multiplanarunet_amd.predict import multi_view_predict
+    vol, views, model, fm = _predict_setup(device, quiet, D, V, K, C)
     batch = batch or (int(os.environ["MPU_BENCH_PREDICT_BATCH"]) if "MPU_BENCH_PREDICT_BATCH" in os.environ else None)
     multi_view_predict(model, vol, views, D, float(D), fm, batch_size=batch, want_probs=False)      # warm-up
     torch.cuda.synchronize()
-    best, tim, labels = None, None, None
+    runs, labels = [], None
     for _ in range(reps):
         t = {}
         t0 = time.perf_counter()
         _, labels = multi_view_predict(model, vol, views, D, float(D), fm, batch_size=batch, want_probs=False, timings=t)
         torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        if best is None or el < best:
-            best, tim = el, t
+        runs.append((time.perf_counter() - t0, t))
+    runs.sort(key=lambda r: r[0])
+    best, tim = runs[len(runs) // 2]
     hist = torch.bincount(labels.reshape(-1).long(), minlength=K).tolist()          # correctness guard of the leg
     if sum(hist) != D ** 3 or len(hist) != K or sum(1 for h in hist if h > 0) < 2:
         raise SystemExit("bench.py predict guard failed: label histogram %r" % (hist,))
     P = D + 20
     fuse_bytes = D ** 3 * (V * K * 4 + 1)                        # labels only (SURVEY.md 8d: 73 B/voxel)
-    samp_bytes = V * (4 * D ** 3 + 4 * P * D * D)
-    gflop = V * P * unet_forward_gflop(D)
+    samp_bytes = V * (4 * D ** 3 * C + 4 * P * D * D * C)
+    gflop = V * P * unet_forward_gflop(D, n_channels=C, n_classes=K)
     fuse_traffic = fuse_traffic_src = None       # HBM bytes per launch of the fused back-mapping from the round's PMC passes
     if D == 256 and V == 6 and K == 3:
         try:
             gf = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_geometry_pmc.json"))[-1]
             with open(os.path.join(ROOT, "profiles", gf)) as fh:
                 fuse_traffic = int(json.load(fh)["kernels"]["map_fuse_fast_kernel<3,2>"]["hbm_bytes_per_launch"])
-            fuse_traffic_src = "profiles/" + gf
+            fuse_traffic_src = "from_file:profiles/" + gf
         except (IndexError, KeyError, OSError, ValueError):
             pass
     return {"metric": "voxels/sec (6-view predict+fuse)", "value": round(D ** 3 / best, 1), "unit": "voxels/s",
-            "volume": "%d^3x1" % D, "views": V, "planes_per_view": P, "seconds": round(best, 4),
+            "volume": "%d^3x%d" % (D, C), "views": V, "classes": K, "planes_per_view": P, "seconds": round(best, 4),
+            "reps": reps, "statistic": "median", "seconds_all": [round(r[0], 4) for r in runs],
             "sample_ms": round(tim["sample_ms"], 2), "unet_ms": round(tim["unet_ms"], 2),
             "map_fuse_ms": round(tim["map_fuse_ms"], 3),
             "unet_tflops_algorithmic": round(gflop / tim["unet_ms"], 1),
+            "unet_frac_of_mfma_peak": round(gflop / tim["unet_ms"] / PEAK_BF16_TFLOPS, 4),
             "sample_GBs_compulsory": round(samp_bytes / tim["sample_ms"] / 1e6, 1),
             "map_fuse_GBs_algorithmic": round(fuse_bytes / tim["map_fuse_ms"] / 1e6, 1),
             "map_fuse_frac_of_hbm_peak": round(fuse_bytes / tim["map_fuse_ms"] / 1e6 / PEAK_HBM_GBS, 4),
@@ -306,6 +385,46 @@ def bench_predict(device, quiet, D=256, V=6, K=3, reps=2, batch=None):
                          "traffic_source": fuse_traffic_src,
                          "algorithmic_bytes_per_launch": fuse_bytes},
             "label_histogram": hist}
+
+
+def bench_predict_sharded(device, quiet, rank, world, exchange="both", D=256, V=6, K=3, C=1, reps=3):
+    """The same volume over all ranks (multiplanarunet_amd.distributed.multi_view_predict_sharded):
+    every rank holds the volume, runs the U-Net on its (view, plane-chunk) work items and joins the exchange.
+    value = D^3 / (barrier-to-barrier time, max over ranks) = whole-node voxels/s; the exchange (reduce-scatter of
+    the partial fusion sums + finalize + label all-gather, or the all-gather of per-view volumes) is timed on its own."""
+    import torch.distributed as dist
+    from multiplanarunet_amd import distributed as Dm
+    vol, views, model, fm = _predict_setup(device, quiet, D, V, K, C)
+    legs = {}
+    for ex in (("reduce_scatter", "all_gather") if exchange == "both" else (exchange,)):
+        Dm.multi_view_predict_sharded(model, vol, views, D, float(D), fm, exchange=ex)      # warm-up
+        runs = []
+        for _ in range(reps):
+            torch.cuda.synchronize(); dist.barrier()
+            tm = {}
+            t0 = time.perf_counter()
+            labels = Dm.multi_view_predict_sharded(model, vol, views, D, float(D), fm, exchange=ex, timings=tm)
+            torch.cuda.synchronize(); dist.barrier()
+            el = time.perf_counter() - t0
+            t = torch.tensor([el, tm["exchange_s"], tm["compute_s"]], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            runs.append((float(t[0]), float(t[1]), float(t[2]), tm))
+        runs.sort(key=lambda r: r[0])
+        el, ex_s, comp_s, tm = runs[len(runs) // 2]
+        hist = torch.bincount(labels.reshape(-1).long(), minlength=K).tolist()
+        if sum(hist) != D ** 3 or sum(1 for h in hist if h > 0) < 2:
+            raise SystemExit("bench.py sharded predict guard failed: label histogram %r" % (hist,))
+        legs[ex] = {"value": round(D ** 3 / el, 1), "unit": "voxels/s", "seconds": round(el, 4),
+                    "exchange_seconds_max_rank": round(ex_s, 4), "compute_seconds_max_rank": round(comp_s, 4),
+                    "exchange_bytes_per_rank": tm.get("exchange_bytes_per_rank"),
+                    "work_items_rank0": tm.get("work_items"), "planes_rank0": tm.get("planes"),
+                    "reps": reps, "statistic": "median", "label_histogram": hist}
+    main_leg = legs.get("reduce_scatter") or next(iter(legs.values()))
+    out = {"metric": "voxels/sec whole-node (6-view predict+fuse, sharded)", "value": main_leg["value"], "unit": "voxels/s",
+           "volume": "%d^3x%d" % (D, C), "views": V, "classes": K, "planes_per_view": D + 20, "n_gpus": world,
+           "seconds": main_leg["seconds"], "reps": reps, "exchanges": legs,
+           "rccl_ranks": dist.get_world_size(), "dist_backend": dist.get_backend()}
+    return out
 
 
 def cpu_baseline(B, dim, budget_s=20.0):

@@ -370,6 +370,31 @@ int mpu_probe_stream_triad(float* d_a, const float* d_b, const float* d_c, int64
 int mpu_schedule_log_enable(int32_t on);
 int64_t mpu_schedule_log_read(char* buf, int64_t cap);
 
+/* Dev aid: with MPU_STAMPS=1 in the environment a few workgroups of the instrumented kernels (conv_halo8, wgrad_taps)
+ * record s_memtime stamps at their phase boundaries (entry, prologue landed, main loop done, stores issued) into a
+ * 64 x 8 table of uint64 (slot = a function of the workgroup index). Reads and clears it (synchronises the device). */
+int mpu_debug_stamps_read(uint64_t* host_out, int32_t n);
+
+/* Test aid (no reference counterpart): teacher-forced replay of a train step. While a tap is installed on a model,
+ * mpu_unet_forward(training) / mpu_unet_backward call it right after enqueueing every convolution launch with the
+ * device pointers and shapes of that launch, so that a test can synchronise the stream, copy the launch's OWN inputs
+ * and output out of the workspace and compare the output with an independent fp64 convolution of exactly those
+ * inputs -- launch by launch, without the error amplification of the train-mode network between them
+ * (tests/test_gpu_replay.py). kind: 0 forward conv (out = relu(conv(in0|in1) + bias)), 1 data gradient
+ * (out = conv^T(dz) restricted to input channels [n_off, n_off + n_cnt), times the ReLU mask 1[mask > 0] when mask
+ * is set), 2 weight gradient (x = in0|in1, dz; the result lands in the flat gradient buffer at float offset w_off
+ * once the backward pass has returned). H, W = resolution of the launch's OUTPUT (kind 0/1) or of dz (kind 2).
+ * The callback runs on the calling thread; NULL removes the tap. Not for use under graph capture. */
+typedef struct mpu_launch_info {
+    int32_t kind, conv_index, mode, dtype;      /* mode: 0 3x3, 1 up-conv 2x2, 3 1x1 (the LAYER's mode) */
+    int32_t B, H, W, C0, C1, Cout;              /* C0/C1: channels of in0/in1 (kind 1: C0 = channels of dz) */
+    int32_t n_off, n_cnt, relu, _pad;
+    const void* in0; const void* in1; const void* dz; const void* mask; const void* out;
+    int64_t w_off, b_off;                       /* float offsets of the layer's kernel / bias in the flat buffers */
+} mpu_launch_info;
+typedef void (*mpu_launch_tap_fn)(void* user, const mpu_launch_info* info);
+int mpu_unet_set_launch_tap(mpu_unet* m, mpu_launch_tap_fn fn, void* user);
+
 #ifdef __cplusplus
 }
 #endif

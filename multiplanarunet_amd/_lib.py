@@ -135,7 +135,21 @@ _SIGS = {
     "mpu_schedule_log_enable": (C.c_int, [i32]),
     "mpu_schedule_log_read": (i64, [C.c_char_p, i64]),
     "mpu_conv2d_wgrad": (C.c_int, [i32, i32, c_p, i32, c_p, i32, c_p, i32, i32, i32, i32, c_p, c_p, c_p]),
+    "mpu_unet_set_launch_tap": (C.c_int, [c_p, c_p, c_p]),
+    "mpu_debug_stamps_read": (C.c_int, [c_p, i32]),
 }
+
+
+class LaunchInfo(C.Structure):
+    """mpu_launch_info (include/mpunet_hip.h): one convolution launch of a tapped train step (test aid)."""
+    _fields_ = [("kind", i32), ("conv_index", i32), ("mode", i32), ("dtype", i32),
+                ("B", i32), ("H", i32), ("W", i32), ("C0", i32), ("C1", i32), ("Cout", i32),
+                ("n_off", i32), ("n_cnt", i32), ("relu", i32), ("_pad", i32),
+                ("in0", c_p), ("in1", c_p), ("dz", c_p), ("mask", c_p), ("out", c_p),
+                ("w_off", i64), ("b_off", i64)]
+
+
+LAUNCH_TAP_FN = C.CFUNCTYPE(None, c_p, C.POINTER(LaunchInfo))
 
 _lib = None
 

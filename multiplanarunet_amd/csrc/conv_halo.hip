@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
     const int y0 = (t % tiles_y) * TH; const int b = t / tiles_y;
     const int nch0 = (a.C0 + BKE - 1) / BKE, nch1 = (a.C1 + BKE - 1) / BKE;
     const int nchunks = nch0 + nch1;
-    const int nsteps = nchunks * NT;
+    // (dev aid, MPU_HALO_DEBUG=<n>: the K loop is cut to n steps -- wrong results, the launch's fixed cost in isolation)
+    const int nsteps = (a.dbg & 0xff00) ? ((nchunks * NT < ((a.dbg >> 8) & 0xff)) ? nchunks * NT : ((a.dbg >> 8) & 0xff)) : nchunks * NT;
     constexpr unsigned OOB = 0xfffffff0u;
     const int Hi = MODE == UPCONV2 ? H / 2 : H, Wi = MODE == UPCONV2 ? W / 2 : W;     // input resolution
     const long npix = (long)a.B * Hi * Wi;
@@ -419,6 +420,415 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------- //
+// conv_halo8_kernel (bf16, round 3): the same tile as conv_halo_kernel<BN, 8> but ONE 8-wave workgroup per CU with the
+// halo patch DOUBLE-BUFFERED. At configs[1] sizes every layer is one wave of workgroups that all start together: the
+// single-buffer kernel above runs [patch burst][9 taps][patch burst][9 taps]...[store burst] with the whole chip
+// in the same phase, so the patch bytes (the entire input tensor, once per 64-channel chunk) are read while no MFMA
+// runs. Here chunk cc+1's patch is requested at the first tap of chunk cc (behind that step's weight request, so the
+// counted vmcnt waits leave it in flight for three steps) and lands in the other buffer under the nine taps of chunk
+// cc; the eight waves share one weight ring (half the weight DMA bytes per pixel of two 4-wave workgroups), and the
+// fragment reads of k-step s+1 are issued under the MFMAs of k-step s (the waves of one workgroup run in lockstep
+// behind the per-tap barrier, so nothing else hides LDS latency).
+// ------------------------------------------------------------------------- //
+template <int BN, int TH, int MODE>
+struct Halo8Cfg {
+    static constexpr int NT = MODE == UPCONV2 ? 4 : 9, KW = MODE == UPCONV2 ? 2 : 3;
+    static constexpr int TW = 32, PW = MODE == UPCONV2 ? TW / 2 + 2 : TW + 2, PH = MODE == UPCONV2 ? TH / 2 + 1 : TH + 2;
+    static constexpr int PROWS = (PH * PW + 7) / 8 * 8;
+    static constexpr int PATCH = PROWS * 128;
+    static constexpr int WSTAGE = BN * 128, NWS = 3;
+    static constexpr int BM = TH * TW;
+    static constexpr int OROW = BN * 2 + 16;
+    static constexpr int EPI = BM * OROW + 3 * BN * 4;
+    static constexpr int MAIN = 2 * PATCH + NWS * WSTAGE;
+    static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
+};
+
+template <int BN, int TH, int MODE>
+__global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
+    typedef bf16_t T;
+    using Cfg = Halo8Cfg<BN, TH, MODE>;
+    constexpr int NT = Cfg::NT, KW = Cfg::KW, NWS = 3;
+    constexpr int EPC = 8, BKE = 64, NW = 8, NTHR = 512;
+    constexpr int TW = Cfg::TW, PW = Cfg::PW, PROWS = Cfg::PROWS;
+    constexpr int WAVES_N = BN / 64, WAVES_M = NW / WAVES_N;
+    constexpr int TN = 2, TM = TH / WAVES_M;
+    static_assert(TM >= 1 && TM * WAVES_M == TH, "tile split");
+    constexpr int NPP = PROWS / 8;                               // patch DMA pieces
+    constexpr int NPW = (NPP + NW - 1) / NW;                     // ... per wave (every wave issues exactly NPW: see below)
+    static_assert(NPW >= 2 || NPP % NW == 0, "duplicate-piece padding needs a previous piece");
+    constexpr int GW = BN / (8 * NW);                            // weight DMA pieces per wave and stage
+    static_assert(GW >= 1, "weights");
+    constexpr int BM = Cfg::BM;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long* stamps = (a.dbg_buf && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64 && tid == 0)
+                                     ? a.dbg_buf + (blockIdx.x >> 3) * 8 : nullptr;      // dev aid (MPU_STAMPS=1)
+    if (stamps) stamps[0] = __builtin_amdgcn_s_memtime();
+    const int wn = wave % WAVES_N, wm = wave / WAVES_N;
+    const int H = a.Ho, W = a.Wo;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int tiles_n = (a.Cout + BN - 1) / BN;
+    int t = blockIdx.x;
+    const int n0 = (t % tiles_n) * BN; t /= tiles_n;
+    const int x0 = (t % tiles_x) * TW; t /= tiles_x;
+    const int y0 = (t % tiles_y) * TH; const int b = t / tiles_y;
+    const int nch0 = (a.C0 + BKE - 1) / BKE, nch1 = (a.C1 + BKE - 1) / BKE;
+    const int nchunks = nch0 + nch1;
+    const int nsteps = nchunks * NT;
+    constexpr unsigned OOB = 0xfffffff0u;
+    const int Hi = MODE == UPCONV2 ? H / 2 : H, Wi = MODE == UPCONV2 ? W / 2 : W;
+    const long npix = (long)a.B * Hi * Wi;
+    const i32x4 rs0 = h_make_rsrc(a.in0, npix * a.C0 * 2L);
+    const i32x4 rs1 = h_make_rsrc(a.in1 ? a.in1 : a.in0, a.in1 ? npix * a.C1 * 2L : 0);
+    const i32x4 rsw = h_make_rsrc(a.w, a.w_elems * 2L);
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    const unsigned ldsW = lds0 + 2 * Cfg::PATCH;
+
+    // --- per-lane DMA roles -------------------------------------------------------------
+    const int lrow = lane >> 3, slot = lane & 7;
+    int ppix[NPW], pchunk[NPW], ppiece[NPW];
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+        int piece = wave + NW * k;
+        if (piece >= NPP) piece -= NW;                           // padding: the wave's previous piece again (same bytes, same place)
+        ppiece[k] = piece;
+        const int pr = piece * 8 + lrow;
+        const int py = pr / PW, px = pr % PW;
+        const int iy = MODE == UPCONV2 ? y0 / 2 + py : y0 + py - 1, ix = MODE == UPCONV2 ? x0 / 2 + px : x0 + px - 1;
+        const bool v = pr < Cfg::PH * PW && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+        ppix[k] = v ? (b * Hi + iy) * Wi + ix : -1;
+        pchunk[k] = slot ^ ((pr >> 1) & 7);
+    }
+    auto issue_patch = [&](int cc, int buf) {
+        const bool s1 = cc >= nch0;
+        const int cbase = (s1 ? cc - nch0 : cc) * BKE, Cs = s1 ? a.C1 : a.C0;
+        i32x4 qrs;                                               // source descriptor by scalar selects (no branch per piece)
+        qrs.x = s1 ? rs1.x : rs0.x; qrs.y = s1 ? rs1.y : rs0.y; qrs.z = s1 ? rs1.z : rs0.z; qrs.w = rs0.w;
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            const int ch = cbase + pchunk[k] * EPC;
+            const unsigned off = (ppix[k] >= 0 && ch < Cs) ? (unsigned)((ppix[k] * Cs + ch) * 2) : OOB;
+            const unsigned dst = lds0 + buf * Cfg::PATCH + __builtin_amdgcn_readfirstlane(ppiece[k]) * 1024;
+            h_dma16(qrs, off, dst);
+        }
+    };
+    unsigned wlane[GW]; int wch[GW];
+#pragma unroll
+    for (int g = 0; g < GW; ++g) {
+        const int rl = wave * (BN / NW) + g * 8 + lrow;
+        const int n = n0 + rl;
+        wch[g] = (slot ^ ((rl >> 1) & 7)) * EPC;
+        wlane[g] = n < a.Cout ? (unsigned)((long)n * a.w_row_stride * 2L) + (unsigned)(wch[g] * 2) : OOB;
+    }
+    int w_tap = 0, w_cc = 0;
+    auto issue_w = [&](int stage) {
+        const bool s1 = w_cc >= nch0;
+        const int cbase = (s1 ? w_cc - nch0 : w_cc) * BKE, Cs = s1 ? a.C1 : a.C0;
+        const unsigned soff = (unsigned)(((long)w_tap * a.w_tap_stride + (s1 ? a.C0 : 0) + cbase) * 2L);
+        const unsigned dst = ldsW + stage * Cfg::WSTAGE + wave * (BN / NW) * 128;
+        const int room = Cs - cbase;
+#pragma unroll
+        for (int g = 0; g < GW; ++g) {
+            const unsigned off = (wch[g] < room && wlane[g] != OOB) ? wlane[g] + soff : OOB;
+            h_dma16(rsw, off, dst + g * 8 * 128);
+        }
+        if (++w_tap == NT) { w_tap = 0; ++w_cc; }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fsw = ((lane & 31) >> 1) & 7, fh = lane >> 5;
+    // Fragment addressing of one tap: weight rows of the stage, patch rows shifted by the tap.
+    struct TapAddr { const unsigned char* Wb; const unsigned char* Pr[TM]; int psw[TM]; };
+    auto tap_addr = [&](int tap, int stage, int buf, TapAddr& A) {
+        const int ky = tap / KW, kx = tap - ky * KW;
+        A.Wb = smem + 2 * Cfg::PATCH + stage * Cfg::WSTAGE + (wn * 64 + (lane & 31)) * 128;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int prow = MODE == UPCONV2 ? ((wm * TM + j + ky) >> 1) * PW + ((kx + (lane & 31)) >> 1)
+                                             : (wm * TM + j + ky) * PW + kx + (lane & 31);
+            A.Pr[j] = smem + buf * Cfg::PATCH + prow * 128;
+            A.psw[j] = (prow >> 1) & 7;
+        }
+    };
+    uint4 af[2][TN], bf[2][TM];
+    auto load = [&](const TapAddr& A, int s_, int set) {
+        const int q = 2 * s_ + fh;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) af[set][i] = *(const uint4*)(A.Wb + i * 32 * 128 + ((q ^ fsw) << 4));
+#pragma unroll
+        for (int j = 0; j < TM; ++j) bf[set][j] = *(const uint4*)(A.Pr[j] + ((q ^ A.psw[j]) << 4));
+    };
+    auto mma = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) HMma<T>::run(af[set][i], bf[set][j], acc[i][j]);
+    };
+
+    // --- pipeline ---------------------------------------------------------------------------
+    // A tap = four k-steps of 16 channels on fragment sets 0,1,0,1; the reads of k-step s+1 are issued before the
+    // MFMAs of k-step s. The per-tap barrier sits between k-steps 2 and 3: by then every read of this tap's weight
+    // stage has returned (k-step 3's fragments are in registers), and behind it the NEXT tap's first fragments are
+    // requested under k-step 3's MFMAs -- no tap starts with an exposed LDS round trip.
+    // Request order inside a tap: weights of tap+2 first, then (first tap of a chunk) the next chunk's patch. The
+    // queue is in order, so "at most GW (+ NPW) requests outstanding" means the weights of tap+1 have landed while
+    // the newest weight stage -- and a patch requested in this or the previous tap -- stay in flight; the patch is
+    // forced by the wait of the third tap, six taps before its first reader.
+    issue_patch(0, 0);
+    issue_w(0);
+    if (nsteps > 1) { issue_w(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);                // the younger half loses every arbitration otherwise
+    __builtin_amdgcn_s_barrier();
+    if (stamps) stamps[1] = __builtin_amdgcn_s_memtime();
+    int st = 0, tap = 0, cc = 0;
+    TapAddr cur;
+    tap_addr(0, 0, 0, cur);
+    load(cur, 0, 0);
+    for (int step = 0; step < nsteps; ++step) {
+        const int stn = (st + 2) % NWS;
+        const bool more = step + 2 < nsteps;
+        if (more) issue_w(stn);
+        const bool pre = tap == 0 && cc + 1 < nchunks;
+        if (pre) issue_patch(cc + 1, (cc + 1) & 1);
+        const bool patch_young = tap <= 1 && cc + 1 < nchunks;  // a patch requested in this tap or the previous one
+        int ntap = tap + 1, ncc = cc;
+        if (ntap == NT) { ntap = 0; ++ncc; }
+        const bool last = step + 1 >= nsteps;
+        TapAddr nxt;
+        tap_addr(last ? tap : ntap, last ? st : (st + 1) % NWS, (last ? cc : ncc) & 1, nxt);
+        load(cur, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0);
+        __builtin_amdgcn_sched_barrier(0);
+        load(cur, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1);
+        __builtin_amdgcn_sched_barrier(0);
+        load(cur, 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            if (patch_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW + NPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load(nxt, 0, 0);                                         // (after the last tap: a harmless re-read)
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+        st = (st + 1) % NWS;
+        tap = ntap; cc = ncc;
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (stamps) stamps[2] = __builtin_amdgcn_s_memtime();
+
+    // --- epilogue: as conv_halo_kernel, for 512 threads --------------------------------------
+    constexpr int OROW = Cfg::OROW;
+    float* sbias = (float*)(smem + BM * OROW);
+    if (tid < BN) {
+        const bool nv = n0 + tid < a.Cout;
+        sbias[tid] = (a.bias && nv) ? a.bias[n0 + tid] : 0.f;
+        sbias[BN + tid] = (a.post_scale && nv) ? a.post_scale[n0 + tid] : 1.f;
+        sbias[2 * BN + tid] = (a.post_scale && nv) ? a.post_shift[n0 + tid] : 0.f;
+    }
+    __syncthreads();
+    {
+        const float lo = a.relu ? 0.f : -__builtin_inff();
+        const int nbase = wn * 64 + 4 * (lane >> 5);
+        float4 bq[TN][4];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[i][q] = *(const float4*)(sbias + nbase + i * 32 + 8 * q);
+        unsigned char* drow = smem + ((wm * TM) * TW + (lane & 31)) * OROW + nbase * 2;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4] = {acc[i][j][4 * q] + bq[i][q].x, acc[i][j][4 * q + 1] + bq[i][q].y,
+                                  acc[i][j][4 * q + 2] + bq[i][q].z, acc[i][j][4 * q + 3] + bq[i][q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, __builtin_inff());
+                    if (a.post_scale) {
+                        const int nl = nbase + i * 32 + 8 * q;
+                        const float4 sq = *(const float4*)(sbias + BN + nl), hq = *(const float4*)(sbias + 2 * BN + nl);
+                        v[0] = v[0] * sq.x + hq.x; v[1] = v[1] * sq.y + hq.y;
+                        v[2] = v[2] * sq.z + hq.z; v[3] = v[3] * sq.w + hq.w;
+                    }
+                    uint2 pk;
+                    pk.x = f32x2_to_bf16x2(v[0], v[1]);
+                    pk.y = f32x2_to_bf16x2(v[2], v[3]);
+                    *(uint2*)(drow + j * TW * OROW + (i * 32 + 8 * q) * 2) = pk;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (stamps) stamps[3] = __builtin_amdgcn_s_memtime();
+    {
+        // thread = (16-byte channel piece c, pixel lane r0); a pass covers RPI consecutive pixels of the tile
+        constexpr int CPRO = BN * 2 / 16, RPI = NTHR / CPRO, NIT = BM / RPI;
+        static_assert(BM % RPI == 0 && (RPI % TW == 0 || TW % RPI == 0), "pass shape");
+        const long npo = (long)a.B * H * W;
+        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(npo * a.Cout * 2L), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask ? a.mask : a.out), 0,
+                                                                              (int)(npo * a.Cout * 2L), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bn_x ? a.bn_x : a.out), 0,
+                                                                              (int)(npo * a.Cout * 2L), 0x00020000);
+        const int c = tid % CPRO, r0 = tid / CPRO;
+        const int r0y = r0 / TW, r0x = r0 % TW;
+        const int n = n0 + c * EPC;
+        const int pixB = a.Cout * 2;
+        const int obase = ((b * H + y0) * W + x0) * pixB;
+        const int lane_off = n * 2 + (r0y * W + r0x) * pixB;
+        const unsigned char* srow = smem + r0 * OROW + c * 16;
+        const bool n_ok = n < a.Cout;
+        float ssum[EPC], ssq[EPC], bmu[EPC], bis[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            ssum[e] = 0.f; ssq[e] = 0.f;
+            const bool on = a.bn_x && n + e < a.Cout;
+            bmu[e] = on ? a.bn_mean[n + e] : 0.f; bis[e] = on ? a.bn_invstd[n + e] : 0.f;
+        }
+        auto pass_yx = [&](int it, int& yy, int& xx) {          // tile-local origin of pass `it` (compile-time per pass)
+            if (RPI >= TW) { yy = it * (RPI / TW); xx = 0; }
+            else { constexpr int XPI = TW / (RPI < TW ? RPI : TW); yy = it / XPI; xx = (it % XPI) * RPI; }
+        };
+        u32x4 mkv[NIT], bxv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int yy, xx; pass_yx(it, yy, xx);
+            const bool in = n_ok && (y0 + yy + r0y < H) && (x0 + xx + r0x < W);
+            const unsigned o = (unsigned)(obase + lane_off + (yy * W + xx) * pixB);
+            mkv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsm, (a.mask && in) ? o : OOB, 0, 0);
+            bxv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (a.bn_x && in) ? o : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int yy, xx; pass_yx(it, yy, xx);
+            const bool ok = n_ok && (y0 + yy + r0y < H) && (x0 + xx + r0x < W);
+            u32x4 val = *(const u32x4*)(srow + it * RPI * OROW);
+            if (a.stats && ok) {
+                const uint32_t wv[4] = {val.x, val.y, val.z, val.w};
+                const uint32_t xw[4] = {bxv[it].x, bxv[it].y, bxv[it].z, bxv[it].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __uint_as_float(wv[e] << 16), hi = __uint_as_float(wv[e] & 0xffff0000u);
+                    const float xl = __uint_as_float(xw[e] << 16), xh = __uint_as_float(xw[e] & 0xffff0000u);
+                    const float fl = a.bn_x ? (xl - bmu[2 * e]) * bis[2 * e] : lo;
+                    const float fh2 = a.bn_x ? (xh - bmu[2 * e + 1]) * bis[2 * e + 1] : hi;
+                    ssum[2 * e] += lo; ssq[2 * e] += lo * fl; ssum[2 * e + 1] += hi; ssq[2 * e + 1] += hi * fh2;
+                }
+            }
+            const unsigned off = ok ? (unsigned)(obase + lane_off + (yy * W + xx) * pixB) : OOB;
+            if (a.mask) {
+                const u32x4 mk = mkv[it];
+                auto keep = [](uint32_t mw, uint32_t vw) {
+                    const uint32_t lo16 = ((mw & 0x8000u) == 0 && (mw & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
+                    const uint32_t hi16 = ((mw & 0x80000000u) == 0 && (mw & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+                    return vw & (lo16 | hi16);
+                };
+                val.x = keep(mk.x, val.x); val.y = keep(mk.y, val.y);
+                val.z = keep(mk.z, val.z); val.w = keep(mk.w, val.w);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(val, rso, off, 0, 0);
+        }
+        if (a.pooled) {
+            constexpr int PW2 = TW / 2, PPIX = BM / 4;
+            const int Hp = H >> 1, Wp = W >> 1;
+            const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(a.pooled, 0, (int)((npo >> 2) * a.Cout * 2L), 0x00020000);
+            for (int v = tid; v < PPIX * CPRO; v += NTHR) {
+                const int pc = v % CPRO, pp = v / CPRO;
+                const int py = pp / PW2, px = pp % PW2;
+                const unsigned char* s0 = smem + ((2 * py) * TW + 2 * px) * OROW + pc * 16;
+                const u32x4 q0 = *(const u32x4*)s0, q1 = *(const u32x4*)(s0 + OROW), q2 = *(const u32x4*)(s0 + TW * OROW),
+                            q3 = *(const u32x4*)(s0 + TW * OROW + OROW);
+                u32x4 m;
+                m.x = piece_max<T>(piece_max<T>(q0.x, q1.x), piece_max<T>(q2.x, q3.x));
+                m.y = piece_max<T>(piece_max<T>(q0.y, q1.y), piece_max<T>(q2.y, q3.y));
+                m.z = piece_max<T>(piece_max<T>(q0.z, q1.z), piece_max<T>(q2.z, q3.z));
+                m.w = piece_max<T>(piece_max<T>(q0.w, q1.w), piece_max<T>(q2.w, q3.w));
+                const int gy = (y0 >> 1) + py, gx = (x0 >> 1) + px, nn = n0 + pc * EPC;
+                const bool okp = gy < Hp && gx < Wp && nn < a.Cout;
+                const unsigned offp = okp ? (unsigned)((((b * Hp + gy) * Wp + gx) * a.Cout + nn) * 2) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(m, rsp, offp, 0, 0);
+            }
+        }
+        if (a.stats) {
+            __syncthreads();
+            float* red = (float*)smem;                                            // [RPI][BN][2]
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                red[(r0 * BN + c * EPC + e) * 2] = ssum[e];
+                red[(r0 * BN + c * EPC + e) * 2 + 1] = ssq[e];
+            }
+            __syncthreads();
+            const int ptile = blockIdx.x / tiles_n;
+            for (int v = tid; v < BN * 2; v += NTHR) {
+                const int col = v >> 1, st2 = v & 1;
+                double acc2 = 0.0;
+                for (int rl = 0; rl < RPI; ++rl) acc2 += (double)red[(rl * BN + col) * 2 + st2];
+                if (n0 + col < a.Cout) a.stats[((long)st2 * a.Cout + n0 + col) * (gridDim.x / tiles_n) + ptile] = (float)acc2;
+            }
+        }
+    }
+    if (stamps) {
+        stamps[4] = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamps[5] = __builtin_amdgcn_s_memtime();
+        stamps[6] = (unsigned long long)nsteps;
+    }
+}
+
+template <int BN, int TH, int MODE>
+int launch_halo8_cfg(const ConvArgs& a_in, hipStream_t st) {
+    using Cfg = Halo8Cfg<BN, TH, MODE>;
+    auto kern = conv_halo8_kernel<BN, TH, MODE>;
+    ConvArgs a = a_in;
+    if (a.w_elems <= 0) a.w_elems = (Cfg::NT - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        attr_set = true;
+    }
+    const long M = (long)a.B * a.Ho * a.Wo;
+    const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
+    const long Min = MODE == UPCONV2 ? M / 4 : M;
+    if (Min * cmax * 2L >= (1L << 31) || a.w_elems * 2L >= (1L << 31) || M * a.Cout * 2L >= (1L << 31))
+        return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
+    const long tiles = (long)a.B * cdiv(a.Ho, TH) * cdiv(a.Wo, Cfg::TW) * cdiv(a.Cout, BN);
+    const long ptiles = tiles / cdiv(a.Cout, BN);
+    if (a.stats && a.stats_rows) {
+        if (ptiles * 2 * a.Cout <= a.stats_cap) *a.stats_rows = (int)ptiles;
+        else { a.stats = nullptr; *a.stats_rows = 0; }
+    } else a.stats = nullptr;
+    if (a.pooled && a.pooled_done && MODE == CONV3 && !a.mask && !(a.Ho & 1) && !(a.Wo & 1) && TH % 2 == 0) *a.pooled_done = 1;
+    else a.pooled = nullptr;
+    a.dbg_buf = stamp_buffer();
+    if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);
+    kern<<<dim3((unsigned)tiles), dim3(512), Cfg::SMEM, st>>>(a);
+    if (prof_on()) prof_end(st);
+    return launch_ok();
+}
+
 template <typename T, int BN, int TH, int NWS, int MODE = CONV3>
 int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
     using Cfg = HaloCfg<T, BN, TH, NWS, MODE>;
@@ -444,6 +854,9 @@ int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
     } else a.stats = nullptr;
     if (a.pooled && a.pooled_done && MODE == CONV3 && !a.mask && !(a.Ho & 1) && !(a.Wo & 1) && TH % 2 == 0) *a.pooled_done = 1;
     else a.pooled = nullptr;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("MPU_HALO_DEBUG"); dbg = e ? (atoi(e) & 0xff) << 8 : 0; }
+    a.dbg = dbg;
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);
     kern<<<dim3((unsigned)tiles), dim3(256), Cfg::SMEM, st>>>(a);
     if (prof_on()) prof_end(st);
@@ -452,10 +865,32 @@ int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
 
 }  // namespace
 
-// 1 = launched, 0 = shape not suited (caller falls back to the plain implicit GEMM), < 0 = error
+// 1 = launched (2: the 8-wave double-buffered variant), 0 = shape not suited (caller falls back to the plain
+// implicit GEMM), < 0 = error
 int try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
     if ((mode != CONV3 && mode != UPCONV2) || a.Wo < 32 || a.Ho < 4) return 0;
     int rc;
+    {   // round 3: one 8-wave workgroup per CU with a double-buffered patch, for grids of about one workgroup per CU
+        // (configs[1] levels 1-2: the single-buffer kernel's patch bursts are exposed there). MPU_HALO8=0 disables,
+        // MPU_HALO8_MAX_WGS / _MIN_WGS bound the grids it takes.
+        static int h8 = -1; static long h8_max = 0, h8_min = 0;
+        if (h8 < 0) {
+            const char* e = getenv("MPU_HALO8"); h8 = (e && e[0] == '0') ? 0 : 1;
+            const char* m = getenv("MPU_HALO8_MAX_WGS"); h8_max = m ? atol(m) : 640;
+            const char* n = getenv("MPU_HALO8_MIN_WGS"); h8_min = n ? atol(n) : 192;
+        }
+        if (h8 && dtype == MPU_BF16 && a.Ho % 8 == 0 && !a.head_w && (mode == CONV3 || !(a.Wo & 1))) {
+            const long pt = (long)a.B * (a.Ho / 8) * cdiv(a.Wo, 32);
+            const long g128 = pt * cdiv(a.Cout, 128), g64 = pt * cdiv(a.Cout, 64);
+            const bool wide = a.Cout > 64 && g128 >= h8_min;
+            const long g = wide ? g128 : g64;
+            if (g >= h8_min && g <= h8_max) {
+                if (mode == CONV3) rc = wide ? launch_halo8_cfg<128, 8, CONV3>(a, st) : launch_halo8_cfg<64, 8, CONV3>(a, st);
+                else rc = wide ? launch_halo8_cfg<128, 8, UPCONV2>(a, st) : launch_halo8_cfg<64, 8, UPCONV2>(a, st);
+                return rc ? rc : 2;
+            }
+        }
+    }
     if (mode == UPCONV2) {                       // low-resolution patch variant of the up-convolution
         static int up_on = -1;
         if (up_on < 0) { const char* e = getenv("MPU_HALO_UPCONV"); up_on = (e && e[0] == '0') ? 0 : 1; }

@@ -448,7 +448,19 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradArgs a) {
 
 // second stage: dW[e] = sum_s partial[s][e]  (fixed order: deterministic); 16-B loads, 4 splits in flight
 // Blocks past `main_blocks` finish the fused bias gradient (db = sum of the wgrad kernel's column-sum partials).
-struct DbFin { const float* partial; float* db; int nshare, C, main_blocks; };
+struct DbFin { const float* partial; float* db; int nshare, C, main_blocks; int il4_cout = 0; };
+
+// Write the sum of one 16-byte partial column. il4_cout == 0: the partials are in dW's own layout. il4_cout = Cout
+// (wgrad_taps): the partials are [tap][ci / 4][co][4 ci] -- a lane of that kernel holds four consecutive input
+// channels of one output channel, so its accumulator leaves as ONE 16-byte store (the [ci][co] layout cost four 4-byte
+// stores, and the kernel's tail was store-issue bound); index e = (tap * Cin/4 + ci/4) * Cout + co, the four values
+// belong to rows 4 * (e / Cout) .. + 3 of dW [tap * Cin + ci][co]. Consecutive threads write consecutive co.
+__device__ __forceinline__ void store_dw_sum(float* __restrict__ dW, long e, const float4& s, int il4_cout) {
+    if (!il4_cout) { reinterpret_cast<float4*>(dW)[e] = s; return; }
+    const unsigned row = (unsigned)e / (unsigned)il4_cout, co = (unsigned)e - row * (unsigned)il4_cout;
+    float* d = dW + (long)row * 4 * il4_cout + co;
+    d[0] = s.x; d[il4_cout] = s.y; d[2 * (long)il4_cout] = s.z; d[3 * (long)il4_cout] = s.w;
+}
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int ksplit, long n,
                                                            float* __restrict__ dW, DbFin f) {
@@ -479,7 +491,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                 s.x += on ? v[u].x : 0.f; s.y += on ? v[u].y : 0.f; s.z += on ? v[u].z : 0.f; s.w += on ? v[u].w : 0.f;
             }
         }
-        reinterpret_cast<float4*>(dW)[e] = s;
+        store_dw_sum(dW, e, s, f.il4_cout);
     }
 }
 
@@ -522,7 +534,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kl4_kernel(const float* __re
     if (kl == 0 && e < n4) {
 #pragma unroll
         for (int j = 1; j < 4; ++j) { const float4 v = red[j * 64 + col]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-        reinterpret_cast<float4*>(dW)[e] = s;
+        store_dw_sum(dW, e, s, f.il4_cout);
     }
 }
 
@@ -563,7 +575,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(ReduceTable t) {
                     s.x += on ? v[u].x : 0.f; s.y += on ? v[u].y : 0.f; s.z += on ? v[u].z : 0.f; s.w += on ? v[u].w : 0.f;
                 }
             }
-            reinterpret_cast<float4*>(q.dW)[e] = s;
+            store_dw_sum(q.dW, e, s, q.il4_cout);
         }
         return;
     }
@@ -596,7 +608,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(ReduceTable t) {
     if (kl == 0 && e < n4) {
 #pragma unroll
         for (int jj = 1; jj < 4; ++jj) { const float4 v = red[jj * 64 + col]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-        reinterpret_cast<float4*>(q.dW)[e] = s;
+        store_dw_sum(q.dW, e, s, q.il4_cout);
     }
 }
 
@@ -689,7 +701,7 @@ int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
             const int pf = try_conv_pipe_first(dtype, mode, a, st);
             if (pf != 0) { note("pipe"); return pf < 0 ? pf : MPU_OK; }
             const int h = try_conv_halo(dtype, mode, a, st);
-            if (h != 0) { note("halo"); return h < 0 ? h : MPU_OK; }
+            if (h != 0) { note(h == 2 ? "halo8" : "halo"); return h < 0 ? h : MPU_OK; }
         }
         const int rc = launch_conv_glds(dtype, mode, a, st);
         note(last_glds_schedule());
@@ -791,6 +803,7 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue
     int rc = launch_ok();
     if (rc) return rc;
     DbFin f; f.partial = nullptr; f.db = nullptr; f.nshare = 0; f.C = 0; f.main_blocks = 0;
+    f.il4_cout = taps.use ? a.Cout : 0;                        // wgrad_taps writes ci-interleaved partial columns
     int db_blocks = 0;
     if (a.fuse_db) {         // bias gradient: sum the [ksplit * taps * ci-tiles][Cout] partials of the LDS-DMA kernel
         const bool big128 = sizeof(T) == 2 && Cin >= 128 && a.Cout >= 128 && (a.C1 == 0 || a.C0 % 128 == 0);
@@ -808,7 +821,7 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue
         ReduceJob& j = rq->job[rq->njobs++];
         j.partial = a.partial; j.dW = dW; j.n = a.ksplit > 1 ? n : 0; j.ksplit = a.ksplit; j.kl4 = kl4 ? 1 : 0;
         j.db_partial = f.partial; j.db = f.db; j.nshare = f.nshare; j.C = f.C;
-        j.blk_begin = rq->nblocks; j.main_blocks = a.ksplit > 1 ? f.main_blocks : 0; j.db_blocks = db_blocks; j._pad = 0;
+        j.blk_begin = rq->nblocks; j.main_blocks = a.ksplit > 1 ? f.main_blocks : 0; j.db_blocks = db_blocks; j.il4_cout = f.il4_cout;
         rq->nblocks += j.main_blocks + j.db_blocks;
         return MPU_OK;
     }

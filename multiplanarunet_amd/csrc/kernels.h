@@ -53,6 +53,7 @@ struct WgradArgs {
     int fuse_db;                 // set by the launcher: the wgrad kernel also produces the db partials
     int c0_logical;              // image channels actually present in an 8-channel x0 (first layer); 0 = unknown
     long partial_cap = 0;        // floats available at `partial` (0 = unknown: schedules with their own layout refuse)
+    unsigned long long* dbg_buf = nullptr;   // dev aid (MPU_STAMPS=1): s_memtime stamps of a few workgroups
 };
 
 // element-wise maximum of two 16-byte pieces of T (8 bf16 or 4 f32)
@@ -65,6 +66,9 @@ template <typename T> __device__ __forceinline__ uint32_t piece_max(uint32_t a, 
     if (sizeof(T) == 2) return bf16x2_max(a, b);
     return __float_as_uint(fmaxf(__uint_as_float(a), __uint_as_float(b)));
 }
+
+// dev aid: device buffer for in-kernel s_memtime stamps (nullptr unless MPU_STAMPS=1); 64 slots of 8 stamps
+unsigned long long* stamp_buffer();
 
 // ---- profile.hip: optional per-launch HIP-event timing of the MFMA kernels ----
 enum { PROF_CONV = 0, PROF_WGRAD = 1, PROF_KINDS = 2 };
@@ -95,7 +99,7 @@ int  launch_wgrad_taps(int mode, const WgradArgs& a, const TapsPlan& p, hipStrea
 struct ReduceJob {
     const float* partial; float* dW; long n; int ksplit, kl4;    // main part (n = 0: none)
     const float* db_partial; float* db; int nshare, C;           // bias gradient (db = nullptr: none)
-    int blk_begin, main_blocks, db_blocks, _pad;
+    int blk_begin, main_blocks, db_blocks, il4_cout;             // il4_cout: see store_dw_sum (conv_igemm.hip)
 };
 constexpr int REDUCE_MAX_JOBS = 32;
 struct ReduceQueue { int njobs = 0, nblocks = 0; ReduceJob job[REDUCE_MAX_JOBS]; };

@@ -3,6 +3,7 @@
 #include <vector>
 #include <string>
 #include <stdarg.h>
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace mpu {
@@ -34,11 +35,34 @@ void sched_note(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
     g_sched += buf; g_sched += '\n';
 }
+// ---- dev aid: in-kernel s_memtime stamps (MPU_STAMPS=1) -------------------------------------------------------
+namespace { unsigned long long* g_stamps = nullptr; int g_stamps_state = -1; }
+unsigned long long* stamp_buffer() {
+    if (g_stamps_state < 0) {
+        const char* e = getenv("MPU_STAMPS");
+        g_stamps_state = (e && e[0] == '1') ? 1 : 0;
+        if (g_stamps_state) {
+            if (hipMalloc((void**)&g_stamps, 64 * 8 * sizeof(unsigned long long)) != hipSuccess) { g_stamps = nullptr; g_stamps_state = 0; }
+            else (void)hipMemset(g_stamps, 0, 64 * 8 * sizeof(unsigned long long));
+        }
+    }
+    return g_stamps;
+}
 }  // namespace mpu
 
 using namespace mpu;
 
 extern "C" {
+
+int mpu_debug_stamps_read(uint64_t* host_out, int32_t n) {
+    MPU_REQUIRE(host_out && n >= 0 && n <= 64 * 8, "mpu_debug_stamps_read: bad argument");
+    unsigned long long* b = stamp_buffer();
+    if (!b) { for (int i = 0; i < n; ++i) host_out[i] = 0; return MPU_OK; }
+    MPU_CHECK_HIP(hipDeviceSynchronize());
+    MPU_CHECK_HIP(hipMemcpy(host_out, b, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    MPU_CHECK_HIP(hipMemset(b, 0, 64 * 8 * sizeof(unsigned long long)));
+    return MPU_OK;
+}
 
 int mpu_profile_enable(int32_t on) {
     for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }

@@ -44,6 +44,7 @@ struct mpu_unet {
     // backward-pass concurrency: weight gradients run on a side stream next to the data gradients
     mutable hipStream_t side = nullptr;
     mutable hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    mpu_launch_tap_fn tap = nullptr; void* tap_user = nullptr;      // test aid: mpu_unet_set_launch_tap
 
     // indices into conv / bn
     int enc_c1(int i) const { return 2 * i; }
@@ -235,7 +236,15 @@ int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* i
     a.w = r.wf(c); a.w_tap_stride = (long)c.Cin * c.Cout; a.w_row_stride = c.Cin;
     a.bias = r.params + c.b; a.mask = nullptr; a.out = out;
     a.B = r.B; a.Ho = r.m->cfg.H >> lvl; a.Wo = r.m->cfg.W >> lvl; a.Cout = c.Cout; a.relu = 1;
-    return launch_conv(r.m->cfg.dtype, c.mode, a, r.st);
+    const int rc = launch_conv(r.m->cfg.dtype, c.mode, a, r.st);
+    if (!rc && r.m->tap && !post_scale) {
+        mpu_launch_info li{};
+        li.kind = 0; li.conv_index = (int)(&c - &r.m->conv[0]); li.mode = c.mode; li.dtype = r.m->cfg.dtype;
+        li.B = a.B; li.H = a.Ho; li.W = a.Wo; li.C0 = C0; li.C1 = C1; li.Cout = c.Cout; li.n_off = 0; li.n_cnt = c.Cin; li.relu = 1;
+        li.in0 = in0; li.in1 = in1; li.dz = nullptr; li.mask = nullptr; li.out = out; li.w_off = c.w; li.b_off = c.b;
+        r.m->tap(r.m->tap_user, &li);
+    }
+    return rc;
 }
 
 // data gradient of conv `c` w.r.t. input channels [n_off, n_off + n_cnt); out_lvl = resolution of the result
@@ -260,7 +269,15 @@ int conv_dgrad(const Run& r, const Conv& c, const void* dz, const void* mask, vo
     a.B = r.B; a.Ho = r.m->cfg.H >> out_lvl; a.Wo = r.m->cfg.W >> out_lvl; a.Cout = n_cnt; a.relu = 0;
     // the data gradient costs the forward's FLOPs (at the conv's own output level), pro rata of the slice
     a.flops = conv_flops(r, c, c.mode == UPCONV2 ? out_lvl - 1 : out_lvl) * ((double)n_cnt / c.Cin);
-    return launch_conv(r.m->cfg.dtype, c.mode == UPCONV2 ? CONV3S2 : CONV3, a, r.st);
+    const int rc = launch_conv(r.m->cfg.dtype, c.mode == UPCONV2 ? CONV3S2 : CONV3, a, r.st);
+    if (!rc && r.m->tap) {
+        mpu_launch_info li{};
+        li.kind = 1; li.conv_index = (int)(&c - &r.m->conv[0]); li.mode = c.mode; li.dtype = r.m->cfg.dtype;
+        li.B = a.B; li.H = a.Ho; li.W = a.Wo; li.C0 = c.Cout; li.C1 = 0; li.Cout = c.Cout; li.n_off = n_off; li.n_cnt = n_cnt;
+        li.relu = 0; li.in0 = nullptr; li.in1 = nullptr; li.dz = dz; li.mask = mask; li.out = out; li.w_off = c.w; li.b_off = c.b;
+        r.m->tap(r.m->tap_user, &li);
+    }
+    return rc;
 }
 
 int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* x1, int C1, const void* dz, int lvl) {
@@ -278,6 +295,13 @@ int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* 
     static int defer = -1;         // MPU_WGRAD_BATCHED_REDUCE=0: reduce right behind every weight-gradient kernel (A/B)
     if (defer < 0) { const char* e = getenv("MPU_WGRAD_BATCHED_REDUCE"); defer = (e && e[0] == '0') ? 0 : 1; }
     ReduceQueue* q = defer ? &r.rq : nullptr;
+    if (r.m->tap) {
+        mpu_launch_info li{};
+        li.kind = 2; li.conv_index = (int)ci_; li.mode = c.mode; li.dtype = r.m->cfg.dtype;
+        li.B = a.B; li.H = a.Ho; li.W = a.Wo; li.C0 = C0; li.C1 = C1; li.Cout = c.Cout; li.n_off = 0; li.n_cnt = c.Cin; li.relu = 0;
+        li.in0 = x0; li.in1 = x1; li.dz = dz; li.mask = nullptr; li.out = nullptr; li.w_off = c.w; li.b_off = c.b;
+        r.m->tap(r.m->tap_user, &li);                  // (before the launch: x and dz are final, dW is read after the pass)
+    }
     if (!r.overlap) return launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st, q);
     // fork: the side stream waits until dz (and everything before it) is produced on the main stream
     MPU_CHECK_HIP(hipEventRecord(r.m->ev_ready, r.st));
@@ -578,6 +602,12 @@ void mpu_unet_destroy(mpu_unet* m) {
     if (!m) return;
     if (m->side) { (void)hipStreamDestroy(m->side); (void)hipEventDestroy(m->ev_ready); (void)hipEventDestroy(m->ev_done); }
     delete m;
+}
+
+int mpu_unet_set_launch_tap(mpu_unet* m, mpu_launch_tap_fn fn, void* user) {
+    MPU_REQUIRE(m, "mpu_unet_set_launch_tap: null model");
+    m->tap = fn; m->tap_user = user;
+    return MPU_OK;
 }
 
 int64_t mpu_unet_param_floats(const mpu_unet* m) { return m ? m->n_params : 0; }

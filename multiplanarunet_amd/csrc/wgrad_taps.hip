@@ -22,7 +22,7 @@
 // the end they add their accumulators through LDS (taps 0-4 end up in group 0, taps 5-8 in group 1)
 // so only one fp32 partial copy per PAIR of strips goes to HBM: the partial write + re-read is
 // this kernel's dominant HBM traffic.
-// Output: fp32 partials [pair][tap][ci][co] (+ bias partials [pair][co]) reduced in fixed order
+// Output: fp32 partials [pair][tap][ci/4][co][4] (+ bias partials [pair][co]) reduced in fixed order
 // by wgrad_reduce*_kernel: deterministic, no atomics.
 #include <stdlib.h>
 #include "kernels.h"
@@ -79,6 +79,10 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave8 >> 2, wave = wave8 & 3;
+    // dev aid (MPU_STAMPS=1): phase boundaries of every 8th workgroup, wave 0
+    unsigned long long* stamps = (a.dbg_buf && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64 && tid == 0)
+                                     ? a.dbg_buf + (blockIdx.x >> 3) * 8 : nullptr;
+    if (stamps) stamps[0] = __builtin_amdgcn_s_memtime();
     unsigned char* smem = smem_all + grp * GROUP_LDS;
     const int H = a.Ho, W = a.Wo;
     const int Cin = a.C0 + a.C1;
@@ -198,6 +202,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
     // wait for the first group (rows 0..2 + dZ 0); the second may still be in flight
     wait_keep_one_group();
     __builtin_amdgcn_s_barrier();
+    if (stamps) stamps[1] = __builtin_amdgcn_s_memtime();
     for (int t = 0; t < nsteps_wg; ++t) {
         if (t >= nsteps) {                                       // the other group still has rows to do
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -237,6 +242,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
         __builtin_amdgcn_s_barrier();
     }
 
+    if (stamps) stamps[2] = __builtin_amdgcn_s_memtime();
     // ---- combine the two groups through LDS (the rings are free now): group 0 ends up with taps 0-4 and the
     // bias sums, group 1 with taps 5-8; each stores its share of the pair's partial copy -----------------
     {
@@ -278,24 +284,33 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
                     for (int r = 0; r < 4; ++r) acc[tp][cb][r] += xb[(((tp - NA) * 4 + cb) * 4 + r) * 64];
         }
     }
-    // ---- partial sums: [pair][tap][ci][co] ---------------------------------------------------------------
+    if (stamps) stamps[3] = __builtin_amdgcn_s_memtime();
+    // ---- partial sums: [pair][tap][ci / 4][co][4 ci] -- a lane's accumulator (four consecutive input channels of one
+    // output channel) is ONE 16-byte store, 16 lanes cover 256 contiguous bytes; the [ci][co] layout needed four
+    // 4-byte stores per accumulator and the tail of the kernel was store-issue bound. The reduction un-interleaves
+    // (store_dw_sum, conv_igemm.hip).
     float* P = a.partial + (long)pair * NTALL * Cin * a.Cout;
+    const int cin4 = Cin >> 2;
+    const int cib = (ci0 + wave * 16 + 4 * g) >> 2;
 #pragma unroll
     for (int tp = 0; tp < NT; ++tp) {
         if ((tp < (NT + 1) / 2) != (grp == 0)) continue;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
             const int co = co0 + cb * 16 + i;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ci = ci0 + wave * 16 + 4 * g + r;
-                if (ci < Cin && co < a.Cout) P[((long)(T0 + tp) * Cin + ci) * a.Cout + co] = acc[tp][cb][r];
-            }
+            if (cib < cin4 && co < a.Cout)
+                *(f32x4*)(P + (((long)(T0 + tp) * cin4 + cib) * a.Cout + co) * 4) = acc[tp][cb];
         }
     }
     if (a.fuse_db && T0 == 0 && grp == 0 && ci0 == 0 && g == 0) {          // every row of accdb holds the column sums: take row 0
         const int co = co0 + wave * 16 + i;
         if (co < a.Cout) a.db_partial[(long)pair * a.Cout + co] = accdb[0];
+    }
+    if (stamps) {
+        stamps[4] = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamps[5] = __builtin_amdgcn_s_memtime();
+        stamps[6] = (unsigned long long)nsteps_wg;
     }
 }
 
@@ -355,11 +370,15 @@ TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C
     if (!best) return p;
     p.RH = best; p.sx = sx; p.sy = cdiv(H, best); p.nstrips = B * sx * p.sy;
     if ((long)p.nstrips * ntile < 128) return p;                 // too little parallelism: the per-tap kernel splits finer
+    if (p.nstrips < 3) return p;                                 // (one strip pair would write straight into dW, which is not in the
+                                                                 //  ci-interleaved partial layout: always go through the reduction)
     p.use = 1;
     return p;
 }
 
-int launch_wgrad_taps(int mode, const WgradArgs& a, const TapsPlan& p, hipStream_t st) {
+int launch_wgrad_taps(int mode, const WgradArgs& a_in, const TapsPlan& p, hipStream_t st) {
+    WgradArgs a = a_in;
+    a.dbg_buf = stamp_buffer();
     const int Cin = a.C0 + a.C1;
     const int ntile = cdiv(Cin, 64) * cdiv(a.Cout, 64) * (p.split ? 2 : 1);
     const int npairs = (p.nstrips + 1) / 2;

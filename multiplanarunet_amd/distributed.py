@@ -122,10 +122,19 @@ class DataParallelTrainer:
     def __call__(self, grads):
         if world_size() == 1:
             return
+        timing = getattr(self, "timing", False) and grads.is_cuda
+        if timing:                                 # where the backward pass ends on the compute stream
+            e_bwd = torch.cuda.Event(enable_timing=True)
+            e_bwd.record()
         if not self.overlap:
+            if timing:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             allreduce_sum_(grads, self.bucket_bytes)
+            if timing:
+                e1.record()
+                self._timed.append((e_bwd, [(e0, e1)]))
             return
-        works = []
         # The comm stream is ordered behind the backward pass ONLY through the ready events. If this step's
         # backward did not record them (forward_backward called without ready_events), they are stale: order
         # the comm stream behind everything enqueued so far instead (no overlap, but never a race).
@@ -133,14 +142,45 @@ class DataParallelTrainer:
         self.model._ready_events_fresh = False
         if not fresh:
             self.comm.wait_stream(torch.cuda.current_stream())
+        spans = []
         with torch.cuda.stream(self.comm):
             for k, lo, hi in self.buckets:
                 if fresh:
                     self.comm.wait_event(self.ready_events[k])
-                works.append(dist.all_reduce(grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
-        for w in works:
-            w.wait()                               # the compute stream waits for the collectives
+                if timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                w = dist.all_reduce(grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+                w.wait()                           # the COMM stream waits for the collective (buckets run in order anyway)
+                if timing:
+                    e1.record()
+                    spans.append((e0, e1))
         torch.cuda.current_stream().wait_stream(self.comm)
+        if timing:
+            self._timed.append((e_bwd, spans))
+
+    # ---- communication timing (bench.py): events on the comm stream around every bucket ----------------------
+    def start_timing(self):
+        self.timing, self._timed = True, []
+
+    def stop_timing(self):
+        """Per-step means over the timed steps: comm_ms = sum of the bucket spans on the communication stream
+        (from 'bucket ready' to 'collective done'), exposed_ms = how long after the end of the backward pass the
+        last bucket finished (what Adam actually waits for), overlap_fraction = 1 - exposed / comm."""
+        self.timing = False
+        if not getattr(self, "_timed", None):
+            return None
+        torch.cuda.synchronize()
+        comm, exposed = [], []
+        for e_bwd, spans in self._timed:
+            comm.append(sum(a.elapsed_time(b) for a, b in spans))
+            exposed.append(max(0.0, e_bwd.elapsed_time(spans[-1][1])) if spans else 0.0)
+        self._timed = []
+        c, x = float(np.mean(comm)), float(np.mean(exposed))
+        return {"comm_ms_per_step": round(c, 4), "exposed_ms_per_step": round(x, 4),
+                "overlap_fraction": round(1.0 - x / c, 4) if c > 0 else None, "buckets": len(self.buckets) or 1,
+                "bucket_mb": [round((hi - lo) * 4 / 2 ** 20, 1) for _, lo, hi in self.buckets] or None,
+                "steps_timed": len(comm)}
 
 
 # --------------------------------------------------------------------------- #
@@ -226,7 +266,7 @@ def all_gather_slabs(slab, X):
 
 
 def multi_view_predict_sharded(model, volume, views, dim, real_space_span, fusion_model=None,
-                               sum_fusion=False, batch_size=None, n_planes="same+20", exchange=None):
+                               sum_fusion=False, batch_size=None, n_planes="same+20", exchange=None, timings=None):
     """
     multiplanarunet_amd.predict.multi_view_predict over all ranks. Every rank
     holds the full input volume; returns the full uint8 label volume on every rank.
@@ -241,7 +281,7 @@ def multi_view_predict_sharded(model, volume, views, dim, real_space_span, fusio
     exchange = exchange or os.environ.get("MPU_PREDICT_EXCHANGE") or "reduce_scatter"
     if exchange == "all_gather":
         return _multi_view_predict_allgather(model, volume, views, dim, real_space_span, fusion_model,
-                                             sum_fusion, batch_size, n_planes)
+                                             sum_fusion, batch_size, n_planes, timings)
     if exchange != "reduce_scatter":
         raise ValueError("exchange must be 'reduce_scatter' or 'all_gather'")
     from .interpolation import ViewGeometry, sample_view, map_accumulate, fusion_finalize
@@ -249,6 +289,11 @@ def multi_view_predict_sharded(model, volume, views, dim, real_space_span, fusio
     rank = dist.get_rank() if world > 1 else 0
     K = model.n_classes
     X, Y, Z = (int(v) for v in volume.image.shape[:3])
+    if timings is not None:
+        import time
+        if volume.device.type == "cuda":
+            torch.cuda.synchronize()
+        timings["_t0"] = time.perf_counter()
     z = torch.zeros((X, Y, Z, K), dtype=torch.float32, device=volume.device)
     geoms = [ViewGeometry(v, dim, real_space_span, n_planes) for v in views]
     items = plane_work_items(len(views), geoms[0].n_planes, world)[rank]
@@ -267,16 +312,35 @@ def multi_view_predict_sharded(model, volume, views, dim, real_space_span, fusio
             Wv = fusion_model.W[vi]
         map_accumulate(volume, pred, (g.real_axis, g.real_axis, g.offsets), g.inv_basis, Wv,
                        lo, hi, owns_oob=(lo == 0), z=z)
+    # timings (bench.py): the rank's own work up to here, then the exchange (reduce-scatter + finalize + all-gather);
+    # with the blocking collectives a host clock around a synchronised region is the honest measure
+    if timings is not None:
+        import time
+        torch.cuda.synchronize() if z.is_cuda else None
+        t1 = time.perf_counter()
+        timings["compute_s"] = t1 - timings.pop("_t0", t1)
+        timings["work_items"] = len(items)
+        timings["planes"] = sum(hi_ - lo_ for _, lo_, hi_ in items)
     zs, (lo, hi) = reduce_scatter_slabs(z)
     b = None if sum_fusion else fusion_model.b
     _, labels = fusion_finalize(zs, b, sum_fusion=sum_fusion, want_probs=False)
-    return all_gather_slabs(labels, X)
+    out = all_gather_slabs(labels, X)
+    if timings is not None:
+        torch.cuda.synchronize() if z.is_cuda else None
+        timings["exchange_s"] = time.perf_counter() - t1
+        timings["exchange_bytes_per_rank"] = int(z.numel() * 4 * (world - 1) // max(world, 1) + out.numel() * (world - 1) // max(world, 1))
+    return out
 
 
 def _multi_view_predict_allgather(model, volume, views, dim, real_space_span, fusion_model, sum_fusion,
-                                  batch_size, n_planes):
+                                  batch_size, n_planes, timings=None):
     from .interpolation import ViewGeometry, sample_view, map_real_space_pred, pred_to_class
+    import time
     world = world_size()
+    t_ex = 0.0
+    sync = (lambda: torch.cuda.synchronize()) if volume.device.type == "cuda" else (lambda: None)
+    if timings is not None:
+        sync(); t_begin = time.perf_counter()
     rank = dist.get_rank() if world > 1 else 0
     K, V = model.n_classes, len(views)
     X, Y, Z = (int(v) for v in volume.image.shape[:3])
@@ -295,8 +359,12 @@ def _multi_view_predict_allgather(model, volume, views, dim, real_space_span, fu
             mine = map_real_space_pred(pred.permute(1, 2, 0, 3), (g.real_axis, g.real_axis, g.offsets),
                                        g.inv_basis, volume)
         if world > 1:
+            if timings is not None:
+                sync(); t1 = time.perf_counter()
             parts = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(parts, mine)
+            if timings is not None:
+                sync(); t_ex += time.perf_counter() - t1
         else:
             parts = [mine]
         for q, part in enumerate(parts):
@@ -309,4 +377,10 @@ def _multi_view_predict_allgather(model, volume, views, dim, real_space_span, fu
         merged = fusion_model.predict(x, batch_size=10 ** 4)
         if not torch.is_tensor(merged):
             merged = torch.as_tensor(merged, device=dev)
-    return pred_to_class(merged.reshape(X, Y, Z, K), img_dims=3)
+    out = pred_to_class(merged.reshape(X, Y, Z, K), img_dims=3)
+    if timings is not None:
+        sync()
+        timings["exchange_s"] = t_ex
+        timings["compute_s"] = time.perf_counter() - t_begin - t_ex
+        timings["exchange_bytes_per_rank"] = int(rounds * X * Y * Z * K * 4 * (world - 1))
+    return out

@@ -335,7 +335,11 @@ def test_first_layer_wgrad_scratch_does_not_overrun_the_next_layer(n_channels, c
     g = m.grads.cpu().numpy()
     assert np.isfinite(g).all()
     r64 = U.bf16_matched_step(w, x, y, sw, depth=D, dtype=torch.float64)
+    r32 = U.bf16_matched_step(w, x, y, sw, depth=D, dtype=torch.float32)
     rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
     for name, g64 in r64["grads"].items():
-        e = rel(_grad(m, g, name).astype(np.float64), g64)
-        assert e <= 3e-2, (name, e)
+        a = _grad(m, g, name).astype(np.float64)
+        e = min(rel(a, g64), rel(a, r32["grads"][name]))
+        floor = rel(r32["grads"][name], g64)                   # two evaluations of the matched model (f32 / f64 arithmetic)
+        # an overrun replaces ~4 % of encoder_L0_conv2's partial sums with foreign data: O(1) relative error there
+        assert e <= max(5e-2, 2 * floor), (name, e, floor)

@@ -1,0 +1,54 @@
+"""
+bench.py under torch.distributed.run with N > 1: two ranks share the one GPU of the test box
+(MPU_SHARE_GPU=1) over gloo, so that every leg the driver's SCALE run will execute on an 8-GPU node -- the
+data-parallel train step with the overlapped all-reduce and its communication timing, the sharded 6-view
+predict+fuse with both exchanges, --config 3 (global batch 32 of 256x256, strong scaling) and --config 4
+(512^3 x 2, K = 5; here at a reduced edge) -- runs end to end and prints the JSON the driver parses.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, port):
+    env = dict(os.environ, MPU_SHARE_GPU="1", MPU_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_default_config_has_train_comm_and_sharded_predict_legs():
+    d = _run(["--steps", "3", "--warmup", "1", "--predict-dim", "64", "--no-cpu-baseline", "--no-peaks"], 29611)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["rccl_ranks"] == 2 and d["value"] > 0
+    assert d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+    c = d["comm"]
+    assert c["steps_timed"] == 3 and c["comm_ms_per_step"] > 0 and c["allreduce_bytes"] == 4 * 31046339 + 4 * (c["allreduce_bytes"] // 4 - 31046339)
+    assert 0.0 <= c["exposed_ms_per_step"] and c["overlap_fraction"] is not None and c["overlap_fraction"] <= 1.0
+    pf = d["predict_fuse"]
+    assert pf["n_gpus"] == 2 and pf["volume"] == "64^3x1" and set(pf["exchanges"]) == {"reduce_scatter", "all_gather"}
+    for ex in pf["exchanges"].values():
+        assert ex["value"] > 0 and ex["exchange_seconds_max_rank"] >= 0 and sum(ex["label_histogram"]) == 64 ** 3
+    # both exchanges fuse the same predictions (fp32 sums in a different order: a handful of near-tie voxels may flip)
+    ha, hb = pf["exchanges"]["reduce_scatter"]["label_histogram"], pf["exchanges"]["all_gather"]["label_histogram"]
+    assert sum(abs(p - q) for p, q in zip(ha, hb)) <= 1e-4 * 64 ** 3, (ha, hb)
+    assert d["roofline"]["frac"] > 0 and d["guard"]["finite"]
+
+
+def test_bench_two_ranks_config3_strong_scaling_and_config4_sharded_predict():
+    d = _run(["--config", "3", "--steps", "2", "--warmup", "1", "--no-predict", "--no-cpu-baseline", "--no-peaks"], 29613)
+    assert d["scaling"] == "strong" and d["config"]["global_batch"] == 32 and d["config"]["slices_per_gpu"] == 16
+    assert "256x256" in d["config"]["workload"] and "configs[3]" in d["config"]["workload"] and d["comm"]["comm_ms_per_step"] > 0
+    d = _run(["--config", "4", "--predict-dim", "64", "--exchange", "reduce_scatter"], 29615)
+    assert d["unit"] == "voxels/s" and d["n_gpus"] == 2 and "configs[4]" in d["config"]["workload"]
+    pf = d["predict_fuse"]
+    assert pf["volume"] == "64^3x2" and pf["classes"] == 5 and pf["exchanges"]["reduce_scatter"]["value"] == d["value"]

@@ -73,6 +73,36 @@ DEEP_CASES = [
 ]
 
 
+# Grids of about one workgroup per CU with 8-row tiles: the 8-wave kernel with the double-buffered patch (conv_halo8,
+# round 3) -- the BASELINE configs[1] level-1 / level-2 layers at their real shapes, and ragged variants.
+HALO8_CASES = [
+    # mode,   B, H,  W,  C0,  C1,  Cout
+    (CONV3,   16, 64, 64, 128, 0, 128),     # encoder_L1_conv2: 256 tiles of 128 channels, two chunks (one patch prefetch)
+    (CONV3,   16, 32, 32, 256, 0, 256),     # encoder_L2_conv2: 64-channel tiles (TM = 1), four chunks
+    (CONV3,   16, 64, 64, 128, 128, 136),   # concat (second source = chunks 2..3) + ragged N (two 128-channel tiles)
+    (CONV3,   13, 64, 40, 72, 0, 64),       # ragged W tile, channel tail (72 = 64 + 8)
+    (UPCONV2, 16, 64, 64, 256, 0, 128),     # upsample_L2_conv1: low-resolution patch, 128-channel tiles
+    (UPCONV2, 9, 64, 72, 72, 0, 40),        # up-conv: ragged W tile, channel tail, ragged N (216 tiles)
+]
+
+
+@pytest.mark.parametrize("case", HALO8_CASES)
+def test_halo8_double_buffered_patch_schedule(case):
+    import ctypes as C
+    from multiplanarunet_amd import _lib
+    lib = _lib.load()
+    lib.mpu_schedule_log_enable(1)
+    try:
+        _run_case(case, torch.bfloat16)
+        n = lib.mpu_schedule_log_read(None, 0)
+        buf = C.create_string_buffer(int(n) + 1)
+        lib.mpu_schedule_log_read(buf, n + 1)
+    finally:
+        lib.mpu_schedule_log_enable(0)
+    conv = [l.split()[1] for l in buf.value.decode().splitlines() if l.startswith("conv ")]
+    assert conv and conv[0] == "halo8", conv                    # the forward launch of the case took the new schedule
+
+
 @pytest.mark.parametrize("case", DEEP_CASES)
 def test_deep_level_layers_split_k_schedule(case):
     """bf16, with the split-K workspace (the path mpu_unet_forward / backward take at the deep levels)."""
