@@ -279,6 +279,16 @@ int mpu_unet_l2_regularizer(const mpu_unet* m, const float* d_params, float* d_g
                             float* d_reg_loss, void* stream);
 int64_t mpu_unet_l2_workspace_doubles(void);
 
+/* The optimizer step of a U-Net in ONE launch: the Adam update of mpu_adam_step over the model's whole flat
+ * parameter buffer AND the refresh of the packed MFMA operands (mpu_unet_pack_weights), tile by tile -- the updated
+ * kernel tile is written to d_params and, converted, to both packed copies while it is in registers / LDS. Bit-identical
+ * to mpu_adam_step followed by mpu_unet_pack_weights (tests/test_gpu_unet.py), 0.25 GB less HBM traffic per step of the
+ * configs[1] network. d_step != NULL: step count t-1 in device memory, incremented by the call (graph replay, as
+ * mpu_adam_step_device_counter); else t is the 1-based step. Replaces, for this path, Keras' optimizer.apply_gradients
+ * inside Model.fit (mpunet/train/trainer.py:246). */
+int mpu_unet_adam_pack(const mpu_unet* m, float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t t,
+                       int64_t* d_step, double lr, double beta1, double beta2, double eps, void* d_packed, void* stream);
+
 /* Keras Adam (TF ApplyAdam form), t = 1-based step; YAML defaults
  * lr 5e-5, beta_1 .9, beta_2 .999, epsilon 1e-8
  * (mpunet/bin/defaults/MultiPlanar/train_hparams.yaml:126). */
@@ -361,6 +371,10 @@ int mpu_geometry_check_cell_division(const mpu_axis* axis, int64_t count, uint64
  * a = b + 1.5 c over n floats (n % 4 == 0), 12 * n bytes of HBM traffic. */
 int mpu_probe_mfma_bf16(int32_t blocks, int32_t iters, float* d_sink, double* flops, void* stream);
 int mpu_probe_stream_triad(float* d_a, const float* d_b, const float* d_c, int64_t n, void* stream);
+/* out[i] = x[3i] + x[3i+1] + x[3i+2]: 12 contiguous bytes per lane, 12 n bytes read exactly once -- the access width of
+ * the fused back-mapping's K = 3 gathers; calibrates rocprofv3's FETCH_SIZE for that width (MI355X_MICROARCH.md: the
+ * gfx950 x2 correction is established for 16-byte accesses only). */
+int mpu_probe_gather12(const float* d_x, float* d_out, int64_t n, void* stream);
 
 /* Test aid (no reference counterpart): when enabled, every convolution / weight-gradient launch appends one text
  * line naming the kernel schedule the dispatcher chose for the layer shape ("conv halo mode=0 B=.. H=.. W=.. Cin=..

@@ -933,7 +933,7 @@ static int launch_pipe(const ConvArgs& a_in, int ks, hipStream_t st) {
 
 // 1 = launched by the one-workgroup-per-CU schedule, 0 = shape not suited, < 0 = error
 template <typename T, int MODE>
-static int try_pipe(const ConvArgs& a, hipStream_t st, bool big = false) {
+static int try_pipe(const ConvArgs& a, hipStream_t st) {
     if constexpr (sizeof(T) != 2 || MODE == CONV1) return 0;
     else {
         static int on = -1, min_steps = 12, wgs = 256, dbg = 0;
@@ -947,7 +947,7 @@ static int try_pipe(const ConvArgs& a, hipStream_t st, bool big = false) {
         const long M = (long)a.B * a.Ho * a.Wo;
         const long tiles = (long)cdiv(M, PipeCfg::BM) * cdiv(a.Cout, PipeCfg::BN);
         const int nit = GModeTraits<MODE>::NTAPS * (cdiv(a.C0, 64) + cdiv(a.C1, 64));
-        if ((!big && tiles > 2L * wgs) || nit < min_steps) return 0;     // large grids: the two-workgroup schedules fill the chip
+        if (tiles > 2L * wgs || nit < min_steps) return 0;      // large grids: the two-workgroup schedules fill the chip
         {   // 32-bit offsets with a poison margin: every operand (and the f32 output rows) below 2 GiB - 8 KiB
             const long hi = MODE == UPCONV2 ? a.Ho / 2 : (MODE == CONV3S2 ? a.Ho * 2 : a.Ho);
             const long wi = MODE == UPCONV2 ? a.Wo / 2 : (MODE == CONV3S2 ? a.Wo * 2 : a.Wo);
@@ -989,30 +989,6 @@ static int try_pipe(const ConvArgs& a, hipStream_t st, bool big = false) {
         }
         return rc ? rc : 1;
     }
-}
-
-// experimental dispatch (MPU_PIPE_FIRST=1): 3x3 layers with ~256 tiles of 256 x 128 take this schedule before the
-// halo kernels (level 1 of configs[1])
-int try_conv_pipe_first(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("MPU_PIPE_FIRST"); on = (e && e[0] == '1') ? 1 : 0; }
-    static int big = -1;
-    if (big < 0) { const char* e = getenv("MPU_PIPE_BIG"); big = e ? atoi(e) : 0; }
-    if (dtype != MPU_BF16 || a.Cout < 128) return 0;
-    const long M = (long)a.B * a.Ho * a.Wo;
-    const long tiles = (long)cdiv(M, PipeCfg::BM) * cdiv(a.Cout, PipeCfg::BN);
-    // Many-tile layers (predict batches), one tile after the other per CU: MPU_PIPE_BIG=1 = the 1024-filter bottom
-    // level and the wide transposed convs, = N > 1 = every such layer with >= N input channels. OFF by default:
-    // in isolation (138 x 256^2 batch, gpurun r2p) those layers ran 7-16 % faster than on the halo / glds
-    // schedules and the other 3x3 layers 5-25 % slower, but the whole 6-view predict did not move (182.9 vs
-    // 181.5 ms, gpurun r2q).
-    if (big > 0 && tiles > 512 && (mode == CONV3 || mode == UPCONV2)) {
-        const bool pick = big > 1 ? a.C0 + a.C1 >= big : ((mode == UPCONV2 && a.C0 >= 512) || (mode == CONV3 && a.Cout >= 1024));
-        if (pick) return mode == CONV3 ? try_pipe<bf16_t, CONV3>(a, st, true) : try_pipe<bf16_t, UPCONV2>(a, st, true);
-    }
-    if (!on || mode != CONV3) return 0;
-    if (tiles < 192 || tiles > 512) return 0;
-    return try_pipe<bf16_t, CONV3>(a, st);
 }
 
 static thread_local const char* g_glds_sched = "glds";       // which schedule the last launch_conv_glds took (schedule log)

@@ -698,8 +698,6 @@ int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
             if (c != 0) { note("c8"); return c < 0 ? c : MPU_OK; }
             const int w = try_conv_ws(dtype, mode, a, st);
             if (w != 0) { note("ws"); return w < 0 ? w : MPU_OK; }
-            const int pf = try_conv_pipe_first(dtype, mode, a, st);
-            if (pf != 0) { note("pipe"); return pf < 0 ? pf : MPU_OK; }
             const int h = try_conv_halo(dtype, mode, a, st);
             if (h != 0) { note(h == 2 ? "halo8" : "halo"); return h < 0 ? h : MPU_OK; }
         }

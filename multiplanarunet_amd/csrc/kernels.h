@@ -84,7 +84,6 @@ const char* last_glds_schedule();               // "glds" or "pipe": what the la
 int  try_conv_c8(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // <= 8 input channels: first layer (conv_c8.hip)
 int  try_conv_ws(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // register-stationary weights, persistent (conv_ws.hip)
 int  try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st);     // LDS-resident patch variant (conv_halo.hip)
-int  try_conv_pipe_first(int dtype, int mode, const ConvArgs& a, hipStream_t st);   // MPU_PIPE_FIRST=1 (conv_glds.hip)
 long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out);
 // all-taps weight gradient for the high-resolution 3x3 layers (wgrad_taps.hip)
 struct TapsPlan { int use, RH, sx, sy, nstrips, split; };
@@ -123,6 +122,11 @@ struct PackJob { int mode, Cin, Cout, unit_begin, fwd_units, _pad; long w, wf, w
 constexpr int PACK_MAX_JOBS = 40;
 struct PackTable { int njobs, _pad; PackJob job[PACK_MAX_JOBS]; };
 int launch_pack_all(int dtype, PackTable& tab, const float* params, void* packed, hipStream_t st);
+// Adam on the whole flat buffer + both packed operand copies of the listed kernels in ONE launch (unet_ops.hip);
+// step != NULL: device-resident step counter (graph replay; incremented afterwards), else t_host (1-based)
+int launch_adam_pack_all(int dtype, PackTable& jobs, float* params, const float* grads, float* am, float* av, long n_params,
+                         void* packed, long long* step, long long t_host, double lr, double b1, double b2, float eps,
+                         hipStream_t st);
 int launch_pack_weights(int dtype, int mode, const float* W, int Cin, int Cout,
                         void* w_fwd, void* w_dgrad, hipStream_t st);
 int launch_cast_pad(int dtype, const float* x, long M, int Cin, int Cpad, void* out, hipStream_t st);

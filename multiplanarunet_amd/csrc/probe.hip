@@ -43,12 +43,31 @@ __global__ __launch_bounds__(256) void probe_triad_kernel(float4* __restrict__ a
     }
 }
 
+// out[i] = x[3i] + x[3i+1] + x[3i+2]: every lane reads 12 contiguous bytes (the K = 3 gather width of the fused
+// back-mapping), the wave 768 contiguous bytes: 12 n bytes read exactly once. Calibrates FETCH_SIZE for 12-byte accesses.
+__global__ __launch_bounds__(256) void probe_gather12_kernel(const float* __restrict__ x, float* __restrict__ out, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v[3];
+        __builtin_memcpy(v, x + 3 * i, 12);
+        out[i] = v[0] + v[1] + v[2];
+    }
+}
+
 }  // namespace
 }  // namespace mpu
 
 using namespace mpu;
 
 extern "C" {
+
+// 12 n bytes read (each once, 12 per lane), 4 n written.
+int mpu_probe_gather12(const float* d_x, float* d_out, int64_t n, void* stream) {
+    MPU_REQUIRE(d_x && d_out && n > 0, "mpu_probe_gather12: bad argument");
+    long blocks = (n + 255) / 256; if (blocks > 256L * 32) blocks = 256L * 32;
+    probe_gather12_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(d_x, d_out, n);
+    return launch_ok();
+}
 
 // Launches the MFMA probe on `blocks` workgroups of 4 waves; *flops = the bf16 FLOPs it executes.
 int mpu_probe_mfma_bf16(int32_t blocks, int32_t iters, float* d_sink, double* flops, void* stream) {

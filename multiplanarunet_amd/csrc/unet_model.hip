@@ -41,9 +41,6 @@ struct mpu_unet {
     long infer_off = 0;                      // byte offset of the inference BN coefficients inside the packed buffer
     int head_C = 0; long head_w = 0, head_b = 0;
     int cmax = 0;
-    // backward-pass concurrency: weight gradients run on a side stream next to the data gradients
-    mutable hipStream_t side = nullptr;
-    mutable hipEvent_t ev_ready = nullptr, ev_done = nullptr;
     mpu_launch_tap_fn tap = nullptr; void* tap_user = nullptr;      // test aid: mpu_unet_set_launch_tap
 
     // indices into conv / bn
@@ -186,8 +183,6 @@ Plan make_plan(const mpu_unet* m, int B) {
 
 struct Run {
     const mpu_unet* m; int B; hipStream_t st; unsigned char* ws; Plan P;
-    bool overlap = false;          // weight gradients on the model's side stream
-    mutable bool pending = false;  // a weight gradient is in flight on the side stream
     const float* params; const unsigned char* packed; float* state; float* grads;
     void* const* ready_events = nullptr; int n_ready = 0;        // gradient-ready points (mpu_unet_backward_events)
     mutable ReduceQueue rq;                                      // deferred weight-gradient reductions (one launch per flush)
@@ -302,30 +297,7 @@ int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* 
         li.in0 = x0; li.in1 = x1; li.dz = dz; li.mask = nullptr; li.out = nullptr; li.w_off = c.w; li.b_off = c.b;
         r.m->tap(r.m->tap_user, &li);                  // (before the launch: x and dz are final, dW is read after the pass)
     }
-    if (!r.overlap) return launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st, q);
-    // fork: the side stream waits until dz (and everything before it) is produced on the main stream
-    MPU_CHECK_HIP(hipEventRecord(r.m->ev_ready, r.st));
-    MPU_CHECK_HIP(hipStreamWaitEvent(r.m->side, r.m->ev_ready, 0));
-    int rc = launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.m->side, q);
-    if (rc) return rc;
-    MPU_CHECK_HIP(hipEventRecord(r.m->ev_done, r.m->side));
-    r.pending = true;
-    return MPU_OK;
-}
-
-int wgrad_join(const Run& r);
-int conv_wgrad_after_join(const Run& r, const Conv& c, const void* x0, int C0, const void* x1, int C1, const void* dz, int lvl) {
-    int rc = wgrad_join(r);      // one weight gradient in flight at a time (they share the split-K scratch)
-    return rc ? rc : conv_wgrad(r, c, x0, C0, x1, C1, dz, lvl);
-}
-
-// join: the main stream may not overwrite a buffer the in-flight weight gradient still reads
-int wgrad_join(const Run& r) {
-    if (r.pending) {
-        MPU_CHECK_HIP(hipStreamWaitEvent(r.st, r.m->ev_done, 0));
-        r.pending = false;
-    }
-    return MPU_OK;
+    return launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st, q);
 }
 
 int bn_fwd(const Run& r, const BN& b, const void* x, int lvl, int training, void* y, void* pooled, int stats_rows = 0) {
@@ -441,15 +413,11 @@ int run_forward(const Run& r, const float* d_x, int training, float* d_out) {
     return MPU_OK;
 }
 
-int wgrad_join(const Run& r);
-
 // gradient-ready point k (see mpu_unet_grad_ready_points): everything the backward pass will write at or
 // above that offset of the flat gradient buffer has been enqueued; record the caller's event there
 int mark_ready(const Run& r, int k) {
     if (!r.ready_events || k >= r.n_ready || !r.ready_events[k]) return MPU_OK;
-    int rc = wgrad_join(r);
-    if (rc) return rc;
-    rc = flush_wgrad_reduces(r.rq, r.st);          // the gradients above this point must be final before the event
+    int rc = flush_wgrad_reduces(r.rq, r.st);      // the gradients above this point must be final before the event
     if (rc) return rc;
     MPU_CHECK_HIP(hipEventRecord((hipEvent_t)r.ready_events[k], r.st));
     return MPU_OK;
@@ -466,8 +434,8 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
                             (float*)r.at(P.partial), gA, r.grads + m->head_w, r.grads + m->head_b, d_loss, r.st));
     int point = 0;
     RC(mark_ready(r, point++));                                                            // head
-    // Each weight gradient (side stream) runs next to the data gradient of the same layer (main stream);
-    // wgrad_join() precedes the first main-stream kernel that overwrites the dz buffer it reads.
+    // (weight gradients on a side stream next to the data gradients were measured twice -- 3.08 vs 3.03 ms in round 2 --
+    // and removed in round 3: both kernels need a whole CU's LDS, so they never share one)
     int rowsA = 0;       // partial rows of BN-backward sums already produced for the dn in gA (0: head_backward wrote it)
     for (int j = D - 1; j >= 0; --j) {
         const int lvl = D - 1 - j, f = m->F[lvl];
@@ -475,17 +443,14 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
         const Conv& c3 = m->conv[m->up_c(j, 2)];
         const void* prev = j > 0 ? r.at(P.n2[j - 1]) : r.at(P.nb);
         const int Cprev = j > 0 ? m->F[lvl + 1] : m->F[D];
-        RC(wgrad_join(r));                                                                 // gB is about to be written
         RC(bn_bwd(r, m->bn[m->up_bn(j, 1)], gA, r.at(P.c3u[j]), lvl, gB, rowsA, 1));       // dz3 -> gB
         RC(conv_wgrad(r, c3, r.at(P.c2u[j]), f, nullptr, 0, gB, lvl));                     //   reads gB
         RC(conv_dgrad(r, c3, gB, r.at(P.c2u[j]), gA, lvl, 0, f));                          // dz2 -> gA
-        RC(wgrad_join(r));
         RC(conv_wgrad(r, c2, r.at(P.n[lvl]), f, r.at(P.n1[j]), f, gA, lvl));               //   reads gA
         RC(conv_dgrad(r, c2, gA, nullptr, r.at(P.dskip[lvl]), lvl, 0, f));                 // d skip
         int rowsB = 0;                                                                     // (BN-backward sums from the epilogue)
         RC(conv_dgrad(r, c2, gA, nullptr, gB, lvl, f, f, &m->bn[m->up_bn(j, 0)], r.at(P.u1[j]), &rowsB));   // d n1 -> gB
         RC(bn_bwd(r, m->bn[m->up_bn(j, 0)], gB, r.at(P.u1[j]), lvl, gC, rowsB, 1));        // dz up-conv -> gC
-        RC(wgrad_join(r));                                                                 // gA is about to be written
         RC(conv_wgrad(r, cu, prev, Cprev, nullptr, 0, gC, lvl));                           //   reads gC
         // d prev -> gA: the dn of the previous block's second BatchNorm (or of the bottom one)
         const BN& pbn = j > 0 ? m->bn[m->up_bn(j - 1, 1)] : m->bn[m->bot_bn()];
@@ -498,16 +463,15 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
         const void* xin = D > 0 ? r.at(P.p[D - 1]) : r.at(P.xin);
         const int Cx = D > 0 ? m->F[D - 1] : m->cin_pad;
         RC(bn_bwd(r, m->bn[m->bot_bn()], gA, r.at(P.c2b), D, gB, D > 0 ? rowsA : 0, 1));   // gC reader may still run: gB is free
-        RC(conv_wgrad_after_join(r, c2, r.at(P.c1b), m->F[D], nullptr, 0, gB, D));
+        RC(conv_wgrad(r, c2, r.at(P.c1b), m->F[D], nullptr, 0, gB, D));
         RC(conv_dgrad(r, c2, gB, r.at(P.c1b), gA, D, 0, m->F[D]));
-        RC(conv_wgrad_after_join(r, c1, xin, Cx, nullptr, 0, gA, D));
+        RC(conv_wgrad(r, c1, xin, Cx, nullptr, 0, gA, D));
         if (D > 0) RC(conv_dgrad(r, c1, gA, nullptr, gB, D, 0, Cx));                       // d pooled -> gB (gB reader joined above)
         RC(mark_ready(r, point++));                                                        // bottom
     }
     for (int i = D - 1; i >= 0; --i) {
         const Conv& c1 = m->conv[m->enc_c1(i)]; const Conv& c2 = m->conv[m->enc_c2(i)];
         const int H = m->cfg.H >> i, W = m->cfg.W >> i;
-        RC(wgrad_join(r));                                                                 // gA is about to be written
         // skip gradient + un-pooled gradient, and in the same pass the BN-backward sums of the result
         const BN& eb = m->bn[m->enc_bn(i)];
         int bwd_rows = 0;
@@ -519,11 +483,10 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
         RC(conv_dgrad(r, c2, gB, r.at(P.c1[i]), gA, i, 0, m->F[i]));
         const void* xin = i > 0 ? r.at(P.p[i - 1]) : r.at(P.xin);
         const int Cx = i > 0 ? m->F[i - 1] : m->cin_pad;
-        RC(conv_wgrad_after_join(r, c1, xin, Cx, nullptr, 0, gA, i));
+        RC(conv_wgrad(r, c1, xin, Cx, nullptr, 0, gA, i));
         if (i > 0) RC(conv_dgrad(r, c1, gA, nullptr, gB, i, 0, Cx));
         RC(mark_ready(r, point++));                                                        // encoder level i
     }
-    RC(wgrad_join(r));               // the gradient buffer is complete when the main stream continues
     return flush_wgrad_reduces(r.rq, r.st);
 }
 
@@ -534,13 +497,6 @@ int make_run(Run& r, const mpu_unet* m, int batch, const float* params, const vo
     r.m = m; r.B = batch; r.st = (hipStream_t)stream; r.ws = (unsigned char*)ws; r.P = make_plan(m, batch);
     r.params = params; r.packed = (const unsigned char*)packed; r.state = state; r.grads = grads;
     r.esz = m->cfg.dtype == MPU_BF16 ? 2 : 4;
-    const char* ov = getenv("MPU_WGRAD_OVERLAP");
-    r.overlap = grads != nullptr && ov && ov[0] == '1';    // measured: no gain on MI355X (both kernels fill the chip); off by default
-    if (r.overlap && !m->side) {
-        MPU_CHECK_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
-        MPU_CHECK_HIP(hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming));
-        MPU_CHECK_HIP(hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming));
-    }
     return MPU_OK;
 }
 
@@ -600,7 +556,6 @@ mpu_unet* mpu_unet_create(const mpu_unet_config* cfg) {
 
 void mpu_unet_destroy(mpu_unet* m) {
     if (!m) return;
-    if (m->side) { (void)hipStreamDestroy(m->side); (void)hipEventDestroy(m->ev_ready); (void)hipEventDestroy(m->ev_done); }
     delete m;
 }
 
@@ -650,6 +605,22 @@ int mpu_unet_pack_weights(const mpu_unet* m, const float* d_params, void* d_pack
         j.w = c.w; j.wf = c.wf; j.wd = c.wd;
     }
     return launch_pack_all(m->cfg.dtype, tab, d_params, d_packed, (hipStream_t)stream);
+}
+
+int mpu_unet_adam_pack(const mpu_unet* m, float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t t,
+                       int64_t* d_step, double lr, double beta1, double beta2, double eps, void* d_packed, void* stream) {
+    MPU_REQUIRE(m && d_params && d_grads && d_m && d_v && d_packed, "mpu_unet_adam_pack: null argument");
+    MPU_REQUIRE(d_step || t >= 1, "mpu_unet_adam_pack: need a device step counter or a 1-based step number");
+    PackTable tab; tab.njobs = 0; tab._pad = 0;
+    for (const Conv& c : m->conv) {
+        if (c.mode == CONV1) continue;
+        MPU_REQUIRE(tab.njobs < PACK_MAX_JOBS, "mpu_unet_adam_pack: too many layers");
+        PackJob& j = tab.job[tab.njobs++];
+        j.mode = c.mode; j.Cin = c.Cin; j.Cout = c.Cout; j.unit_begin = j.fwd_units = j._pad = 0;
+        j.w = c.w; j.wf = c.wf; j.wd = c.wd;
+    }
+    return launch_adam_pack_all(m->cfg.dtype, tab, d_params, d_grads, d_m, d_v, m->n_params, d_packed, (long long*)d_step,
+                                (long long)t, lr, beta1, beta2, (float)eps, (hipStream_t)stream);
 }
 
 int mpu_unet_prepare_inference(const mpu_unet* m, const float* d_params, const float* d_bn_state, void* d_packed,

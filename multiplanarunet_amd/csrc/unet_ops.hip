@@ -6,6 +6,7 @@
 //
 // Reference semantics: mpunet/models/unet.py:114-216 (layer order), Keras
 // defaults restated in SURVEY.md section 8a rows a6/a7, oracle/unet_ref.py.
+#include <cmath>
 #include "kernels.h"
 #include "reduce.h"
 
@@ -1176,14 +1177,270 @@ int launch_head_backward(int dtype, const void* n, const float* probs, const uin
 }
 
 // TF ApplyAdam: m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= m*alpha/(sqrt(v)+eps)
+// (one definition for the plain and the fused kernels: the same instruction sequence, bit-identical results)
+// No FMA contraction inside (pragma): the compiler contracted the multiply-adds in one kernel and not in the other, and
+// the fused and the plain path differed by one ulp in 1.4 % of the first moments (HIP's __fadd_rn & co. are plain
+// operators and contract just the same).
+__device__ __forceinline__ void adam_update(float gg, float& m, float& v, float& p, float alpha, float b1, float b2, float eps) {
+#pragma clang fp contract(off)
+    const float d1 = gg - m, o1 = 1.f - b1;
+    const float mm = m + d1 * o1;
+    const float g2 = gg * gg;
+    const float d2 = g2 - v, o2 = 1.f - b2;
+    const float vv = v + d2 * o2;
+    m = mm; v = vv;
+    const float num = mm * alpha, den = sqrtf(vv) + eps;
+    p = p - num / den;
+}
+__device__ __forceinline__ float adam_alpha_dev(const long long* step, double lr, double b1d, double b2d) {
+    const double t = (double)(*step + 1);
+    return (float)(lr * sqrt(1.0 - pow(b2d, t)) / (1.0 - pow(b1d, t)));
+}
+
+// ---- Adam + weight packing in ONE pass (round 3) ---------------------------------------------------------------
+// The separate chain read the gradients and wrote the parameters (adam_kernel), then read the parameters twice more
+// to write the two bf16 operand copies (pack_all_kernel). Here a unit loads g, m, v, p of one kernel tile, updates
+// them, and writes m, v, p AND both packed copies from the tile: 0.25 GB less traffic per step and one launch less.
+//   CONV3 job  : unit = (tap, 64 ci, 64 co) tile; forward copy [tap][co][ci] transposed through LDS, data-gradient
+//                copy [8 - tap][ci][co] from the same tile (16-byte stores).
+//   UPCONV2 job: unit = (32 ci, 32 co) x the four taps (the data-gradient copy is the 3x3 stride-2 combination
+//                W_eff[dy][dx] = sum of the taps S(dy) x S(dx), which needs all four updated taps of an element).
+//   plain units: everything that is not a 3x3 / 2x2 kernel (biases, BatchNorm gamma / beta, the 1x1 head): Adam only,
+//                1024 floats per unit, ranges in the table.
+struct AdamRange { long off, n; int unit_begin, _pad; };
+constexpr int ADAM_MAX_RANGES = 48;
+struct AdamPackTable { int njobs, nranges, plain_begin, _pad; PackJob job[PACK_MAX_JOBS]; AdamRange range[ADAM_MAX_RANGES]; };
+
+template <typename T>
+__device__ __forceinline__ void adam_pack_conv3_tile(const PackJob& j, int t, float* __restrict__ params,
+                                                     const float* __restrict__ grads, float* __restrict__ am,
+                                                     float* __restrict__ av, T* packed, float (*tile)[65], float alpha,
+                                                     float b1, float b2, float eps) {
+    constexpr int N = Vec<T>::N;
+    const int Cin = j.Cin, Cout = j.Cout;
+    const int tci = (Cin + 63) / 64, tco = (Cout + 63) / 64;
+    const int tap = t / (tci * tco); const int r = t % (tci * tco);
+    const int ci0 = (r / tco) * 64, co0 = (r % tco) * 64;
+    const long base = j.w + (long)tap * Cin * Cout;
+    {
+        const int ty = threadIdx.x >> 4, tx4 = (threadIdx.x & 15) * 4;
+        float4 g4[4], m4[4], v4[4], p4[4];
+        long off[4]; bool in[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                            // all 16 loads of the thread in flight together
+            const int ci = ci0 + ty + 16 * k, co = co0 + tx4;
+            in[k] = ci < Cin && co < Cout;
+            off[k] = base + (long)(ci < Cin ? ci : Cin - 1) * Cout + (co < Cout ? co : Cout - 4);
+            g4[k] = *reinterpret_cast<const float4*>(grads + off[k]); m4[k] = *reinterpret_cast<const float4*>(am + off[k]);
+            v4[k] = *reinterpret_cast<const float4*>(av + off[k]); p4[k] = *reinterpret_cast<const float4*>(params + off[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            adam_update(g4[k].x, m4[k].x, v4[k].x, p4[k].x, alpha, b1, b2, eps);
+            adam_update(g4[k].y, m4[k].y, v4[k].y, p4[k].y, alpha, b1, b2, eps);
+            adam_update(g4[k].z, m4[k].z, v4[k].z, p4[k].z, alpha, b1, b2, eps);
+            adam_update(g4[k].w, m4[k].w, v4[k].w, p4[k].w, alpha, b1, b2, eps);
+            if (in[k]) {                                         // (a clamped duplicate would be updated twice: in-range only)
+                *reinterpret_cast<float4*>(am + off[k]) = m4[k]; *reinterpret_cast<float4*>(av + off[k]) = v4[k];
+                *reinterpret_cast<float4*>(params + off[k]) = p4[k];
+            }
+            const int cil = ty + 16 * k;
+            const float4 q = in[k] ? p4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            tile[cil][tx4] = q.x; tile[cil][tx4 + 1] = q.y; tile[cil][tx4 + 2] = q.z; tile[cil][tx4 + 3] = q.w;
+        }
+    }
+    __syncthreads();
+    T* dstf = packed + j.wf + (long)tap * Cin * Cout;
+    constexpr int GPR = 64 / N, RPP = 256 / GPR;
+#pragma unroll
+    for (int pass = 0; pass < 64 / RPP; ++pass) {                // forward copy [co][ci]: columns of the tile
+        const int col = threadIdx.x / GPR + pass * RPP, cil = (threadIdx.x % GPR) * N;
+        const int co = co0 + col, ci = ci0 + cil;
+        if (ci < Cin && co < Cout) {
+            float v[N];
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = tile[cil + e][col];
+            Vec<T>::store(dstf + (long)co * Cin + ci, v);
+        }
+    }
+    T* dstd = packed + j.wd + (long)(8 - tap) * Cin * Cout;      // data-gradient copy: 180-degree rotated taps, rows of the tile
+#pragma unroll
+    for (int pass = 0; pass < 64 / RPP; ++pass) {
+        const int row = threadIdx.x / GPR + pass * RPP, col = (threadIdx.x % GPR) * N;
+        const int ci = ci0 + row, co = co0 + col;
+        if (ci < Cin && co < Cout) {
+            float v[N];
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = tile[row][col + e];
+            Vec<T>::store(dstd + (long)ci * Cout + co, v);
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void adam_pack_upconv_tile(const PackJob& j, int t, float* __restrict__ params,
+                                                      const float* __restrict__ grads, float* __restrict__ am,
+                                                      float* __restrict__ av, T* packed, float (*tile64)[65], float alpha,
+                                                      float b1, float b2, float eps) {
+    constexpr int N = Vec<T>::N;
+    float (*tile)[32][33] = reinterpret_cast<float (*)[32][33]>(&tile64[0][0]);       // [4 taps][32 ci][33] (the kernel's LDS array is sized for it)
+    const int Cin = j.Cin, Cout = j.Cout;
+    const int tco = (Cout + 31) / 32;
+    const int ci0 = (t / tco) * 32, co0 = (t % tco) * 32;
+    const long per_tap = (long)Cin * Cout;
+    {
+        const int cil = threadIdx.x >> 3, tx4 = (threadIdx.x & 7) * 4;
+        const int ci = ci0 + cil, co = co0 + tx4;
+        const bool in = ci < Cin && co < Cout;
+        const long o0 = j.w + (long)(ci < Cin ? ci : Cin - 1) * Cout + (co < Cout ? co : Cout - 4);
+        float4 g4[4], m4[4], v4[4], p4[4];
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            const long o = o0 + tp * per_tap;
+            g4[tp] = *reinterpret_cast<const float4*>(grads + o); m4[tp] = *reinterpret_cast<const float4*>(am + o);
+            v4[tp] = *reinterpret_cast<const float4*>(av + o); p4[tp] = *reinterpret_cast<const float4*>(params + o);
+        }
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            adam_update(g4[tp].x, m4[tp].x, v4[tp].x, p4[tp].x, alpha, b1, b2, eps);
+            adam_update(g4[tp].y, m4[tp].y, v4[tp].y, p4[tp].y, alpha, b1, b2, eps);
+            adam_update(g4[tp].z, m4[tp].z, v4[tp].z, p4[tp].z, alpha, b1, b2, eps);
+            adam_update(g4[tp].w, m4[tp].w, v4[tp].w, p4[tp].w, alpha, b1, b2, eps);
+            const long o = o0 + tp * per_tap;
+            if (in) {
+                *reinterpret_cast<float4*>(am + o) = m4[tp]; *reinterpret_cast<float4*>(av + o) = v4[tp];
+                *reinterpret_cast<float4*>(params + o) = p4[tp];
+            }
+            const float4 q = in ? p4[tp] : make_float4(0.f, 0.f, 0.f, 0.f);
+            tile[tp][cil][tx4] = q.x; tile[tp][cil][tx4 + 1] = q.y; tile[tp][cil][tx4 + 2] = q.z; tile[tp][cil][tx4 + 3] = q.w;
+        }
+    }
+    __syncthreads();
+    constexpr int GPR = 32 / N;                                  // 16-byte groups per 32-element row
+    // forward copy [tap][co][ci]
+    for (int idx = threadIdx.x; idx < 4 * 32 * GPR; idx += 256) {
+        const int tp = idx / (32 * GPR), rem = idx % (32 * GPR);
+        const int col = rem / GPR, cil = (rem % GPR) * N;
+        const int co = co0 + col, ci = ci0 + cil;
+        if (ci < Cin && co < Cout) {
+            float v[N];
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = tile[tp][cil + e][col];
+            Vec<T>::store(packed + j.wf + tp * per_tap + (long)co * Cin + ci, v);
+        }
+    }
+    // data-gradient copy [tap'][ci][co], tap' = (dy+1)*3 + (dx+1): S(-1) = {1}, S(0) = {0, 1}, S(1) = {0} per axis
+    // (same summation order as pack_dgrad_chunk: ky outer, kx inner)
+    for (int idx = threadIdx.x; idx < 9 * 32 * GPR; idx += 256) {
+        const int tp = idx / (32 * GPR), rem = idx % (32 * GPR);
+        const int row = rem / GPR, col = (rem % GPR) * N;
+        const int ci = ci0 + row, co = co0 + col;
+        if (ci < Cin && co < Cout) {
+            const int dy = tp / 3 - 1, dx = tp % 3 - 1;
+            float v[N];
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = 0.f;
+            for (int ky = 0; ky < 2; ++ky) {
+                if ((dy == -1 && ky != 1) || (dy == 1 && ky != 0)) continue;
+                for (int kx = 0; kx < 2; ++kx) {
+                    if ((dx == -1 && kx != 1) || (dx == 1 && kx != 0)) continue;
+#pragma unroll
+                    for (int e = 0; e < N; ++e) v[e] += tile[ky * 2 + kx][row][col + e];
+                }
+            }
+            Vec<T>::store(packed + j.wd + tp * per_tap + (long)ci * Cout + co, v);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void adam_pack_all_kernel(AdamPackTable tab, float* __restrict__ params,
+                                                            const float* __restrict__ grads, float* __restrict__ am,
+                                                            float* __restrict__ av, T* packed, const long long* __restrict__ step,
+                                                            double lr, double b1d, double b2d, float alpha_host, float eps) {
+    __shared__ float tile_raw[4 * 32 * 33];                      // >= 64 x 65: both tile views live here
+    float (*tile)[65] = reinterpret_cast<float (*)[65]>(tile_raw);
+    const float alpha = step ? adam_alpha_dev(step, lr, b1d, b2d) : alpha_host;
+    const float b1 = (float)b1d, b2 = (float)b2d;
+    const int u0 = (int)blockIdx.x;
+    if (u0 >= tab.plain_begin) {                                 // biases, BatchNorm parameters, 1x1 head
+        int ri = 0;
+        while (ri + 1 < tab.nranges && u0 >= tab.range[ri + 1].unit_begin) ++ri;
+        const AdamRange& r = tab.range[ri];
+        const long e = (long)(u0 - r.unit_begin) * 1024 + threadIdx.x * 4;
+        if (e >= r.n) return;
+        const long o = r.off + e;
+        if (e + 4 <= r.n && (o & 3) == 0) {
+            float4 g4 = *reinterpret_cast<const float4*>(grads + o), m4 = *reinterpret_cast<float4*>(am + o),
+                   v4 = *reinterpret_cast<float4*>(av + o), p4 = *reinterpret_cast<float4*>(params + o);
+            adam_update(g4.x, m4.x, v4.x, p4.x, alpha, b1, b2, eps); adam_update(g4.y, m4.y, v4.y, p4.y, alpha, b1, b2, eps);
+            adam_update(g4.z, m4.z, v4.z, p4.z, alpha, b1, b2, eps); adam_update(g4.w, m4.w, v4.w, p4.w, alpha, b1, b2, eps);
+            *reinterpret_cast<float4*>(am + o) = m4; *reinterpret_cast<float4*>(av + o) = v4; *reinterpret_cast<float4*>(params + o) = p4;
+        } else {
+            for (int i = 0; i < 4 && e + i < r.n; ++i) {
+                float mm = am[o + i], vv = av[o + i], pp = params[o + i];
+                adam_update(grads[o + i], mm, vv, pp, alpha, b1, b2, eps);
+                am[o + i] = mm; av[o + i] = vv; params[o + i] = pp;
+            }
+        }
+        return;
+    }
+    int ji = 0;
+    while (ji + 1 < tab.njobs && u0 >= tab.job[ji + 1].unit_begin) ++ji;
+    const PackJob& j = tab.job[ji];
+    const int u = u0 - j.unit_begin;
+    if (j.mode == UPCONV2) adam_pack_upconv_tile<T>(j, u, params, grads, am, av, packed, tile, alpha, b1, b2, eps);
+    else adam_pack_conv3_tile<T>(j, u, params, grads, am, av, packed, tile, alpha, b1, b2, eps);
+}
+
+__global__ void incr_step_kernel(long long* step);
+
+// jobs: the 3x3 / 2x2 conv kernels (PackTable fields w, wf, wd, mode, Cin, Cout set); n_params = length of the flat buffers.
+int launch_adam_pack_all(int dtype, PackTable& jobs, float* params, const float* grads, float* am, float* av, long n_params,
+                         void* packed, long long* step, long long t_host, double lr, double b1, double b2, float eps,
+                         hipStream_t st) {
+    AdamPackTable tab; tab.njobs = jobs.njobs; tab.nranges = 0; tab._pad = 0;
+    int units = 0;
+    for (int i = 0; i < jobs.njobs; ++i) {
+        PackJob& j = jobs.job[i];
+        if (i > 0 && jobs.job[i - 1].w > j.w) return fail(MPU_EINVAL, "%s", "adam_pack: jobs must be ordered by parameter offset");
+        j.unit_begin = units;
+        j.fwd_units = j.mode == UPCONV2 ? cdiv(j.Cin, 32) * cdiv(j.Cout, 32) : 9 * cdiv(j.Cin, 64) * cdiv(j.Cout, 64);
+        units += j.fwd_units;
+        tab.job[i] = j;
+    }
+    tab.plain_begin = units;
+    long cur = 0;                                                // the complement of the packed kernels inside [0, n_params)
+    for (int i = 0; i <= jobs.njobs; ++i) {
+        const long lo = i < jobs.njobs ? jobs.job[i].w : n_params;
+        if (lo > cur) {
+            if (tab.nranges >= ADAM_MAX_RANGES) return fail(MPU_EINVAL, "%s", "adam_pack: too many parameter ranges");
+            AdamRange& r = tab.range[tab.nranges++];
+            r.off = cur; r.n = lo - cur; r.unit_begin = units; r._pad = 0;
+            units += (int)cdiv(r.n, 1024L);
+        }
+        if (i < jobs.njobs) {
+            const PackJob& j = jobs.job[i];
+            cur = j.w + (long)(j.mode == UPCONV2 ? 4 : 9) * j.Cin * j.Cout;
+        }
+    }
+    if (units == 0) return MPU_OK;
+    float alpha_host = 0.f;
+    if (!step) alpha_host = (float)(lr * std::sqrt(1.0 - std::pow(b2, (double)t_host)) / (1.0 - std::pow(b1, (double)t_host)));
+    if (dtype == MPU_BF16)
+        adam_pack_all_kernel<bf16_t><<<units, 256, 0, st>>>(tab, params, grads, am, av, (bf16_t*)packed, step, lr, b1, b2, alpha_host, eps);
+    else
+        adam_pack_all_kernel<float><<<units, 256, 0, st>>>(tab, params, grads, am, av, (float*)packed, step, lr, b1, b2, alpha_host, eps);
+    if (step) incr_step_kernel<<<1, 1, 0, st>>>(step);
+    return launch_ok();
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long n, float alpha, float b1, float b2, float eps) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const float gg = g[e];
-        const float mm = m[e] + (gg - m[e]) * (1.f - b1);
-        const float vv = v[e] + (gg * gg - v[e]) * (1.f - b2);
-        m[e] = mm; v[e] = vv;
-        p[e] = p[e] - (mm * alpha) / (sqrtf(vv) + eps);
+        float mm = m[e], vv = v[e], pp = p[e];
+        adam_update(g[e], mm, vv, pp, alpha, b1, b2, eps);
+        m[e] = mm; v[e] = vv; p[e] = pp;
     }
 }
 // graph-replayable variant: the 1-based step count lives in device memory (a captured launch cannot take a
@@ -1191,15 +1448,12 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                 float* __restrict__ v, long n, const long long* __restrict__ step, double lr,
                                 double b1d, double b2d, float eps) {
-    const double t = (double)(*step + 1);
-    const float alpha = (float)(lr * sqrt(1.0 - pow(b2d, t)) / (1.0 - pow(b1d, t)));
+    const float alpha = adam_alpha_dev(step, lr, b1d, b2d);
     const float b1 = (float)b1d, b2 = (float)b2d;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const float gg = g[e];
-        const float mm = m[e] + (gg - m[e]) * (1.f - b1);
-        const float vv = v[e] + (gg * gg - v[e]) * (1.f - b2);
-        m[e] = mm; v[e] = vv;
-        p[e] = p[e] - (mm * alpha) / (sqrtf(vv) + eps);
+        float mm = m[e], vv = v[e], pp = p[e];
+        adam_update(g[e], mm, vv, pp, alpha, b1, b2, eps);
+        m[e] = mm; v[e] = vv; p[e] = pp;
     }
 }
 __global__ void incr_step_kernel(long long* step) { *step += 1; }

@@ -65,23 +65,24 @@ constexpr int TAPS_SMEM = XCH_A + XCH_B > 2 * GROUP_LDS ? XCH_A + XCH_B : 2 * GR
 // MODE CONV3: nine taps, X rows y-1..y+1 at full resolution. MODE UPCONV2 (nearest-upsample x2 + 2x2 conv): four
 // taps; staged "X row r" is the low-resolution row (y0 + r) >> 1 (each low-res row is staged for both upsampled rows
 // it feeds), 17 low-res pixels wide, and tap (ky, kx) reads staged row t + ky at pixel (px + kx) >> 1.
-// The body handles the taps [T0, T1) of one (strip pair, channel tile): all of them, or -- TapsPlan.split -- one half
-// (the two halves are neighbouring workgroups on one XCD: they stage the same X / dZ rows, the second one from L2).
-// Splitting the taps halves the workgroup's share of the fp32 partial copy, and with the workgroup count kept at ~one
-// per CU every workgroup covers twice the pixels: half as many partial copies, half the partial write + re-read.
+// The body handles the taps [T0, T1) of one (strip pair, channel tile) -- all of them in every instantiation in use.
+// (Round 3, s_memtime stamps inside the loop: a K step takes ~2300 cycles against ~1260 of MFMA issue for the two waves
+// of a SIMD; the counted vmcnt wait costs < 100 of them and a ring one step deeper changes nothing -- the loop is
+// bound by MFMA issue + the LDS transpose reads in front of them, not by the L2 -> LDS latency.)
 template <int MODE, int T0, int T1>
 __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPlan& p, unsigned char* smem_all,
                                                 const int tile, const int pair) {
     constexpr int NT = T1 - T0, KW = MODE == UPCONV2 ? 2 : 3;
     constexpr int NTALL = MODE == UPCONV2 ? 4 : 9;
+    constexpr int NXRT = NXR, NZRT = NZR, DIST = 2;              // request distance (steps)
     constexpr int NXP = MODE == UPCONV2 ? 3 : 5;                 // DMA pieces (8 pixels) per staged X row
     constexpr unsigned OOB = 0xfffffff0u;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave8 >> 2, wave = wave8 & 3;
     // dev aid (MPU_STAMPS=1): phase boundaries of every 8th workgroup, wave 0
-    unsigned long long* stamps = (a.dbg_buf && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64 && tid == 0)
-                                     ? a.dbg_buf + (blockIdx.x >> 3) * 8 : nullptr;
+    unsigned long long* stamps = (a.dbg_buf && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 32 && tid == 0)
+                                     ? a.dbg_buf + (blockIdx.x >> 3) * 16 : nullptr;
     if (stamps) stamps[0] = __builtin_amdgcn_s_memtime();
     unsigned char* smem = smem_all + grp * GROUP_LDS;
     const int H = a.Ho, W = a.Wo;
@@ -136,7 +137,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
         int iy; bool rowok;
         if (MODE == UPCONV2) { const int uy = y0 + r; rowok = uy < H; iy = uy >> 1; }
         else { iy = y0 - 1 + r; rowok = (unsigned)iy < (unsigned)H; }
-        const unsigned base = lds0 + (r % NXR) * XROWB;
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (r % NXRT) * XROWB);
         const unsigned rowoff = (unsigned)(((b * Hi + iy) * Wi) * Cs * 2);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -149,18 +150,24 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
     };
     auto issue_z = [&](int t) {                                  // dZ row of step t = image row y0 + t
         const int y = y0 + t;
-        const unsigned base = ldsZ + (t % NZR) * ZROWB;
+        const unsigned base = __builtin_amdgcn_readfirstlane(ldsZ + (t % NZRT) * ZROWB);
         const unsigned rowoff = (unsigned)(((b * H + y) * W) * a.Cout * 2);
         const unsigned off = (y < H && zlane != OOB) ? rowoff + zlane : OOB;
         t_dma16(rsz, off, base + wave * 1024);
     };
     // DMAs per wave in one step group (X row pieces wave, wave+4, ... < NXP, plus one dZ piece): wait until only the
     // group issued last is outstanding
-    auto wait_keep_one_group = [&]() {
-        const int nx = (NXP - wave + 3) / 4;                     // CONV3: 2,1,1,1   UPCONV2: 1,1,1,0
-        if (nx == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else if (nx == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    // a step group = this wave's X row pieces (wave, wave+4, ... < NXP) plus one dZ piece; wait until only the `keep`
+    // groups issued last are outstanding
+    auto wait_keep_groups = [&](int keep) {
+        const int per = (NXP - wave + 3) / 4 + 1;                // CONV3: 3,2,2,2   UPCONV2: 2,2,2,1
+        const int n = per * keep;
+        if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
     // ---- fragment addressing (16x16x32: lane group g = lane>>4 holds k = 8g..8g+7; i = lane&15 the row/col) ----
@@ -199,8 +206,8 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
         issue_x(0); issue_x(1); issue_x(2); issue_z(0);
         issue_x(3); issue_z(1);
     }
-    // wait for the first group (rows 0..2 + dZ 0); the second may still be in flight
-    wait_keep_one_group();
+    // wait for the first group (rows 0..2 + dZ 0); the later ones may still be in flight
+    wait_keep_groups(DIST - 1);
     __builtin_amdgcn_s_barrier();
     if (stamps) stamps[1] = __builtin_amdgcn_s_memtime();
     for (int t = 0; t < nsteps_wg; ++t) {
@@ -209,14 +216,14 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
             __builtin_amdgcn_s_barrier();
             continue;
         }
-        if (t + 2 < nsteps) { issue_x(t + 4); issue_z(t + 2); }
-        const unsigned char* zb = smem + NXR * XROWB + (t % NZR) * ZROWB;
+        if (t + DIST < nsteps) { issue_x(t + DIST + 2); issue_z(t + DIST); }
+        const unsigned char* zb = smem + NXR * XROWB + (t % NZRT) * ZROWB;
         s16x8 bz[4];
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) bz[cb] = t_frag(zb + offB[cb][0], zb + offB[cb][1]);
         const unsigned char* xr[KW];
 #pragma unroll
-        for (int ky = 0; ky < KW; ++ky) xr[ky] = smem + ((t + ky) % NXR) * XROWB;
+        for (int ky = 0; ky < KW; ++ky) xr[ky] = smem + ((t + ky) % NXRT) * XROWB;
         s16x8 af = t_frag(xr[T0 / KW] + offA[T0 % KW][0], xr[T0 / KW] + offA[T0 % KW][1]);
 #pragma unroll
         for (int tp = 0; tp < NT; ++tp) {
@@ -235,11 +242,18 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
             if (wave == 1) bw = bz[1]; else if (wave == 2) bw = bz[2]; else if (wave == 3) bw = bz[3];
             accdb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bw, accdb, 0, 0, 0);
         }
-        // group t+1 has landed (group t+2, just issued, may be in flight); all waves are done with step t's rows
-        if (t + 2 < nsteps) wait_keep_one_group();
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (stamps && (t == 4 || t == 5)) stamps[8 + 4 * (t - 4)] = __builtin_amdgcn_s_memtime();
+        // group t+1 has landed (the DIST-1 groups behind it may be in flight); all waves are done with step t's rows
+        {
+            int younger = nsteps - 2 - t;                        // groups t+2 .. min(t+DIST, nsteps-1) are outstanding behind group t+1
+            if (younger > DIST - 1) younger = DIST - 1;
+            wait_keep_groups(younger > 0 ? younger : 0);
+        }
+        if (stamps && (t == 4 || t == 5)) stamps[9 + 4 * (t - 4)] = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (stamps && (t == 4 || t == 5)) stamps[10 + 4 * (t - 4)] = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();
+        if (stamps && (t == 4 || t == 5)) stamps[11 + 4 * (t - 4)] = __builtin_amdgcn_s_memtime();
     }
 
     if (stamps) stamps[2] = __builtin_amdgcn_s_memtime();
@@ -316,19 +330,17 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
 
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPlan p) {
-    constexpr int NTALL = MODE == UPCONV2 ? 4 : 9, NH = (NTALL + 1) / 2;
+    constexpr int NTALL = MODE == UPCONV2 ? 4 : 9;
     extern __shared__ __attribute__((aligned(128))) unsigned char smem_all[];
     const int Cin = a.C0 + a.C1;
     const int ntile = ((a.Cout + 63) / 64) * ((Cin + 63) / 64);
     // XCD-aware decode: the tiles (and tap halves) of one strip pair run on one XCD (shared X / dZ in its L2)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int npairs = (p.nstrips + 1) / 2;
-    const int nsub = p.split ? ntile * 2 : ntile;
+    const int nsub = ntile;
     const int sub = slot % nsub, pair = (slot / nsub) * 8 + xcd;
     if (pair >= npairs) return;
-    if (!p.split) wgrad_taps_body<MODE, 0, NTALL>(a, p, smem_all, sub, pair);
-    else if ((sub & 1) == 0) wgrad_taps_body<MODE, 0, NH>(a, p, smem_all, sub >> 1, pair);
-    else wgrad_taps_body<MODE, NH, NTALL>(a, p, smem_all, sub >> 1, pair);
+    wgrad_taps_body<MODE, 0, NTALL>(a, p, smem_all, sub, pair);
 }
 
 }  // namespace
@@ -351,11 +363,9 @@ TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C
     if ((long)Cin * Cout > max_cico) return p;
     const long M = (long)B * H * W;
     if (M * (C0 > C1 ? C0 : C1) * 2L >= (1L << 31) || M * Cout * 2L >= (1L << 31)) return p;
-    static int split_on = -1;
-    // measured on configs[1] (r2k): the split halves the partial traffic but doubles the K steps of every workgroup and
-    // comes out 8-25 % SLOWER per layer (3.16 vs 3.12 ms per train step): off unless MPU_WGRAD_TAPS_SPLIT=1
-    if (split_on < 0) { const char* e = getenv("MPU_WGRAD_TAPS_SPLIT"); split_on = (e && e[0] == '1') ? 1 : 0; }
-    p.split = split_on;
+    // (splitting the nine taps of a strip pair over two workgroups halves the partial traffic but doubles the K steps of
+    // every workgroup: measured 8-25 % slower per layer on configs[1], round 2; removed)
+    p.split = 0;
     const int ntile = cdiv(Cin, 64) * cdiv(Cout, 64) * (p.split ? 2 : 1);       // workgroups per strip pair
     const int sx = cdiv(W, 32);
     int best = 0; long bestd = 1L << 60;

@@ -9,6 +9,7 @@ C ABI: mpu_unet_forward / mpu_unet_backward / mpu_adam_step /
 mpu_unet_pack_weights. There is no eager / CPU fallback.
 """
 import ctypes as C
+import os
 import numpy as np
 import torch
 
@@ -467,11 +468,19 @@ class UNet:
                   float(self.l2_reg), _lib.ptr(self._l2_ws), _lib.ptr(self.reg_loss) if want_loss else None,
                   _lib.stream_ptr())
 
-    def apply_gradients(self):
-        """Keras Adam on the flat parameter buffer, then refresh the packed MFMA operands."""
+    def apply_gradients(self, fused=True):
+        """Keras Adam on the flat parameter buffer + refresh of the packed MFMA operands: one launch
+        (mpu_unet_adam_pack); fused=False runs the two separate passes (mpu_adam_step, mpu_unet_pack_weights;
+        bit-identical, kept for the equality test)."""
         self._ensure_adam()
         self.iterations += 1
         k = self.optimizer_kwargs
+        if fused:
+            _lib.call("mpu_unet_adam_pack", self._h, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self._adam_m),
+                      _lib.ptr(self._adam_v), self.iterations, None, float(k["lr"]), float(k["beta_1"]),
+                      float(k["beta_2"]), float(k["epsilon"]), _lib.ptr(self.packed), _lib.stream_ptr())
+            self._infer_dirty = True
+            return
         _lib.call("mpu_adam_step", _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self._adam_m),
                   _lib.ptr(self._adam_v), self.params.numel(), self.iterations, float(k["lr"]),
                   float(k["beta_1"]), float(k["beta_2"]), float(k["epsilon"]), _lib.stream_ptr())
@@ -496,10 +505,16 @@ class UNet:
         def body():
             self.forward_backward(x, y, sample_weight, want_loss=False)
             self._add_l2()
-            _lib.call("mpu_adam_step_device_counter", _lib.ptr(self.params), _lib.ptr(self.grads),
-                      _lib.ptr(self._adam_m), _lib.ptr(self._adam_v), self.params.numel(), _lib.ptr(step_dev),
-                      float(k["lr"]), float(k["beta_1"]), float(k["beta_2"]), float(k["epsilon"]), _lib.stream_ptr())
-            self._repack()
+            if os.environ.get("MPU_FUSED_ADAM") == "0":         # A/B: the two separate passes
+                _lib.call("mpu_adam_step_device_counter", _lib.ptr(self.params), _lib.ptr(self.grads),
+                          _lib.ptr(self._adam_m), _lib.ptr(self._adam_v), self.params.numel(), _lib.ptr(step_dev),
+                          float(k["lr"]), float(k["beta_1"]), float(k["beta_2"]), float(k["epsilon"]), _lib.stream_ptr())
+                self._repack()
+                return
+            _lib.call("mpu_unet_adam_pack", self._h, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self._adam_m),
+                      _lib.ptr(self._adam_v), 0, _lib.ptr(step_dev), float(k["lr"]), float(k["beta_1"]),
+                      float(k["beta_2"]), float(k["epsilon"]), _lib.ptr(self.packed), _lib.stream_ptr())
+            self._infer_dirty = True
 
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())

@@ -343,3 +343,75 @@ def test_first_layer_wgrad_scratch_does_not_overrun_the_next_layer(n_channels, c
         floor = rel(r32["grads"][name], g64)                   # two evaluations of the matched model (f32 / f64 arithmetic)
         # an overrun replaces ~4 % of encoder_L0_conv2's partial sums with foreign data: O(1) relative error there
         assert e <= max(5e-2, 2 * floor), (name, e, floor)
+
+
+def test_configs0_single_slice_f32_one_train_step_vs_f64_oracle():
+    """BASELINE configs[0], literally: ONE 128x128x1 slice, 3 classes, through the depth-4 / 64-filter network, one
+    train step (forward with batch statistics, sparse CE on clipped probabilities, backward, Keras Adam, BN moving
+    statistics) -- the reference's `mp train --cpu` plumbing case, here in the exact-f32 MFMA mode against the f64
+    oracle: probabilities / loss / every gradient tensor / updated weights (tests/test_gpu_unet.py has the bounds).
+    With a batch of ONE slice the batch-statistics BatchNorm of the bottom level normalises over 64 samples per
+    channel and the graph is badly conditioned: a plain torch-f32 evaluation is already 1.8 % away from f64 in the
+    deep kernels' gradients; the gradients are held to 8x that measured floor here (3x in the B >= 2 cases), up to 3 %
+    of a tensor's elements with a ~0 gradient may take their +-lr Adam step the other way (1 % elsewhere), the forward
+    side keeps the usual bounds."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_unet_tests", os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                              "test_gpu_unet.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.test_f32_train_step_vs_oracle((3, 1, 4, 1, 128, 128, 1), noise_mult=8, flip_frac=3e-2)
+
+
+def test_default_yaml_network_cf2_bf16_inference_step_and_dispatch():
+    """The network a default `mp init_project` builds (complexity_factor: 2 => 90/181/362/724/1448 filters,
+    mpunet/bin/defaults/MultiPlanar/train_hparams.yaml:82) at 128x128, B = 8, bf16: odd channel counts are
+    padded to multiples of 8 in storage (96/184/368/728/1448), every conv runs with channel tails. Inference
+    probabilities against the matched-rounding model (well conditioned), a train step's head-side tensors and the
+    absence of gradient leakage into the channel padding, the kernel schedules logged."""
+    from multiplanarunet_amd.unet import UNet
+    from oracle import unet_ref as U
+    B, K, D, cf = 8, 3, 4, 2
+    w = U.init_weights(K, 1, D, cf, seed=51)
+    rng = np.random.RandomState(52)
+    for k in w:
+        v = k.split("/")[1]
+        if v == "bias":
+            w[k] = rng.uniform(-.1, .1, w[k].shape).astype(np.float32)
+        elif v == "gamma":
+            w[k] = rng.uniform(.5, 1.5, w[k].shape).astype(np.float32)
+        elif v in ("beta", "moving_mean"):
+            w[k] = rng.uniform(-.3, .3, w[k].shape).astype(np.float32)
+        elif v == "moving_variance":
+            w[k] = rng.uniform(.5, 2., w[k].shape).astype(np.float32)
+    assert w["encoder_L0_conv1/kernel"].shape[-1] == 90 and w["bottom_conv2/kernel"].shape[-1] == 1448
+    x = rng.randn(B, 128, 128, 1).astype(np.float32)
+    y = rng.randint(0, K, (B, 128 * 128, 1)).astype(np.uint8)
+    m = UNet(n_classes=K, dim=128, n_channels=1, depth=D, complexity_factor=cf, dtype="bf16", logger=quiet)
+    m.set_weights_dict(w)
+    xi = x[:2]
+    ref = U.bf16_matched_forward(w, xi, depth=D, out_activation="softmax")
+    got, log = _schedule_log(lambda: m.predict(xi, batch_size=2))
+    d = np.abs(got - ref)
+    scheds = lambda ls: {k: sum(1 for l in ls if l[1] == k) for k in sorted({l[1] for l in ls})}
+    print("cf=2 bf16 inference probs vs matched model: max %.3g mean %.3g; schedules %s"
+          % (d.max(), d.mean(), scheds([l for l in log if l[0] == "conv"])))
+    assert d.max() <= 1.5e-2 and d.mean() <= 3e-3
+    assert "regs" not in scheds([l for l in log if l[0] == "conv"])
+    # train step: finite, loss of the right size, head-side tensors tight, no gradient in the padding
+    m.flatten_output = True
+    (probs, loss), log = _schedule_log(lambda: m.forward_backward(x, y, np.ones(B, np.float32)))
+    print("cf=2 bf16 train step schedules: conv %s wgrad %s" % (scheds([l for l in log if l[0] == "conv"]),
+                                                               scheds([l for l in log if l[0] == "wgrad"])))
+    g = m.grads.cpu().numpy()
+    assert np.isfinite(g).all() and torch.isfinite(loss).all()
+    r32 = U.bf16_matched_step(w, x, y, np.ones(B, np.float32), depth=D, dtype=torch.float32)
+    rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+    for name in ("conv2d/kernel", "conv2d/bias"):
+        assert rel(_grad(m, g, name).astype(np.float64), r32["grads"][name]) <= 3e-2, name
+    for name, (kind, off, ps, ls) in m._tensors.items():
+        if kind != 0 or tuple(ps) == tuple(ls):
+            continue
+        a = g[off:off + int(np.prod(ps))].reshape(ps)
+        assert np.count_nonzero(a) == np.count_nonzero(m._from_stored(name, a, ps, ls)), "gradient leaked into padding of " + name
+    assert abs(float(loss.mean().item()) - float(r32["loss"].mean())) <= 3e-2 * abs(float(r32["loss"].mean()))

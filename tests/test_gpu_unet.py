@@ -66,7 +66,7 @@ def test_f32_forward_logits_vs_oracle(cfg, training):
 
 
 @pytest.mark.parametrize("cfg", CFGS)
-def test_f32_train_step_vs_oracle(cfg):
+def test_f32_train_step_vs_oracle(cfg, noise_mult=3, flip_frac=1e-2):
     from multiplanarunet_amd.unet import UNet
     from oracle import unet_ref as U
     K, C, D, cf, H, W, B = cfg
@@ -97,7 +97,7 @@ def test_f32_train_step_vs_oracle(cfg):
         e = np.abs(a - gr).max() / scale
         noise = np.abs(ref32["grads"][name] - gr).max() / scale
         worst = max(worst, e)
-        assert e <= max(2e-3, 3 * noise), (name, e, noise)
+        assert e <= max(2e-3, noise_mult * noise), (name, e, noise)
     # Adam + BN moving statistics
     m.apply_gradients()
     new = m.get_weights_dict()
@@ -108,7 +108,7 @@ def test_f32_train_step_vs_oracle(cfg):
     def close(name, got, val, steps):
         d = np.abs(got - val)
         bad = d > 2e-6 + 1e-5 * np.abs(val).max()
-        allowed = max(4, (1e-2 if steps == 1 else 3e-2) * bad.size)   # ~0-gradient elements: Adam moves them by +-lr on noise
+        allowed = max(4, (flip_frac if steps == 1 else 3e-2) * bad.size)   # ~0-gradient elements: Adam moves them by +-lr on noise
         assert bad.sum() <= allowed and d.max() <= 2.2 * lr * steps + 1e-5 * np.abs(val).max(), \
             (name, bad.sum(), bad.size, d.max())
     for name, val in ref["weights"].items():
@@ -201,6 +201,29 @@ def test_graphed_train_step_matches_eager():
     assert b.iterations == a.iterations == 4
     assert torch.equal(a.params, b.params) and torch.equal(a.bn_state, b.bn_state)
     assert torch.equal(a.predict_on_batch(x), b.predict_on_batch(x))
+
+
+@pytest.mark.parametrize("dtype,cf,C", [("bf16", 1, 1), ("bf16", 2, 2), ("f32", 0.25, 1)])
+def test_fused_adam_pack_equals_adam_then_pack(dtype, cf, C):
+    """mpu_unet_adam_pack (one launch: Adam + both packed operand copies) == mpu_adam_step + mpu_unet_pack_weights,
+    bit for bit: parameters, Adam moments and every byte of the packed buffer (3x3 rotated-tap and 2x2 combined-tap
+    data-gradient copies included), over three steps; odd filter counts (cf=2: 90/181/...) exercise the channel tails."""
+    from multiplanarunet_amd.unet import UNet
+    rng = np.random.RandomState(8)
+    B, H, D = 2, 32, 2
+    x = torch.tensor(rng.randn(B, H, H, C).astype(np.float32), device="cuda")
+    y = torch.tensor(rng.randint(0, 3, (B, H * H, 1)).astype(np.uint8), device="cuda")
+    a = UNet(n_classes=3, dim=H, n_channels=C, depth=D, complexity_factor=cf, dtype=dtype, logger=quiet, seed=0)
+    b = UNet(n_classes=3, dim=H, n_channels=C, depth=D, complexity_factor=cf, dtype=dtype, logger=quiet, seed=0)
+    a.compile("Adam", "SparseCategoricalCrossentropy", optimizer_kwargs=dict(lr=1e-3))
+    b.compile("Adam", "SparseCategoricalCrossentropy", optimizer_kwargs=dict(lr=1e-3))
+    for _ in range(3):
+        a.forward_backward(x, y, None, want_loss=False)
+        a.apply_gradients(fused=True)
+        b.forward_backward(x, y, None, want_loss=False)
+        b.apply_gradients(fused=False)
+        assert torch.equal(a.params, b.params) and torch.equal(a._adam_m, b._adam_m) and torch.equal(a._adam_v, b._adam_v)
+        assert torch.equal(a.packed.view(torch.uint8), b.packed.view(torch.uint8))
 
 
 def test_backward_ready_events_same_gradients():

@@ -277,3 +277,123 @@ def test_encoder_block_backward_independent_numpy_derivation():
     for name, got, ref in (("gamma", dgam, tg.grad), ("beta", dbet, tbt.grad), ("k2", dk2, tk2.grad), ("b2", db2, tb2.grad),
                            ("k1", dk1, tk1.grad), ("b1", db1, tb1.grad), ("x", dx, tx.grad)):
         np.testing.assert_allclose(got, ref.numpy(), rtol=1e-9, atol=1e-10, err_msg=name)
+
+
+def test_up_block_backward_independent_numpy_derivation():
+    """An independent BACKWARD of one whole up block -- UpSampling2D(2, nearest) -> 2x2 conv with TensorFlow's SAME
+    padding for even kernels (0 before, 1 after) + ReLU -> BatchNorm(train) -> concat [skip | up] -> 3x3 conv + ReLU ->
+    3x3 conv + ReLU -> BatchNorm(train) (mpunet/models/unet.py:148-180) -- written out with NumPy loops from the
+    textbook formulas: the 2x2 conv gradient as explicit correlations over the asymmetrically padded window, the
+    gradient of the nearest up-sampling as the sum over each 2x2 block, the concat gradient split into its skip and up
+    halves. Checked against autograd through the oracle's own layer functions (the encoder-block KAT
+    above covered the contracting path only)."""
+    import torch.nn.functional as F
+    rng = np.random.RandomState(21)
+    B, h, w_, Cp, C = 2, 3, 2, 3, 2                 # low-res input [B, h, w, Cp]; the block works at [2h, 2w] with C filters
+    H, W = 2 * h, 2 * w_
+    xlow = rng.randn(B, h, w_, Cp)
+    skip = rng.randn(B, H, W, C)
+    ku = rng.randn(2, 2, Cp, C) * 0.5; bu = rng.randn(C) * 0.2
+    k2 = rng.randn(3, 3, 2 * C, C) * 0.4; b2 = rng.randn(C) * 0.2
+    k3 = rng.randn(3, 3, C, C) * 0.5; b3 = rng.randn(C) * 0.2
+    g1 = rng.uniform(0.5, 1.5, C); g1[0] = -0.6
+    be1 = rng.randn(C) * 0.3
+    g2 = rng.uniform(0.5, 1.5, C); be2 = rng.randn(C) * 0.3
+    R = rng.randn(B, H, W, C)                       # cotangent of the block's output
+    eps = 1e-3
+
+    # ---- oracle side -------------------------------------------------------------------------------------------------
+    t = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    txl, tsk, tku, tbu, tk2, tb2, tk3, tb3, tg1, tbe1, tg2, tbe2 = (t(a) for a in (xlow, skip, ku, bu, k2, b2, k3, b3, g1, be1, g2, be2))
+    p = {"bn1/gamma": tg1, "bn1/beta": tbe1, "bn2/gamma": tg2, "bn2/beta": tbe2}
+    up = F.interpolate(txl.permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
+    u1 = U._conv(up, tku, tbu)
+    n1 = U._bn(u1, p, "bn1", True, None)
+    cat = torch.cat([tsk.permute(0, 3, 1, 2), n1], dim=1)        # skip first (unet.py:163)
+    c2 = U._conv(cat, tk2, tb2)
+    c3 = U._conv(c2, tk3, tb3)
+    n2 = U._bn(c3, p, "bn2", True, None)
+    (n2.permute(0, 2, 3, 1) * torch.tensor(R)).sum().backward()
+
+    # ---- independent side --------------------------------------------------------------------------------------------
+    def conv3_fwd(inp, k, b):
+        out = np.zeros(inp.shape[:3] + (k.shape[3],))
+        for bb in range(B):
+            out[bb] = naive_conv_same(inp[bb], k, b, relu=False)
+        return out
+
+    def conv3_bwd(inp, k, dz):
+        dinp, dk = np.zeros_like(inp), np.zeros_like(k)
+        for bb in range(B):
+            for i in range(H):
+                for j in range(W):
+                    for a in range(3):
+                        for c in range(3):
+                            ii, jj = i + a - 1, j + c - 1
+                            if 0 <= ii < H and 0 <= jj < W:
+                                dk[a, c] += np.outer(inp[bb, ii, jj], dz[bb, i, j])
+                                dinp[bb, ii, jj] += k[a, c] @ dz[bb, i, j]
+        return dinp, dk, dz.sum((0, 1, 2))
+
+    def bn_fwd(a, gam, bet):
+        mean, var = a.mean((0, 1, 2)), a.var((0, 1, 2))
+        invstd = 1.0 / np.sqrt(var + eps)
+        xhat = (a - mean) * invstd
+        return xhat * gam + bet, xhat, invstd
+
+    def bn_bwd(dn, xhat, invstd, gam):
+        N = dn.shape[0] * dn.shape[1] * dn.shape[2]
+        dgam, dbet = (dn * xhat).sum((0, 1, 2)), dn.sum((0, 1, 2))
+        return gam * invstd * (dn - dbet / N - xhat * dgam / N), dgam, dbet
+
+    # forward
+    xup = np.zeros((B, H, W, Cp))
+    for i in range(H):
+        for j in range(W):
+            xup[:, i, j] = xlow[:, i // 2, j // 2]
+    zu = np.zeros((B, H, W, C))                      # 2x2 conv, window rows i..i+1, cols j..j+1, zero beyond the far edge
+    for bb in range(B):
+        for i in range(H):
+            for j in range(W):
+                acc = bu.copy()
+                for a in range(2):
+                    for c in range(2):
+                        if i + a < H and j + c < W:
+                            acc = acc + xup[bb, i + a, j + c] @ ku[a, c]
+                zu[bb, i, j] = acc
+    au = np.maximum(zu, 0)
+    nn1, xh1, is1 = bn_fwd(au, g1, be1)
+    catn = np.concatenate([skip, nn1], -1)
+    z2 = conv3_fwd(catn, k2, b2); a2 = np.maximum(z2, 0)
+    z3 = conv3_fwd(a2, k3, b3); a3 = np.maximum(z3, 0)
+    nn2, xh2, is2 = bn_fwd(a3, g2, be2)
+    np.testing.assert_allclose(nn2, n2.detach().permute(0, 2, 3, 1).numpy(), rtol=1e-10, atol=1e-11)
+
+    # backward
+    da3, dg2, dbe2 = bn_bwd(R, xh2, is2, g2)
+    dz3 = da3 * (z3 > 0)
+    da2, dk3, db3 = conv3_bwd(a2, k3, dz3)
+    dz2 = da2 * (z2 > 0)
+    dcat, dk2, db2 = conv3_bwd(catn, k2, dz2)
+    dskip, dn1 = dcat[..., :C], dcat[..., C:]        # the concat gradient: first C channels to the skip, the rest to the up path
+    dau, dg1, dbe1 = bn_bwd(dn1, xh1, is1, g1)
+    dzu = dau * (zu > 0)
+    dku, dxup = np.zeros_like(ku), np.zeros_like(xup)
+    for bb in range(B):
+        for i in range(H):
+            for j in range(W):
+                for a in range(2):
+                    for c in range(2):
+                        if i + a < H and j + c < W:
+                            dku[a, c] += np.outer(xup[bb, i + a, j + c], dzu[bb, i, j])
+                            dxup[bb, i + a, j + c] += ku[a, c] @ dzu[bb, i, j]
+    dbu = dzu.sum((0, 1, 2))
+    dxlow = np.zeros_like(xlow)                      # nearest up-sampling: every low-res pixel collects its 2x2 block
+    for i in range(H):
+        for j in range(W):
+            dxlow[:, i // 2, j // 2] += dxup[:, i, j]
+
+    for name, got, ref in (("gamma2", dg2, tg2.grad), ("beta2", dbe2, tbe2.grad), ("k3", dk3, tk3.grad), ("b3", db3, tb3.grad),
+                           ("k2", dk2, tk2.grad), ("b2", db2, tb2.grad), ("skip", dskip, tsk.grad), ("gamma1", dg1, tg1.grad),
+                           ("beta1", dbe1, tbe1.grad), ("k_up", dku, tku.grad), ("b_up", dbu, tbu.grad), ("x_low", dxlow, txl.grad)):
+        np.testing.assert_allclose(got, ref.numpy(), rtol=1e-9, atol=1e-10, err_msg=name)
