@@ -1058,8 +1058,14 @@ template <int ROWB> __device__ __forceinline__ int wg_swz16(int row) {   // XOR 
     return ROWB == 256 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2);
 }
 
+template <typename T, int BCI, int BCO> struct WgradGldsCfg {
+    static constexpr int KP = 32, RX = BCI * sizeof(T), RZ = BCO * sizeof(T), STAGE = KP * (RX + RZ), NSTAGE = 3;
+    static constexpr int SMEM = NSTAGE * STAGE;
+};
+
+// one workgroup: bid = its index inside the job's 1-D grid, smem = the kernel's LDS array (WgradGldsCfg::SMEM bytes)
 template <typename T, int MODE, int BCI, int BCO>
-__global__ __launch_bounds__(256, 2) void wgrad_glds_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_glds_body(const WgradArgs& a, const unsigned bid, unsigned char* smem) {
     constexpr int EPC = 16 / sizeof(T);
     constexpr int KP = 32;
     constexpr int RX = BCI * sizeof(T), RZ = BCO * sizeof(T);            // row bytes: 128 or 256
@@ -1071,7 +1077,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_glds_kernel(WgradArgs a) {
     static_assert(NPX >= 1 && NPZ >= 1, "tile too small");
     constexpr int WCI = BCI / 2, WCO = BCO / 2, TI = WCI / 32, TJ = WCO / 32;
     constexpr int KW = GModeTraits<MODE>::KW;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
+    static_assert(NSTAGE * STAGE == WgradGldsCfg<T, BCI, BCO>::SMEM, "LDS size");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1084,7 +1090,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_glds_kernel(WgradArgs a) {
     constexpr int NTAPS_ = GModeTraits<MODE>::NTAPS;
     const int ntile = tiles_co * ((Cin + BCI - 1) / BCI);
     // locality unit = (pixel chunk z, output tile): its taps sit on one XCD, units are dealt round-robin
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = bid & 7, slot = bid >> 3;
     const int tap = slot % NTAPS_, unit = (slot / NTAPS_) * 8 + xcd;
     if (unit >= a.ksplit * ntile) return;
     const int tile = unit % ntile, zsplit = unit / ntile;
@@ -1300,6 +1306,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_glds_kernel(WgradArgs a) {
     }
 }
 
+template <typename T, int MODE, int BCI, int BCO>
+__global__ __launch_bounds__(256, 2) void wgrad_glds_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WgradGldsCfg<T, BCI, BCO>::SMEM];
+    wgrad_glds_body<T, MODE, BCI, BCO>(a, blockIdx.x, smem);
+}
+
+// Every deferred wgrad_glds job (bf16, 128 x 128 channel tiles: the deep levels) of a backward pass in ONE launch
+// (kernels.h: WgradGroup): workgroup -> job by the table's block ranges (multiples of 8: the XCD decode stays aligned).
+struct GldsGroupTable { int njobs, _pad; GldsGroupJob job[GLDS_GROUP_MAX]; };
+__global__ __launch_bounds__(256, 2) void wgrad_glds_group_kernel(GldsGroupTable t) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WgradGldsCfg<bf16_t, 128, 128>::SMEM];
+    int j = 0;
+#pragma unroll 1
+    for (int k = 1; k < t.njobs; ++k) if ((int)blockIdx.x >= t.job[k].blk_begin) j = k;
+    const WgradArgs a = t.job[j].a;
+    const unsigned bid = blockIdx.x - (unsigned)t.job[j].blk_begin;
+    if (t.job[j].mode == UPCONV2) wgrad_glds_body<bf16_t, UPCONV2, 128, 128>(a, bid, smem);
+    else wgrad_glds_body<bf16_t, CONV3, 128, 128>(a, bid, smem);
+}
+
 bool wgrad_glds_supported(int dtype, int mode, const WgradArgs& a) {
     const int esz = dtype == MPU_BF16 ? 2 : 4;
     if (mode != CONV3 && mode != UPCONV2 && mode != CONV1) return false;
@@ -1334,6 +1360,31 @@ static int try_wgrad_glds_mode(const WgradArgs& a, hipStream_t st) {
     }
     int rc = launch_ok();
     return rc ? rc : 1;
+}
+
+// workgroups of a job on the groupable variant (bf16, 3x3 or 2x2, 128 x 128 channel tiles); 0 = some other variant
+long wgrad_glds_grid(int mode, const WgradArgs& a) {
+    if ((mode != CONV3 && mode != UPCONV2) || !wgrad_glds_supported(MPU_BF16, mode, a)) return 0;
+    const int Cin = a.C0 + a.C1;
+    if (!(Cin >= 128 && a.Cout >= 128 && (a.C1 == 0 || a.C0 % 128 == 0))) return 0;
+    const long units = (long)a.ksplit * cdiv(Cin, 128) * cdiv(a.Cout, 128);
+    return 8 * ((units + 7) / 8) * (mode == UPCONV2 ? 4 : 9);
+}
+
+int launch_wgrad_glds_group(int dtype, const GldsGroupJob* jobs, int n, hipStream_t st) {
+    if (n <= 0) return MPU_OK;
+    if (dtype != MPU_BF16 || n > GLDS_GROUP_MAX) return fail(MPU_EINVAL, "%s", "wgrad_glds group: bad job list");
+    GldsGroupTable t; t.njobs = n; t._pad = 0;
+    long grid = 0;
+    for (int k = 0; k < n; ++k) {
+        t.job[k] = jobs[k];
+        t.job[k].blk_begin = (int)grid;
+        const long g = wgrad_glds_grid(jobs[k].mode, jobs[k].a);
+        if (g <= 0) return fail(MPU_EINVAL, "%s", "wgrad_glds group: job is not on the grouped variant");
+        grid += g;
+    }
+    wgrad_glds_group_kernel<<<dim3((unsigned)grid), dim3(256), 0, st>>>(t);
+    return launch_ok();
 }
 
 int try_wgrad_glds(int dtype, int mode, const WgradArgs& a, hipStream_t st) {

@@ -621,6 +621,25 @@ int flush_wgrad_reduces(ReduceQueue& q, hipStream_t st) {
     return launch_ok();
 }
 
+// every recorded weight-gradient kernel: the wgrad_taps jobs as one launch, the wgrad_glds jobs as another
+int flush_wgrad_group(int dtype, WgradGroup& g, hipStream_t st) {
+    int rc = MPU_OK;
+    if (g.ntaps) {
+        if (prof_on()) prof_begin(PROF_WGRAD, g.taps_flops, st);
+        rc = launch_wgrad_taps_group(g.taps, g.ntaps, st);
+        if (prof_on()) prof_end(st);
+        if (sched_log_on()) sched_note("wgrad-group taps jobs=%d", g.ntaps);
+    }
+    if (!rc && g.nglds) {
+        if (prof_on()) prof_begin(PROF_WGRAD, g.glds_flops, st);
+        rc = launch_wgrad_glds_group(dtype, g.glds, g.nglds, st);
+        if (prof_on()) prof_end(st);
+        if (sched_log_on()) sched_note("wgrad-group glds jobs=%d", g.nglds);
+    }
+    g.ntaps = g.nglds = 0; g.taps_flops = g.glds_flops = 0;
+    return rc;
+}
+
 // MPU_CONV_IMPL=regs selects the register-staged kernel of this file; default is the LDS-DMA
 // kernel of conv_glds.hip (same tiling, same results).
 static int conv_impl() {
@@ -750,7 +769,7 @@ long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, i
 }
 
 template <typename T, int MODE>
-static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue* rq) {
+static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue* rq, WgradGroup* grp) {
     const int Cin = a.C0 + a.C1;
     const int dt_ = sizeof(T) == 2 ? MPU_BF16 : MPU_F32;
     if (conv_impl() == 1) {                      // first layer: 1-2 image channels in 8-channel records
@@ -774,16 +793,34 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue
     if (a.ksplit == 1) a.partial = dW;            // single split: the kernel's output IS the weight gradient
     const int ntaps = ModeTraits<MODE>::NTAPS;
     const long n = (long)ntaps * Cin * a.Cout;
-    if (prof_on())
+    const bool will_defer = grp && rq && rq->njobs < REDUCE_MAX_JOBS && conv_impl() == 1 && dt_ == MPU_BF16 &&
+                            ((taps.use && grp->ntaps < TAPS_GROUP_MAX) || (!taps.use && grp->nglds < GLDS_GROUP_MAX && wgrad_glds_grid(MODE, a) > 0));
+    if (prof_on() && !will_defer)
         prof_begin(PROF_WGRAD, a.flops > 0 ? a.flops : 2.0 * a.B * a.Ho * a.Wo * (double)n, st);
     bool big = false;
     int g_ = 0;
-    if (taps.use) { g_ = launch_wgrad_taps(MODE, a, taps, st); if (g_) return g_; g_ = 1; }
-    else if (conv_impl() == 1) g_ = try_wgrad_glds(dt_, MODE, a, st);
+    bool deferred = false;                       // recorded in the group instead of launched (needs the deferred reduction too)
+    if (grp && rq && rq->njobs < REDUCE_MAX_JOBS && conv_impl() == 1 && dt_ == MPU_BF16) {
+        if (taps.use && grp->ntaps < TAPS_GROUP_MAX) {
+            TapsGroupJob& j = grp->taps[grp->ntaps++];
+            j.a = a; j.p = taps; j.mode = MODE; j.blk_begin = 0;
+            grp->taps_flops += a.flops > 0 ? a.flops : 2.0 * a.B * a.Ho * a.Wo * (double)n;
+            deferred = true; g_ = 1;
+        } else if (!taps.use && grp->nglds < GLDS_GROUP_MAX && wgrad_glds_grid(MODE, a) > 0) {
+            GldsGroupJob& j = grp->glds[grp->nglds++];
+            j.a = a; j.mode = MODE; j.blk_begin = 0;
+            grp->glds_flops += a.flops > 0 ? a.flops : 2.0 * a.B * a.Ho * a.Wo * (double)n;
+            deferred = true; g_ = 1;
+        }
+    }
+    if (!deferred) {                             // (a deferred job is timed as part of its grouped launch at the flush)
+        if (taps.use) { g_ = launch_wgrad_taps(MODE, a, taps, st); if (g_) return g_; g_ = 1; }
+        else if (conv_impl() == 1) g_ = try_wgrad_glds(dt_, MODE, a, st);
+    }
     if (g_ < 0) return g_;
     if (sched_log_on())
-        sched_note("wgrad %s mode=%d B=%d H=%d W=%d Cin=%d Cout=%d ksplit=%d", taps.use ? "taps" : (g_ == 1 ? "glds" : "regs"),
-                   MODE, a.B, a.Ho, a.Wo, Cin, a.Cout, a.ksplit);
+        sched_note("wgrad %s mode=%d B=%d H=%d W=%d Cin=%d Cout=%d ksplit=%d%s", taps.use ? "taps" : (g_ == 1 ? "glds" : "regs"),
+                   MODE, a.B, a.Ho, a.Wo, Cin, a.Cout, a.ksplit, deferred ? " grouped" : "");
     if (g_ == 1) big = true;                      // launched by an LDS-DMA kernel
     else
     if constexpr (sizeof(T) == 2) {
@@ -797,7 +834,7 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue
         dim3 g((unsigned)(cdiv(Cin, 64) * cdiv(a.Cout, 64)), ntaps, a.ksplit);
         wgrad_igemm_kernel<T, MODE, 64, 64><<<g, dim3(256), 0, st>>>(a);
     }
-    if (prof_on()) prof_end(st);
+    if (prof_on() && !deferred) prof_end(st);
     int rc = launch_ok();
     if (rc) return rc;
     DbFin f; f.partial = nullptr; f.db = nullptr; f.nshare = 0; f.C = 0; f.main_blocks = 0;
@@ -849,12 +886,12 @@ long wgrad_scratch_need(int dtype, int mode, int B, int H, int W, int C0, int C1
     return (need + 63) / 64 * 64 + 64;
 }
 
-int launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st, ReduceQueue* rq) {
+int launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st, ReduceQueue* rq, WgradGroup* grp) {
 #define MPU_WG_CASE(TT)                                                            \
     switch (mode) {                                                                \
-        case CONV3: return launch_wgrad_mode<TT, CONV3>(a, dW, st, rq);            \
-        case UPCONV2: return launch_wgrad_mode<TT, UPCONV2>(a, dW, st, rq);        \
-        case CONV1: return launch_wgrad_mode<TT, CONV1>(a, dW, st, rq);            \
+        case CONV3: return launch_wgrad_mode<TT, CONV3>(a, dW, st, rq, grp);            \
+        case UPCONV2: return launch_wgrad_mode<TT, UPCONV2>(a, dW, st, rq, grp);        \
+        case CONV1: return launch_wgrad_mode<TT, CONV1>(a, dW, st, rq, grp);            \
         default: return fail(MPU_EINVAL, "%s", "wgrad: bad mode");                 \
     }
     if (dtype == MPU_BF16) { MPU_WG_CASE(bf16_t) }

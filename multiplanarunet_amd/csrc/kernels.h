@@ -103,11 +103,31 @@ struct ReduceJob {
 constexpr int REDUCE_MAX_JOBS = 32;
 struct ReduceQueue { int njobs = 0, nblocks = 0; ReduceJob job[REDUCE_MAX_JOBS]; };
 int  flush_wgrad_reduces(ReduceQueue& q, hipStream_t st);
+// Deferred weight-gradient KERNELS (round 3): the weight gradients of a backward pass do not depend on each other, so
+// launch_wgrad(.., q, grp) only prepares them (schedule, split, scratch) and records them here; flush_wgrad_group() runs
+// all recorded wgrad_taps jobs as ONE launch and the wgrad_glds jobs as one launch per tile variant. A grid of many
+// waves of workgroups amortises what a one-wave launch pays in full -- dispatch ramp, prologue, the tail behind the
+// slowest workgroup and the L2 write-back of the fp32 partials at the kernel boundary (measured on configs[1] shapes:
+// four times the workgroups of one layer in one launch take 0.77-0.94 of four launches). Inputs (x, dz) must stay
+// untouched until the flush: every conv owns its dz buffer (Plan::dz).
+struct TapsGroupJob { WgradArgs a; TapsPlan p; int mode, blk_begin; };
+struct GldsGroupJob { WgradArgs a; int mode, blk_begin; };
+constexpr int TAPS_GROUP_MAX = 16, GLDS_GROUP_MAX = 12;
+struct WgradGroup {
+    int ntaps = 0, nglds = 0; double taps_flops = 0, glds_flops = 0;
+    TapsGroupJob taps[TAPS_GROUP_MAX]; GldsGroupJob glds[GLDS_GROUP_MAX];
+};
+int  flush_wgrad_group(int dtype, WgradGroup& g, hipStream_t st);
+int  launch_wgrad_taps_group(const TapsGroupJob* jobs, int n, hipStream_t st);          // wgrad_taps.hip
+int  launch_wgrad_glds_group(int dtype, const GldsGroupJob* jobs, int n, hipStream_t st);   // conv_glds.hip (bf16, 128 x 128 tiles)
+int  wgrad_taps_grid(int mode, const WgradArgs& a, const TapsPlan& p);                  // workgroups of one job
+long wgrad_glds_grid(int mode, const WgradArgs& a);                                      // (0: not the groupable variant)
 // exact scratch need (floats) of one layer's weight gradient: K-split partials + bias-gradient partials
 // c0_logical: image channels of an 8-channel first layer (selects the wgrad_c8 schedule, which has its own layout)
 long wgrad_scratch_need(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout, int c0_logical = 0);
 long wgrad_c8_scratch_floats(int dtype, int mode, int B, int H, int W, int C0, int C1, int c0_logical, int Cout);   // 0 = not eligible
-int  launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st, ReduceQueue* q = nullptr);
+int  launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st, ReduceQueue* q = nullptr,
+                  WgradGroup* grp = nullptr);
 int  try_wgrad_c8(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st);   // first layer (wgrad_c8.hip)
 int  try_wgrad_glds(int dtype, int mode, const WgradArgs& a, hipStream_t st);   // 1 launched, 0 unsupported shape
 bool wgrad_glds_supported(int dtype, int mode, const WgradArgs& a);

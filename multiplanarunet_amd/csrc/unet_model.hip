@@ -105,6 +105,8 @@ struct Plan {
     std::vector<long> u1, n1, c2u, c3u, n2;         // up levels
     long probs, gA, gB, gC, partial, partial_floats, partial2, wpartial, wpartial_floats, cpartial, cpartial_floats, coeffs, stats, total;
     std::vector<long> wscratch;                     // per conv: float offset of its weight-gradient scratch inside wpartial
+    std::vector<long> dz;                           // per conv: its own dz (gradient at the conv's pre-activation output): the weight
+                                                    // gradients of a whole backward pass run as grouped launches at its end
 };
 
 Plan make_plan(const mpu_unet* m, int B) {
@@ -132,6 +134,13 @@ Plan make_plan(const mpu_unet* m, int B) {
         if (e > gmax) gmax = e;
     }
     P.gA = take(gmax * esz); P.gB = take(gmax * esz); P.gC = take(gmax * esz);
+    P.dz.assign(m->conv.size(), -1);
+    for (size_t i = 0; i < m->conv.size(); ++i) {
+        if (m->conv[i].mode == CONV1) continue;
+        const int nenc = 2 * D;
+        const int l = (int)i < nenc ? (int)i / 2 : ((int)i < nenc + 2 ? D : D - 1 - ((int)i - nenc - 2) / 3);
+        P.dz[i] = act(l, m->conv[i].Cout);
+    }
     long pe = (long)RED_MAX_BLOCKS * 2 * m->cmax;
     const long he = (long)HEAD_BWD_MAX_BLOCKS * (m->head_C * m->cfg.n_classes + m->cfg.n_classes);
     if (he > pe) pe = he;
@@ -186,6 +195,8 @@ struct Run {
     const float* params; const unsigned char* packed; float* state; float* grads;
     void* const* ready_events = nullptr; int n_ready = 0;        // gradient-ready points (mpu_unet_backward_events)
     mutable ReduceQueue rq;                                      // deferred weight-gradient reductions (one launch per flush)
+    mutable WgradGroup grp;                                      // deferred weight-gradient kernels (grouped launches at the end)
+    bool group = false;
     int esz;
     void* at(long off) const { return ws + off; }
     const void* wf(const Conv& c) const { return packed + c.wf * esz; }
@@ -297,7 +308,7 @@ int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* 
         li.in0 = x0; li.in1 = x1; li.dz = dz; li.mask = nullptr; li.out = nullptr; li.w_off = c.w; li.b_off = c.b;
         r.m->tap(r.m->tap_user, &li);                  // (before the launch: x and dz are final, dW is read after the pass)
     }
-    return launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st, q);
+    return launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st, q, (r.group && q) ? &r.grp : nullptr);
 }
 
 int bn_fwd(const Run& r, const BN& b, const void* x, int lvl, int training, void* y, void* pooled, int stats_rows = 0) {
@@ -417,7 +428,9 @@ int run_forward(const Run& r, const float* d_x, int training, float* d_out) {
 // above that offset of the flat gradient buffer has been enqueued; record the caller's event there
 int mark_ready(const Run& r, int k) {
     if (!r.ready_events || k >= r.n_ready || !r.ready_events[k]) return MPU_OK;
-    int rc = flush_wgrad_reduces(r.rq, r.st);      // the gradients above this point must be final before the event
+    int rc = flush_wgrad_group(r.m->cfg.dtype, r.grp, r.st);     // the gradients above this point must be final before the event
+    if (rc) return rc;
+    rc = flush_wgrad_reduces(r.rq, r.st);
     if (rc) return rc;
     MPU_CHECK_HIP(hipEventRecord((hipEvent_t)r.ready_events[k], r.st));
     return MPU_OK;
@@ -427,7 +440,7 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
     const mpu_unet* m = r.m; const int D = m->cfg.depth; const Plan& P = r.P;
     const int dt = m->cfg.dtype;
     const long M0 = (long)r.B * m->cfg.H * m->cfg.W;
-    void* gA = r.at(P.gA); void* gB = r.at(P.gB); void* gC = r.at(P.gC);
+    void* gA = r.at(P.gA); void* gB = r.at(P.gB);
     const void* last = D > 0 ? r.at(P.n2[D - 1]) : r.at(P.nb);
     RC(launch_head_backward(dt, last, (const float*)r.at(P.probs), d_y, d_sw, M0, (long)m->cfg.H * m->cfg.W,
                             m->head_C, m->cfg.n_classes, r.params + m->head_w, m->cfg.n_classes,
@@ -437,40 +450,43 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
     // (weight gradients on a side stream next to the data gradients were measured twice -- 3.08 vs 3.03 ms in round 2 --
     // and removed in round 3: both kernels need a whole CU's LDS, so they never share one)
     int rowsA = 0;       // partial rows of BN-backward sums already produced for the dn in gA (0: head_backward wrote it)
+    auto DZ = [&](int ci) { return r.at(P.dz[ci]); };            // every conv's dz lives in its own buffer until the pass ends
     for (int j = D - 1; j >= 0; --j) {
         const int lvl = D - 1 - j, f = m->F[lvl];
-        const Conv& cu = m->conv[m->up_c(j, 0)]; const Conv& c2 = m->conv[m->up_c(j, 1)];
-        const Conv& c3 = m->conv[m->up_c(j, 2)];
+        const int iu = m->up_c(j, 0), i2 = m->up_c(j, 1), i3 = m->up_c(j, 2);
+        const Conv& cu = m->conv[iu]; const Conv& c2 = m->conv[i2]; const Conv& c3 = m->conv[i3];
         const void* prev = j > 0 ? r.at(P.n2[j - 1]) : r.at(P.nb);
         const int Cprev = j > 0 ? m->F[lvl + 1] : m->F[D];
-        RC(bn_bwd(r, m->bn[m->up_bn(j, 1)], gA, r.at(P.c3u[j]), lvl, gB, rowsA, 1));       // dz3 -> gB
-        RC(conv_wgrad(r, c3, r.at(P.c2u[j]), f, nullptr, 0, gB, lvl));                     //   reads gB
-        RC(conv_dgrad(r, c3, gB, r.at(P.c2u[j]), gA, lvl, 0, f));                          // dz2 -> gA
-        RC(conv_wgrad(r, c2, r.at(P.n[lvl]), f, r.at(P.n1[j]), f, gA, lvl));               //   reads gA
-        RC(conv_dgrad(r, c2, gA, nullptr, r.at(P.dskip[lvl]), lvl, 0, f));                 // d skip
+        RC(bn_bwd(r, m->bn[m->up_bn(j, 1)], gA, r.at(P.c3u[j]), lvl, DZ(i3), rowsA, 1));   // dz3
+        RC(conv_wgrad(r, c3, r.at(P.c2u[j]), f, nullptr, 0, DZ(i3), lvl));
+        RC(conv_dgrad(r, c3, DZ(i3), r.at(P.c2u[j]), DZ(i2), lvl, 0, f));                  // dz2
+        RC(conv_wgrad(r, c2, r.at(P.n[lvl]), f, r.at(P.n1[j]), f, DZ(i2), lvl));
+        RC(conv_dgrad(r, c2, DZ(i2), nullptr, r.at(P.dskip[lvl]), lvl, 0, f));             // d skip
         int rowsB = 0;                                                                     // (BN-backward sums from the epilogue)
-        RC(conv_dgrad(r, c2, gA, nullptr, gB, lvl, f, f, &m->bn[m->up_bn(j, 0)], r.at(P.u1[j]), &rowsB));   // d n1 -> gB
-        RC(bn_bwd(r, m->bn[m->up_bn(j, 0)], gB, r.at(P.u1[j]), lvl, gC, rowsB, 1));        // dz up-conv -> gC
-        RC(conv_wgrad(r, cu, prev, Cprev, nullptr, 0, gC, lvl));                           //   reads gC
+        RC(conv_dgrad(r, c2, DZ(i2), nullptr, gB, lvl, f, f, &m->bn[m->up_bn(j, 0)], r.at(P.u1[j]), &rowsB));   // d n1 -> gB
+        RC(bn_bwd(r, m->bn[m->up_bn(j, 0)], gB, r.at(P.u1[j]), lvl, DZ(iu), rowsB, 1));    // dz of the up-conv
+        RC(conv_wgrad(r, cu, prev, Cprev, nullptr, 0, DZ(iu), lvl));
         // d prev -> gA: the dn of the previous block's second BatchNorm (or of the bottom one)
         const BN& pbn = j > 0 ? m->bn[m->up_bn(j - 1, 1)] : m->bn[m->bot_bn()];
         const void* pbx = j > 0 ? r.at(P.c3u[j - 1]) : r.at(P.c2b);
-        RC(conv_dgrad(r, cu, gC, nullptr, gA, lvl + 1, 0, Cprev, &pbn, pbx, &rowsA));
+        RC(conv_dgrad(r, cu, DZ(iu), nullptr, gA, lvl + 1, 0, Cprev, &pbn, pbx, &rowsA));
         RC(mark_ready(r, point++));                                                        // up block j
     }
     {   // bottom
-        const Conv& c1 = m->conv[m->bot_c1()]; const Conv& c2 = m->conv[m->bot_c2()];
+        const int i1 = m->bot_c1(), i2 = m->bot_c2();
+        const Conv& c1 = m->conv[i1]; const Conv& c2 = m->conv[i2];
         const void* xin = D > 0 ? r.at(P.p[D - 1]) : r.at(P.xin);
         const int Cx = D > 0 ? m->F[D - 1] : m->cin_pad;
-        RC(bn_bwd(r, m->bn[m->bot_bn()], gA, r.at(P.c2b), D, gB, D > 0 ? rowsA : 0, 1));   // gC reader may still run: gB is free
-        RC(conv_wgrad(r, c2, r.at(P.c1b), m->F[D], nullptr, 0, gB, D));
-        RC(conv_dgrad(r, c2, gB, r.at(P.c1b), gA, D, 0, m->F[D]));
-        RC(conv_wgrad(r, c1, xin, Cx, nullptr, 0, gA, D));
-        if (D > 0) RC(conv_dgrad(r, c1, gA, nullptr, gB, D, 0, Cx));                       // d pooled -> gB (gB reader joined above)
+        RC(bn_bwd(r, m->bn[m->bot_bn()], gA, r.at(P.c2b), D, DZ(i2), D > 0 ? rowsA : 0, 1));
+        RC(conv_wgrad(r, c2, r.at(P.c1b), m->F[D], nullptr, 0, DZ(i2), D));
+        RC(conv_dgrad(r, c2, DZ(i2), r.at(P.c1b), DZ(i1), D, 0, m->F[D]));
+        RC(conv_wgrad(r, c1, xin, Cx, nullptr, 0, DZ(i1), D));
+        if (D > 0) RC(conv_dgrad(r, c1, DZ(i1), nullptr, gB, D, 0, Cx));                   // d pooled -> gB
         RC(mark_ready(r, point++));                                                        // bottom
     }
     for (int i = D - 1; i >= 0; --i) {
-        const Conv& c1 = m->conv[m->enc_c1(i)]; const Conv& c2 = m->conv[m->enc_c2(i)];
+        const int i1 = m->enc_c1(i), i2 = m->enc_c2(i);
+        const Conv& c1 = m->conv[i1]; const Conv& c2 = m->conv[i2];
         const int H = m->cfg.H >> i, W = m->cfg.W >> i;
         // skip gradient + un-pooled gradient, and in the same pass the BN-backward sums of the result
         const BN& eb = m->bn[m->enc_bn(i)];
@@ -478,15 +494,17 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
         RC(launch_maxpool_bwd_add_stats(dt, r.at(P.n[i]), r.at(P.dskip[i]), gB, r.B, H, W, m->F[i], gA, r.at(P.c2[i]),
                                         r.stat(eb, 0), r.stat(eb, 1), (float*)r.at(P.partial), P.partial_floats, &bwd_rows,
                                         r.st));
-        RC(bn_bwd(r, eb, gA, r.at(P.c2[i]), i, gB, bwd_rows));
-        RC(conv_wgrad(r, c2, r.at(P.c1[i]), m->F[i], nullptr, 0, gB, i));
-        RC(conv_dgrad(r, c2, gB, r.at(P.c1[i]), gA, i, 0, m->F[i]));
+        RC(bn_bwd(r, eb, gA, r.at(P.c2[i]), i, DZ(i2), bwd_rows));
+        RC(conv_wgrad(r, c2, r.at(P.c1[i]), m->F[i], nullptr, 0, DZ(i2), i));
+        RC(conv_dgrad(r, c2, DZ(i2), r.at(P.c1[i]), DZ(i1), i, 0, m->F[i]));
         const void* xin = i > 0 ? r.at(P.p[i - 1]) : r.at(P.xin);
         const int Cx = i > 0 ? m->F[i - 1] : m->cin_pad;
-        RC(conv_wgrad(r, c1, xin, Cx, nullptr, 0, gA, i));
-        if (i > 0) RC(conv_dgrad(r, c1, gA, nullptr, gB, i, 0, Cx));
+        RC(conv_wgrad(r, c1, xin, Cx, nullptr, 0, DZ(i1), i));
+        if (i > 0) RC(conv_dgrad(r, c1, DZ(i1), nullptr, gB, i, 0, Cx));
         RC(mark_ready(r, point++));                                                        // encoder level i
     }
+    // the deferred weight-gradient kernels of the whole pass as grouped launches, then their reductions in one more
+    RC(flush_wgrad_group(r.m->cfg.dtype, r.grp, r.st));
     return flush_wgrad_reduces(r.rq, r.st);
 }
 
@@ -497,6 +515,9 @@ int make_run(Run& r, const mpu_unet* m, int batch, const float* params, const vo
     r.m = m; r.B = batch; r.st = (hipStream_t)stream; r.ws = (unsigned char*)ws; r.P = make_plan(m, batch);
     r.params = params; r.packed = (const unsigned char*)packed; r.state = state; r.grads = grads;
     r.esz = m->cfg.dtype == MPU_BF16 ? 2 : 4;
+    static int group = -1;          // MPU_WGRAD_GROUP=0: every weight-gradient kernel as its own launch, in place (A/B)
+    if (group < 0) { const char* e = getenv("MPU_WGRAD_GROUP"); group = (e && e[0] == '0') ? 0 : 1; }
+    r.group = group != 0;
     return MPU_OK;
 }
 

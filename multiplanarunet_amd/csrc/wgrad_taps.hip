@@ -71,7 +71,7 @@ constexpr int TAPS_SMEM = XCH_A + XCH_B > 2 * GROUP_LDS ? XCH_A + XCH_B : 2 * GR
 // bound by MFMA issue + the LDS transpose reads in front of them, not by the L2 -> LDS latency.)
 template <int MODE, int T0, int T1>
 __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPlan& p, unsigned char* smem_all,
-                                                const int tile, const int pair) {
+                                                const int tile, const int pair, const unsigned bid) {
     constexpr int NT = T1 - T0, KW = MODE == UPCONV2 ? 2 : 3;
     constexpr int NTALL = MODE == UPCONV2 ? 4 : 9;
     constexpr int NXRT = NXR, NZRT = NZR, DIST = 2;              // request distance (steps)
@@ -81,8 +81,8 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave8 >> 2, wave = wave8 & 3;
     // dev aid (MPU_STAMPS=1): phase boundaries of every 8th workgroup, wave 0
-    unsigned long long* stamps = (a.dbg_buf && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 32 && tid == 0)
-                                     ? a.dbg_buf + (blockIdx.x >> 3) * 16 : nullptr;
+    unsigned long long* stamps = (a.dbg_buf && (bid & 7) == 0 && (bid >> 3) < 32 && tid == 0)
+                                     ? a.dbg_buf + (bid >> 3) * 16 : nullptr;
     if (stamps) stamps[0] = __builtin_amdgcn_s_memtime();
     unsigned char* smem = smem_all + grp * GROUP_LDS;
     const int H = a.Ho, W = a.Wo;
@@ -328,19 +328,39 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
     }
 }
 
+// one workgroup of a job: bid = its index inside the job's grid (XCD-aware decode: the tiles of one strip pair run on one
+// XCD -- shared X / dZ in its L2; a job's first workgroup sits at a multiple of 8 of the launch grid)
 template <int MODE>
-__global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPlan p) {
+__device__ __forceinline__ void wgrad_taps_entry(const WgradArgs& a, const TapsPlan& p, unsigned bid, unsigned char* smem_all) {
     constexpr int NTALL = MODE == UPCONV2 ? 4 : 9;
-    extern __shared__ __attribute__((aligned(128))) unsigned char smem_all[];
     const int Cin = a.C0 + a.C1;
     const int ntile = ((a.Cout + 63) / 64) * ((Cin + 63) / 64);
-    // XCD-aware decode: the tiles (and tap halves) of one strip pair run on one XCD (shared X / dZ in its L2)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = bid & 7, slot = bid >> 3;
     const int npairs = (p.nstrips + 1) / 2;
-    const int nsub = ntile;
-    const int sub = slot % nsub, pair = (slot / nsub) * 8 + xcd;
+    const int sub = slot % ntile, pair = (slot / ntile) * 8 + xcd;
     if (pair >= npairs) return;
-    wgrad_taps_body<MODE, 0, NTALL>(a, p, smem_all, sub, pair);
+    wgrad_taps_body<MODE, 0, NTALL>(a, p, smem_all, sub, pair, bid);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPlan p) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem_all[];
+    wgrad_taps_entry<MODE>(a, p, blockIdx.x, smem_all);
+}
+
+// Every deferred wgrad_taps job of a backward pass in ONE launch (kernels.h: WgradGroup): workgroup -> job by the table's
+// block ranges (each a multiple of 8), then exactly the single-job kernel.
+struct TapsGroupTable { int njobs, _pad; TapsGroupJob job[TAPS_GROUP_MAX]; };
+__global__ __launch_bounds__(512, 1) void wgrad_taps_group_kernel(TapsGroupTable t) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem_all[];
+    int j = 0;
+#pragma unroll 1
+    for (int k = 1; k < t.njobs; ++k) if ((int)blockIdx.x >= t.job[k].blk_begin) j = k;
+    const WgradArgs a = t.job[j].a;
+    const TapsPlan p = t.job[j].p;
+    const unsigned bid = blockIdx.x - (unsigned)t.job[j].blk_begin;
+    if (t.job[j].mode == UPCONV2) wgrad_taps_entry<UPCONV2>(a, p, bid, smem_all);
+    else wgrad_taps_entry<CONV3>(a, p, bid, smem_all);
 }
 
 }  // namespace
@@ -386,21 +406,52 @@ TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C
     return p;
 }
 
-int launch_wgrad_taps(int mode, const WgradArgs& a_in, const TapsPlan& p, hipStream_t st) {
-    WgradArgs a = a_in;
-    a.dbg_buf = stamp_buffer();
+int wgrad_taps_grid(int /*mode*/, const WgradArgs& a, const TapsPlan& p) {
     const int Cin = a.C0 + a.C1;
-    const int ntile = cdiv(Cin, 64) * cdiv(a.Cout, 64) * (p.split ? 2 : 1);
+    const int ntile = cdiv(Cin, 64) * cdiv(a.Cout, 64);
     const int npairs = (p.nstrips + 1) / 2;
-    const int grid = cdiv(npairs, 8) * 8 * ntile;
+    return cdiv(npairs, 8) * 8 * ntile;
+}
+
+static int taps_attrs() {
     static bool attr_set = false;
     if (!attr_set) {
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel<CONV3>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel<UPCONV2>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
+        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
         attr_set = true;
     }
+    return MPU_OK;
+}
+
+int launch_wgrad_taps(int mode, const WgradArgs& a_in, const TapsPlan& p, hipStream_t st) {
+    WgradArgs a = a_in;
+    a.dbg_buf = stamp_buffer();
+    const int grid = wgrad_taps_grid(mode, a, p);
+    { const int rc = taps_attrs(); if (rc) return rc; }
     if (mode == UPCONV2) wgrad_taps_kernel<UPCONV2><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(a, p);
     else wgrad_taps_kernel<CONV3><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(a, p);
+    return launch_ok();
+}
+
+int launch_wgrad_taps_group(const TapsGroupJob* jobs, int n, hipStream_t st) {
+    if (n <= 0) return MPU_OK;
+    if (n > TAPS_GROUP_MAX) return fail(MPU_EINVAL, "%s", "wgrad_taps group: too many jobs");
+    { const int rc = taps_attrs(); if (rc) return rc; }
+    TapsGroupTable t; t.njobs = n; t._pad = 0;
+    int grid = 0;
+    // the longest jobs first: the tail of the launch is then made of short workgroups
+    int order[TAPS_GROUP_MAX];
+    for (int k = 0; k < n; ++k) order[k] = k;
+    for (int i = 1; i < n; ++i)
+        for (int k = i; k > 0 && jobs[order[k]].p.RH > jobs[order[k - 1]].p.RH; --k) { const int tmp = order[k]; order[k] = order[k - 1]; order[k - 1] = tmp; }
+    for (int k = 0; k < n; ++k) {
+        t.job[k] = jobs[order[k]];
+        t.job[k].a.dbg_buf = nullptr;
+        t.job[k].blk_begin = grid;
+        grid += wgrad_taps_grid(t.job[k].mode, t.job[k].a, t.job[k].p);      // a multiple of 8: the XCD decode of every job stays aligned
+    }
+    wgrad_taps_group_kernel<<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(t);
     return launch_ok();
 }
 
