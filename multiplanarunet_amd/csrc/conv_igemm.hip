@@ -740,7 +740,7 @@ int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
 }
 
 // workspace (floats) the split-K partials of a wgrad call need
-long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out) {
+long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out, bool grouped) {
     const int ntaps = mode == UPCONV2 ? 4 : (mode == CONV1 ? 1 : 9);
     const int bc = (Cin >= 128 && Cout >= 128) ? 128 : 64;
     const long tiles = (long)cdiv(Cin, bc) * cdiv(Cout, bc) * ntaps;
@@ -749,7 +749,10 @@ long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, i
         const char* e = getenv("MPU_WGRAD_SPLIT_TARGET"); target = e ? atol(e) : 512;
         const char* n = getenv("MPU_WGRAD_NOSPLIT_TILES"); nosplit = n ? atol(n) : 384;
     }
-    long ks = tiles >= nosplit ? 1 : (target + tiles - 1) / tiles;   // aim at ~512 workgroups (2 per CU: measured best, fewer fp32 partial copies);
+    // stand-alone launch: aim at ~512 workgroups (2 per CU: measured best); inside a grouped launch (many jobs, several waves
+    // of workgroups): ~256 per job -- half the fp32 partial copies (round 3 sweep: 2.77 -> 2.70 ms per step; 128: 2.74)
+    const long tgt = grouped ? (target + 1) / 2 : target;
+    long ks = tiles >= nosplit ? 1 : (tgt + tiles - 1) / tiles;
                                                           // no split (and no reduce pass) once the tile grid fills the chip
     const long maxks = (M + 511) / 512;                   // at least 512 pixels per split
     if (ks > maxks) ks = maxks;
@@ -780,7 +783,8 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue
         }
     }
     TapsPlan taps; taps.use = 0;
-    if (conv_impl() == 1) taps = wgrad_taps_plan(dt_, MODE, a.B, a.Ho, a.Wo, a.C0, a.C1, a.Cout);
+    const bool can_group = grp && rq && rq->njobs < REDUCE_MAX_JOBS && conv_impl() == 1 && dt_ == MPU_BF16;
+    if (conv_impl() == 1) taps = wgrad_taps_plan(dt_, MODE, a.B, a.Ho, a.Wo, a.C0, a.C1, a.Cout, can_group && grp->ntaps < TAPS_GROUP_MAX);
     if (taps.use) a.ksplit = (taps.nstrips + 1) / 2;   // one partial copy per pair of pixel strips
     // the LDS-DMA kernels also sum dz over the pixels (bias gradient) when they handle the shape
     a.fuse_db = (a.db && conv_impl() == 1 && (taps.use || wgrad_glds_supported(dt_, MODE, a))) ? 1 : 0;

@@ -84,13 +84,15 @@ const char* last_glds_schedule();               // "glds" or "pipe": what the la
 int  try_conv_c8(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // <= 8 input channels: first layer (conv_c8.hip)
 int  try_conv_ws(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // register-stationary weights, persistent (conv_ws.hip)
 int  try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st);     // LDS-resident patch variant (conv_halo.hip)
-long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out);
+// grouped: the job will run inside a grouped launch (WgradGroup): it need not fill the chip on its own, so it takes
+// about half the workgroups (K splits / pixel strips) of a stand-alone launch -- half the fp32 partial copies
+long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out, bool grouped = false);
 // all-taps weight gradient for the high-resolution 3x3 layers (wgrad_taps.hip)
 struct TapsPlan { int use, RH, sx, sy, nstrips, split; };
 constexpr long TAPS_MAX_CICO = 512L * 512;     // eligible layers: Cin * Cout up to this
 constexpr int TAPS_MAX_WGS = 1024;             // strips * 64x64 tiles; bounds the fp32 partial workspace (one copy of
                                                // dW per strip): <= 1024 * 9 * 4096 floats = 151 MB for any layer
-TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout);
+TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout, bool grouped = false);
 int  launch_wgrad_taps(int mode, const WgradArgs& a, const TapsPlan& p, hipStream_t st);
 // Deferred second stage of the weight gradients: launch_wgrad(.., q) records its reduction (fixed-order sum of the
 // K-split partials into dW, bias-gradient finalize) in q instead of launching it; flush_wgrad_reduces() runs every

@@ -295,7 +295,7 @@ int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* 
     a.B = r.B; a.Ho = r.m->cfg.H >> lvl; a.Wo = r.m->cfg.W >> lvl;
     a.flops = conv_flops(r, c, lvl);
     const long M = (long)a.B * a.Ho * a.Wo;
-    wgrad_partial_elems(c.mode, c.Cin, c.Cout, M, &a.ksplit, &a.mchunk);
+    wgrad_partial_elems(c.mode, c.Cin, c.Cout, M, &a.ksplit, &a.mchunk, r.group);
     a.db = r.grads + c.b; a.db_partial = nullptr; a.colsum_scratch = (float*)r.at(r.P.partial2); a.fuse_db = 0;
     a.c0_logical = (C1 == 0 && C0 == c.Cin) ? c.lCin : 0;
     static int defer = -1;         // MPU_WGRAD_BATCHED_REDUCE=0: reduce right behind every weight-gradient kernel (A/B)

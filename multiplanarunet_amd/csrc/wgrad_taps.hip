@@ -367,7 +367,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_group_kernel(TapsGroupTable
 
 // Strip decomposition: 32-pixel-wide column strips of RH rows; aims at ~2 workgroups per CU while keeping
 // the number of fp32 partial copies (one per strip) small: their write + re-read is the kernel's HBM traffic.
-TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout) {
+TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout, bool grouped) {
     TapsPlan p; p.use = 0; p.RH = 0; p.sx = 0; p.sy = 0; p.nstrips = 0; p.split = 0;
     static int on = -1, target = 0; static long max_cico = 0;
     if (on < 0) {
@@ -393,13 +393,18 @@ TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C
         const long ns = (long)B * sx * cdiv(H, rh);
         if (ns * ntile > TAPS_MAX_WGS) continue;
         const long wgs = ns * ntile;
-        const long d = wgs > target ? wgs - target : target - wgs;
+        // a job of a grouped launch need not fill the chip on its own: a quarter of the strips (64 workgroups of four
+        // times the rows per layer instead of 256): a quarter of the fp32 partial copies, the per-workgroup prologue /
+        // epilogue amortised over four times the K steps (round 3 sweep on configs[1]: 3.03 -> 2.94 -> 2.91 ms per step
+        // for 512 / 256 / 128 strips x tiles; 64: the layers fall below the parallelism bound)
+        const long tg = grouped ? (target + 3) / 4 : target;
+        const long d = wgs > tg ? wgs - tg : tg - wgs;
         if (d < bestd) { bestd = d; best = rh; }
         if (rh >= H) break;
     }
     if (!best) return p;
     p.RH = best; p.sx = sx; p.sy = cdiv(H, best); p.nstrips = B * sx * p.sy;
-    if ((long)p.nstrips * ntile < 128) return p;                 // too little parallelism: the per-tap kernel splits finer
+    if ((long)p.nstrips * ntile < (grouped ? 64 : 128)) return p;   // too little parallelism: the per-tap kernel splits finer
     if (p.nstrips < 3) return p;                                 // (one strip pair would write straight into dW, which is not in the
                                                                  //  ci-interleaved partial layout: always go through the reduction)
     p.use = 1;
