@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmpunet_hip.so")
+LIB_PATH = os.environ.get("MPU_LIB_PATH") or os.path.join(_HERE, "lib", "libmpunet_hip.so")   # (override: A/B of two builds)
 
 c_p = C.c_void_p
 i32, i64, f32, f64, u8 = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint8
