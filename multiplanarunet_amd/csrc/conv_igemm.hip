@@ -448,18 +448,29 @@ __global__ __launch_bounds__(256) void wgrad_igemm_kernel(WgradArgs a) {
 
 // second stage: dW[e] = sum_s partial[s][e]  (fixed order: deterministic); 16-B loads, 4 splits in flight
 // Blocks past `main_blocks` finish the fused bias gradient (db = sum of the wgrad kernel's column-sum partials).
-struct DbFin { const float* partial; float* db; int nshare, C, main_blocks; int il4_cout = 0; };
+struct DbFin { const float* partial; float* db; int nshare, C, main_blocks; int il4_cout = 0; int cout = 0, cin_job = 0, cin_total = 0, ci_base = 0; };
 
-// Write the sum of one 16-byte partial column. il4_cout == 0: the partials are in dW's own layout. il4_cout = Cout
-// (wgrad_taps): the partials are [tap][ci / 4][co][4 ci] -- a lane of that kernel holds four consecutive input
-// channels of one output channel, so its accumulator leaves as ONE 16-byte store (the [ci][co] layout cost four 4-byte
-// stores, and the kernel's tail was store-issue bound); index e = (tap * Cin/4 + ci/4) * Cout + co, the four values
-// belong to rows 4 * (e / Cout) .. + 3 of dW [tap * Cin + ci][co]. Consecutive threads write consecutive co.
-__device__ __forceinline__ void store_dw_sum(float* __restrict__ dW, long e, const float4& s, int il4_cout) {
-    if (!il4_cout) { reinterpret_cast<float4*>(dW)[e] = s; return; }
-    const unsigned row = (unsigned)e / (unsigned)il4_cout, co = (unsigned)e - row * (unsigned)il4_cout;
-    float* d = dW + (long)row * 4 * il4_cout + co;
-    d[0] = s.x; d[il4_cout] = s.y; d[2 * (long)il4_cout] = s.z; d[3 * (long)il4_cout] = s.w;
+// Write the sum of one 16-byte partial column.
+//  * il4_cout == 0: the partials are [tap][ci][co] like dW: float4 e holds four consecutive co.
+//  * il4_cout = Cout (wgrad_taps): the partials are [tap][ci / 4][co][4 ci] -- a lane of that kernel holds four consecutive
+//    input channels of one output channel, so its accumulator leaves as ONE 16-byte store; e = (tap * Cin/4 + ci/4) * Cout
+//    + co, the four values belong to four consecutive rows of dW. Consecutive threads write consecutive co.
+//  * cin_job > 0 (one source of a concat layer as its own job): the job's taps hold cin_job rows each, which are rows
+//    [ci_base, ci_base + cin_job) of dW's cin_total-row taps.
+__device__ __forceinline__ void store_dw_sum(float* __restrict__ dW, long e, const float4& s, int il4_cout, int cout, int cin_job,
+                                             int cin_total, int ci_base) {
+    if (il4_cout) {
+        const unsigned row = (unsigned)e / (unsigned)il4_cout, co = (unsigned)e - row * (unsigned)il4_cout;   // row = tap * cin_job/4 + ci/4
+        long drow = (long)row * 4;
+        if (cin_job) { const unsigned c4 = (unsigned)cin_job >> 2, tap = row / c4, cib = row - tap * c4; drow = (long)tap * cin_total + ci_base + 4L * cib; }
+        float* d = dW + drow * il4_cout + co;
+        d[0] = s.x; d[il4_cout] = s.y; d[2 * (long)il4_cout] = s.z; d[3 * (long)il4_cout] = s.w;
+        return;
+    }
+    if (!cin_job) { reinterpret_cast<float4*>(dW)[e] = s; return; }
+    const unsigned el = (unsigned)e * 4u, row = el / (unsigned)cout, co = el - row * (unsigned)cout;         // row = tap * cin_job + ci
+    const unsigned tap = row / (unsigned)cin_job, ci = row - tap * (unsigned)cin_job;
+    *reinterpret_cast<float4*>(dW + ((long)tap * cin_total + ci_base + ci) * cout + co) = s;
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int ksplit, long n,
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                 s.x += on ? v[u].x : 0.f; s.y += on ? v[u].y : 0.f; s.z += on ? v[u].z : 0.f; s.w += on ? v[u].w : 0.f;
             }
         }
-        store_dw_sum(dW, e, s, f.il4_cout);
+        store_dw_sum(dW, e, s, f.il4_cout, f.cout, f.cin_job, f.cin_total, f.ci_base);
     }
 }
 
@@ -534,7 +545,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kl4_kernel(const float* __re
     if (kl == 0 && e < n4) {
 #pragma unroll
         for (int j = 1; j < 4; ++j) { const float4 v = red[j * 64 + col]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-        store_dw_sum(dW, e, s, f.il4_cout);
+        store_dw_sum(dW, e, s, f.il4_cout, f.cout, f.cin_job, f.cin_total, f.ci_base);
     }
 }
 
@@ -575,7 +586,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(ReduceTable t) {
                     s.x += on ? v[u].x : 0.f; s.y += on ? v[u].y : 0.f; s.z += on ? v[u].z : 0.f; s.w += on ? v[u].w : 0.f;
                 }
             }
-            store_dw_sum(q.dW, e, s, q.il4_cout);
+            store_dw_sum(q.dW, e, s, q.il4_cout, q.cout, q.cin_job, q.cin_total, q.ci_base);
         }
         return;
     }
@@ -608,7 +619,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(ReduceTable t) {
     if (kl == 0 && e < n4) {
 #pragma unroll
         for (int jj = 1; jj < 4; ++jj) { const float4 v = red[jj * 64 + col]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-        store_dw_sum(q.dW, e, s, q.il4_cout);
+        store_dw_sum(q.dW, e, s, q.il4_cout, q.cout, q.cin_job, q.cin_total, q.ci_base);
     }
 }
 
@@ -773,8 +784,33 @@ long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, i
 
 template <typename T, int MODE>
 static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue* rq, WgradGroup* grp) {
-    const int Cin = a.C0 + a.C1;
     const int dt_ = sizeof(T) == 2 ? MPU_BF16 : MPU_F32;
+    // A concat layer whose first source is not a multiple of 64 channels (complexity_factor 2: 96 | 96, 184 | 184, ...)
+    // cannot be tiled over both sources by the LDS-DMA kernels (a 64-channel tile would straddle them): each source runs
+    // as its own job with its own partials, and the reduction writes its rows of dW (ReduceJob::cin_job).
+    if (a.C1 > 0 && a.C0 % 64 != 0 && a.cin_total == 0 && conv_impl() == 1 && dt_ == MPU_BF16 && rq && MODE == CONV3 &&
+        rq->njobs + 2 <= REDUCE_MAX_JOBS) {
+        WgradArgs h[2] = {a, a};
+        h[0].C1 = 0; h[0].x1 = nullptr; h[0].cin_total = a.C0 + a.C1; h[0].ci_base = 0;
+        h[1].x0 = a.x1; h[1].C0 = a.C1; h[1].C1 = 0; h[1].x1 = nullptr; h[1].cin_total = a.C0 + a.C1; h[1].ci_base = a.C0;
+        h[1].db = nullptr;                                       // the bias gradient (sum of dz) belongs to the layer once
+        bool ok = true;
+        long need[2];
+        for (int k = 0; k < 2; ++k) {
+            const bool grouped = grp != nullptr;
+            ok = ok && (wgrad_taps_plan(dt_, MODE, a.B, a.Ho, a.Wo, h[k].C0, 0, a.Cout, grouped).use || wgrad_glds_supported(dt_, MODE, h[k]));
+            wgrad_partial_elems(MODE, h[k].C0, a.Cout, (long)a.B * a.Ho * a.Wo, &h[k].ksplit, &h[k].mchunk, grouped);
+            need[k] = wgrad_scratch_need(dt_, MODE, a.B, a.Ho, a.Wo, h[k].C0, 0, a.Cout);
+            h[k].flops = a.flops * ((double)h[k].C0 / (a.C0 + a.C1));
+        }
+        if (ok && a.partial_cap > 0 && need[0] + need[1] <= a.partial_cap) {   // (unknown capacity: keep the one-job fallback)
+            h[1].partial = a.partial + need[0];
+            h[0].partial_cap = need[0]; h[1].partial_cap = need[1];
+            for (int k = 0; k < 2; ++k) { const int rc = launch_wgrad_mode<T, MODE>(h[k], dW, st, rq, grp); if (rc) return rc; }
+            return MPU_OK;
+        }
+    }
+    const int Cin = a.C0 + a.C1;
     if (conv_impl() == 1) {                      // first layer: 1-2 image channels in 8-channel records
         const int c8 = try_wgrad_c8(dt_, MODE, a, dW, st);
         if (c8 != 0) {
@@ -794,7 +830,8 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue
     }
     const long n_ = (long)ModeTraits<MODE>::NTAPS * Cin * a.Cout;
     a.db_partial = a.partial + (long)a.ksplit * n_;   // tail of the workspace
-    if (a.ksplit == 1) a.partial = dW;            // single split: the kernel's output IS the weight gradient
+    const bool strided = a.cin_total > 0;         // one source of a concat layer: always through the reduction (row remap)
+    if (a.ksplit == 1 && !strided) a.partial = dW;   // single split: the kernel's output IS the weight gradient
     const int ntaps = ModeTraits<MODE>::NTAPS;
     const long n = (long)ntaps * Cin * a.Cout;
     const bool will_defer = grp && rq && rq->njobs < REDUCE_MAX_JOBS && conv_impl() == 1 && dt_ == MPU_BF16 &&
@@ -843,6 +880,8 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue
     if (rc) return rc;
     DbFin f; f.partial = nullptr; f.db = nullptr; f.nshare = 0; f.C = 0; f.main_blocks = 0;
     f.il4_cout = taps.use ? a.Cout : 0;                        // wgrad_taps writes ci-interleaved partial columns
+    f.cout = a.Cout;
+    if (strided) { f.cin_job = Cin; f.cin_total = a.cin_total; f.ci_base = a.ci_base; }
     int db_blocks = 0;
     if (a.fuse_db) {         // bias gradient: sum the [ksplit * taps * ci-tiles][Cout] partials of the LDS-DMA kernel
         const bool big128 = sizeof(T) == 2 && Cin >= 128 && a.Cout >= 128 && (a.C1 == 0 || a.C0 % 128 == 0);
@@ -852,19 +891,20 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue
     }
     const long n4 = n / 4;
     const bool kl4 = a.ksplit >= 8 && n4 <= 64L * 8192;
-    if (a.ksplit > 1) {
+    if (a.ksplit > 1 || strided) {
         if (kl4) f.main_blocks = (int)((n4 + 63) / 64);
         else { long blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096; f.main_blocks = (int)blocks; }
     }
-    if (rq && (a.ksplit > 1 || db_blocks) && rq->njobs < REDUCE_MAX_JOBS) {      // deferred: one launch for many layers
+    if (rq && (a.ksplit > 1 || strided || db_blocks) && rq->njobs < REDUCE_MAX_JOBS) {      // deferred: one launch for many layers
         ReduceJob& j = rq->job[rq->njobs++];
-        j.partial = a.partial; j.dW = dW; j.n = a.ksplit > 1 ? n : 0; j.ksplit = a.ksplit; j.kl4 = kl4 ? 1 : 0;
+        j.partial = a.partial; j.dW = dW; j.n = (a.ksplit > 1 || strided) ? n : 0; j.ksplit = a.ksplit; j.kl4 = kl4 ? 1 : 0;
+        j.cout = a.Cout; j.cin_job = f.cin_job; j.cin_total = f.cin_total; j.ci_base = f.ci_base;
         j.db_partial = f.partial; j.db = f.db; j.nshare = f.nshare; j.C = f.C;
-        j.blk_begin = rq->nblocks; j.main_blocks = a.ksplit > 1 ? f.main_blocks : 0; j.db_blocks = db_blocks; j.il4_cout = f.il4_cout;
+        j.blk_begin = rq->nblocks; j.main_blocks = (a.ksplit > 1 || strided) ? f.main_blocks : 0; j.db_blocks = db_blocks; j.il4_cout = f.il4_cout;
         rq->nblocks += j.main_blocks + j.db_blocks;
         return MPU_OK;
     }
-    if (a.ksplit == 1) return db_blocks ? launch_colsum_finalize(a.db_partial, f.nshare, a.Cout, a.db, st) : MPU_OK;
+    if (a.ksplit == 1 && !strided) return db_blocks ? launch_colsum_finalize(a.db_partial, f.nshare, a.Cout, a.db, st) : MPU_OK;
     if (kl4)
         wgrad_reduce_kl4_kernel<<<dim3((unsigned)(f.main_blocks + db_blocks)), dim3(256), 0, st>>>(a.partial, a.ksplit, n, dW, f);
     else
@@ -883,6 +923,9 @@ long wgrad_scratch_need(int dtype, int mode, int B, int H, int W, int C0, int C1
     if (conv_impl() == 1) taps = wgrad_taps_plan(dtype, mode, B, H, W, C0, C1, Cout);
     if (taps.use) ks = (taps.nstrips + 1) / 2;
     const long nshare = taps.use ? ks : (long)ks * ntaps * cdiv(Cin, 64);
+    if (C1 > 0 && C0 % 64 != 0 && conv_impl() == 1 && dtype == MPU_BF16 && mode == CONV3)   // two jobs (launch_wgrad_mode): both regions
+        return wgrad_scratch_need(dtype, mode, B, H, W, C0, 0, Cout) + wgrad_scratch_need(dtype, mode, B, H, W, C1, 0, Cout) +
+               (((long)ks * n + nshare * Cout + 63) / 64 * 64 + 64);                            // (+ the unsplit need: the fallback still fits)
     long need = (long)ks * n + nshare * Cout;
     // the first-layer schedule (tried first) keeps one compact row per strip of image rows: its own layout and size
     const long c8 = conv_impl() == 1 ? wgrad_c8_scratch_floats(dtype, mode, B, H, W, C0, C1, c0_logical, Cout) : 0;

@@ -54,6 +54,9 @@ struct WgradArgs {
     int c0_logical;              // image channels actually present in an 8-channel x0 (first layer); 0 = unknown
     long partial_cap = 0;        // floats available at `partial` (0 = unknown: schedules with their own layout refuse)
     unsigned long long* dbg_buf = nullptr;   // dev aid (MPU_STAMPS=1): s_memtime stamps of a few workgroups
+    // One SOURCE of a concat layer run as its own job (round 3): x0 / C0 is that source alone (C1 = 0), the result belongs
+    // to rows [ci_base, ci_base + C0) of every tap of a kernel with cin_total input channels. 0 = the whole layer.
+    int cin_total = 0, ci_base = 0;
 };
 
 // element-wise maximum of two 16-byte pieces of T (8 bf16 or 4 f32)
@@ -101,6 +104,8 @@ struct ReduceJob {
     const float* partial; float* dW; long n; int ksplit, kl4;    // main part (n = 0: none)
     const float* db_partial; float* db; int nshare, C;           // bias gradient (db = nullptr: none)
     int blk_begin, main_blocks, db_blocks, il4_cout;             // il4_cout: see store_dw_sum (conv_igemm.hip)
+    int cin_job = 0, cin_total = 0, ci_base = 0, cout = 0;       // cout: output channels; cin_job > 0: the partials hold cin_job input channels per tap that
+                                                                 // belong to rows [ci_base, ci_base + cin_job) of a cin_total-row tap of dW
 };
 constexpr int REDUCE_MAX_JOBS = 32;
 struct ReduceQueue { int njobs = 0, nblocks = 0; ReduceJob job[REDUCE_MAX_JOBS]; };

@@ -770,7 +770,10 @@ int mpu_conv2d_igemm_ws(int32_t dtype, int32_t mode, const void* d_in0, int32_t 
 }
 
 int64_t mpu_conv2d_wgrad_workspace_floats(int32_t mode, int32_t Cin, int32_t Cout, int64_t M) {
-    return wgrad_partial_elems(mode, Cin, Cout, M, nullptr, nullptr);
+    // the whole layer as one job, plus -- a concat layer whose first source is not a multiple of 64 channels runs as one job
+    // per source -- room for two half-layer jobs (an upper bound that needs no image shape)
+    const int half = ((Cin + 1) / 2 + 7) / 8 * 8;
+    return wgrad_partial_elems(mode, Cin, Cout, M, nullptr, nullptr) + 2 * (wgrad_partial_elems(mode, half, Cout, M, nullptr, nullptr) + 128) + 256;
 }
 
 int mpu_conv2d_wgrad(int32_t dtype, int32_t mode, const void* d_x0, int32_t C0, const void* d_x1, int32_t C1,
@@ -781,9 +784,13 @@ int mpu_conv2d_wgrad(int32_t dtype, int32_t mode, const void* d_x0, int32_t C0, 
     WgradArgs a;
     a.x0 = d_x0; a.x1 = d_x1; a.C0 = C0; a.C1 = C1; a.dz = d_dz; a.Cout = Cout; a.partial = d_workspace;
     a.B = B; a.Ho = Ho; a.Wo = Wo; a.flops = 0; a.db = nullptr; a.db_partial = nullptr; a.colsum_scratch = nullptr; a.fuse_db = 0;
-    a.c0_logical = 0; a.partial_cap = 0;
+    a.c0_logical = 0;
+    a.partial_cap = C1 == C0 ? mpu_conv2d_wgrad_workspace_floats(mode, C0 + C1, Cout, (long)B * Ho * Wo) : 0;   // (the query's contract)
     wgrad_partial_elems(mode, C0 + C1, Cout, (long)B * Ho * Wo, &a.ksplit, &a.mchunk);
-    return launch_wgrad(dtype, mode, a, d_dW, (hipStream_t)stream);
+    ReduceQueue q;                               // second stages recorded, then run as one launch (as the U-Net does)
+    int rc = launch_wgrad(dtype, mode, a, d_dW, (hipStream_t)stream, &q);
+    if (rc) return rc;
+    return flush_wgrad_reduces(q, (hipStream_t)stream);
 }
 
 /* first layer: x0 holds n_image_channels (<= 8) real channels in 8-channel pixel records */

@@ -426,10 +426,12 @@ def test_default_yaml_network_cf2_bf16_inference_step_and_dispatch():
                                                                scheds([l for l in log if l[0] == "wgrad"])))
     g = m.grads.cpu().numpy()
     assert np.isfinite(g).all() and torch.isfinite(loss).all()
+    assert "regs" not in scheds([l for l in log if l[0] == "wgrad"])      # concat layers (96 | 96 ...): one LDS-DMA job per source
     r32 = U.bf16_matched_step(w, x, y, np.ones(B, np.float32), depth=D, dtype=torch.float32)
     rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
-    for name in ("conv2d/kernel", "conv2d/bias"):
-        assert rel(_grad(m, g, name).astype(np.float64), r32["grads"][name]) <= 3e-2, name
+    for name, bound in (("conv2d/kernel", 3e-2), ("conv2d/bias", 3e-2), ("upsample_L3_conv3/kernel", 1e-1),
+                        ("upsample_L3_conv2/kernel", 1e-1)):     # (the concat conv: a wrong row mapping of its two jobs is O(1))
+        assert rel(_grad(m, g, name).astype(np.float64), r32["grads"][name]) <= bound, name
     for name, (kind, off, ps, ls) in m._tensors.items():
         if kind != 0 or tuple(ps) == tuple(ls):
             continue

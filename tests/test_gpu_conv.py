@@ -46,6 +46,9 @@ CASES = [
     (CONV3,   2, 8, 8, 64, 64, 128),       # concat of two sources
     (CONV3,   3, 32, 32, 128, 0, 136),     # 128-wide tiles with ragged N (LDS-resident patch kernel)
     (CONV3,   2, 36, 40, 64, 64, 64),      # patch kernel: ragged H and W tiles, concat, 64-channel tile
+    (CONV3,   2, 36, 40, 72, 72, 64),      # concat whose first source is NOT a multiple of 64 channels: the weight gradient runs
+                                           #   as one job per source (strip kernel), the reduction writes each source's rows of dW
+    (CONV3,   4, 16, 16, 136, 136, 200),   # ... the same on the per-tap kernel (W < 32), ragged N
     (CONV3,   1, 64, 96, 72, 0, 40),       # patch kernel: channel tail (72 = 64 + 8), ragged N
     (CONV3,   2, 8, 64, 192, 0, 128),      # patch kernel: three channel chunks (patch reloaded twice)
     (CONV3,   4, 130, 250, 8, 0, 24),      # register-stationary-weights kernel (>= 1024 tiles): ragged H, W, N; tiny Cin
