@@ -359,3 +359,60 @@ np.savez(sys.argv[1], **out)
     assert np.array_equal(res["1"]["f32"], res["nohead"]["f32"])
     d = np.abs(res["1"]["bf16"] - res["nohead"]["bf16"]).max()
     assert 0 < d <= 2e-5, d
+
+
+_DEPTH6_SCRIPT = r"""
+import sys, ctypes as C, numpy as np, torch
+sys.path.insert(0, %r)
+from multiplanarunet_amd.unet import UNet
+from multiplanarunet_amd import _lib
+K, D, cf, H, B = 3, 6, 0.0625, 64, 4
+m = UNet(n_classes=K, dim=H, n_channels=1, depth=D, complexity_factor=cf, dtype="bf16", logger=lambda *a, **k: None,
+         flatten_output=True, seed=3)
+rng = np.random.RandomState(14)
+x = rng.randn(B, H, H, 1).astype(np.float32)
+y = rng.randint(0, K, (B, H * H, 1)).astype(np.uint8)
+lib = _lib.load()
+lib.mpu_schedule_log_enable(1)
+m.forward_backward(x, y, np.ones(B, np.float32))
+n = lib.mpu_schedule_log_read(None, 0)
+buf = C.create_string_buffer(int(n) + 1)
+lib.mpu_schedule_log_read(buf, n + 1)
+lines = buf.value.decode().splitlines()
+wg = [l for l in lines if l.startswith("wgrad ")]
+print("WG", len(wg), sum("grouped" in l for l in wg), len([l for l in lines if l.startswith("wgrad-group")]))
+np.save(sys.argv[1], m.grads.cpu().numpy())
+"""
+
+
+def test_depth6_network_overflows_the_wgrad_group_and_reduce_tables(tmp_path):
+    """A depth-6 network has 32 3x3 / 2x2 conv layers: more than the 16 + 12 slots of the grouped weight-gradient launches
+    (kernels.h: WgradGroup) and as many as the deferred-reduction table holds (REDUCE_MAX_JOBS = 32). Layers beyond the
+    tables fall back to their own launches / an immediate reduction. The weight gradients of a layer depend on the
+    grouping only through their fp32 summation order (x and dz come from the forward pass and the data-gradient chain),
+    so the whole gradient buffer of a train step with MPU_WGRAD_GROUP=1 must equal the one with MPU_WGRAD_GROUP=0 to fp32
+    rounding, tensor by tensor (the switch is read once per process: two subprocesses)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for grp in ("1", "0"):
+        f = str(tmp_path / ("g%s.npy" % grp))
+        r = subprocess.run([sys.executable, "-c", _DEPTH6_SCRIPT % root, f], env=dict(os.environ, MPU_WGRAD_GROUP=grp),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        tag = [l for l in r.stdout.splitlines() if l.startswith("WG ")][0].split()
+        out[grp] = (np.load(f), int(tag[1]), int(tag[2]), int(tag[3]))
+    g1, n1, grouped1, launches1 = out["1"]
+    g0, n0, grouped0, launches0 = out["0"]
+    print("depth-6: %d wgrad layers; grouped build: %d in %d group launches (the rest on their own); ungrouped: %d" %
+          (n1, grouped1, launches1, grouped0))
+    assert n1 >= 32 and 0 < grouped1 < n1 and launches1 >= 2 and grouped0 == 0     # the tables overflowed: both paths ran
+    assert np.isfinite(g1).all() and np.isfinite(g0).all()
+    from multiplanarunet_amd.unet import UNet
+    m = UNet(n_classes=3, dim=64, n_channels=1, depth=6, complexity_factor=0.0625, dtype="bf16", logger=quiet, device="cpu")
+    for name, (kind, off, ps, ls) in m._tensors.items():
+        if kind != 0:
+            continue
+        a, b = g1[off:off + int(np.prod(ps))], g0[off:off + int(np.prod(ps))]
+        scale = np.abs(b).max() + 1e-30
+        assert np.abs(a - b).max() <= 2e-5 * scale, (name, np.abs(a - b).max() / scale)
