@@ -182,7 +182,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fsw = ((lane & 31) >> 1) & 7, fh = lane >> 5;
-    auto compute = [&](int tap, int stage) {
+    // kv = k-steps of 16 channels that hold any channel of the chunk (a 96-channel source: 4 + 2); the rest of a tail
+    // chunk is zero fill and its MFMAs are skipped in pairs
+    auto chunk_ksteps = [&](int cc) {
+        bool s1; int cbase, Cs; chunk_src(cc, s1, cbase, Cs);
+        const int left = Cs - cbase;
+        return left >= BKE ? 4 : (left * (int)sizeof(T) + 31) / 32;
+    };
+    auto compute = [&](int tap, int stage, int kv) {
         const int ky = tap / KW, kx = tap - ky * KW;
         const unsigned char* Wb = smem + Cfg::PATCH + stage * Cfg::WSTAGE + (wn * 64 + (lane & 31)) * 128;
         int prow[TM], psw[TM];
@@ -198,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
         constexpr int SG = (TN + TM > 4) ? 2 : 4;                // k-steps requested together (register budget)
 #pragma unroll
         for (int g0 = 0; g0 < 4; g0 += SG) {
+            if (g0 >= kv) break;                                 // (workgroup-uniform)
             uint4 af[SG][TN], bf[SG][TM];
 #pragma unroll
             for (int s = 0; s < SG; ++s) {
@@ -226,12 +234,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int st = 0, tap = 0, cc = 0;
+    int kv = chunk_ksteps(0);
     for (int step = 0; step < nsteps; ++step) {
         constexpr int AHEAD = NWS - 1;                           // prefetch distance
         const int stn = (st + AHEAD) % NWS;
         const bool more = step + AHEAD < nsteps;
         if (more) issue_w(step + AHEAD, stn);
-        compute(tap, st);
+        compute(tap, st, kv);
         const bool reload = (tap == NT - 1) && (cc + 1 < nchunks);
         if (reload) {
             // every wave has finished reading the patch before it is overwritten
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
         }
         __builtin_amdgcn_s_barrier();
         st = (st + 1) % NWS;
-        if (++tap == NT) { tap = 0; ++cc; }
+        if (++tap == NT) { tap = 0; ++cc; kv = cc < nchunks ? chunk_ksteps(cc) : 4; }
     }
 
     // --- epilogue: bias -> LDS, tile -> LDS, coalesced 16-byte row stores ------------------
@@ -454,7 +463,7 @@ struct Halo8Cfg {
     static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
 };
 
-template <int BN, int TH, int MODE, int NWS_>
+template <int BN, int TH, int MODE, int NWS_, int SCHED>
 __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
     typedef bf16_t T;
     using Cfg = Halo8Cfg<BN, TH, MODE, NWS_>;
@@ -603,61 +612,188 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
     // queue is in order, so "at most GW (+ NPW) requests outstanding" means the weights of tap+1 have landed while
     // the newest weight stage -- and a patch requested in this or the previous tap -- stay in flight; the patch is
     // forced by the wait of the third tap, six taps before its first reader.
-    issue_patch(0, 0);
-    issue_w(0);
-    if (nsteps >= AHEAD) {                                       // (layers have >= 4 taps: always)
-#pragma unroll
-        for (int k = 1; k < AHEAD; ++k) issue_w(k);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * GW) : "memory");
-    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);                // the younger half loses every arbitration otherwise
-    __builtin_amdgcn_s_barrier();
-    if (stamps) stamps[1] = __builtin_amdgcn_s_memtime();
-    int st = 0, tap = 0, cc = 0;
-    TapAddr cur;
-    tap_addr(0, 0, 0, cur);
-    load(cur, 0, 0);
-    for (int step = 0; step < nsteps; ++step) {
-        const int stn = (st + AHEAD) % NWS;
-        const bool more = step + AHEAD < nsteps;
-        if (more) issue_w(stn);
-        const bool pre = tap == 0 && cc + 1 < nchunks;
-        if (pre) issue_patch(cc + 1, (cc + 1) & 1);
-        const bool patch_young = tap <= AHEAD - 1 && cc + 1 < nchunks;  // a patch requested within the last AHEAD taps
-        int ntap = tap + 1, ncc = cc;
-        if (ntap == NT) { ntap = 0; ++ncc; }
-        const bool last = step + 1 >= nsteps;
-        TapAddr nxt;
-        tap_addr(last ? tap : ntap, last ? st : (st + 1) % NWS, (last ? cc : ncc) & 1, nxt);
-        load(cur, 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(0);
-        __builtin_amdgcn_sched_barrier(0);
-        load(cur, 2, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1);
-        __builtin_amdgcn_sched_barrier(0);
-        load(cur, 3, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (stamps && (step == 4 || step == 5)) stamps[8 + 4 * (step - 4)] = __builtin_amdgcn_s_memtime();
-        if (more) {
-            if (patch_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * GW + NPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * GW) : "memory");
+    if constexpr (SCHED == 0) {
+        issue_patch(0, 0);
+        issue_w(0);
+        if (nsteps >= AHEAD) {                                       // (layers have >= 4 taps: always)
+    #pragma unroll
+            for (int k = 1; k < AHEAD; ++k) issue_w(k);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * GW) : "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (stamps && (step == 4 || step == 5)) stamps[9 + 4 * (step - 4)] = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (stamps && (step == 4 || step == 5)) stamps[10 + 4 * (step - 4)] = __builtin_amdgcn_s_memtime();
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);                // the younger half loses every arbitration otherwise
         __builtin_amdgcn_s_barrier();
-        if (stamps && (step == 4 || step == 5)) stamps[11 + 4 * (step - 4)] = __builtin_amdgcn_s_memtime();
-        load(nxt, 0, 0);                                         // (after the last tap: a harmless re-read)
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1);
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
-        st = (st + 1) % NWS;
-        tap = ntap; cc = ncc;
+        if (stamps) stamps[1] = __builtin_amdgcn_s_memtime();
+        int st = 0, tap = 0, cc = 0;
+        TapAddr cur;
+        tap_addr(0, 0, 0, cur);
+        load(cur, 0, 0);
+        for (int step = 0; step < nsteps; ++step) {
+            const int stn = (st + AHEAD) % NWS;
+            const bool more = step + AHEAD < nsteps;
+            if (more) issue_w(stn);
+            const bool pre = tap == 0 && cc + 1 < nchunks;
+            if (pre) issue_patch(cc + 1, (cc + 1) & 1);
+            const bool patch_young = tap <= AHEAD - 1 && cc + 1 < nchunks;  // a patch requested within the last AHEAD taps
+            int ntap = tap + 1, ncc = cc;
+            if (ntap == NT) { ntap = 0; ++ncc; }
+            const bool last = step + 1 >= nsteps;
+            TapAddr nxt;
+            tap_addr(last ? tap : ntap, last ? st : (st + 1) % NWS, (last ? cc : ncc) & 1, nxt);
+            load(cur, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0);
+            __builtin_amdgcn_sched_barrier(0);
+            load(cur, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1);
+            __builtin_amdgcn_sched_barrier(0);
+            load(cur, 3, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (stamps && (step == 4 || step == 5)) stamps[8 + 4 * (step - 4)] = __builtin_amdgcn_s_memtime();
+            if (more) {
+                if (patch_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * GW + NPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * GW) : "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (stamps && (step == 4 || step == 5)) stamps[9 + 4 * (step - 4)] = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (stamps && (step == 4 || step == 5)) stamps[10 + 4 * (step - 4)] = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            if (stamps && (step == 4 || step == 5)) stamps[11 + 4 * (step - 4)] = __builtin_amdgcn_s_memtime();
+            load(nxt, 0, 0);                                         // (after the last tap: a harmless re-read)
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+            st = (st + 1) % NWS;
+            tap = ntap; cc = ncc;
+        }
+    } else {
+        // SCHED 1 (round 3): the two halves of the workgroup run ONE PHASE APART. A tap is a load phase L (every
+        // fragment of the tap's four k-steps read into registers, the tap's address arithmetic, counted waits) and a
+        // compute phase C (the tap's MFMAs with the DMA requests in their shadow: weights of tap+3, a share of the
+        // next chunk's patch); a workgroup barrier closes each phase, and waves 4-7 start one barrier late: while one
+        // half's MFMAs own the matrix pipes, the other half's LDS reads run beside them (waves w and w+4 share a SIMD)
+        // instead of in front of its own MFMAs.
+        //   interval:   I0    I1    I2    I3    I4 ...
+        //   waves 0-3:  L(0)  C(0)  L(1)  C(1)  L(2)
+        //   waves 4-7:   -    L(0)  C(0)  L(1)  C(1)
+        // Hazards (B(k) = the barrier that ends interval k): the weights of tap u (stage u % 4) are read in I(2u) and
+        // I(2u+1); tap u+4 is requested into that stage in C(u+1) = I(2u+3) / I(2u+4), behind B(2u+1) and each reader's
+        // lgkmcnt(0). Every wave ends L(v) with a counted vmcnt that forces its pieces of tap v+1 (requested in
+        // C(v-2); the queue is in order: w(v+1) p(v-2) w(v+2) p(v-1), p = patch pieces of that tap if any), so they
+        // have landed when it arrives at B(2v) (first half) / B(2v+1) (second half), and the first reader of tap v+1
+        // starts behind B(2v+1). The next chunk's patch goes to the other buffer, PPT pieces per wave and tap in the
+        // first taps of a chunk; that buffer's last reader finished before B(2u-1), u the chunk's first tap, and the
+        // pieces are forced three taps after their request, at least three taps before their first reader.
+        static_assert(NWS == 4, "four weight stages: requests three taps ahead");
+        constexpr int PPT = 2;                                   // patch pieces per wave and tap
+        static_assert(NPW % PPT == 0 && NPW / PPT <= NT - 3 + (MODE == UPCONV2 ? 2 : 0), "patch pieces spread over the first taps of a chunk");
+        constexpr int PTAPS = NPW / PPT;
+        const bool second = wave >= 4;
+        const bool prio_c = a.dbg & 1, prio_l = a.dbg & 2;      // (tuning aid: MPU_HALO8_PRIO)
+        uint4 fa[4][TN], fb[4][TM];
+        issue_patch(0, 0);
+        issue_w(0);
+        if (nsteps > 1) issue_w(1);
+        if (nsteps > 2) issue_w(2);
+        if (nsteps > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (stamps) stamps[1] = __builtin_amdgcn_s_memtime();
+        if (second) __builtin_amdgcn_s_barrier();                // one phase behind
+        int st = 0, tap = 0, cc = 0;
+        bool pp1 = false, pp2 = false;                           // patch pieces requested in C(step-1), C(step-2)
+        // k-steps of 16 channels that hold any channel of the chunk: the zero fill of a tail chunk (a 96-channel source:
+        // 64 + 32) is neither read nor multiplied (skipped in pairs)
+        auto chunk_ksteps = [&](int c_) {
+            const bool s1 = c_ >= nch0;
+            const int left = (s1 ? a.C1 : a.C0) - (s1 ? c_ - nch0 : c_) * BKE;
+            return left >= BKE ? 4 : (left + 15) / 16;
+        };
+        int kv = chunk_ksteps(0);
+        for (int step = 0; step < nsteps; ++step) {
+            // ---- L(step): fragments of the tap
+            if (stamps && (step == 4 || step == 5)) stamps[8 + 4 * (step - 4)] = __builtin_amdgcn_s_memtime();
+            if (prio_l) __builtin_amdgcn_s_setprio(1);
+            TapAddr A;
+            tap_addr(tap, st, cc & 1, A);
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                if (s_ == 2 && kv <= 2) break;
+                const int q = 2 * s_ + fh;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) fa[s_][i] = *(const uint4*)(A.Wb + i * 32 * 128 + ((q ^ fsw) << 4));
+#pragma unroll
+                for (int j = 0; j < TM; ++j) fb[s_][j] = *(const uint4*)(A.Pr[j] + ((q ^ A.psw[j]) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 2 < nsteps) {                             // in flight behind w(step+1): p(step-2) w(step+2) p(step-1)
+                const int np = (pp1 ? 1 : 0) + (pp2 ? 1 : 0);
+                if (np == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory");
+                else if (np == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW + PPT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW + 2 * PPT) : "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (stamps && (step == 4 || step == 5)) stamps[9 + 4 * (step - 4)] = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (stamps && (step == 4 || step == 5)) stamps[10 + 4 * (step - 4)] = __builtin_amdgcn_s_memtime();
+            if (prio_l) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- C(step): the tap's MFMAs; DMA requests between them
+            if (stamps && (step == 4 || step == 5)) stamps[11 + 4 * (step - 4)] = __builtin_amdgcn_s_memtime();
+            if (prio_c) __builtin_amdgcn_s_setprio(1);
+            const bool more = step + 3 < nsteps;
+            const bool pp = tap < PTAPS && cc + 1 < nchunks;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) HMma<T>::run(fa[0][i], fb[0][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) issue_w((st + 3) % NWS);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) HMma<T>::run(fa[1][i], fb[1][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pp) {
+                const int ncc = cc + 1;
+                const bool s1 = ncc >= nch0;
+                const int cbase = (s1 ? ncc - nch0 : ncc) * BKE, Cs = s1 ? a.C1 : a.C0;
+                i32x4 qrs;
+                qrs.x = s1 ? rs1.x : rs0.x; qrs.y = s1 ? rs1.y : rs0.y; qrs.z = s1 ? rs1.z : rs0.z; qrs.w = rs0.w;
+#pragma unroll
+                for (int kk = 0; kk < PTAPS; ++kk) {
+                    if (tap == kk) {
+#pragma unroll
+                        for (int k = PPT * kk; k < PPT * kk + PPT; ++k) {
+                            const int ch = cbase + pchunk[k] * EPC;
+                            const unsigned off = (ppix[k] >= 0 && ch < Cs) ? (unsigned)((ppix[k] * Cs + ch) * 2) : OOB;
+                            h_dma16(qrs, off, lds0 + (ncc & 1) * Cfg::PATCH + __builtin_amdgcn_readfirstlane(ppiece[k]) * 1024);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kv > 2) {
+#pragma unroll
+                for (int s_ = 2; s_ < 4; ++s_)
+#pragma unroll
+                    for (int i = 0; i < TN; ++i)
+#pragma unroll
+                        for (int j = 0; j < TM; ++j) HMma<T>::run(fa[s_][i], fb[s_][j], acc[i][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (prio_c) __builtin_amdgcn_s_setprio(0);
+            if (stamps && step == 4) stamps[7] = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            pp2 = pp1; pp1 = pp;
+            st = (st + 1) % NWS;
+            if (++tap == NT) { tap = 0; ++cc; kv = cc < nchunks ? chunk_ksteps(cc) : 4; }
+        }
+        if (!second) __builtin_amdgcn_s_barrier();               // the second half's last compute phase
     }
     __builtin_amdgcn_s_setprio(0);
     if (stamps) stamps[2] = __builtin_amdgcn_s_memtime();
@@ -821,11 +957,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
     }
 }
 
-template <int BN, int TH, int MODE, int NWS_>
+template <int BN, int TH, int MODE, int NWS_, int SCHED>
 int launch_halo8_cfg_n(const ConvArgs& a_in, hipStream_t st) {
     using Cfg = Halo8Cfg<BN, TH, MODE, NWS_>;
     static_assert(Cfg::SMEM <= 160 * 1024, "LDS");
-    auto kern = conv_halo8_kernel<BN, TH, MODE, NWS_>;
+    auto kern = conv_halo8_kernel<BN, TH, MODE, NWS_, SCHED>;
     ConvArgs a = a_in;
     if (a.w_elems <= 0) a.w_elems = (Cfg::NT - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
     static bool attr_set = false;
@@ -847,6 +983,9 @@ int launch_halo8_cfg_n(const ConvArgs& a_in, hipStream_t st) {
     if (a.pooled && a.pooled_done && MODE == CONV3 && !a.mask && !(a.Ho & 1) && !(a.Wo & 1) && TH % 2 == 0) *a.pooled_done = 1;
     else a.pooled = nullptr;
     a.dbg_buf = stamp_buffer();
+    static int prio = -1;                                        // MPU_HALO8_PRIO (SCHED 1): bit 0 = s_setprio 1 in the compute phase, bit 1 = in the load phase
+    if (prio < 0) { const char* e = getenv("MPU_HALO8_PRIO"); prio = e ? atoi(e) & 3 : 2; }
+    a.dbg = prio;
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);
     kern<<<dim3((unsigned)tiles), dim3(512), Cfg::SMEM, st>>>(a);
     if (prof_on()) prof_end(st);
@@ -892,7 +1031,11 @@ int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
 // (three weight stages = requests two taps ahead; a fourth stage measured the same: the in-loop stamps show < 100
 // cycles in the counted vmcnt wait, the tap is bound by MFMA issue + fragment reads)
 template <int BN, int TH, int MODE>
-int launch_halo8_cfg(const ConvArgs& a, hipStream_t st) { return launch_halo8_cfg_n<BN, TH, MODE, 3>(a, st); }
+int launch_halo8_cfg(const ConvArgs& a, hipStream_t st) {
+    static int sched = -1;                                       // MPU_HALO8_SCHED: 0 = lockstep halves, 1 = one phase apart (default)
+    if (sched < 0) { const char* e = getenv("MPU_HALO8_SCHED"); sched = e ? atoi(e) : 1; }
+    return sched == 1 ? launch_halo8_cfg_n<BN, TH, MODE, 4, 1>(a, st) : launch_halo8_cfg_n<BN, TH, MODE, 3, 0>(a, st);
+}
 
 // 1 = launched (2: the 8-wave double-buffered variant), 0 = shape not suited (caller falls back to the plain
 // implicit GEMM), < 0 = error
@@ -905,7 +1048,7 @@ int try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
         static int h8 = -1; static long h8_max = 0, h8_min = 0;
         if (h8 < 0) {
             const char* e = getenv("MPU_HALO8"); h8 = (e && e[0] == '0') ? 0 : 1;
-            const char* m = getenv("MPU_HALO8_MAX_WGS"); h8_max = m ? atol(m) : 640;
+            const char* m = getenv("MPU_HALO8_MAX_WGS"); h8_max = m ? atol(m) : 400;
             const char* n = getenv("MPU_HALO8_MIN_WGS"); h8_min = n ? atol(n) : 192;
         }
         if (h8 && dtype == MPU_BF16 && a.Ho % 8 == 0 && !a.head_w && (mode == CONV3 || !(a.Wo & 1))) {

@@ -82,7 +82,7 @@ HALO8_CASES = [
     # mode,   B, H,  W,  C0,  C1,  Cout
     (CONV3,   16, 64, 64, 128, 0, 128),     # encoder_L1_conv2: 256 tiles of 128 channels, two chunks (one patch prefetch)
     (CONV3,   16, 32, 32, 256, 0, 256),     # encoder_L2_conv2: 64-channel tiles (TM = 1), four chunks
-    (CONV3,   16, 64, 64, 128, 128, 136),   # concat (second source = chunks 2..3) + ragged N (two 128-channel tiles)
+    (CONV3,   12, 64, 64, 128, 128, 136),   # concat (second source = chunks 2..3) + ragged N (two 128-channel tiles: 384 workgroups)
     (CONV3,   13, 64, 40, 72, 0, 64),       # ragged W tile, channel tail (72 = 64 + 8)
     (UPCONV2, 16, 64, 64, 256, 0, 128),     # upsample_L2_conv1: low-resolution patch, 128-channel tiles
     (UPCONV2, 9, 64, 72, 72, 0, 40),        # up-conv: ragged W tile, channel tail, ragged N (216 tiles)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3 call S: final validation of the committed build: smoke, whole GPU suite, the driver's bench command
+# round 3 final validation of the committed build: smoke, whole GPU suite, the driver's bench command
 R="$GRAFT_REPO_ROOT"; O=$R/gpurun_out/R3s; mkdir -p $O
 cd $R
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -3 $O/smoke.log

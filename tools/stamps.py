@@ -52,3 +52,6 @@ for name in names:
         e = np.stack([s[:, 9] - s[:, 8], s[:, 10] - s[:, 9], s[:, 11] - s[:, 10], s[:, 12] - s[:, 8]], 1)
         for j, l in enumerate(["step4 vmcnt wait", "step4 lgkmcnt wait", "step4 barrier", "step period (4->5)"]):
             print("   %-22s mean %8.0f  min %8.0f  max %8.0f ticks" % (l, e[:, j].mean(), e[:, j].min(), e[:, j].max()))
+        if s[:, 7].min() > 0:   # MPU_HALO8_SCHED=1: stamp 8 = start of the load phase, 11 = start of the compute phase, 7 = its end
+            c = s[:, 7] - s[:, 11]
+            print("   %-22s mean %8.0f  min %8.0f  max %8.0f ticks" % ("step4 compute phase", c.mean(), c.min(), c.max()))
