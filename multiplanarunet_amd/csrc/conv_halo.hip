@@ -483,8 +483,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned long long* stamps = (a.dbg_buf && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 32 && tid == 0)
-                                     ? a.dbg_buf + (blockIdx.x >> 3) * 16 : nullptr;     // dev aid (MPU_STAMPS=1)
+    // SCHED: 0 = lockstep halves, 1 = halves one phase apart, 2 = 1 + the dev aids (s_memtime stamps, MPU_STAMPS=1; the
+    // s_setprio placement switchable at run time, MPU_HALO8_PRIO): their ~30 scalar instructions per tap stay out of 1
+    constexpr bool DBG = SCHED != 1;
+    unsigned long long* stamps = (DBG && a.dbg_buf && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 32 && tid == 0)
+                                     ? a.dbg_buf + (blockIdx.x >> 3) * 16 : nullptr;
     if (stamps) stamps[0] = __builtin_amdgcn_s_memtime();
     const int wn = wave % WAVES_N, wm = wave / WAVES_N;
     const int H = a.Ho, W = a.Wo;
@@ -552,10 +555,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
         wlane[g] = n < a.Cout ? (unsigned)((long)n * a.w_row_stride * 2L) + (unsigned)(wch[g] * 2) : OOB;
     }
     int w_tap = 0, w_cc = 0;
+    const unsigned w_tap_bytes = (unsigned)(a.w_tap_stride * 2L);   // (the launcher checks w_elems * 2 < 2 GiB)
+    unsigned w_tapoff = 0;                                       // w_tap * w_tap_bytes, kept running
     auto issue_w = [&](int stage) {
         const bool s1 = w_cc >= nch0;
         const int cbase = (s1 ? w_cc - nch0 : w_cc) * BKE, Cs = s1 ? a.C1 : a.C0;
-        const unsigned soff = (unsigned)(((long)w_tap * a.w_tap_stride + (s1 ? a.C0 : 0) + cbase) * 2L);
+        const unsigned soff = w_tapoff + (unsigned)(((s1 ? a.C0 : 0) + cbase) * 2);
         const unsigned dst = ldsW + stage * Cfg::WSTAGE + wave * (BN / NW) * 128;
         const int room = Cs - cbase;
 #pragma unroll
@@ -563,7 +568,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
             const unsigned off = (wch[g] < room && wlane[g] != OOB) ? wlane[g] + soff : OOB;
             h_dma16(rsw, off, dst + g * 8 * 128);
         }
-        if (++w_tap == NT) { w_tap = 0; ++w_cc; }
+        w_tapoff += w_tap_bytes;
+        if (++w_tap == NT) { w_tap = 0; w_tapoff = 0; ++w_cc; }
     };
 
     f32x16 acc[TN][TM];
@@ -577,8 +583,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
     const int fsw = ((lane & 31) >> 1) & 7, fh = lane >> 5;
     // Fragment addressing of one tap: weight rows of the stage, patch rows shifted by the tap.
     struct TapAddr { const unsigned char* Wb; const unsigned char* Pr[TM]; int psw[TM]; };
-    auto tap_addr = [&](int tap, int stage, int buf, TapAddr& A) {
-        const int ky = tap / KW, kx = tap - ky * KW;
+    auto tap_addr_yx = [&](int ky, int kx, int stage, int buf, TapAddr& A) {
         A.Wb = smem + 2 * Cfg::PATCH + stage * Cfg::WSTAGE + (wn * 64 + (lane & 31)) * 128;
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
@@ -587,6 +592,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
             A.Pr[j] = smem + buf * Cfg::PATCH + prow * 128;
             A.psw[j] = (prow >> 1) & 7;
         }
+    };
+    auto tap_addr = [&](int tap, int stage, int buf, TapAddr& A) {
+        const int ky = tap / KW;
+        tap_addr_yx(ky, tap - ky * KW, stage, buf, A);
     };
     uint4 af[2][TN], bf[2][TM];
     auto load = [&](const TapAddr& A, int s_, int set) {
@@ -692,106 +701,126 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
         static_assert(NPW % PPT == 0 && NPW / PPT <= NT - 3 + (MODE == UPCONV2 ? 2 : 0), "patch pieces spread over the first taps of a chunk");
         constexpr int PTAPS = NPW / PPT;
         const bool second = wave >= 4;
-        const bool prio_c = a.dbg & 1, prio_l = a.dbg & 2;      // (tuning aid: MPU_HALO8_PRIO)
+        const bool prio_c = DBG ? (a.dbg & 1) != 0 : false, prio_l = DBG ? (a.dbg & 2) != 0 : true;   // (DBG: MPU_HALO8_PRIO)
         uint4 fa[4][TN], fb[4][TM];
+        // The nine (four) taps of a chunk are unrolled: tap position, patch-piece schedule, counted waits and the tap's
+        // patch-row shift are compile-time, only the weight stage (period 4) and the chunk's scalars stay in registers --
+        // the wave issues in order, and every scalar / address instruction of the loop sits in front of an MFMA or a
+        // fragment read (the lean instantiation runs the 64-channel tiles 8 % faster than the one with ~30 more scalar
+        // instructions per tap).
+        // per chunk: byte offset of its channels inside a weight row, channels left in its source, k-steps that hold data
+        auto chunk_woff = [&](int c_) { const bool s1 = c_ >= nch0; return (unsigned)(((s1 ? a.C0 : 0) + (s1 ? c_ - nch0 : c_) * BKE) * 2); };
+        auto chunk_room = [&](int c_) { const bool s1 = c_ >= nch0; return (s1 ? a.C1 : a.C0) - (s1 ? c_ - nch0 : c_) * BKE; };
+        auto ksteps_of = [&](int room) { return room >= BKE ? 4 : (room + 15) / 16; };
+        auto request_w = [&](unsigned soff, int room, int stage) {         // weights of one tap: GW pieces per wave
+            const unsigned dst = ldsW + stage * Cfg::WSTAGE + wave * (BN / NW) * 128;
+#pragma unroll
+            for (int g = 0; g < GW; ++g) {
+                const unsigned off = (wch[g] < room && wlane[g] != OOB) ? wlane[g] + soff : OOB;
+                h_dma16(rsw, off, dst + g * 8 * 128);
+            }
+        };
+        const unsigned w_tap_b = (unsigned)(a.w_tap_stride * 2L);
+        unsigned woffA = chunk_woff(0); int roomA = chunk_room(0);
         issue_patch(0, 0);
-        issue_w(0);
-        if (nsteps > 1) issue_w(1);
-        if (nsteps > 2) issue_w(2);
-        if (nsteps > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        request_w(woffA, roomA, 0);
+        request_w(woffA + w_tap_b, roomA, 1);
+        request_w(woffA + 2 * w_tap_b, roomA, 2);                 // (NT >= 4: the first three taps are of chunk 0)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GW) : "memory");
         __builtin_amdgcn_s_barrier();
         if (stamps) stamps[1] = __builtin_amdgcn_s_memtime();
         if (second) __builtin_amdgcn_s_barrier();                // one phase behind
-        int st = 0, tap = 0, cc = 0;
-        bool pp1 = false, pp2 = false;                           // patch pieces requested in C(step-1), C(step-2)
-        // k-steps of 16 channels that hold any channel of the chunk: the zero fill of a tail chunk (a 96-channel source:
-        // 64 + 32) is neither read nor multiplied (skipped in pairs)
-        auto chunk_ksteps = [&](int c_) {
-            const bool s1 = c_ >= nch0;
-            const int left = (s1 ? a.C1 : a.C0) - (s1 ? c_ - nch0 : c_) * BKE;
-            return left >= BKE ? 4 : (left + 15) / 16;
-        };
-        int kv = chunk_ksteps(0);
-        for (int step = 0; step < nsteps; ++step) {
-            // ---- L(step): fragments of the tap
-            if (stamps && (step == 4 || step == 5)) stamps[8 + 4 * (step - 4)] = __builtin_amdgcn_s_memtime();
-            if (prio_l) __builtin_amdgcn_s_setprio(1);
-            TapAddr A;
-            tap_addr(tap, st, cc & 1, A);
+        int st = 0;
+        for (int cc = 0; cc < nchunks; ++cc) {
+            const bool hasnext = cc + 1 < nchunks;
+            const int kv = ksteps_of(roomA);
+            const unsigned woffB = hasnext ? chunk_woff(cc + 1) : 0u;
+            const int roomB = hasnext ? chunk_room(cc + 1) : 0;
+            const unsigned pbuf = (unsigned)(cc & 1) * Cfg::PATCH, pnext = (unsigned)((cc + 1) & 1) * Cfg::PATCH;
+            // next chunk's patch source (requested in the first PTAPS compute phases)
+            const int ncc = cc + 1;
+            const bool ns1 = ncc >= nch0;
+            const int ncbase = (ns1 ? ncc - nch0 : ncc) * BKE, nCs = ns1 ? a.C1 : a.C0;
+            i32x4 qrs;
+            qrs.x = ns1 ? rs1.x : rs0.x; qrs.y = ns1 ? rs1.y : rs0.y; qrs.z = ns1 ? rs1.z : rs0.z; qrs.w = rs0.w;
 #pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) {
-                if (s_ == 2 && kv <= 2) break;
-                const int q = 2 * s_ + fh;
+            for (int tap = 0; tap < NT; ++tap) {
+                constexpr int dummy = 0; (void)dummy;
+                const int ky = tap / KW, kx = tap % KW;           // (compile-time)
+                // patch pieces in flight behind w(tap+1) at the end of this load phase: requested in C(tap-1), C(tap-2)
+                const int cnt = ((tap >= 1 && tap - 1 < PTAPS) ? 1 : 0) + ((tap >= 2 && tap - 2 < PTAPS) ? 1 : 0);
+                const bool stamp_here = DBG && stamps && cc == 0 && (tap == 4 % NT || tap == 5 % NT) && NT > 5;
+                const int sidx = tap == 4 ? 0 : 1;
+                // ---- L: fragments of the tap
+                if (stamp_here) stamps[8 + 4 * sidx] = __builtin_amdgcn_s_memtime();
+                if (prio_l) __builtin_amdgcn_s_setprio(1);
+                TapAddr A;
+                tap_addr_yx(ky, kx, st, 0, A);
 #pragma unroll
-                for (int i = 0; i < TN; ++i) fa[s_][i] = *(const uint4*)(A.Wb + i * 32 * 128 + ((q ^ fsw) << 4));
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    if (s_ == 2 && kv <= 2) break;
+                    const int q = 2 * s_ + fh;
 #pragma unroll
-                for (int j = 0; j < TM; ++j) fb[s_][j] = *(const uint4*)(A.Pr[j] + ((q ^ A.psw[j]) << 4));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (step + 2 < nsteps) {                             // in flight behind w(step+1): p(step-2) w(step+2) p(step-1)
-                const int np = (pp1 ? 1 : 0) + (pp2 ? 1 : 0);
-                if (np == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory");
-                else if (np == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW + PPT) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW + 2 * PPT) : "memory");
-            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (stamps && (step == 4 || step == 5)) stamps[9 + 4 * (step - 4)] = __builtin_amdgcn_s_memtime();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (stamps && (step == 4 || step == 5)) stamps[10 + 4 * (step - 4)] = __builtin_amdgcn_s_memtime();
-            if (prio_l) __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_s_barrier();
-            // ---- C(step): the tap's MFMAs; DMA requests between them
-            if (stamps && (step == 4 || step == 5)) stamps[11 + 4 * (step - 4)] = __builtin_amdgcn_s_memtime();
-            if (prio_c) __builtin_amdgcn_s_setprio(1);
-            const bool more = step + 3 < nsteps;
-            const bool pp = tap < PTAPS && cc + 1 < nchunks;
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < TN; ++i) fa[s_][i] = *(const uint4*)(A.Wb + i * 32 * 128 + ((q ^ fsw) << 4));
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+                    for (int j = 0; j < TM; ++j) fb[s_][j] = *(const uint4*)(A.Pr[j] + pbuf + ((q ^ A.psw[j]) << 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap >= NT - 2 && !hasnext) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing requested behind w(tap+1)
+                else if (cnt == 2 && hasnext) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW + 2 * PPT) : "memory");
+                else if (cnt == 1 && hasnext) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW + PPT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory");
+                if (stamp_here) stamps[9 + 4 * sidx] = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (stamp_here) stamps[10 + 4 * sidx] = __builtin_amdgcn_s_memtime();
+                if (prio_l) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_barrier();
+                // ---- C: the tap's MFMAs; DMA requests between them
+                if (stamp_here) stamps[11 + 4 * sidx] = __builtin_amdgcn_s_memtime();
+                if (prio_c) __builtin_amdgcn_s_setprio(1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < TM; ++j) HMma<T>::run(fa[0][i], fb[0][j], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) issue_w((st + 3) % NWS);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+                    for (int j = 0; j < TM; ++j) HMma<T>::run(fa[0][i], fb[0][j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                {   // weights three taps ahead: of this chunk, or the first taps of the next one
+                    const int wt = tap + 3;
+                    if (wt < NT) request_w(woffA + (unsigned)wt * w_tap_b, roomA, (st + 3) & 3);
+                    else if (hasnext) request_w(woffB + (unsigned)(wt - NT) * w_tap_b, roomB, (st + 3) & 3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < TM; ++j) HMma<T>::run(fa[1][i], fb[1][j], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (pp) {
-                const int ncc = cc + 1;
-                const bool s1 = ncc >= nch0;
-                const int cbase = (s1 ? ncc - nch0 : ncc) * BKE, Cs = s1 ? a.C1 : a.C0;
-                i32x4 qrs;
-                qrs.x = s1 ? rs1.x : rs0.x; qrs.y = s1 ? rs1.y : rs0.y; qrs.z = s1 ? rs1.z : rs0.z; qrs.w = rs0.w;
+                for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int kk = 0; kk < PTAPS; ++kk) {
-                    if (tap == kk) {
+                    for (int j = 0; j < TM; ++j) HMma<T>::run(fa[1][i], fb[1][j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap < PTAPS && hasnext) {
 #pragma unroll
-                        for (int k = PPT * kk; k < PPT * kk + PPT; ++k) {
-                            const int ch = cbase + pchunk[k] * EPC;
-                            const unsigned off = (ppix[k] >= 0 && ch < Cs) ? (unsigned)((ppix[k] * Cs + ch) * 2) : OOB;
-                            h_dma16(qrs, off, lds0 + (ncc & 1) * Cfg::PATCH + __builtin_amdgcn_readfirstlane(ppiece[k]) * 1024);
+                    for (int k = PPT * tap; k < PPT * tap + PPT; ++k) {
+                        if (k < NPW) {
+                            const int ch = ncbase + pchunk[k] * EPC;
+                            const unsigned off = (ppix[k] >= 0 && ch < nCs) ? (unsigned)((ppix[k] * nCs + ch) * 2) : OOB;
+                            h_dma16(qrs, off, lds0 + pnext + __builtin_amdgcn_readfirstlane(ppiece[k]) * 1024);
                         }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kv > 2) {
+#pragma unroll
+                    for (int s_ = 2; s_ < 4; ++s_)
+#pragma unroll
+                        for (int i = 0; i < TN; ++i)
+#pragma unroll
+                            for (int j = 0; j < TM; ++j) HMma<T>::run(fa[s_][i], fb[s_][j], acc[i][j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (prio_c) __builtin_amdgcn_s_setprio(0);
+                if (stamp_here && tap == 4) stamps[7] = __builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_s_barrier();
+                st = (st + 1) & 3;
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (kv > 2) {
-#pragma unroll
-                for (int s_ = 2; s_ < 4; ++s_)
-#pragma unroll
-                    for (int i = 0; i < TN; ++i)
-#pragma unroll
-                        for (int j = 0; j < TM; ++j) HMma<T>::run(fa[s_][i], fb[s_][j], acc[i][j]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (prio_c) __builtin_amdgcn_s_setprio(0);
-            if (stamps && step == 4) stamps[7] = __builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_s_barrier();
-            pp2 = pp1; pp1 = pp;
-            st = (st + 1) % NWS;
-            if (++tap == NT) { tap = 0; ++cc; kv = cc < nchunks ? chunk_ksteps(cc) : 4; }
+            woffA = woffB; roomA = roomB;
         }
         if (!second) __builtin_amdgcn_s_barrier();               // the second half's last compute phase
     }
@@ -1034,7 +1063,10 @@ template <int BN, int TH, int MODE>
 int launch_halo8_cfg(const ConvArgs& a, hipStream_t st) {
     static int sched = -1;                                       // MPU_HALO8_SCHED: 0 = lockstep halves, 1 = one phase apart (default)
     if (sched < 0) { const char* e = getenv("MPU_HALO8_SCHED"); sched = e ? atoi(e) : 1; }
-    return sched == 1 ? launch_halo8_cfg_n<BN, TH, MODE, 4, 1>(a, st) : launch_halo8_cfg_n<BN, TH, MODE, 3, 0>(a, st);
+    if (sched != 1) return launch_halo8_cfg_n<BN, TH, MODE, 3, 0>(a, st);
+    static int dev = -1;                                         // stamps or a priority override asked for: the instrumented build
+    if (dev < 0) dev = (stamp_buffer() != nullptr || getenv("MPU_HALO8_PRIO") != nullptr) ? 1 : 0;
+    return dev ? launch_halo8_cfg_n<BN, TH, MODE, 4, 2>(a, st) : launch_halo8_cfg_n<BN, TH, MODE, 4, 1>(a, st);
 }
 
 // 1 = launched (2: the 8-wave double-buffered variant), 0 = shape not suited (caller falls back to the plain
