@@ -92,8 +92,6 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
     const int y0 = (t % tiles_y) * TH; const int b = t / tiles_y;
     const int nch0 = (a.C0 + BKE - 1) / BKE, nch1 = (a.C1 + BKE - 1) / BKE;
     const int nchunks = nch0 + nch1;
-    // (dev aid, MPU_HALO_DEBUG=<n>: the K loop is cut to n steps -- wrong results, the launch's fixed cost in isolation)
-    const int nsteps = (a.dbg & 0xff00) ? ((nchunks * NT < ((a.dbg >> 8) & 0xff)) ? nchunks * NT : ((a.dbg >> 8) & 0xff)) : nchunks * NT;
     constexpr unsigned OOB = 0xfffffff0u;
     const int Hi = MODE == UPCONV2 ? H / 2 : H, Wi = MODE == UPCONV2 ? W / 2 : W;     // input resolution
     const long npix = (long)a.B * Hi * Wi;
@@ -158,20 +156,6 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
         wch[g] = wchunk[g] * EPC;
         wlane[g] = wrow[g] == OOB ? OOB : wrow[g] + (unsigned)(wch[g] * (int)sizeof(T));
     }
-    int w_tap = 0, w_cc = 0;                                     // position of the next request
-    auto issue_w = [&](int /*step*/, int stage) {
-        const bool s1 = w_cc >= nch0;
-        const int cbase = (s1 ? w_cc - nch0 : w_cc) * BKE, Cs = s1 ? a.C1 : a.C0;
-        const unsigned soff = (unsigned)(((long)w_tap * a.w_tap_stride + (s1 ? a.C0 : 0) + cbase) * (long)sizeof(T));
-        const unsigned dst = ldsW + stage * Cfg::WSTAGE + wave * (BN / 4) * 128;
-        const int room = Cs - cbase;                             // channels left in this source: only a tail chunk masks
-#pragma unroll
-        for (int g = 0; g < GW; ++g) {
-            const unsigned off = (wch[g] < room && wlane[g] != OOB) ? wlane[g] + soff : OOB;
-            h_dma16(rsw, off, dst + g * 8 * 128);
-        }
-        if (++w_tap == NT) { w_tap = 0; ++w_cc; }
-    };
 
     f32x16 acc[TN][TM];
 #pragma unroll
@@ -184,19 +168,18 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
     const int fsw = ((lane & 31) >> 1) & 7, fh = lane >> 5;
     // kv = k-steps of 16 channels that hold any channel of the chunk (a 96-channel source: 4 + 2); the rest of a tail
     // chunk is zero fill and its MFMAs are skipped in pairs
-    auto chunk_ksteps = [&](int cc) {
-        bool s1; int cbase, Cs; chunk_src(cc, s1, cbase, Cs);
-        const int left = Cs - cbase;
-        return left >= BKE ? 4 : (left * (int)sizeof(T) + 31) / 32;
-    };
-    auto compute = [&](int tap, int stage, int kv) {
-        const int ky = tap / KW, kx = tap - ky * KW;
-        const unsigned char* Wb = smem + Cfg::PATCH + stage * Cfg::WSTAGE + (wn * 64 + (lane & 31)) * 128;
+    auto compute = [&](int ky, int kx, int stage, int kv) {
+        // (with the taps unrolled the fragment addresses of all nine taps are loop invariants; the 8 x 2 accumulator
+        // tile has no registers for them -- 140 spilled -- so there the lane term is made opaque per tap and the
+        // ~40 address instructions are recomputed, as the rolled loop did)
+        int l31 = lane & 31;
+        if constexpr (TN * TM >= 8) asm volatile("" : "+v"(l31));
+        const unsigned char* Wb = smem + Cfg::PATCH + stage * Cfg::WSTAGE + (wn * 64 + l31) * 128;
         int prow[TM], psw[TM];
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-            prow[j] = MODE == UPCONV2 ? ((wm * TM + j + ky) >> 1) * PW + ((kx + (lane & 31)) >> 1)
-                                      : (wm * TM + j + ky) * PW + kx + (lane & 31);   // patch row of this lane's pixel
+            prow[j] = MODE == UPCONV2 ? ((wm * TM + j + ky) >> 1) * PW + ((kx + l31) >> 1)
+                                      : (wm * TM + j + ky) * PW + kx + l31;   // patch row of this lane's pixel
             psw[j] = (prow[j] >> 1) & 7;
         }
         // All fragments of the tap are requested before the first MFMA (sched_barrier keeps the compiler from sinking
@@ -228,34 +211,58 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
     };
 
     // --- pipeline: patch once per chunk (single buffer), weights through an NWS-stage ring ---
+    // The taps of a chunk are unrolled (round 3, after conv_halo8: every scalar / address instruction of the loop
+    // sits in front of an MFMA or a fragment read of an in-order wave): tap position, request target and the counted
+    // waits are compile-time; the chunk's scalars and the weight stage stay in registers.
+    constexpr int AHEAD = NWS - 1;                               // prefetch distance (taps)
+    static_assert(AHEAD >= 1 && AHEAD < NT, "request distance");
+    auto chunk_woff = [&](int c_) { const bool s1 = c_ >= nch0; return (unsigned)(((s1 ? a.C0 : 0) + (s1 ? c_ - nch0 : c_) * BKE) * (int)sizeof(T)); };
+    auto chunk_room = [&](int c_) { const bool s1 = c_ >= nch0; return (s1 ? a.C1 : a.C0) - (s1 ? c_ - nch0 : c_) * BKE; };
+    auto request_w = [&](unsigned soff, int room, int stage) {
+        const unsigned dst = ldsW + stage * Cfg::WSTAGE + wave * (BN / 4) * 128;
+#pragma unroll
+        for (int g = 0; g < GW; ++g) {
+            const unsigned off = (wch[g] < room && wlane[g] != OOB) ? wlane[g] + soff : OOB;
+            h_dma16(rsw, off, dst + g * 8 * 128);
+        }
+    };
+    const unsigned w_tap_b = (unsigned)(a.w_tap_stride * (long)sizeof(T));
+    unsigned woffA = chunk_woff(0); int roomA = chunk_room(0);
     issue_patch(0);
-    issue_w(0, 0);
-    if (NWS == 3 && nsteps > 1) { issue_w(1, 1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory"); }
+    request_w(woffA, roomA, 0);
+    if (AHEAD == 2) { request_w(woffA + w_tap_b, roomA, 1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    int st = 0, tap = 0, cc = 0;
-    int kv = chunk_ksteps(0);
-    for (int step = 0; step < nsteps; ++step) {
-        constexpr int AHEAD = NWS - 1;                           // prefetch distance
-        const int stn = (st + AHEAD) % NWS;
-        const bool more = step + AHEAD < nsteps;
-        if (more) issue_w(step + AHEAD, stn);
-        compute(tap, st, kv);
-        const bool reload = (tap == NT - 1) && (cc + 1 < nchunks);
-        if (reload) {
-            // every wave has finished reading the patch before it is overwritten
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int st = 0;
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const bool hasnext = cc + 1 < nchunks;
+        const int left = roomA;
+        const int kv = left >= BKE ? 4 : (left * (int)sizeof(T) + 31) / 32;
+        const unsigned woffB = hasnext ? chunk_woff(cc + 1) : 0u;
+        const int roomB = hasnext ? chunk_room(cc + 1) : 0;
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap) {
+            const int wt = tap + AHEAD;                          // weights requested now (compile-time position)
+            const bool more = wt < NT || hasnext;
+            int stn = st + AHEAD; if (stn >= NWS) stn -= NWS;
+            if (wt < NT) request_w(woffA + (unsigned)wt * w_tap_b, roomA, stn);
+            else if (hasnext) request_w(woffB + (unsigned)(wt - NT) * w_tap_b, roomB, stn);
+            compute(tap / KW, tap % KW, st, kv);
+            if (tap == NT - 1 && hasnext) {
+                // every wave has finished reading the patch before it is overwritten
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                issue_patch(cc + 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (AHEAD == 2 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
-            issue_patch(cc + 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            if (NWS == 3 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (++st == NWS) st = 0;
         }
-        __builtin_amdgcn_s_barrier();
-        st = (st + 1) % NWS;
-        if (++tap == NT) { tap = 0; ++cc; kv = cc < nchunks ? chunk_ksteps(cc) : 4; }
+        woffA = woffB; roomA = roomB;
     }
 
     // --- epilogue: bias -> LDS, tile -> LDS, coalesced 16-byte row stores ------------------
@@ -1046,9 +1053,6 @@ int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
     } else a.stats = nullptr;
     if (a.pooled && a.pooled_done && MODE == CONV3 && !a.mask && !(a.Ho & 1) && !(a.Wo & 1) && TH % 2 == 0) *a.pooled_done = 1;
     else a.pooled = nullptr;
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("MPU_HALO_DEBUG"); dbg = e ? (atoi(e) & 0xff) << 8 : 0; }
-    a.dbg = dbg;
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);
     kern<<<dim3((unsigned)tiles), dim3(256), Cfg::SMEM, st>>>(a);
     if (prof_on()) prof_end(st);
