@@ -33,6 +33,7 @@ __device__ __forceinline__ void h_dma16(const i32x4& rsrc, unsigned voff, unsign
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
                  :: "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
 }
+constexpr unsigned HALO_POISON = 0x80001000u;                    // + any in-range byte offset (< 2 GiB - 8 KiB) stays >= num_records
 template <typename T> struct HMma;
 template <> struct HMma<bf16_t> {
     static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
         const int py = pr / PW, px = pr % PW;
         const int iy = MODE == UPCONV2 ? y0 / 2 + py : y0 + py - 1, ix = MODE == UPCONV2 ? x0 / 2 + px : x0 + px - 1;
         const bool v = piece < NPP && pr < Cfg::PH * PW && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
-        ppix[k] = v ? (b * Hi + iy) * Wi + ix : -1;
+        ppix[k] = v ? (b * Hi + iy) * Wi + ix : (int)npix;      // padding: the first pixel BEYOND the tensor (out of range for either source)
         pchunk[k] = slot ^ ((pr >> 1) & 7);
     }
     unsigned wrow[GW]; int wchunk[GW];
@@ -136,12 +137,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
     };
     auto issue_patch = [&](int cc) {
         bool s1; int cbase, Cs; chunk_src(cc, s1, cbase, Cs);
+        const bool tail = Cs - cbase < BKE;                      // only a tail chunk masks channels
 #pragma unroll
         for (int k = 0; k < NPW; ++k) {
             const int piece = wave + 4 * k;
             if (piece < NPP) {                                   // wave-uniform
                 const int ch = cbase + pchunk[k] * EPC;
-                const unsigned off = (ppix[k] >= 0 && ch < Cs) ? (unsigned)((ppix[k] * Cs + ch) * (int)sizeof(T)) : OOB;
+                unsigned off = (unsigned)((ppix[k] * Cs + ch) * (int)sizeof(T));
+                if (tail) off = ch < Cs ? off : OOB;
                 if (s1) h_dma16(rs1, off, lds0 + piece * 1024);
                 else    h_dma16(rs0, off, lds0 + piece * 1024);
             }
@@ -218,12 +221,19 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
     static_assert(AHEAD >= 1 && AHEAD < NT, "request distance");
     auto chunk_woff = [&](int c_) { const bool s1 = c_ >= nch0; return (unsigned)(((s1 ? a.C0 : 0) + (s1 ? c_ - nch0 : c_) * BKE) * (int)sizeof(T)); };
     auto chunk_room = [&](int c_) { const bool s1 = c_ >= nch0; return (s1 ? a.C1 : a.C0) - (s1 ? c_ - nch0 : c_) * BKE; };
+    // rows beyond Cout carry a poison offset that stays out of range after the add (operands < 2 GiB - 8 KiB: checked
+    // by the launcher), so a request is one add per piece; only a tail chunk masks channels
+    unsigned wpo[GW];
+#pragma unroll
+    for (int g = 0; g < GW; ++g) wpo[g] = wlane[g] == OOB ? HALO_POISON : wlane[g];
     auto request_w = [&](unsigned soff, int room, int stage) {
         const unsigned dst = ldsW + stage * Cfg::WSTAGE + wave * (BN / 4) * 128;
+        if (room >= BKE) {
 #pragma unroll
-        for (int g = 0; g < GW; ++g) {
-            const unsigned off = (wch[g] < room && wlane[g] != OOB) ? wlane[g] + soff : OOB;
-            h_dma16(rsw, off, dst + g * 8 * 128);
+            for (int g = 0; g < GW; ++g) h_dma16(rsw, wpo[g] + soff, dst + g * 8 * 128);
+        } else {
+#pragma unroll
+            for (int g = 0; g < GW; ++g) h_dma16(rsw, wch[g] < room ? wpo[g] + soff : HALO_POISON, dst + g * 8 * 128);
         }
     };
     const unsigned w_tap_b = (unsigned)(a.w_tap_stride * (long)sizeof(T));
@@ -537,7 +547,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
         const int py = pr / PW, px = pr % PW;
         const int iy = MODE == UPCONV2 ? y0 / 2 + py : y0 + py - 1, ix = MODE == UPCONV2 ? x0 / 2 + px : x0 + px - 1;
         const bool v = pr < Cfg::PH * PW && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
-        ppix[k] = v ? (b * Hi + iy) * Wi + ix : -1;
+        ppix[k] = v ? (b * Hi + iy) * Wi + ix : (int)npix;      // padding: the first pixel beyond the tensor
         pchunk[k] = slot ^ ((pr >> 1) & 7);
     }
     auto issue_patch = [&](int cc, int buf) {
@@ -545,10 +555,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
         const int cbase = (s1 ? cc - nch0 : cc) * BKE, Cs = s1 ? a.C1 : a.C0;
         i32x4 qrs;                                               // source descriptor by scalar selects (no branch per piece)
         qrs.x = s1 ? rs1.x : rs0.x; qrs.y = s1 ? rs1.y : rs0.y; qrs.z = s1 ? rs1.z : rs0.z; qrs.w = rs0.w;
+        const bool tail = Cs - cbase < BKE;
 #pragma unroll
         for (int k = 0; k < NPW; ++k) {
             const int ch = cbase + pchunk[k] * EPC;
-            const unsigned off = (ppix[k] >= 0 && ch < Cs) ? (unsigned)((ppix[k] * Cs + ch) * 2) : OOB;
+            unsigned off = (unsigned)((ppix[k] * Cs + ch) * 2);
+            if (tail) off = ch < Cs ? off : OOB;
             const unsigned dst = lds0 + buf * Cfg::PATCH + __builtin_amdgcn_readfirstlane(ppiece[k]) * 1024;
             h_dma16(qrs, off, dst);
         }
@@ -719,12 +731,17 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
         auto chunk_woff = [&](int c_) { const bool s1 = c_ >= nch0; return (unsigned)(((s1 ? a.C0 : 0) + (s1 ? c_ - nch0 : c_) * BKE) * 2); };
         auto chunk_room = [&](int c_) { const bool s1 = c_ >= nch0; return (s1 ? a.C1 : a.C0) - (s1 ? c_ - nch0 : c_) * BKE; };
         auto ksteps_of = [&](int room) { return room >= BKE ? 4 : (room + 15) / 16; };
+        unsigned wpo[GW];                                         // (poison offset: see conv_halo_kernel)
+#pragma unroll
+        for (int g = 0; g < GW; ++g) wpo[g] = wlane[g] == OOB ? HALO_POISON : wlane[g];
         auto request_w = [&](unsigned soff, int room, int stage) {         // weights of one tap: GW pieces per wave
             const unsigned dst = ldsW + stage * Cfg::WSTAGE + wave * (BN / NW) * 128;
+            if (room >= BKE) {
 #pragma unroll
-            for (int g = 0; g < GW; ++g) {
-                const unsigned off = (wch[g] < room && wlane[g] != OOB) ? wlane[g] + soff : OOB;
-                h_dma16(rsw, off, dst + g * 8 * 128);
+                for (int g = 0; g < GW; ++g) h_dma16(rsw, wpo[g] + soff, dst + g * 8 * 128);
+            } else {
+#pragma unroll
+                for (int g = 0; g < GW; ++g) h_dma16(rsw, wch[g] < room ? wpo[g] + soff : HALO_POISON, dst + g * 8 * 128);
             }
         };
         const unsigned w_tap_b = (unsigned)(a.w_tap_stride * 2L);
@@ -807,7 +824,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
                     for (int k = PPT * tap; k < PPT * tap + PPT; ++k) {
                         if (k < NPW) {
                             const int ch = ncbase + pchunk[k] * EPC;
-                            const unsigned off = (ppix[k] >= 0 && ch < nCs) ? (unsigned)((ppix[k] * nCs + ch) * 2) : OOB;
+                            unsigned off = (unsigned)((ppix[k] * nCs + ch) * 2);
+                            if (nCs - ncbase < BKE) off = ch < nCs ? off : OOB;
                             h_dma16(qrs, off, lds0 + pnext + __builtin_amdgcn_readfirstlane(ppiece[k]) * 1024);
                         }
                     }
@@ -1008,7 +1026,7 @@ int launch_halo8_cfg_n(const ConvArgs& a_in, hipStream_t st) {
     const long M = (long)a.B * a.Ho * a.Wo;
     const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
     const long Min = MODE == UPCONV2 ? M / 4 : M;
-    if (Min * cmax * 2L >= (1L << 31) || a.w_elems * 2L >= (1L << 31) || M * a.Cout * 2L >= (1L << 31))
+    if (Min * cmax * 2L >= (1L << 31) - 8192 || a.w_elems * 2L >= (1L << 31) - 8192 || M * a.Cout * 2L >= (1L << 31) - 8192)
         return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
     const long tiles = (long)a.B * cdiv(a.Ho, TH) * cdiv(a.Wo, Cfg::TW) * cdiv(a.Cout, BN);
     const long ptiles = tiles / cdiv(a.Cout, BN);
@@ -1042,8 +1060,8 @@ int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
     const long M = (long)a.B * a.Ho * a.Wo;
     const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
     const long Min = MODE == UPCONV2 ? M / 4 : M;                // input pixels (32-bit DMA / buffer-store offsets)
-    if (Min * cmax * (long)sizeof(T) >= (1L << 31) || a.w_elems * (long)sizeof(T) >= (1L << 31) ||
-        M * a.Cout * (long)sizeof(T) >= (1L << 31))
+    if (Min * cmax * (long)sizeof(T) >= (1L << 31) - 8192 || a.w_elems * (long)sizeof(T) >= (1L << 31) - 8192 ||
+        M * a.Cout * (long)sizeof(T) >= (1L << 31) - 8192)
         return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
     const long tiles = (long)a.B * cdiv(a.Ho, TH) * cdiv(a.Wo, Cfg::TW) * cdiv(a.Cout, BN);
     const long ptiles = tiles / cdiv(a.Cout, BN);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3 call AD: the 4-wave conv_halo kernel with unrolled taps: parity, predict A/B against the previous build (MPU_LIB_PATH)
+# round 3 calls AD, AE: conv_halo variants: parity, predict and train A/B against the previous build (MPU_LIB_PATH)
 R="$GRAFT_REPO_ROOT"; O=$R/gpurun_out/R3ad; mkdir -p $O; cd $R
 timeout 600 python -m pytest tests/test_gpu_conv.py -x -q > $O/pytest_conv.log 2>&1; tail -2 $O/pytest_conv.log
 P=$R/multiplanarunet_amd/lib/libmpunet_hip_prev.so
