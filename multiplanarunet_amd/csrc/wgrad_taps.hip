@@ -69,7 +69,14 @@ constexpr int TAPS_SMEM = XCH_A + XCH_B > 2 * GROUP_LDS ? XCH_A + XCH_B : 2 * GR
 // (Round 3, s_memtime stamps inside the loop: a K step takes ~2300 cycles against ~1260 of MFMA issue for the two waves
 // of a SIMD; the counted vmcnt wait costs < 100 of them and a ring one step deeper changes nothing -- the loop is
 // bound by MFMA issue + the LDS transpose reads in front of them, not by the L2 -> LDS latency.)
-template <int MODE, int T0, int T1>
+// STAG (round 3, after conv_halo8): the two 4-wave groups run ONE PHASE APART. A step is a load phase L (the 26 transposing
+// fragment reads of the step's dZ row and nine shifted X fragments, into registers) and a compute phase C (the step's 36
+// MFMAs, the DMA requests of step t+3 between them); a workgroup barrier closes each phase and group 1 starts one barrier
+// late, so one group's MFMAs run beside the other group's LDS reads on the SIMDs they share. The rings allow the longer
+// request distance because the request follows the reads of the slot it overwrites (X row t+5 -> slot of row t, dZ row
+// t+3 -> slot of row t, both read in L(t)); a wave ends L(t) with only the group it requested in C(t-1) in flight. No
+// stamps / run-time ring arithmetic in this variant: the ring slots are running scalars.
+template <int MODE, int T0, int T1, bool STAG>
 __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPlan& p, unsigned char* smem_all,
                                                 const int tile, const int pair, const unsigned bid) {
     constexpr int NT = T1 - T0, KW = MODE == UPCONV2 ? 2 : 3;
@@ -81,7 +88,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave8 >> 2, wave = wave8 & 3;
     // dev aid (MPU_STAMPS=1): phase boundaries of every 8th workgroup, wave 0
-    unsigned long long* stamps = (a.dbg_buf && (bid & 7) == 0 && (bid >> 3) < 32 && tid == 0)
+    unsigned long long* stamps = (!STAG && a.dbg_buf && (bid & 7) == 0 && (bid >> 3) < 32 && tid == 0)
                                      ? a.dbg_buf + (bid >> 3) * 16 : nullptr;
     if (stamps) stamps[0] = __builtin_amdgcn_s_memtime();
     unsigned char* smem = smem_all + grp * GROUP_LDS;
@@ -201,61 +208,160 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
     f32x4 accdb = {0.f, 0.f, 0.f, 0.f};
     const s16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
 
-    // ---- pipeline: step t uses X rows t, t+1, t+2 and dZ row t; issues X row t+4 and dZ row t+2 -----------
-    if (valid) {
-        issue_x(0); issue_x(1); issue_x(2); issue_z(0);
-        issue_x(3); issue_z(1);
-    }
-    // wait for the first group (rows 0..2 + dZ 0); the later ones may still be in flight
-    wait_keep_groups(DIST - 1);
-    __builtin_amdgcn_s_barrier();
-    if (stamps) stamps[1] = __builtin_amdgcn_s_memtime();
-    for (int t = 0; t < nsteps_wg; ++t) {
-        if (t >= nsteps) {                                       // the other group still has rows to do
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            continue;
+    if constexpr (!STAG) {
+        // ---- pipeline: step t uses X rows t, t+1, t+2 and dZ row t; issues X row t+4 and dZ row t+2 -----------
+        if (valid) {
+            issue_x(0); issue_x(1); issue_x(2); issue_z(0);
+            issue_x(3); issue_z(1);
         }
-        if (t + DIST < nsteps) { issue_x(t + DIST + 2); issue_z(t + DIST); }
-        const unsigned char* zb = smem + NXR * XROWB + (t % NZRT) * ZROWB;
-        s16x8 bz[4];
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) bz[cb] = t_frag(zb + offB[cb][0], zb + offB[cb][1]);
-        const unsigned char* xr[KW];
-#pragma unroll
-        for (int ky = 0; ky < KW; ++ky) xr[ky] = smem + ((t + ky) % NXRT) * XROWB;
-        s16x8 af = t_frag(xr[T0 / KW] + offA[T0 % KW][0], xr[T0 / KW] + offA[T0 % KW][1]);
-#pragma unroll
-        for (int tp = 0; tp < NT; ++tp) {
-            s16x8 an = af;
-            if (tp + 1 < NT) {
-                const int ky = (T0 + tp + 1) / KW, kx = (T0 + tp + 1) % KW;
-                an = t_frag(xr[ky] + offA[kx][0], xr[ky] + offA[kx][1]);
-            }
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-                acc[tp][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bz[cb], acc[tp][cb], 0, 0, 0);
-            af = an;
-        }
-        if (a.fuse_db && T0 == 0) {                              // (the half that holds tap 0 also sums dZ)
-            s16x8 bw = bz[0];
-            if (wave == 1) bw = bz[1]; else if (wave == 2) bw = bz[2]; else if (wave == 3) bw = bz[3];
-            accdb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bw, accdb, 0, 0, 0);
-        }
-        if (stamps && (t == 4 || t == 5)) stamps[8 + 4 * (t - 4)] = __builtin_amdgcn_s_memtime();
-        // group t+1 has landed (the DIST-1 groups behind it may be in flight); all waves are done with step t's rows
-        {
-            int younger = nsteps - 2 - t;                        // groups t+2 .. min(t+DIST, nsteps-1) are outstanding behind group t+1
-            if (younger > DIST - 1) younger = DIST - 1;
-            wait_keep_groups(younger > 0 ? younger : 0);
-        }
-        if (stamps && (t == 4 || t == 5)) stamps[9 + 4 * (t - 4)] = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (stamps && (t == 4 || t == 5)) stamps[10 + 4 * (t - 4)] = __builtin_amdgcn_s_memtime();
+        // wait for the first group (rows 0..2 + dZ 0); the later ones may still be in flight
+        wait_keep_groups(DIST - 1);
         __builtin_amdgcn_s_barrier();
-        if (stamps && (t == 4 || t == 5)) stamps[11 + 4 * (t - 4)] = __builtin_amdgcn_s_memtime();
-    }
+        if (stamps) stamps[1] = __builtin_amdgcn_s_memtime();
+        for (int t = 0; t < nsteps_wg; ++t) {
+            if (t >= nsteps) {                                       // the other group still has rows to do
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                continue;
+            }
+            if (t + DIST < nsteps) { issue_x(t + DIST + 2); issue_z(t + DIST); }
+            const unsigned char* zb = smem + NXR * XROWB + (t % NZRT) * ZROWB;
+            s16x8 bz[4];
+    #pragma unroll
+            for (int cb = 0; cb < 4; ++cb) bz[cb] = t_frag(zb + offB[cb][0], zb + offB[cb][1]);
+            const unsigned char* xr[KW];
+    #pragma unroll
+            for (int ky = 0; ky < KW; ++ky) xr[ky] = smem + ((t + ky) % NXRT) * XROWB;
+            s16x8 af = t_frag(xr[T0 / KW] + offA[T0 % KW][0], xr[T0 / KW] + offA[T0 % KW][1]);
+    #pragma unroll
+            for (int tp = 0; tp < NT; ++tp) {
+                s16x8 an = af;
+                if (tp + 1 < NT) {
+                    const int ky = (T0 + tp + 1) / KW, kx = (T0 + tp + 1) % KW;
+                    an = t_frag(xr[ky] + offA[kx][0], xr[ky] + offA[kx][1]);
+                }
+    #pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[tp][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bz[cb], acc[tp][cb], 0, 0, 0);
+                af = an;
+            }
+            if (a.fuse_db && T0 == 0) {                              // (the half that holds tap 0 also sums dZ)
+                s16x8 bw = bz[0];
+                if (wave == 1) bw = bz[1]; else if (wave == 2) bw = bz[2]; else if (wave == 3) bw = bz[3];
+                accdb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bw, accdb, 0, 0, 0);
+            }
+            if (stamps && (t == 4 || t == 5)) stamps[8 + 4 * (t - 4)] = __builtin_amdgcn_s_memtime();
+            // group t+1 has landed (the DIST-1 groups behind it may be in flight); all waves are done with step t's rows
+            {
+                int younger = nsteps - 2 - t;                        // groups t+2 .. min(t+DIST, nsteps-1) are outstanding behind group t+1
+                if (younger > DIST - 1) younger = DIST - 1;
+                wait_keep_groups(younger > 0 ? younger : 0);
+            }
+            if (stamps && (t == 4 || t == 5)) stamps[9 + 4 * (t - 4)] = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (stamps && (t == 4 || t == 5)) stamps[10 + 4 * (t - 4)] = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            if (stamps && (t == 4 || t == 5)) stamps[11 + 4 * (t - 4)] = __builtin_amdgcn_s_memtime();
+        }
 
+    } else {
+        // ---- staggered pipeline (see the comment above the template) ----------------------------------------
+        const int per = (NXP - wave + 3) / 4 + 1;                // DMA pieces of this wave per step group (CONV3: 3,2,2,2)
+        // running request state: next X row / dZ row to request, their ring slots and global row offsets
+        const int xrow_b = Wi * Cs * 2, zrow_b = W * a.Cout * 2;     // bytes per input / dZ image row
+        int rx = 0;                                              // next staged X row index
+        unsigned xslot = 0, zslot = 0;                           // ring slot byte offsets of the next requests
+        int iy_next = MODE == UPCONV2 ? 0 : y0 - 1;              // (CONV3) image row of staged row rx
+        auto req_x = [&]() {
+            int iy; bool rowok;
+            if (MODE == UPCONV2) { const int uy = y0 + rx; rowok = uy < H; iy = uy >> 1; }
+            else { iy = iy_next; rowok = (unsigned)iy < (unsigned)H; }
+            const unsigned rowoff = (unsigned)((b * Hi + iy) * xrow_b);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int q = wave + 4 * k;
+                if (q < NXP) {
+                    const unsigned off = (rowok && xlane[k] != OOB) ? rowoff + xlane[k] : OOB;
+                    t_dma16(rsx, off, lds0 + xslot + q * 1024);
+                }
+            }
+            ++rx; ++iy_next;
+            xslot += XROWB; if (xslot == NXR * XROWB) xslot = 0;
+        };
+        int rz = 0;
+        auto req_z = [&]() {
+            const int y = y0 + rz;
+            const unsigned rowoff = (unsigned)((b * H + y) * zrow_b);
+            const unsigned off = (y < H && zlane != OOB) ? rowoff + zlane : OOB;
+            t_dma16(rsz, off, ldsZ + zslot + wave * 1024);
+            ++rz;
+            zslot += ZROWB; if (zslot == NZR * ZROWB) zslot = 0;
+        };
+        auto wait_keep = [&](int groups) {                       // this wave's pieces of the `groups` youngest step groups stay in flight
+            if (groups <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (groups == 1) { if (per == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else if (per == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+            else { if (per == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else if (per == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        };
+        if (valid) {
+            req_x(); req_x(); req_x(); req_z();                  // step 0: rows 0..2, dZ 0
+            req_x(); req_z();                                    // step 1
+            req_x(); req_z();                                    // step 2
+        }
+        wait_keep(2);
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();              // one phase behind
+        unsigned x0s = 0, x1s = XROWB, x2s = 2 * XROWB, zs = 0;  // ring slots of rows t, t+1, t+2 and dZ row t
+        const bool dbw = a.fuse_db && T0 == 0;
+        for (int t = 0; t < nsteps_wg; ++t) {
+            if (t >= nsteps) {                                   // the other group still has rows to do
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
+                continue;
+            }
+            // ---- L(t)
+            __builtin_amdgcn_s_setprio(1);
+            const unsigned char* zb = smem + NXR * XROWB + zs;
+            s16x8 bz[4], af[NT];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) bz[cb] = t_frag(zb + offB[cb][0], zb + offB[cb][1]);
+#pragma unroll
+            for (int tp = 0; tp < NT; ++tp) {
+                const int ky = (T0 + tp) / KW, kx = (T0 + tp) % KW;
+                const unsigned char* xr = smem + (ky == 0 ? x0s : (ky == 1 ? x1s : x2s));
+                af[tp] = t_frag(xr + offA[kx][0], xr + offA[kx][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // step t+1's group (requested in C(t-2)) has landed; the one requested in C(t-1) may be in flight
+            wait_keep(t + 2 < nsteps ? 1 : 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- C(t)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tp = 0; tp < NT; ++tp) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[tp][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tp], bz[cb], acc[tp][cb], 0, 0, 0);
+                if (tp == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 3 < nsteps) { req_x(); req_z(); }    // step t+3: X row t+5 -> slot of row t, dZ row t+3 -> slot of dZ row t
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (dbw) {
+                s16x8 bw = bz[0];
+                if (wave == 1) bw = bz[1]; else if (wave == 2) bw = bz[2]; else if (wave == 3) bw = bz[3];
+                accdb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bw, accdb, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            x0s = x1s; x1s = x2s; x2s += XROWB; if (x2s == NXR * XROWB) x2s = 0;
+            zs += ZROWB; if (zs == NZR * ZROWB) zs = 0;
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();              // group 1's last compute phase
+    }
     if (stamps) stamps[2] = __builtin_amdgcn_s_memtime();
     // ---- combine the two groups through LDS (the rings are free now): group 0 ends up with taps 0-4 and the
     // bias sums, group 1 with taps 5-8; each stores its share of the pair's partial copy -----------------
@@ -330,7 +436,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
 
 // one workgroup of a job: bid = its index inside the job's grid (XCD-aware decode: the tiles of one strip pair run on one
 // XCD -- shared X / dZ in its L2; a job's first workgroup sits at a multiple of 8 of the launch grid)
-template <int MODE>
+template <int MODE, bool STAG>
 __device__ __forceinline__ void wgrad_taps_entry(const WgradArgs& a, const TapsPlan& p, unsigned bid, unsigned char* smem_all) {
     constexpr int NTALL = MODE == UPCONV2 ? 4 : 9;
     const int Cin = a.C0 + a.C1;
@@ -339,18 +445,19 @@ __device__ __forceinline__ void wgrad_taps_entry(const WgradArgs& a, const TapsP
     const int npairs = (p.nstrips + 1) / 2;
     const int sub = slot % ntile, pair = (slot / ntile) * 8 + xcd;
     if (pair >= npairs) return;
-    wgrad_taps_body<MODE, 0, NTALL>(a, p, smem_all, sub, pair, bid);
+    wgrad_taps_body<MODE, 0, NTALL, STAG>(a, p, smem_all, sub, pair, bid);
 }
 
-template <int MODE>
+template <int MODE, bool STAG>
 __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPlan p) {
     extern __shared__ __attribute__((aligned(128))) unsigned char smem_all[];
-    wgrad_taps_entry<MODE>(a, p, blockIdx.x, smem_all);
+    wgrad_taps_entry<MODE, STAG>(a, p, blockIdx.x, smem_all);
 }
 
 // Every deferred wgrad_taps job of a backward pass in ONE launch (kernels.h: WgradGroup): workgroup -> job by the table's
 // block ranges (each a multiple of 8), then exactly the single-job kernel.
 struct TapsGroupTable { int njobs, _pad; TapsGroupJob job[TAPS_GROUP_MAX]; };
+template <bool STAG>
 __global__ __launch_bounds__(512, 1) void wgrad_taps_group_kernel(TapsGroupTable t) {
     extern __shared__ __attribute__((aligned(128))) unsigned char smem_all[];
     int j = 0;
@@ -359,8 +466,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_group_kernel(TapsGroupTable
     const WgradArgs a = t.job[j].a;
     const TapsPlan p = t.job[j].p;
     const unsigned bid = blockIdx.x - (unsigned)t.job[j].blk_begin;
-    if (t.job[j].mode == UPCONV2) wgrad_taps_entry<UPCONV2>(a, p, bid, smem_all);
-    else wgrad_taps_entry<CONV3>(a, p, bid, smem_all);
+    if (t.job[j].mode == UPCONV2) wgrad_taps_entry<UPCONV2, STAG>(a, p, bid, smem_all);
+    else wgrad_taps_entry<CONV3, STAG>(a, p, bid, smem_all);
 }
 
 }  // namespace
@@ -418,12 +525,21 @@ int wgrad_taps_grid(int /*mode*/, const WgradArgs& a, const TapsPlan& p) {
     return cdiv(npairs, 8) * 8 * ntile;
 }
 
+static bool taps_stag() {                                        // MPU_WGRAD_TAPS_STAG=0: the lockstep groups
+    static int stag = -1;
+    if (stag < 0) { const char* e = getenv("MPU_WGRAD_TAPS_STAG"); stag = (e && e[0] == '0') ? 0 : 1; }
+    return stag != 0;
+}
+
 static int taps_attrs() {
     static bool attr_set = false;
     if (!attr_set) {
-        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel<CONV3>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
-        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel<UPCONV2>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
-        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
+        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel<CONV3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
+        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel<UPCONV2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
+        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel<CONV3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
+        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel<UPCONV2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
+        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_group_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
+        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
         attr_set = true;
     }
     return MPU_OK;
@@ -434,8 +550,13 @@ int launch_wgrad_taps(int mode, const WgradArgs& a_in, const TapsPlan& p, hipStr
     a.dbg_buf = stamp_buffer();
     const int grid = wgrad_taps_grid(mode, a, p);
     { const int rc = taps_attrs(); if (rc) return rc; }
-    if (mode == UPCONV2) wgrad_taps_kernel<UPCONV2><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(a, p);
-    else wgrad_taps_kernel<CONV3><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(a, p);
+    if (taps_stag() && !a.dbg_buf) {                             // (the stamps live in the lockstep variant)
+        if (mode == UPCONV2) wgrad_taps_kernel<UPCONV2, true><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(a, p);
+        else wgrad_taps_kernel<CONV3, true><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(a, p);
+    } else {
+        if (mode == UPCONV2) wgrad_taps_kernel<UPCONV2, false><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(a, p);
+        else wgrad_taps_kernel<CONV3, false><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(a, p);
+    }
     return launch_ok();
 }
 
@@ -456,7 +577,8 @@ int launch_wgrad_taps_group(const TapsGroupJob* jobs, int n, hipStream_t st) {
         t.job[k].blk_begin = grid;
         grid += wgrad_taps_grid(t.job[k].mode, t.job[k].a, t.job[k].p);      // a multiple of 8: the XCD decode of every job stays aligned
     }
-    wgrad_taps_group_kernel<<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(t);
+    if (taps_stag()) wgrad_taps_group_kernel<true><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(t);
+    else wgrad_taps_group_kernel<false><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(t);
     return launch_ok();
 }
 
