@@ -717,7 +717,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
         // pieces are forced three taps after their request, at least three taps before their first reader.
         static_assert(NWS == 4, "four weight stages: requests three taps ahead");
         constexpr int PPT = 2;                                   // patch pieces per wave and tap
-        static_assert(NPW % PPT == 0 && NPW / PPT <= NT - 3 + (MODE == UPCONV2 ? 2 : 0), "patch pieces spread over the first taps of a chunk");
+        static_assert(NPW % PPT == 0 && NPW / PPT <= NT - 3, "patch pieces of tap k are forced at the end of L(k+3): before the chunk ends");
         constexpr int PTAPS = NPW / PPT;
         const bool second = wave >= 4;
         const bool prio_c = DBG ? (a.dbg & 1) != 0 : false, prio_l = DBG ? (a.dbg & 2) != 0 : true;   // (DBG: MPU_HALO8_PRIO)
