@@ -416,3 +416,50 @@ def test_depth6_network_overflows_the_wgrad_group_and_reduce_tables(tmp_path):
         a, b = g1[off:off + int(np.prod(ps))], g0[off:off + int(np.prod(ps))]
         scale = np.abs(b).max() + 1e-30
         assert np.abs(a - b).max() <= 2e-5 * scale, (name, np.abs(a - b).max() / scale)
+
+
+_SCHED_SCRIPT = r"""
+import sys, numpy as np, torch, ctypes as C
+sys.path.insert(0, %r)
+from multiplanarunet_amd.unet import UNet
+from multiplanarunet_amd import _lib
+lib = _lib.load()
+quiet = lambda *a, **k: None
+B, K, D = 16, 3, 4
+m = UNet(n_classes=K, dim=128, n_channels=1, depth=D, complexity_factor=1, dtype="bf16", logger=quiet, flatten_output=True, seed=5)
+rng = np.random.RandomState(7)
+x = rng.randn(B, 128, 128, 1).astype(np.float32)
+y = rng.randint(0, K, (B, 128 * 128, 1)).astype(np.uint8)
+lib.mpu_schedule_log_enable(1)
+probs, loss = m.forward_backward(x, y, np.ones(B, np.float32))
+n = lib.mpu_schedule_log_read(None, 0); buf = C.create_string_buffer(int(n) + 1); lib.mpu_schedule_log_read(buf, n + 1)
+lib.mpu_schedule_log_enable(0)
+conv = [l.split()[1] for l in buf.value.decode().splitlines() if l.startswith("conv ")]
+print("SCHED halo8=%%d" %% sum(1 for c in conv if c == "halo8"))
+np.save(sys.argv[1], m.grads.cpu().numpy())
+np.save(sys.argv[1] + ".probs.npy", probs.float().cpu().numpy() if hasattr(probs, "cpu") else np.asarray(probs))
+"""
+
+
+def test_staggered_schedules_equal_the_lockstep_ones_bitwise(tmp_path):
+    """Round 3 schedules (conv_halo8 with its two halves one phase apart and unrolled taps; wgrad_taps with its two groups
+    one phase apart) change WHEN an MFMA is issued, never the order in which an accumulator receives its products:
+    the BASELINE configs[1] train step (B = 16 of 128x128, 64 filters, bf16) must give the same probabilities and the same
+    gradient buffer, bit for bit, with MPU_HALO8_SCHED=0 MPU_WGRAD_TAPS_STAG=0 (the lockstep reference schedules). The
+    switches are read once per process: two subprocesses."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, env in (("new", {}), ("lockstep", {"MPU_HALO8_SCHED": "0", "MPU_WGRAD_TAPS_STAG": "0"})):
+        f = str(tmp_path / (tag + ".npy"))
+        r = subprocess.run([sys.executable, "-c", _SCHED_SCRIPT % root, f], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        nh8 = int([l for l in r.stdout.splitlines() if l.startswith("SCHED ")][0].split("=")[1])
+        out[tag] = (np.load(f), np.load(f + ".probs.npy"), nh8)
+    (g1, p1, n1), (g0, p0, n0) = out["new"], out["lockstep"]
+    print("configs[1] step: %d conv launches on conv_halo8 in both runs; gradient buffer %d floats" % (n1, g1.size))
+    assert n1 >= 15 and n1 == n0                                   # levels 1-2 of the step took the 8-wave kernel in both
+    assert np.isfinite(g1).all() and np.abs(g1).max() > 0
+    assert np.array_equal(p1, p0)
+    assert np.array_equal(g1, g0)
