@@ -1124,40 +1124,53 @@ __device__ __forceinline__ void wgrad_glds_body(const WgradArgs& a, const unsign
         zrow[g] = piece * (64 / SPRZ) + lane / SPRZ;
         zch[g] = ((lane % SPRZ) ^ wg_swz16<RZ>(zrow[g])) * EPC;
     }
-    // Requests advance by KP pixels per step: every lane keeps the (ox, oy, image) of its next X pixel and steps them
-    // incrementally - the former per-request 64-bit divisions cost several hundred instructions per DMA, more than
-    // the step's MFMAs.
-    int xm[NPX], xox[NPX], xoy[NPX], xb[NPX], zm[NPZ];
+    // Requests advance by KP pixels per step. Every lane keeps the (image, oy, ox) of its next X pixel; round 3: no
+    // loops and no divergent branches in the advance (the former `while (ox >= Wo)` carry ran 2-4 masked iterations per
+    // piece at the deep levels' 8- and 16-pixel rows and the step carried ~350 instructions beside its 8 MFMAs):
+    //   * Wo divides KP (deep levels): ox is a lane constant, oy advances by KP / Wo with at most one wrap;
+    //   * otherwise the coordinates are decoded from the pixel index with multiply-high divisions (exact for
+    //     M * max(Wo, Ho) < 2^32: wgrad_glds_supported).
+    // dZ rows beyond the chunk's end are zero (dZ descriptor bounded to mend), so the X side needs no `m < mend` test:
+    // whatever it fetches for those rows is multiplied by zero.
+    int xm[NPX], xox[NPX], xoy[NPX], xb[NPX];
+    const unsigned magic_w = 0xffffffffu / (unsigned)a.Wo + 1u, magic_h = 0xffffffffu / (unsigned)a.Ho + 1u;   // ceil(2^32 / d)
+    auto decode = [&](int g) {
+        const unsigned m = (unsigned)xm[g];
+        const unsigned t = __umulhi(m, magic_w);
+        xox[g] = (int)(m - t * (unsigned)a.Wo);
+        const unsigned bb = __umulhi(t, magic_h);
+        xoy[g] = (int)(t - bb * (unsigned)a.Ho); xb[g] = (int)bb;
+    };
 #pragma unroll
-    for (int g = 0; g < NPX; ++g) {
-        const long m = mbeg + xrow[g];
-        xm[g] = (int)m;
-        xox[g] = (int)(m % a.Wo); const long t = m / a.Wo;
-        xoy[g] = (int)(t % a.Ho); xb[g] = (int)(t / a.Ho);
-    }
+    for (int g = 0; g < NPX; ++g) { xm[g] = (int)(mbeg + xrow[g]); decode(g); }
+    const int dY = KP / a.Wo;
+    const bool fastw = dY * a.Wo == KP && dY <= a.Ho;            // (workgroup-uniform)
+    const i32x4 rszb = make_rsrc(a.dz, mend * a.Cout * (long)sizeof(T));          // dZ rows >= mend read as zeros
+    unsigned zoffl[NPZ];                                         // running dZ offsets (poison: channel beyond Cout)
 #pragma unroll
-    for (int g = 0; g < NPZ; ++g) zm[g] = (int)(mbeg + zrow[g]);
-    const int mend_i = (int)mend;
+    for (int g = 0; g < NPZ; ++g)
+        zoffl[g] = co0 + zch[g] < a.Cout ? (unsigned)(((mbeg + zrow[g]) * a.Cout + co0 + zch[g]) * (long)sizeof(T)) : PIPE_POISON;
+    const unsigned zstep = (unsigned)(KP * a.Cout * (int)sizeof(T));
     auto issue = [&](long /*mb: sequential, KP apart*/, int stage) {
         const unsigned sb = lds0 + stage * STAGE;
 #pragma unroll
         for (int g = 0; g < NPX; ++g) {
-            unsigned off = OOB;
-            if (xm[g] < mend_i && cs0 + xch[g] < Cs) {
-                int iy, ix;
-                if (g_tap_src<MODE>(xoy[g], xox[g], ky, kx, a.Ho, a.Wo, iy, ix))
-                    off = (unsigned)((((xb[g] * Hi + iy) * Wi + ix) * Cs + cs0 + xch[g]) * (int)sizeof(T));
-            }
+            int iy, ix;
+            const bool v = g_tap_src<MODE>(xoy[g], xox[g], ky, kx, a.Ho, a.Wo, iy, ix) && cs0 + xch[g] < Cs;
+            const unsigned off = v ? (unsigned)((((xb[g] * Hi + iy) * Wi + ix) * Cs + cs0 + xch[g]) * (int)sizeof(T)) : OOB;
             dma16(rsx, off, sb + (wave * NPX + g) * 1024);
-            xm[g] += KP; xox[g] += KP;
-            while (xox[g] >= a.Wo) { xox[g] -= a.Wo; if (++xoy[g] == a.Ho) { xoy[g] = 0; ++xb[g]; } }
+            xm[g] += KP;
+            if (fastw) {
+                xoy[g] += dY;
+                const bool wrap = xoy[g] >= a.Ho;
+                xoy[g] = wrap ? xoy[g] - a.Ho : xoy[g];
+                xb[g] += wrap ? 1 : 0;
+            } else decode(g);
         }
 #pragma unroll
         for (int g = 0; g < NPZ; ++g) {
-            const unsigned off = (zm[g] < mend_i && co0 + zch[g] < a.Cout)
-                                     ? (unsigned)((zm[g] * a.Cout + co0 + zch[g]) * (int)sizeof(T)) : OOB;
-            dma16(rsz, off, sb + KP * RX + (wave * NPZ + g) * 1024);
-            zm[g] += KP;
+            dma16(rszb, zoffl[g], sb + KP * RX + (wave * NPZ + g) * 1024);
+            zoffl[g] += zstep;                                   // (poison + steps stays out of range: M * Cout bytes < 2 GiB - 8 KiB)
         }
     };
 
@@ -1267,11 +1280,13 @@ __device__ __forceinline__ void wgrad_glds_body(const WgradArgs& a, const unsign
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         int st = 0;
+        int dbc = a.fuse_db ? share : -1;                        // steps until this workgroup's next bias-gradient share (it % nshare == share)
         for (int it = 0; it < nit; ++it) {
             const int st2 = st >= 1 ? st - 1 : 2;
             if (it + 2 < nit) issue(mbeg + (long)(it + 2) * KP, st2);
             compute(st);
-            if (a.fuse_db && (it % nshare) == share) colsum_stage(st);
+            if (dbc == 0) { colsum_stage(st); dbc = nshare; }
+            if (dbc > 0) --dbc;
             if (it + 2 < nit) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1332,7 +1347,8 @@ bool wgrad_glds_supported(int dtype, int mode, const WgradArgs& a) {
     const long M = (long)a.B * a.Ho * a.Wo;
     const long hi = mode == UPCONV2 ? a.Ho / 2 : a.Ho, wi = mode == UPCONV2 ? a.Wo / 2 : a.Wo;
     const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
-    if ((long)a.B * hi * wi * cmax * esz >= (1L << 31) || M * a.Cout * esz >= (1L << 31)) return false;
+    if ((long)a.B * hi * wi * cmax * esz >= (1L << 31) - 8192 || M * a.Cout * esz >= (1L << 31) - 8192) return false;
+    if ((M + 64) * (a.Wo > a.Ho ? a.Wo : a.Ho) >= (1L << 32)) return false;     // the multiply-high pixel decode is exact below this
     const int Cin = a.C0 + a.C1;
     const bool big = esz == 2 && Cin >= 128 && a.Cout >= 128 && (a.C1 == 0 || a.C0 % 128 == 0);
     if (!big && a.C1 > 0 && a.C0 % 64 != 0) return false;
