@@ -137,15 +137,9 @@ int launch_c8(const ConvArgs& a_in, hipStream_t st) {
     const long M = (long)a.B * a.Ho * a.Wo;
     if (M * 16L >= (1L << 31) || M * a.Cout * 2L >= (1L << 31) || a.w_elems * 2L >= (1L << 31))
         return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
-    static int rows_env = -1;
-    if (rows_env < 0) {
-        const char* e = getenv("MPU_C8_ROWS");
-        rows_env = e ? atoi(e) : 0;
-        if (rows_env < 4 || rows_env % 4) rows_env = 0;
-    }
     // measured (B=16 128x128 / B=138 256x256, 64 channels): 16 rows 12.7 / 357 us, 32 rows 15.0 / 342 us, 8 rows 13.4 / 377 us
-    int rows = rows_env ? rows_env : C8_ROWS_DEFAULT;
-    if (!rows_env && (long)a.B * cdiv(a.Wo, 32) * cdiv(a.Ho, C8_ROWS_DEFAULT) >= 4096) rows = 2 * C8_ROWS_DEFAULT;
+    int rows = C8_ROWS_DEFAULT;
+    if ((long)a.B * cdiv(a.Wo, 32) * cdiv(a.Ho, C8_ROWS_DEFAULT) >= 4096) rows = 2 * C8_ROWS_DEFAULT;
     const int tx = cdiv(a.Wo, 32), ty = cdiv(a.Ho, rows);
     const long tiles = (long)a.B * tx * ty;
     if (tiles >= (1L << 31)) return fail(MPU_EUNSUPPORTED, "%s", "conv: too many tiles");

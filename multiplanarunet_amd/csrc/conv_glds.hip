@@ -936,12 +936,11 @@ template <typename T, int MODE>
 static int try_pipe(const ConvArgs& a, hipStream_t st) {
     if constexpr (sizeof(T) != 2 || MODE == CONV1) return 0;
     else {
-        static int on = -1, min_steps = 12, wgs = 256, dbg = 0;
+        static int on = -1, dbg = 0;
+        constexpr int min_steps = 12, wgs = 256;                 // >= 12 K steps per workgroup; about one workgroup per CU
         if (on < 0) {
             const char* d = getenv("MPU_PIPE_DEBUG"); if (d) dbg = atoi(d);
             const char* e = getenv("MPU_CONV_PIPE"); on = (e && e[0] == '0') ? 0 : 1;
-            const char* s = getenv("MPU_PIPE_MIN_STEPS"); if (s) min_steps = atoi(s);
-            const char* w = getenv("MPU_PIPE_WGS"); if (w) wgs = atoi(w);
         }
         if (!on || a.Cout < 128) return 0;
         const long M = (long)a.B * a.Ho * a.Wo;
@@ -1011,11 +1010,7 @@ static int launch_glds_mode(const ConvArgs& a_in, hipStream_t st) {
     if (a.Cout >= 128 && a.partial && t128 < 256) {
         constexpr int BKE = 128 / sizeof(T);
         const int nit = GModeTraits<MODE>::NTAPS * (cdiv(a.C0, BKE) + cdiv(a.C1, BKE));
-        static long sk_target = -1, sk_max = 8;
-        if (sk_target < 0) {
-            const char* e = getenv("MPU_SPLITK_TARGET"); sk_target = e ? atol(e) : 512;
-            const char* m = getenv("MPU_SPLITK_MAX"); sk_max = m ? atol(m) : 8;
-        }
+        constexpr long sk_target = 512, sk_max = 8;              // ~2 workgroups per CU, at most 8 partial copies
         long ks = sk_target / (t128 > 0 ? t128 : 1);
         if (ks > sk_max) ks = sk_max;
         if (ks > nit / 8) ks = nit / 8;

@@ -1037,9 +1037,7 @@ int launch_halo8_cfg_n(const ConvArgs& a_in, hipStream_t st) {
     if (a.pooled && a.pooled_done && MODE == CONV3 && !a.mask && !(a.Ho & 1) && !(a.Wo & 1) && TH % 2 == 0) *a.pooled_done = 1;
     else a.pooled = nullptr;
     a.dbg_buf = stamp_buffer();
-    static int prio = -1;                                        // MPU_HALO8_PRIO (SCHED 1): bit 0 = s_setprio 1 in the compute phase, bit 1 = in the load phase
-    if (prio < 0) { const char* e = getenv("MPU_HALO8_PRIO"); prio = e ? atoi(e) & 3 : 2; }
-    a.dbg = prio;
+    a.dbg = 2;                                                   // (SCHED 2: s_setprio 1 in the load phase, as SCHED 1 has it compiled in)
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);
     kern<<<dim3((unsigned)tiles), dim3(512), Cfg::SMEM, st>>>(a);
     if (prof_on()) prof_end(st);
@@ -1086,8 +1084,8 @@ int launch_halo8_cfg(const ConvArgs& a, hipStream_t st) {
     static int sched = -1;                                       // MPU_HALO8_SCHED: 0 = lockstep halves, 1 = one phase apart (default)
     if (sched < 0) { const char* e = getenv("MPU_HALO8_SCHED"); sched = e ? atoi(e) : 1; }
     if (sched != 1) return launch_halo8_cfg_n<BN, TH, MODE, 3, 0>(a, st);
-    static int dev = -1;                                         // stamps or a priority override asked for: the instrumented build
-    if (dev < 0) dev = (stamp_buffer() != nullptr || getenv("MPU_HALO8_PRIO") != nullptr) ? 1 : 0;
+    static int dev = -1;                                         // stamps asked for (MPU_STAMPS=1): the instrumented build
+    if (dev < 0) dev = stamp_buffer() != nullptr ? 1 : 0;
     return dev ? launch_halo8_cfg_n<BN, TH, MODE, 4, 2>(a, st) : launch_halo8_cfg_n<BN, TH, MODE, 4, 1>(a, st);
 }
 
@@ -1097,14 +1095,11 @@ int try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
     if ((mode != CONV3 && mode != UPCONV2) || a.Wo < 32 || a.Ho < 4) return 0;
     int rc;
     {   // round 3: one 8-wave workgroup per CU with a double-buffered patch, for grids of about one workgroup per CU
-        // (configs[1] levels 1-2: the single-buffer kernel's patch bursts are exposed there). MPU_HALO8=0 disables,
-        // MPU_HALO8_MAX_WGS / _MIN_WGS bound the grids it takes.
-        static int h8 = -1; static long h8_max = 0, h8_min = 0;
-        if (h8 < 0) {
-            const char* e = getenv("MPU_HALO8"); h8 = (e && e[0] == '0') ? 0 : 1;
-            const char* m = getenv("MPU_HALO8_MAX_WGS"); h8_max = m ? atol(m) : 400;
-            const char* n = getenv("MPU_HALO8_MIN_WGS"); h8_min = n ? atol(n) : 192;
-        }
+        // (configs[1] levels 1-2: the single-buffer kernel's patch bursts are exposed there). MPU_HALO8=0 disables.
+        // Grids of 192..400 workgroups (sweeps R3ag / R3aa: below, half the CUs idle; above, two rounds of one
+        // workgroup per CU lose to the 4-wave kernel's two workgroups per CU).
+        static int h8 = -1; constexpr long h8_max = 400, h8_min = 192;
+        if (h8 < 0) { const char* e = getenv("MPU_HALO8"); h8 = (e && e[0] == '0') ? 0 : 1; }
         if (h8 && dtype == MPU_BF16 && a.Ho % 8 == 0 && !a.head_w && (mode == CONV3 || !(a.Wo & 1))) {
             const long pt = (long)a.B * (a.Ho / 8) * cdiv(a.Wo, 32);
             const long g128 = pt * cdiv(a.Cout, 128), g64 = pt * cdiv(a.Cout, 64);
@@ -1131,19 +1126,15 @@ int try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
             rc = a.Cout > 64 ? launch_halo_cfg<bf16_t, 128, 4, 3, UPCONV2>(a, st) : launch_halo_cfg<bf16_t, 64, 4, 3, UPCONV2>(a, st);
         return rc ? rc : 1;
     }
-    static int variant = -1;                      // MPU_HALO_VARIANT: tuning aid
-    if (variant < 0) { const char* e = getenv("MPU_HALO_VARIANT"); variant = e ? atoi(e) : 0; }
     const long tiles8 = (long)a.B * cdiv(a.Ho, 8) * cdiv(a.Wo, 32);
-    const bool tall = a.Ho % 8 == 0 && tiles8 * cdiv(a.Cout, 64) >= 512 && variant != 1;
+    const bool tall = a.Ho % 8 == 0 && tiles8 * cdiv(a.Cout, 64) >= 512;
     // 128-channel tiles: 8-row pixel tiles halve the weight re-streaming per pixel (the L2->LDS fill bounds this
     // kernel) but need >= ~4 workgroups per CU to keep the chip busy: large batches / images only (predict)
-    static long th8_min = -1;
-    if (th8_min < 0) { const char* e = getenv("MPU_HALO_TH8_MIN"); th8_min = e ? atol(e) : 768; }
-    const bool tall128 = a.Ho % 8 == 0 && variant != 1 && (variant == 2 || tiles8 * cdiv(a.Cout, 128) >= th8_min);
+    constexpr long th8_min = 768;
+    const bool tall128 = a.Ho % 8 == 0 && tiles8 * cdiv(a.Cout, 128) >= th8_min;
     // few 128-channel tiles (deep levels at small batch): 64-channel tiles double the workgroup count at nearly the
     // same L2->LDS bytes per flop (patch + 9 x 8 KB vs patch + 9 x 16 KB per chunk, half the flops)
-    static long bn64_below = -1;
-    if (bn64_below < 0) { const char* e = getenv("MPU_HALO_BN64_BELOW"); bn64_below = e ? atol(e) : 768; }
+    constexpr long bn64_below = 768;
     const long tiles4 = (long)a.B * cdiv(a.Ho, 4) * cdiv(a.Wo, 32);
     const bool narrow = a.Cout > 64 && tiles4 * cdiv(a.Cout, 128) < bn64_below;
     if (dtype == MPU_BF16) {

@@ -755,11 +755,7 @@ long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, i
     const int ntaps = mode == UPCONV2 ? 4 : (mode == CONV1 ? 1 : 9);
     const int bc = (Cin >= 128 && Cout >= 128) ? 128 : 64;
     const long tiles = (long)cdiv(Cin, bc) * cdiv(Cout, bc) * ntaps;
-    static long target = -1, nosplit = 384;
-    if (target < 0) {
-        const char* e = getenv("MPU_WGRAD_SPLIT_TARGET"); target = e ? atol(e) : 512;
-        const char* n = getenv("MPU_WGRAD_NOSPLIT_TILES"); nosplit = n ? atol(n) : 384;
-    }
+    constexpr long target = 512, nosplit = 384;
     // stand-alone launch: aim at ~512 workgroups (2 per CU: measured best); inside a grouped launch (many jobs, several waves
     // of workgroups): ~256 per job -- half the fp32 partial copies (round 3 sweep: 2.77 -> 2.70 ms per step; 128: 2.74)
     const long tgt = grouped ? (target + 1) / 2 : target;

@@ -1151,7 +1151,7 @@ int mpu_sample_view_planes(const float* d_vol, const uint8_t* d_labels, const in
     // straight-line kernel: ImagePair voxel axes (kind 2), 1 or 2 channels, 32-bit element offsets
     // (single planes -- the train-time sampler cuts one candidate plane per call -- stay on the one-launch kernel: the
     // straight-line kernel needs a second launch for its work list)
-    static const long fast_min = getenv("MPU_SAMPLE_FAST_MIN") ? atol(getenv("MPU_SAMPLE_FAST_MIN")) : 262144;
+    constexpr long fast_min = 262144;
     const bool fast = fast_path_host() && (long)a.P * a.dim * a.dim >= fast_min &&
                       a.ax.kind != 0 && a.ay.kind == a.ax.kind && a.az.kind == a.ax.kind && (a.C == 1 || a.C == 2) &&
                       (long)a.X * a.Y * a.Z * a.C < (1L << 29) && a.P < 65536 && (long)a.P * a.dim * a.dim < (1L << 32);
@@ -1228,12 +1228,12 @@ int mpu_map_fuse_views(const mpu_voxel_grid* grid, const mpu_view_pred* views, i
         unsigned* nxt = nullptr;
         { const int rc_ = fuse_scratch(st, &f.count, &nxt, &f.list); if (rc_) return rc_; }
         FuseCounterGuard guard{st, f.list};
-        static const int cfg = getenv("MPU_FUSE_BRICK") ? atoi(getenv("MPU_FUSE_BRICK")) : 2;
+        constexpr int cfg = 2;                                   // brick / lane layout (0 and 1 measured slower: DESIGN section 4.6)
         f.V = n_views; f.X = a.grid.X; f.Y = a.grid.Y; f.Z = a.grid.Z;
         f.W = d_W; f.b = d_b; f.sum_fusion = sum_fusion; f.probs = d_probs; f.labels = d_labels;
         f.cap = FUSE_LIST_CAP;
         long nblk = cfg ? (long)cdiv(f.X, 8) * cdiv(f.Y, 8) * cdiv(f.Z, 16) : (long)cdiv(f.X, 4) * cdiv(f.Y, 4) * cdiv(f.Z, 64);    // bricks
-        static const int morton = getenv("MPU_FUSE_MORTON") ? atoi(getenv("MPU_FUSE_MORTON")) : 2;
+        constexpr int morton = 2;                                // brick order: z slowest inside an XCD's run (1 = z fastest, 3 = interleaved: section 4.6)
         f.morton = 0; f.px2 = f.py2 = 0;
         if (morton) {
             const int nxb = cdiv(f.X, cfg ? 8 : 4), nyb = cdiv(f.Y, cfg ? 8 : 4), nzb = cdiv(f.Z, cfg ? 16 : 64);

@@ -476,13 +476,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_group_kernel(TapsGroupTable
 // the number of fp32 partial copies (one per strip) small: their write + re-read is the kernel's HBM traffic.
 TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout, bool grouped) {
     TapsPlan p; p.use = 0; p.RH = 0; p.sx = 0; p.sy = 0; p.nstrips = 0; p.split = 0;
-    static int on = -1, target = 0; static long max_cico = 0;
-    if (on < 0) {
-        const char* e = getenv("MPU_WGRAD_TAPS"); on = (e && e[0] == '0') ? 0 : 1;
-        const char* t = getenv("MPU_WGRAD_TAPS_WGS"); target = t ? atoi(t) : 512;
-        const char* c = getenv("MPU_WGRAD_TAPS_CICO"); max_cico = c ? atol(c) : TAPS_MAX_CICO;
-        if (max_cico > TAPS_MAX_CICO) max_cico = TAPS_MAX_CICO;
-    }
+    static int on = -1; constexpr int target = 512; constexpr long max_cico = TAPS_MAX_CICO;
+    if (on < 0) { const char* e = getenv("MPU_WGRAD_TAPS"); on = (e && e[0] == '0') ? 0 : 1; }
     const int Cin = C0 + C1;
     if (!on || dtype != MPU_BF16 || (mode != CONV3 && mode != UPCONV2) || W < 32 || H < 8) return p;
     if (mode == UPCONV2 && ((H | W) & 1)) return p;

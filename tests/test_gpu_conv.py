@@ -71,7 +71,7 @@ DEEP_CASES = [
     (CONV3,   16, 16, 16, 512, 512, 512),   # upsample_L0_conv2 (concat)
     (UPCONV2, 16, 16, 16, 1024, 0, 512),    # upsample_L0_conv1 (+ its stride-2 data gradient)
     (CONV3,   3, 8, 12, 136, 72, 200),      # ragged: M = 288 (tail tile), channel tails in both sources, N tail
-    (CONV3,   8, 48, 44, 256, 0, 1024),     # > 512 tiles of 256 x 128 with 1024 filters (predict-batch shape; conv_pipe without K split under MPU_PIPE_BIG=1)
+    (CONV3,   8, 48, 44, 256, 0, 1024),     # > 512 tiles of 256 x 128 with 1024 filters (predict-batch shape: the two-workgroup schedules take it)
     (UPCONV2, 4, 128, 130, 512, 0, 256),    # > 512 tiles, wide transposed conv (same)
 ]
 
