@@ -719,6 +719,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
         constexpr int PPT = 2;                                   // patch pieces per wave and tap
         static_assert(NPW % PPT == 0 && NPW / PPT <= NT - 3, "patch pieces of tap k are forced at the end of L(k+3): before the chunk ends");
         constexpr int PTAPS = NPW / PPT;
+        constexpr bool WREQ_IN_L = TM >= 2;                      // where the weight requests sit: see the load phase
         const bool second = wave >= 4;
         const bool prio_c = DBG ? (a.dbg & 1) != 0 : false, prio_l = DBG ? (a.dbg & 2) != 0 : true;   // (DBG: MPU_HALO8_PRIO)
         uint4 fa[4][TN], fb[4][TM];
@@ -790,10 +791,27 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
                     for (int j = 0; j < TM; ++j) fb[s_][j] = *(const uint4*)(A.Pr[j] + pbuf + ((q ^ A.psw[j]) << 4));
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (WREQ_IN_L) {
+                    // weights three taps ahead, requested HERE (128-channel tiles: the load phase otherwise sits idle in
+                    // its lgkmcnt wait while the compute phase carries the DMA issue): the queue behind w(tap+1) is then
+                    // p(tap-2) w(tap+2) p(tap-1) w(tap+3)
+                    const int wt = tap + 3;
+                    const bool req = wt < NT || hasnext;
+                    if (wt < NT) request_w(woffA + (unsigned)wt * w_tap_b, roomA, (st + 3) & 3);
+                    else if (hasnext) request_w(woffB + (unsigned)(wt - NT) * w_tap_b, roomB, (st + 3) & 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bool w2 = tap + 2 < NT || hasnext;      // w(tap+2) was requested (in L(tap-1))
+                    if (!w2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (!req) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory");             // (last chunk: no patch pieces)
+                    else if (cnt == 2 && hasnext) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GW + 2 * PPT) : "memory");
+                    else if (cnt == 1 && hasnext) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GW + PPT) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GW) : "memory");
+                } else {
                 if (tap >= NT - 2 && !hasnext) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing requested behind w(tap+1)
                 else if (cnt == 2 && hasnext) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW + 2 * PPT) : "memory");
                 else if (cnt == 1 && hasnext) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW + PPT) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory");
+                }
                 if (stamp_here) stamps[9 + 4 * sidx] = __builtin_amdgcn_s_memtime();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (stamp_here) stamps[10 + 4 * sidx] = __builtin_amdgcn_s_memtime();
@@ -808,7 +826,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
 #pragma unroll
                     for (int j = 0; j < TM; ++j) HMma<T>::run(fa[0][i], fb[0][j], acc[i][j]);
                 __builtin_amdgcn_sched_barrier(0);
-                {   // weights three taps ahead: of this chunk, or the first taps of the next one
+                if constexpr (!WREQ_IN_L) {   // weights three taps ahead: of this chunk, or the first taps of the next one
                     const int wt = tap + 3;
                     if (wt < NT) request_w(woffA + (unsigned)wt * w_tap_b, roomA, (st + 3) & 3);
                     else if (hasnext) request_w(woffB + (unsigned)(wt - NT) * w_tap_b, roomB, (st + 3) & 3);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3 call AI: conv_halo8 with one workgroup barrier per tap: parity, per-layer and step A/B against the previous build
+# round 3 calls AI, AN: conv_halo8 variants (one barrier per tap; weight requests in the load phase): parity, per-layer and step A/B against the previous build
 R="$GRAFT_REPO_ROOT"; O=$R/gpurun_out/R3ai; mkdir -p $O; cd $R
 timeout 600 python -m pytest tests/test_gpu_conv.py -x -q > $O/pytest_conv.log 2>&1; tail -2 $O/pytest_conv.log
 P=$R/multiplanarunet_amd/lib/libmpunet_hip_prev.so
