@@ -51,6 +51,8 @@ CASES = [
     (CONV3,   4, 16, 16, 136, 136, 200),   # ... the same on the per-tap kernel (W < 32), ragged N
     (CONV3,   1, 64, 96, 72, 0, 40),       # patch kernel: channel tail (72 = 64 + 8), ragged N
     (CONV3,   2, 8, 64, 192, 0, 128),      # patch kernel: three channel chunks (patch reloaded twice)
+    (CONV3,   33, 8, 32, 128, 0, 128),     # 33 strips of 32 pixels (odd): the last workgroup of the strip weight-gradient kernel has ONE
+                                           #   busy 4-wave group, the other only keeps the barriers (both staggered and lockstep variants)
     (CONV3,   4, 130, 250, 8, 0, 24),      # register-stationary-weights kernel (>= 1024 tiles): ragged H, W, N; tiny Cin
     (CONV3,   2, 256, 256, 64, 0, 64),     # ... full 64 -> 64 layer, 4 tiles per persistent workgroup
     (CONV3,   6, 128, 128, 16, 0, 256),    # large grid of 128-channel tiles: the 8-row patch variant (768 tiles)
