@@ -177,13 +177,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
         // ~40 address instructions are recomputed, as the rolled loop did)
         int l31 = lane & 31;
         if constexpr (TN * TM >= 8) asm volatile("" : "+v"(l31));
-        const unsigned char* Wb = smem + Cfg::PATCH + stage * Cfg::WSTAGE + (wn * 64 + l31) * 128;
-        int prow[TM], psw[TM];
+        // byte offsets of k-step 0; k-step s flips bits 5-6 of the swizzled 16-byte slot: ((2s + fh) ^ sw) << 4 ==
+        // ((fh ^ sw) << 4) ^ (s << 5) (rows are 128 bytes, so those bits belong to the slot alone): one XOR per read
+        const unsigned wo = (unsigned)(Cfg::PATCH + stage * Cfg::WSTAGE + (wn * 64 + l31) * 128) + (unsigned)((fh ^ fsw) << 4);
+        unsigned po[TM];
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-            prow[j] = MODE == UPCONV2 ? ((wm * TM + j + ky) >> 1) * PW + ((kx + l31) >> 1)
-                                      : (wm * TM + j + ky) * PW + kx + l31;   // patch row of this lane's pixel
-            psw[j] = (prow[j] >> 1) & 7;
+            const int prow = MODE == UPCONV2 ? ((wm * TM + j + ky) >> 1) * PW + ((kx + l31) >> 1)
+                                             : (wm * TM + j + ky) * PW + kx + l31;   // patch row of this lane's pixel
+            po[j] = (unsigned)(prow * 128) + (unsigned)((fh ^ ((prow >> 1) & 7)) << 4);
         }
         // All fragments of the tap are requested before the first MFMA (sched_barrier keeps the compiler from sinking
         // the reads back next to their uses, which serialises LDS latency -> wait -> MFMA and ran the loop at ~1/3
@@ -195,11 +197,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
             uint4 af[SG][TN], bf[SG][TM];
 #pragma unroll
             for (int s = 0; s < SG; ++s) {
-                const int q = 2 * (g0 + s) + fh;
+                const unsigned ks = (unsigned)((g0 + s) << 5);
 #pragma unroll
-                for (int i = 0; i < TN; ++i) af[s][i] = *(const uint4*)(Wb + i * 32 * 128 + ((q ^ fsw) << 4));
+                for (int i = 0; i < TN; ++i) af[s][i] = *(const uint4*)(smem + (wo ^ ks) + i * 32 * 128);
 #pragma unroll
-                for (int j = 0; j < TM; ++j) bf[s][j] = *(const uint4*)(smem + prow[j] * 128 + ((q ^ psw[j]) << 4));
+                for (int j = 0; j < TM; ++j) bf[s][j] = *(const uint4*)(smem + (po[j] ^ ks));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
