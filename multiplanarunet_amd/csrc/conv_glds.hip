@@ -662,8 +662,9 @@ __global__ __launch_bounds__(512, 2) void conv_pipe_kernel(ConvArgs a, int tiles
         const int m = m0 + rl;
         pch[g] = (slot ^ ((rl >> 1) & 7)) * EPC;
         if (m < M) {                                             // exact multiply-high division (host-checked range)
-            const int t = (int)__umulhi((unsigned)m, magic_w), ox = m - t * a.Wo;
-            const int b = (int)__umulhi((unsigned)t, magic_h), oy = t - b * a.Ho;
+            // (a magic of 0 = divisor 1: ceil(2^32 / 1) does not fit 32 bits -- 1 x 1 and N x 1 maps)
+            const int t = magic_w ? (int)__umulhi((unsigned)m, magic_w) : m, ox = m - t * a.Wo;
+            const int b = magic_h ? (int)__umulhi((unsigned)t, magic_h) : t, oy = t - b * a.Ho;
             pb[g] = b * Hi * Wi; py[g] = oy; px[g] = ox;
         } else { pb[g] = -1; py[g] = 0; px[g] = 0; }
     }
@@ -1131,9 +1132,9 @@ __device__ __forceinline__ void wgrad_glds_body(const WgradArgs& a, const unsign
     const unsigned magic_w = 0xffffffffu / (unsigned)a.Wo + 1u, magic_h = 0xffffffffu / (unsigned)a.Ho + 1u;   // ceil(2^32 / d)
     auto decode = [&](int g) {
         const unsigned m = (unsigned)xm[g];
-        const unsigned t = __umulhi(m, magic_w);
+        const unsigned t = a.Wo == 1 ? m : __umulhi(m, magic_w);         // (ceil(2^32 / 1) does not fit 32 bits: 1x1 / Nx1 maps)
         xox[g] = (int)(m - t * (unsigned)a.Wo);
-        const unsigned bb = __umulhi(t, magic_h);
+        const unsigned bb = a.Ho == 1 ? t : __umulhi(t, magic_h);
         xoy[g] = (int)(t - bb * (unsigned)a.Ho); xb[g] = (int)bb;
     };
 #pragma unroll

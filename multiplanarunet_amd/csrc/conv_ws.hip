@@ -78,9 +78,9 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
     const int lrow = lane >> 3, slot = lane & 7;
 
     auto tile_coords = [&](int t, int& b, int& y0, int& x0) {      // exact multiply-high division (host-checked range)
-        const int t1 = (int)__umulhi((unsigned)t, magic_x);         // t / tiles_x
+        const int t1 = magic_x ? (int)__umulhi((unsigned)t, magic_x) : t;   // t / tiles_x (magic 0 = one tile column: 2^32 / 1 does not fit)
         x0 = (t - t1 * tiles_x) * TW;
-        b = (int)__umulhi((unsigned)t1, magic_y);                   // t1 / tiles_y
+        b = magic_y ? (int)__umulhi((unsigned)t1, magic_y) : t1;    // t1 / tiles_y
         y0 = (t1 - b * tiles_y) * TH;
     };
     // Patch DMA: source offset = (tile base, scalar) + (lane part, tile-invariant); 24-bit multiplies only

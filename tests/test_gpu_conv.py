@@ -62,6 +62,9 @@ CASES = [
     (UPCONV2, 2, 16, 16, 128, 0, 64),
     (UPCONV2, 1, 8, 12, 72, 0, 40),
     (CONV1,   2, 16, 16, 64, 0, 8),
+    (CONV3,   5, 1, 1, 128, 0, 128),       # 1 x 1 maps (the bottom of a depth-6 network on 64 x 64): every divisor of the pixel decode is 1
+    (CONV3,   3, 2, 1, 136, 0, 72),        # N x 1 maps, channel tails
+    (CONV3,   8, 512, 32, 8, 0, 24),       # ONE column of 32-pixel tiles, 1024 tiles: the persistent level-0 kernel's tile decode divides by 1
 ]
 
 # BASELINE configs[1] deep-level layers at their real shapes (B=16): few pixels, long reductions. With a workspace
