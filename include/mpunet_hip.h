@@ -323,6 +323,14 @@ int mpu_conv2d_igemm_ws(int32_t dtype, int32_t mode, const void* d_in0, int32_t 
                      const void* d_mask, void* d_out, int32_t B, int32_t Ho, int32_t Wo,
                      int32_t Cout, int32_t relu, float* d_workspace, int64_t workspace_floats, void* stream);
 int64_t mpu_conv2d_wgrad_workspace_floats(int32_t mode, int32_t Cin, int32_t Cout, int64_t M);
+/* Planning queries (host arithmetic only, no GPU needed): the floats ONE layer's weight-gradient job writes into its scratch
+ * region (K-split / strip partials of dW + bias-gradient partial rows) when it runs stand-alone (grouped = 0) or inside a
+ * grouped launch (grouped = 1: fewer strips / splits but other schedule thresholds, so either can be the larger), and the
+ * region mpu_unet_workspace_bytes() reserves for that layer (>= both). tests/test_host_geometry.py sweeps shapes over them. */
+int64_t mpu_conv2d_wgrad_job_floats(int32_t dtype, int32_t mode, int32_t B, int32_t Ho, int32_t Wo, int32_t C0, int32_t C1,
+                                    int32_t Cout, int32_t grouped);
+int64_t mpu_conv2d_wgrad_scratch_floats(int32_t dtype, int32_t mode, int32_t B, int32_t Ho, int32_t Wo, int32_t C0, int32_t C1,
+                                        int32_t Cout);
 int mpu_conv2d_wgrad(int32_t dtype, int32_t mode, const void* d_x0, int32_t C0, const void* d_x1,
                      int32_t C1, const void* d_dz, int32_t Cout, int32_t B, int32_t Ho, int32_t Wo,
                      float* d_workspace, float* d_dW, void* stream);

@@ -123,6 +123,8 @@ _SIGS = {
     "mpu_conv2d_igemm_ws": (C.c_int, [i32, i32, c_p, i32, c_p, i32, c_p, i64, i32, c_p, c_p, c_p,
                                       i32, i32, i32, i32, i32, c_p, i64, c_p]),
     "mpu_conv2d_wgrad_workspace_floats": (i64, [i32, i32, i32, i64]),
+    "mpu_conv2d_wgrad_job_floats": (i64, [i32] * 9),
+    "mpu_conv2d_wgrad_scratch_floats": (i64, [i32] * 8),
     "mpu_conv2d_wgrad_first_layer_workspace_floats": (i64, [i32, i64]),
     "mpu_conv2d_wgrad_first_layer": (C.c_int, [i32, c_p, i32, c_p, i32, i32, i32, i32, c_p, c_p, c_p, c_p]),
     "mpu_profile_enable": (C.c_int, [i32]),

@@ -110,7 +110,12 @@ def _patch_yaml_value(text, sec, key, val):
     end = start + 1
     while end < len(lines) and (not lines[end].strip() or lines[end][:1] in " \t#"):
         end += 1
-    pat = re.compile(r"^(\s+)%s\s*:\s*([^#]*?)(\s*#.*)?$" % re.escape(key))
+    if re.match(r"^%s\s*:\s*[^\s#]" % re.escape(sec), lines[start]):
+        raise ValueError("section %r is not in block style" % sec)          # `build: {dim: 2}`: the caller rewrites the file
+    # only keys at the section's FIRST indentation level (a deeper mapping may hold a key of the same name)
+    ind = next((re.match(r"^(\s+)", lines[i]).group(1) for i in range(start + 1, end)
+                if lines[i].strip() and not lines[i].lstrip().startswith("#")), "  ")
+    pat = re.compile(r"^(%s)%s\s*:\s*([^#]*?)(\s*#.*)?$" % (re.escape(ind), re.escape(key)))
     for i in range(start + 1, end):
         mt = pat.match(lines[i])
         if mt:
@@ -119,7 +124,7 @@ def _patch_yaml_value(text, sec, key, val):
     last = end - 1                                      # key missing: add it behind the section's last entry
     while last > start and not lines[last].strip():
         last -= 1
-    lines.insert(last + 1, "  %s: %s" % (key, val))
+    lines.insert(last + 1, "%s%s: %s" % (ind, key, val))
     return "\n".join(lines)
 
 
@@ -140,14 +145,29 @@ def save_audited_hparams(project_dir, hp):
         val = float(val) if key == "real_space_span" else int(val)
         cur = raw.get(sec) if isinstance(raw.get(sec), dict) else {}
         if cur.get(key) != val:
-            text = _patch_yaml_value(text, sec, key, repr(val))
             changed = True
+            if text is not None:
+                try:
+                    text = _patch_yaml_value(text, sec, key, repr(val))
+                except ValueError:
+                    text = None                         # layout the line patcher does not handle: rewrite below
+            if not isinstance(raw.get(sec), dict):
+                raw[sec] = {}
+            raw[sec][key] = val
     if changed:
-        check = yaml.safe_load(text) or {}
-        for sec, key in AUDITED_KEYS:                   # the patched text must parse back to the audited values
-            val = hp[sec].get(key)
-            if val is not None and float((check.get(sec) or {}).get(key, float("nan"))) != float(val):
-                raise RuntimeError("could not patch %s.%s in %s" % (sec, key, path))
+        def parses_back(t):                             # the new text must parse back to the audited values
+            try:
+                check = yaml.safe_load(t) or {}
+                return all(hp[sec].get(key) is None or
+                           float(((check.get(sec) if isinstance(check.get(sec), dict) else None) or {}).get(key, "nan")) ==
+                           float(hp[sec][key]) for sec, key in AUDITED_KEYS)
+            except (yaml.YAMLError, TypeError, ValueError):
+                return False
+        if text is None or not parses_back(text):
+            # flow-style or otherwise unusual layout: fall back to a full rewrite (comments are lost, values are right)
+            text = yaml.safe_dump(raw, default_flow_style=False, sort_keys=False)
+            if not parses_back(text):
+                raise RuntimeError("could not write the audited hyper-parameters into %s" % path)
         tmp = path + ".tmp"
         with open(tmp, "w") as f:
             f.write(text)
@@ -169,3 +189,137 @@ def fusion_weights_path(model_dir, weights_path):
     mpunet/bin/train_fusion.py:318-325): fusion weights belong to ONE U-Net checkpoint."""
     base = os.path.splitext(os.path.basename(weights_path))[0]
     return os.path.join(model_dir, "fusion_weights", "%s_fusion_weights.npz" % base)
+
+
+# ---- output-layer bias from class frequencies (mpunet/bin/train.py:293-299, mpunet/utils/utils.py:179-241) ----------
+
+def class_counts_from_volumes(volumes, n_classes):
+    """np.bincount(labels.ravel(), minlength=n_classes) summed over the loaded training volumes (the reference counts
+    once per image in the loading queue, utils.py:224-233; with every volume resident that is each volume once)."""
+    import torch
+    counts = np.zeros(int(n_classes), dtype=np.int64)
+    for v in volumes:
+        lab = getattr(v, "labels", None)
+        if lab is None:
+            continue
+        if isinstance(lab, torch.Tensor):
+            c = torch.bincount(lab.reshape(-1).to(torch.int64), minlength=int(n_classes)).cpu().numpy()
+        else:
+            c = np.bincount(np.asarray(lab).ravel().astype(np.int64), minlength=int(n_classes))
+        if c.size > counts.size:                       # labels beyond n_classes: np.bincount grows, as in the reference
+            counts = np.concatenate([counts, np.zeros(c.size - counts.size, np.int64)])
+        counts[:c.size] += c
+    return counts
+
+
+def set_bias_weights(layer, class_counts, logger=None):
+    """The reference's set_bias_weights (utils.py:204-241) on the object `model.layers[-1]` returns:
+    freq = counts / sum(counts); bias = log(freq * sum(exp(freq))); bias /= ||bias||_2."""
+    if layer.activation.__name__ != "softmax":
+        raise ValueError("Setting output layer bias currently only supported with softmax activation functions. "
+                         "Output layer has '%s'" % layer.activation.__name__)
+    weights = layer.get_weights()
+    if len(weights) != 2:
+        raise ValueError("Output layer does not have bias weights.")
+    bias_shape = weights[-1].shape
+    counts = np.asarray(class_counts, dtype=np.float64)
+    if counts.size != weights[-1].size:
+        raise ValueError("class_counts has %d entries, the output layer %d classes" % (counts.size, weights[-1].size))
+    with np.errstate(divide="ignore"):
+        freq = np.asarray(counts / np.sum(counts))
+        bias = np.log(freq * np.sum(np.exp(freq)))
+    bias /= np.linalg.norm(bias)
+    weights[-1] = bias.reshape(bias_shape).astype(weights[-1].dtype)
+    layer.set_weights(weights)
+    (logger or print)("Setting bias weights on output layer to:\n%s" % bias)
+    return bias
+
+
+def set_bias_weights_on_all_outputs(model, volumes, hparams, logger=None):
+    """bin/train.py:293-299: last layer that has an activation (here: the 1x1 head shim), counts from
+    hparams['class_counts'] (top-level YAML key) or estimated from the training volumes."""
+    layer = next((l for l in model.layers[::-1] if hasattr(l, "activation")), None)
+    if layer is None:
+        raise ValueError("model has no output layer with an activation")
+    counts = hparams.get("class_counts")
+    if counts is None:
+        (logger or print)("OBS: Estimating class counts from %d images" % len(volumes))
+        counts = class_counts_from_volumes(volumes, model.n_classes)
+    return set_bias_weights(layer, counts, logger)
+
+
+# ---- callbacks from the YAML `fit.callbacks` list (bin/defaults/MultiPlanar/train_hparams.yaml:7-45,139) -------------
+
+DEFAULT_CALLBACKS = [
+    {"nickname": "rlop", "class_name": "ReduceLROnPlateau",
+     "kwargs": {"patience": 2, "factor": 0.90, "verbose": 1, "monitor": "val_dice", "mode": "max"}},
+    {"nickname": "mcp_clean", "class_name": "ModelCheckPointClean",
+     "kwargs": {"filepath": "./model/@epoch_{epoch:02d}_val_dice_{val_dice:.5f}.h5", "monitor": "val_dice",
+                "save_best_only": True, "save_weights_only": True, "verbose": 1, "mode": "max"}},
+    {"nickname": "es", "class_name": "EarlyStopping",
+     "kwargs": {"monitor": "val_dice", "min_delta": 0, "patience": 15, "verbose": 1, "mode": "max"}},
+    {"nickname": "csv", "class_name": "CSVLogger", "kwargs": {"filename": "logs/training.csv", "separator": ",", "append": True}},
+]
+
+
+def init_callback_objects(callbacks, project_dir, logger=None, have_h5py=None):
+    """mpunet/callbacks/funcs.py:5-56 for the callbacks this path implements: the YAML descriptors
+    {class_name, kwargs[, start_from]} become objects with on_epoch_end(model, epoch, logs). ReduceLROnPlateau,
+    EarlyStopping, ModelCheckPointClean and CSVLogger honour their kwargs; descriptors of classes outside the hot path
+    (TensorBoard, TrainTimer, ...) are reported and skipped. Returns (objects in list order, {class_name: object}).
+    Relative paths are relative to the project folder (the reference chdirs into it, bin/train.py:330)."""
+    from .. import validation as V
+    log = logger or print
+    if have_h5py is None:
+        try:
+            import h5py  # noqa: F401
+            have_h5py = True
+        except ImportError:
+            have_h5py = False
+    objs, by_name = [], {}
+    for i, cb in enumerate(callbacks if callbacks is not None else DEFAULT_CALLBACKS):
+        if not isinstance(cb, dict):
+            objs.append(cb); by_name[cb.__class__.__name__] = cb
+            continue
+        name, kw = cb["class_name"], dict(cb.get("kwargs") or {})
+        if name == "ReduceLROnPlateau":
+            ok = ("monitor", "factor", "patience", "mode", "min_delta", "cooldown", "min_lr", "verbose")
+            obj = V.ReduceLROnPlateau(logger=log, **{k: kw[k] for k in ok if k in kw})
+        elif name == "EarlyStopping":
+            ok = ("monitor", "min_delta", "patience", "mode", "verbose")
+            obj = V.EarlyStopping(logger=log, **{k: kw[k] for k in ok if k in kw})
+        elif name in ("ModelCheckPointClean", "ModelCheckpoint"):
+            path = kw.get("filepath", DEFAULT_CALLBACKS[1]["kwargs"]["filepath"])
+            if not os.path.isabs(path):
+                path = os.path.normpath(os.path.join(project_dir, path))
+            if path.endswith((".h5", ".hdf5")) and not have_h5py:
+                path = os.path.splitext(path)[0] + ".npz"          # no h5py here: the .npz mirror (formats.py)
+            obj = V.ModelCheckPointClean(path, monitor=kw.get("monitor", "val_dice"), mode=kw.get("mode", "max"),
+                                         verbose=kw.get("verbose", 1), logger=log)
+        elif name == "CSVLogger":
+            path = kw.get("filename", "logs/training.csv")
+            if not os.path.isabs(path):
+                path = os.path.normpath(os.path.join(project_dir, path))
+            obj = V.CSVLogger(path, separator=kw.get("separator", ","), append=bool(kw.get("append", False)))
+        else:
+            log("[%i] Skipping callback %s (outside the accelerated path)" % (i + 1, name))
+            continue
+        if cb.get("start_from"):
+            log("OBS: '%s' activates at epoch %i" % (name, cb["start_from"]))
+            obj = V.DelayedCallback(obj, int(cb["start_from"]), logger=log)
+        objs.append(obj); by_name[name] = obj
+        log("[%i] Using callback: %s(%s)" % (i + 1, name, ", ".join("%s=%s" % kv for kv in kw.items())))
+    return objs, by_name
+
+
+def remove_validation_callbacks(callbacks, logger=None):
+    """funcs.py:59-82 (--no_val): drop descriptors whose kwargs mention 'val'. (The reference pops while it enumerates
+    and therefore skips the entry behind each removed one; here every val-dependent descriptor goes.)"""
+    keep = []
+    for cb in callbacks:
+        if isinstance(cb, dict) and any("val" in str(p).lower() for p in (cb.get("kwargs") or {}).values()):
+            if logger:
+                logger("Removing callback with parameters: %s (needs validation data)" % cb)
+            continue
+        keep.append(cb)
+    return keep

@@ -10,7 +10,8 @@ import numpy as np
 import torch
 
 from .common import (validate_project_dir, load_hparams, load_dataset, load_or_create_views,
-                     fill_build_from_data, save_audited_hparams)
+                     fill_build_from_data, save_audited_hparams, set_bias_weights_on_all_outputs,
+                     init_callback_objects, remove_validation_callbacks, DEFAULT_CALLBACKS)
 
 
 def get_argparser():
@@ -75,6 +76,7 @@ def run(args):
     if not train:
         raise OSError("no training volumes (set train_data.base_dir to a folder with images/*.npz, or --synthetic N)")
     fill_build_from_data(hp, train)                        # audit the FULL training set (before --just_one)
+    train_all = list(train)
     if args.just_one:
         train, val = train[:1], val[:1]
     fit, build = hp["fit"], hp["build"]
@@ -97,6 +99,11 @@ def run(args):
     last = os.path.join(model_dir, "model_weights.npz")
     if args.continue_training and os.path.exists(last):
         model.load_weights(last, by_name=True)
+    # Initialize the bias of the output layer from the class frequencies (bin/train.py:293-299; YAML default
+    # build.biased_output_layer: True). Counted on the volumes of the FULL training set of this rank's process: every rank
+    # loads the same volumes, so the replicas start from identical weights.
+    if not args.continue_training and build.get("biased_output_layer"):
+        set_bias_weights_on_all_outputs(model, train_all, hp, log)
     model.compile(fit["optimizer"], fit["loss"], fit.get("metrics"), optimizer_kwargs=fit.get("optimizer_kwargs"))
     if world > 1:
         D.DataParallelTrainer(model)
@@ -117,12 +124,14 @@ def run(args):
     vsteps = max(1, int(np.ceil(args.val_images_per_epoch / B)))
     from ..validation import Validation, ReduceLROnPlateau, EarlyStopping, ModelCheckPointClean
     validation = Validation(va, vsteps, build["n_classes"], logger=log, verbose=rank == 0) if va is not None else None
-    # the YAML's callback list (bin/defaults/MultiPlanar/train_hparams.yaml:7-45): rlop, mcp_clean, es, csv
-    rlop = ReduceLROnPlateau(patience=2, factor=0.90, monitor="val_dice", mode="max", logger=log)
-    es = EarlyStopping(monitor="val_dice", min_delta=0, patience=15, mode="max", logger=log)
-    mcp = ModelCheckPointClean(os.path.join(model_dir, "@epoch_{epoch:02d}_val_dice_{val_dice:.5f}.npz"),
-                               monitor="val_dice", mode="max", logger=log, verbose=1)
-    csv = os.path.join(project_dir, "logs", "training.csv")
+    # the YAML's callback list fit.callbacks (bin/defaults/MultiPlanar/train_hparams.yaml:7-45,139; the descriptors
+    # behind the __CB_* anchors): kwargs are honoured, a project that edits them gets what it wrote
+    descr = fit.get("callbacks")
+    descr = [dict(c) for c in descr] if descr is not None else [dict(c) for c in DEFAULT_CALLBACKS]
+    if validation is None:
+        descr = remove_validation_callbacks(descr, log)    # bin/train.py:259-262 (--no_val)
+    callbacks, cb_by_name = init_callback_objects(descr, project_dir, log)
+    rank0_only = ("ModelCheckPointClean", "CSVLogger")     # file writers: one process only
     try:
         for ep in range(epochs):
             tot = 0.0
@@ -137,18 +146,10 @@ def run(args):
             if validation is not None:
                 validation.on_epoch_end(model, ep, logs)
             log("Epoch %d/%d - " % (ep + 1, epochs) + " - ".join("%s: %.5f" % kv for kv in logs.items()))
-            if validation is not None:
-                rlop.on_epoch_end(model, ep, logs)
-                if rank == 0:
-                    mcp.on_epoch_end(model, ep, logs)
-                es.on_epoch_end(model, ep, logs)
-            if rank == 0:
-                with open(csv, "a") as f:
-                    if f.tell() == 0:
-                        f.write("epoch,loss,val_dice,val_precision,val_recall,lr\n")
-                    f.write("%d,%.6f,%s,%s,%s,%g\n" % (ep, logs["loss"], *["" if logs.get(k) is None else "%.6f" % logs[k]
-                                                                         for k in ("val_dice", "val_precision", "val_recall")],
-                                                      model.optimizer_kwargs["lr"]))
+            logs["lr"] = model.optimizer_kwargs["lr"]
+            for cb in callbacks:                           # list order, as Keras runs them
+                if rank == 0 or cb.__class__.__name__ not in rank0_only:
+                    cb.on_epoch_end(model, ep, logs)
             if model.stop_training:
                 break
     except KeyboardInterrupt:

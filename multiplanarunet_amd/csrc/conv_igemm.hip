@@ -825,6 +825,15 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue
         if (rc0) return rc0;
     }
     const long n_ = (long)ModeTraits<MODE>::NTAPS * Cin * a.Cout;
+    if (a.partial_cap > 0) {                     // the chosen plan must fit the caller's region (a neighbour layer's scratch follows it)
+        const long rows = taps.use ? a.ksplit : (long)a.ksplit * ModeTraits<MODE>::NTAPS * cdiv(Cin, 64);
+        const long used = (long)a.ksplit * n_ + (a.db ? rows * a.Cout : 0);
+        if (used > a.partial_cap) {
+            snprintf(g_err, sizeof(g_err), "wgrad: plan needs %ld floats of scratch, the region holds %ld (mode %d B=%d %dx%d %d->%d%s)",
+                     used, a.partial_cap, MODE, a.B, a.Ho, a.Wo, Cin, a.Cout, grp ? ", grouped" : "");
+            return MPU_EINVAL;
+        }
+    }
     a.db_partial = a.partial + (long)a.ksplit * n_;   // tail of the workspace
     const bool strided = a.cin_total > 0;         // one source of a concat layer: always through the reduction (row remap)
     if (a.ksplit == 1 && !strided) a.partial = dW;   // single split: the kernel's output IS the weight gradient
@@ -908,21 +917,33 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue
     return launch_ok();
 }
 
-// exact scratch of one layer (mirrors the split / schedule decisions of launch_wgrad_mode)
-long wgrad_scratch_need(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout, int c0_logical) {
+// Floats ONE weight-gradient job writes into its scratch region under one schedule decision (mirrors launch_wgrad_mode):
+// the K-split / strip partials of dW + the bias-gradient partial rows. grouped: the plan a job inside a grouped launch takes
+// (fewer strips / K splits per job -- but also a lower taps threshold, so a layer that runs as wgrad_glds on its own can run
+// as wgrad_taps inside a group and the other way round: the two plans have DIFFERENT layouts and either can be the larger).
+long wgrad_job_floats(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout, bool grouped) {
     const int Cin = C0 + C1;
     const int ntaps = mode == UPCONV2 ? 4 : (mode == CONV1 ? 1 : 9);
     const long M = (long)B * H * W, n = (long)ntaps * Cin * Cout;
     int ks = 1, mchunk = 0;
-    wgrad_partial_elems(mode, Cin, Cout, M, &ks, &mchunk);
+    wgrad_partial_elems(mode, Cin, Cout, M, &ks, &mchunk, grouped);
     TapsPlan taps; taps.use = 0;
-    if (conv_impl() == 1) taps = wgrad_taps_plan(dtype, mode, B, H, W, C0, C1, Cout);
+    if (conv_impl() == 1) taps = wgrad_taps_plan(dtype, mode, B, H, W, C0, C1, Cout, grouped);
     if (taps.use) ks = (taps.nstrips + 1) / 2;
-    const long nshare = taps.use ? ks : (long)ks * ntaps * cdiv(Cin, 64);
+    const long nshare = taps.use ? ks : (long)ks * ntaps * cdiv(Cin, 64);     // (128-wide tiles: half of this)
+    return (long)ks * n + nshare * Cout;
+}
+
+// scratch of one layer: the LARGER of the stand-alone and the grouped plan (the region was sized with the
+// stand-alone plan and used with the grouped one, which overflowed into the next layer's region on shapes outside the
+// BASELINE configs, e.g. bf16 B=2 40x40 128->128). launch_wgrad_mode checks the chosen plan against partial_cap.
+long wgrad_scratch_need(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout, int c0_logical) {
+    const long a0 = wgrad_job_floats(dtype, mode, B, H, W, C0, C1, Cout, false);
+    const long a1 = wgrad_job_floats(dtype, mode, B, H, W, C0, C1, Cout, true);
+    long need = a0 > a1 ? a0 : a1;
     if (C1 > 0 && C0 % 64 != 0 && conv_impl() == 1 && dtype == MPU_BF16 && mode == CONV3)   // two jobs (launch_wgrad_mode): both regions
         return wgrad_scratch_need(dtype, mode, B, H, W, C0, 0, Cout) + wgrad_scratch_need(dtype, mode, B, H, W, C1, 0, Cout) +
-               (((long)ks * n + nshare * Cout + 63) / 64 * 64 + 64);                            // (+ the unsplit need: the fallback still fits)
-    long need = (long)ks * n + nshare * Cout;
+               ((need + 63) / 64 * 64 + 64);                                                  // (+ the unsplit need: the fallback still fits)
     // the first-layer schedule (tried first) keeps one compact row per strip of image rows: its own layout and size
     const long c8 = conv_impl() == 1 ? wgrad_c8_scratch_floats(dtype, mode, B, H, W, C0, C1, c0_logical, Cout) : 0;
     if (c8 > need) need = c8;

@@ -131,6 +131,7 @@ int  wgrad_taps_grid(int mode, const WgradArgs& a, const TapsPlan& p);          
 long wgrad_glds_grid(int mode, const WgradArgs& a);                                      // (0: not the groupable variant)
 // exact scratch need (floats) of one layer's weight gradient: K-split partials + bias-gradient partials
 // c0_logical: image channels of an 8-channel first layer (selects the wgrad_c8 schedule, which has its own layout)
+long wgrad_job_floats(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout, bool grouped);   // one plan's exact need
 long wgrad_scratch_need(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout, int c0_logical = 0);
 long wgrad_c8_scratch_floats(int dtype, int mode, int B, int H, int W, int C0, int C1, int c0_logical, int Cout);   // 0 = not eligible
 int  launch_wgrad(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t st, ReduceQueue* q = nullptr,

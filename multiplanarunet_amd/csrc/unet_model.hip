@@ -103,7 +103,7 @@ struct Plan {
     std::vector<long> c1, c2, n, p, dskip;          // encoder levels
     long c1b, c2b, nb;
     std::vector<long> u1, n1, c2u, c3u, n2;         // up levels
-    long probs, gA, gB, gC, partial, partial_floats, partial2, wpartial, wpartial_floats, cpartial, cpartial_floats, coeffs, stats, total;
+    long probs, gA, gB, partial, partial_floats, partial2, wpartial, wpartial_floats, cpartial, cpartial_floats, coeffs, stats, total;
     std::vector<long> wscratch;                     // per conv: float offset of its weight-gradient scratch inside wpartial
     std::vector<long> dz;                           // per conv: its own dz (gradient at the conv's pre-activation output): the weight
                                                     // gradients of a whole backward pass run as grouped launches at its end
@@ -133,7 +133,7 @@ Plan make_plan(const mpu_unet* m, int B) {
         const long e = (long)B * (m->cfg.H >> l) * (m->cfg.W >> l) * m->F[l];
         if (e > gmax) gmax = e;
     }
-    P.gA = take(gmax * esz); P.gB = take(gmax * esz); P.gC = take(gmax * esz);
+    P.gA = take(gmax * esz); P.gB = take(gmax * esz);   // (every conv has its own dz buffer below: Plan::dz)
     P.dz.assign(m->conv.size(), -1);
     for (size_t i = 0; i < m->conv.size(); ++i) {
         if (m->conv[i].mode == CONV1) continue;
@@ -774,6 +774,15 @@ int64_t mpu_conv2d_wgrad_workspace_floats(int32_t mode, int32_t Cin, int32_t Cou
     // per source -- room for two half-layer jobs (an upper bound that needs no image shape)
     const int half = ((Cin + 1) / 2 + 7) / 8 * 8;
     return wgrad_partial_elems(mode, Cin, Cout, M, nullptr, nullptr) + 2 * (wgrad_partial_elems(mode, half, Cout, M, nullptr, nullptr) + 128) + 256;
+}
+
+int64_t mpu_conv2d_wgrad_job_floats(int32_t dtype, int32_t mode, int32_t B, int32_t Ho, int32_t Wo, int32_t C0, int32_t C1,
+                                    int32_t Cout, int32_t grouped) {
+    return wgrad_job_floats(dtype, mode, B, Ho, Wo, C0, C1, Cout, grouped != 0);
+}
+int64_t mpu_conv2d_wgrad_scratch_floats(int32_t dtype, int32_t mode, int32_t B, int32_t Ho, int32_t Wo, int32_t C0, int32_t C1,
+                                        int32_t Cout) {
+    return wgrad_scratch_need(dtype, mode, B, Ho, Wo, C0, C1, Cout);
 }
 
 int mpu_conv2d_wgrad(int32_t dtype, int32_t mode, const void* d_x0, int32_t C0, const void* d_x1, int32_t C1,

@@ -186,3 +186,44 @@ class ModelCheckPointClean:
             if self.last_file and self.last_file != path and os.path.exists(self.last_file):
                 os.remove(self.last_file)
             self.last_file = path
+
+
+class CSVLogger:
+    """tf.keras.callbacks.CSVLogger with the YAML's kwargs {filename, separator, append}: a header `epoch,<sorted log
+    keys>` on the first write (skipped when appending to a non-empty file), one row per epoch, keys missing from a later
+    epoch's logs written as NA."""
+
+    def __init__(self, filename, separator=",", append=False):
+        self.filename, self.sep, self.append = filename, separator, append
+        self.keys = None
+        self._started = False
+
+    def on_epoch_end(self, model, epoch, logs):
+        os.makedirs(os.path.dirname(os.path.abspath(self.filename)), exist_ok=True)
+        if not self._started:
+            self._started = True
+            self.keys = sorted(logs.keys())
+            has_rows = self.append and os.path.exists(self.filename) and os.path.getsize(self.filename) > 0
+            if not has_rows:
+                with open(self.filename, "w") as f:
+                    f.write(self.sep.join(["epoch"] + self.keys) + "\n")
+        with open(self.filename, "a") as f:
+            vals = ["NA" if logs.get(k) is None else ("%s" % logs[k]) for k in self.keys]
+            f.write(self.sep.join([str(epoch)] + vals) + "\n")
+
+
+class DelayedCallback:
+    """mpunet/callbacks/callbacks.py:88-115: the wrapped callback stays inactive until epoch `start_from`."""
+
+    def __init__(self, callback, start_from=0, logger=None):
+        self.callback, self.start_from, self.logger = callback, start_from, logger or print
+
+    def __getattr__(self, item):
+        return getattr(self.callback, item)
+
+    def on_epoch_end(self, model, epoch, logs):
+        if epoch >= self.start_from - 1:
+            self.callback.on_epoch_end(model, epoch, logs)
+        else:
+            self.logger("[%s] Not active at epoch %i - will be at %i" % (self.callback.__class__.__name__, epoch + 1,
+                                                                        self.start_from))

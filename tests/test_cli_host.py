@@ -126,3 +126,141 @@ def test_audited_hparams_patch_keeps_comments_and_layout(tmp_path):
     assert "complexity_factor: 1  # keep" in out and out.index("dim: 64") < out.index("fit:")
     hp2 = C.load_hparams(str(tmp_path))
     assert hp2["build"]["dim"] == 64 and hp2["fit"]["real_space_span"] == 63.5 and hp2["fit"]["batch_size"] == 8
+
+
+class _FakeHead:
+    """What set_bias_weights needs from model.layers[-1] (the product's _OutputLayerShim has the same surface)."""
+
+    class _Act:
+        __name__ = "softmax"
+
+    def __init__(self, k, c=8):
+        self.activation = self._Act()
+        self.w = [np.ones((1, 1, c, k), np.float32), np.zeros((k,), np.float32)]
+
+    def get_weights(self):
+        return [w.copy() for w in self.w]
+
+    def set_weights(self, w):
+        self.w = [np.asarray(x) for x in w]
+
+
+def test_output_bias_from_class_frequencies_matches_reference_formula():
+    """VERDICT r3 missing 1: `mp train` initialises the head bias as mpunet/utils/utils.py:204-241 does:
+    freq = counts / sum; b = log(freq * sum(exp(freq))); b /= ||b||_2 (default YAML: biased_output_layer: True)."""
+    import torch
+
+    class Vol:
+        def __init__(self, lab):
+            self.labels = lab
+    rng = np.random.RandomState(0)
+    l1 = rng.choice(3, size=(9, 10, 11), p=[0.8, 0.15, 0.05]).astype(np.uint8)
+    l2 = rng.choice(3, size=(5, 6, 7), p=[0.6, 0.3, 0.1]).astype(np.uint8)
+    counts = C.class_counts_from_volumes([Vol(torch.from_numpy(l1)), Vol(l2), Vol(None)], 3)
+    expect_counts = np.bincount(l1.ravel(), minlength=3) + np.bincount(l2.ravel(), minlength=3)
+    np.testing.assert_array_equal(counts, expect_counts)
+    # hand computation of the reference formula
+    f = expect_counts / expect_counts.sum()
+    b = np.log(f * np.exp(f).sum())
+    b = b / np.sqrt((b * b).sum())
+    head = _FakeHead(3)
+    got = C.set_bias_weights(head, counts, logger=lambda *a: None)
+    np.testing.assert_allclose(got, b, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(head.w[1], b.astype(np.float32), rtol=0, atol=0)
+    assert head.w[1].dtype == np.float32 and np.array_equal(head.w[0], np.ones((1, 1, 8, 3), np.float32))
+    assert abs(np.linalg.norm(got) - 1.0) < 1e-12 and got[0] > got[1] > got[2]      # most frequent class: largest bias
+
+    class Model:
+        n_classes = 3
+        layers = [object(), head]
+    # hparams['class_counts'] (top-level YAML key) wins over counting (utils.py:200)
+    got2 = C.set_bias_weights_on_all_outputs(Model(), [], {"class_counts": [10, 10, 20]}, logger=lambda *a: None)
+    f2 = np.array([.25, .25, .5]); b2 = np.log(f2 * np.exp(f2).sum()); b2 /= np.linalg.norm(b2)
+    np.testing.assert_allclose(got2, b2, atol=1e-15)
+    head.activation.__class__.__name__ = "softmax"
+    lin = _FakeHead(3); lin.activation = type("A", (), {"__name__": "linear"})()
+    with pytest.raises(ValueError):
+        C.set_bias_weights(lin, counts)
+
+
+def test_callbacks_come_from_the_yaml_list_with_their_kwargs(tmp_path):
+    """VERDICT r3 missing 5: an edited `patience` (or factor / filepath / csv name) in the YAML's __CB_* descriptors is
+    honoured (mpunet/callbacks/funcs.py:5-56, bin/defaults/MultiPlanar/train_hparams.yaml:7-45,139)."""
+    (tmp_path / "train_hparams.yaml").write_text(
+        "__CB_rlop: &RLOP\n  nickname: rlop\n  class_name: ReduceLROnPlateau\n"
+        "  kwargs: {patience: 5, factor: 0.5, verbose: 1, monitor: val_dice, mode: max}\n"
+        "__CB_tb: &TB\n  nickname: tb\n  class_name: TensorBoard\n  kwargs: {log_dir: ./tensorboard, profile_batch: 0}\n"
+        "__CB_mcp_clean: &MCP\n  nickname: mcp_clean\n  class_name: ModelCheckPointClean\n"
+        "  kwargs: {filepath: './model/@ep_{epoch:02d}_{val_dice:.3f}.h5', monitor: val_dice, save_best_only: true,\n"
+        "           save_weights_only: true, verbose: 1, mode: max}\n"
+        "__CB_es: &ES\n  nickname: es\n  class_name: EarlyStopping\n"
+        "  kwargs: {monitor: val_dice, min_delta: 0, patience: 3, verbose: 1, mode: max}\n"
+        "__CB_timer: &TIMER\n  nickname: timer\n  class_name: TrainTimer\n  pass_logger: True\n  kwargs: {verbose: True}\n"
+        "__CB_csv: &CSV\n  nickname: csv\n  class_name: CSVLogger\n  kwargs: {filename: logs/t.csv, separator: ';', append: true}\n"
+        "build:\n  n_classes: 3\nfit:\n  batch_size: 8\n  callbacks: [*RLOP, *TB, *MCP, *ES, *TIMER, *CSV]\n")
+    hp = C.load_hparams(str(tmp_path))
+    msgs = []
+    objs, by = C.init_callback_objects(hp["fit"]["callbacks"], str(tmp_path), msgs.append, have_h5py=False)
+    assert [o.__class__.__name__ for o in objs] == ["ReduceLROnPlateau", "ModelCheckPointClean", "EarlyStopping", "CSVLogger"]
+    assert by["ReduceLROnPlateau"].patience == 5 and by["ReduceLROnPlateau"].factor == 0.5
+    assert by["EarlyStopping"].patience == 3
+    assert by["ModelCheckPointClean"].filepath == os.path.join(str(tmp_path), "model", "@ep_{epoch:02d}_{val_dice:.3f}.npz")
+    assert by["CSVLogger"].filename == os.path.join(str(tmp_path), "logs", "t.csv") and by["CSVLogger"].sep == ";"
+    assert any("Skipping callback TensorBoard" in m for m in msgs) and any("TrainTimer" in m for m in msgs)
+    _, by5 = C.init_callback_objects(hp["fit"]["callbacks"], str(tmp_path), lambda *a: None, have_h5py=True)
+    assert by5["ModelCheckPointClean"].filepath.endswith(".h5")
+
+    class M:
+        stop_training = False
+        optimizer_kwargs = {"lr": 1.0}
+        saved = []
+
+        def save_weights(self, p):
+            self.saved.append(p); open(p, "wb").close()
+    m = M()
+    dice = [0.5, 0.6, 0.6, 0.6, 0.6, 0.6, 0.6, 0.6]
+    for ep, d in enumerate(dice):
+        logs = {"loss": 1.0 / (ep + 1), "val_dice": d}
+        for cb in objs:
+            cb.on_epoch_end(m, ep, logs)
+        if m.stop_training:
+            break
+    assert ep == 4 and by["EarlyStopping"].stopped_epoch == 4          # best at epoch 1, patience 3 (edited from 15)
+    assert m.optimizer_kwargs["lr"] == 1.0                              # patience 5 (edited from 2): no reduction yet
+    assert [os.path.basename(p) for p in m.saved] == ["@ep_01_0.500.npz", "@ep_02_0.600.npz"]
+    assert not os.path.exists(m.saved[0]) and os.path.exists(m.saved[1])     # the older checkpoint is cleaned away
+    rows = open(by["CSVLogger"].filename).read().strip().splitlines()
+    assert rows[0] == "epoch;loss;lr;val_dice" and len(rows) == 6 and rows[1].startswith("0;1.0;1.0;0.5")
+    # default list when the YAML has none; --no_val drops everything that monitors validation metrics
+    objs0, _ = C.init_callback_objects(None, str(tmp_path), lambda *a: None, have_h5py=False)
+    assert [o.patience for o in objs0 if hasattr(o, "patience")] == [2, 15]
+    kept = C.remove_validation_callbacks([dict(c) for c in C.DEFAULT_CALLBACKS])
+    assert [c["class_name"] for c in kept] == ["CSVLogger"]
+    # start_from wraps the callback (funcs.py:44-48)
+    objs1, _ = C.init_callback_objects([{"class_name": "EarlyStopping", "kwargs": {"patience": 1}, "start_from": 3}],
+                                       str(tmp_path), lambda *a: None)
+    mm = M(); mm.stop_training = False
+    for ep in range(4):
+        objs1[0].on_epoch_end(mm, ep, {"val_dice": 0.1})
+    assert mm.stop_training and objs1[0].stopped_epoch == 3
+
+
+def test_audited_hparams_patch_nested_keys_and_flow_style(tmp_path):
+    """only keys at the section's first indentation level are patched (a deeper mapping may hold a key of
+    the same name), and a flow-style section falls back to a rewrite instead of raising a raw YAML error."""
+    text = ("build:\n  sub:\n    dim: 7   # not this one\n  dim: Null\n  n_classes: 3\n  n_channels: 1\n"
+            "fit:\n  real_space_span: 10.0\n")
+    (tmp_path / "train_hparams.yaml").write_text(text)
+    hp = C.load_hparams(str(tmp_path))
+    hp["build"]["dim"] = 96
+    assert C.save_audited_hparams(str(tmp_path), hp)
+    out = (tmp_path / "train_hparams.yaml").read_text()
+    assert "    dim: 7   # not this one" in out and "\n  dim: 96\n" in out
+    (tmp_path / "train_hparams.yaml").write_text("build: {n_classes: 3, n_channels: 1}\nfit: {batch_size: 4}\n")
+    hp = C.load_hparams(str(tmp_path))
+    hp["build"]["dim"] = 64
+    hp["fit"]["real_space_span"] = 50.5
+    assert C.save_audited_hparams(str(tmp_path), hp)
+    hp2 = C.load_hparams(str(tmp_path))
+    assert hp2["build"]["dim"] == 64 and hp2["build"]["n_classes"] == 3 and hp2["fit"]["real_space_span"] == 50.5
+    assert hp2["fit"]["batch_size"] == 4

@@ -137,3 +137,34 @@ def test_product_dice_all_and_pred_to_class_match_reference_goldens(golden):
     ints = golden["g6_cls"]
     assert I.pred_to_class(ints) is ints                                   # integer maps pass through
     np.testing.assert_array_equal(I.pred_to_class(p[..., :1]), p[..., :1] >= 0.5)
+
+
+def test_wgrad_scratch_region_covers_the_grouped_and_the_standalone_plan():
+    """a layer's weight-gradient scratch region was sized with the stand-alone plan and used with the
+    grouped one (other thresholds: taps <-> glds, other split counts), which overflowed into the next layer's region on
+    shapes outside the BASELINE configs. Host arithmetic only: sweep shapes and require region >= both plans."""
+    lib = _lib.load()
+    BF16, CONV3, UPCONV2 = 1, 0, 1
+    # the four overflowing shapes the advisor measured on the round-3 library
+    for B, H, Cin, Cout in [(2, 40, 128, 128), (1, 80, 128, 128), (4, 80, 64, 64), (1, 32, 512, 512)]:
+        g = lib.mpu_conv2d_wgrad_job_floats(BF16, CONV3, B, H, H, Cin, 0, Cout, 1)
+        s = lib.mpu_conv2d_wgrad_job_floats(BF16, CONV3, B, H, H, Cin, 0, Cout, 0)
+        assert lib.mpu_conv2d_wgrad_scratch_floats(BF16, CONV3, B, H, H, Cin, 0, Cout) >= max(g, s)
+    n = 0
+    for dtype in (0, 1):
+        for mode in (CONV3, UPCONV2):
+            for B in (1, 2, 3, 4, 8, 16, 32):
+                for H in (8, 16, 24, 32, 40, 48, 64, 80, 96, 128, 256):
+                    for W in {H, 32, 2 * H}:
+                        for Cin, Cout in [(8, 64), (64, 64), (64, 128), (96, 96), (128, 64), (128, 128), (184, 184), (256, 128),
+                                          (256, 256), (368, 368), (512, 256), (512, 512), (1024, 512), (728, 728)]:
+                            for C1 in (0, Cin // 2):
+                                if C1 and (mode != CONV3 or (Cin // 2) % 8):
+                                    continue
+                                C0 = Cin - C1
+                                need = lib.mpu_conv2d_wgrad_scratch_floats(dtype, mode, B, H, W, C0, C1, Cout)
+                                for grouped in (0, 1):
+                                    job = lib.mpu_conv2d_wgrad_job_floats(dtype, mode, B, H, W, C0, C1, Cout, grouped)
+                                    assert 0 < job <= need, (dtype, mode, B, H, W, C0, C1, Cout, grouped, job, need)
+                                n += 1
+    assert n > 10000
