@@ -270,9 +270,14 @@ def main():
         traffic = {}
         try:   # HBM bytes per launch from the rocprofv3 PMC passes of this round (profiles/, see its note)
             tfile = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic_pmc.json"))[-1]
+            from multiplanarunet_amd.srchash import source_sha16, CONV_SOURCES
             with open(os.path.join(ROOT, "profiles", tfile)) as f:
-                traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["classes"].items()}
-            out["config"]["traffic_source"] = "from_file:profiles/" + tfile      # a separate rocprofv3 --pmc pass, not this run
+                tj = json.load(f)
+            if tj.get("source_sha16") == source_sha16(CONV_SOURCES):
+                traffic = {k: v["hbm_bytes_per_launch"] for k, v in tj["classes"].items()}
+                out["config"]["traffic_source"] = "from_file:profiles/" + tfile      # a separate rocprofv3 --pmc pass, not this run
+            else:   # the kernels changed after that counter pass: its bytes are not this build's
+                out["config"]["traffic_source"] = "stale:profiles/%s (kernel sources changed since that PMC pass)" % tfile
         except Exception:
             pass
         if events:
@@ -361,9 +366,14 @@ def bench_predict(device, quiet, D=256, V=6, K=3, reps=5, batch=None, C=1):
     if D == 256 and V == 6 and K == 3:
         try:
             gf = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_geometry_pmc.json"))[-1]
+            from multiplanarunet_amd.srchash import source_sha16, GEOMETRY_SOURCES
             with open(os.path.join(ROOT, "profiles", gf)) as fh:
-                fuse_traffic = int(json.load(fh)["kernels"]["map_fuse_fast_kernel<3,2>"]["hbm_bytes_per_launch"])
-            fuse_traffic_src = "from_file:profiles/" + gf
+                gj = json.load(fh)
+            if gj.get("source_sha16") == source_sha16(GEOMETRY_SOURCES):
+                fuse_traffic = int(gj["kernels"]["map_fuse_fast_kernel<3,2>"]["hbm_bytes_per_launch"])
+                fuse_traffic_src = "from_file:profiles/" + gf
+            else:
+                fuse_traffic_src = "stale:profiles/%s (geometry.hip changed since that PMC pass)" % gf
         except (IndexError, KeyError, OSError, ValueError):
             pass
     return {"metric": "voxels/sec (6-view predict+fuse)", "value": round(D ** 3 / best, 1), "unit": "voxels/s",

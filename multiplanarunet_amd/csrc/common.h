@@ -49,6 +49,16 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
 
+// "done once" flags of per-kernel attributes (hipFuncSetAttribute is per DEVICE): one bit per device of this process, so a
+// process that drives several GPUs sets the attribute on each of them (round 3 kept one flag per process).
+inline bool first_use_on_device(unsigned long long& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    const unsigned long long bit = 1ull << dev;
+    const unsigned long long seen = __atomic_fetch_or(&mask, bit, __ATOMIC_RELAXED);
+    return (seen & bit) == 0;
+}
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace mpu

@@ -532,10 +532,9 @@ static int launch_glds_cfg(const ConvArgs& a_in, hipStream_t st) {
     ConvArgs a = a_in;
     constexpr int NT = GModeTraits<MODE>::NTAPS;
     if (a.w_elems <= 0) a.w_elems = (NT - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (first_use_on_device(attr_set)) {
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
-        attr_set = true;
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const long tiles = (long)cdiv(a.Cout, BN) * cdiv(M, BM);
@@ -915,10 +914,9 @@ static int launch_pipe(const ConvArgs& a_in, int ks, hipStream_t st) {
     ConvArgs a = a_in;
     constexpr int NT = GModeTraits<MODE>::NTAPS;
     if (a.w_elems <= 0) a.w_elems = (NT - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (first_use_on_device(attr_set)) {
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg::SMEM));
-        attr_set = true;
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const int tiles_m = cdiv(M, PipeCfg::BM), tiles_n = cdiv(a.Cout, PipeCfg::BN);

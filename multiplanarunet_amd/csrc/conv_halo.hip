@@ -1038,10 +1038,9 @@ int launch_halo8_cfg_n(const ConvArgs& a_in, hipStream_t st) {
     auto kern = conv_halo8_kernel<BN, TH, MODE, NWS_, SCHED>;
     ConvArgs a = a_in;
     if (a.w_elems <= 0) a.w_elems = (Cfg::NT - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (first_use_on_device(attr_set)) {
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
-        attr_set = true;
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
@@ -1070,10 +1069,9 @@ int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
     auto kern = conv_halo_kernel<T, BN, TH, NWS, MODE>;
     ConvArgs a = a_in;
     if (a.w_elems <= 0) a.w_elems = (Cfg::NT - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (first_use_on_device(attr_set)) {
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
-        attr_set = true;
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;

@@ -671,10 +671,9 @@ static int launch_conv_cfg(const ConvArgs& a_in, hipStream_t st) {
     auto kern = conv_igemm_kernel<T, MODE, BN, BM, WN, WM>;
     ConvArgs a = a_in;
     if (a.w_elems <= 0) a.w_elems = (ModeTraits<MODE>::NTAPS - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (first_use_on_device(attr_set)) {
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        attr_set = true;
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const long tiles = (long)cdiv(a.Cout, BN) * cdiv(M, BM);

@@ -527,15 +527,14 @@ static bool taps_stag() {                                        // MPU_WGRAD_TA
 }
 
 static int taps_attrs() {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (first_use_on_device(attr_set)) {
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel<CONV3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel<UPCONV2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel<CONV3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel<UPCONV2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_group_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
-        attr_set = true;
     }
     return MPU_OK;
 }

@@ -2,7 +2,7 @@
 usage: geometry_pmc.py FETCH_SIZE.db WRITE_SIZE.db out.json
 bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B; the factor 2 was confirmed for
 12-byte-per-lane reads with mpu_probe_gather12 in round 3: 0.805 GB counted for 1.611 GB read)."""
-import json, re, sqlite3, sys
+import json, os, re, sqlite3, sys
 
 
 def sums(path, counter):
@@ -27,5 +27,8 @@ for name, (v, k, t) in fetch.items():
     wv = write.get(name, (0.0, k, 0))[0]
     out["kernels"][short] = {"launches": k, "avg_us_profiled": round(t / k / 1e3, 1), "fetch_KB_raw_per_launch": round(v / k, 1),
                              "write_KB_per_launch": round(wv / k, 1), "hbm_bytes_per_launch": int((2 * v + wv) * 1024 / k)}
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from multiplanarunet_amd.srchash import source_sha16, GEOMETRY_SOURCES
+out["source_sha16"] = source_sha16(GEOMETRY_SOURCES)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))

@@ -1,7 +1,7 @@
 """HBM bytes per launch of the conv / wgrad kernel families from two rocprofv3 PMC passes (dev tool).
 usage: rocpd_traffic.py FETCH_SIZE.db WRITE_SIZE.db out.json
 bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: gfx950 FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section)."""
-import sqlite3, sys, re, json
+import os, sqlite3, sys, re, json
 
 CLASSES = {
     "conv_igemm": (("conv_glds", "conv_halo", "conv_ws", "conv_c8", "conv_igemm", "conv_pipe"), ("splitk_finish",)),
@@ -35,5 +35,8 @@ for name, (v, k) in sorted(fetch.items(), key=lambda kv: -kv[1][0]):
     short = name.replace("_ZN3mpu", "")[:80]
     wv = write.get(name, (0.0, k))[0]
     out["kernels"][short] = {"launches": k, "hbm_MB_per_launch": round((2 * v + wv) * 1024 / k / 1e6, 2)}
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from multiplanarunet_amd.srchash import source_sha16, CONV_SOURCES
+out["source_sha16"] = source_sha16(CONV_SOURCES)           # bench.py reports these bytes only for the sources they were measured on
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out["classes"], indent=1))
