@@ -65,9 +65,14 @@ struct HaloCfg {
     static constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
 };
 
-template <typename T, int BN, int TH, int NWS, int MODE = CONV3>
+// DBG (dev aid; builds with -DMPU_HALO_KNOCKOUT_BUILD only, selected by MPU_HALO_KNOCKOUT=bits): knock-out timing of the
+// kernel's components, the mask a COMPILE-TIME constant (a run-time mask spilled 1.1 KB of registers and ran 30x slower:
+// gpurun R4a) -- bit 0: no global stores, 1: no MFMAs, 2: no weight requests after the prologue, 3: no fragment reads,
+// 4: no patch reloads, 5: no epilogue at all, 6: no per-tap barrier. Results are garbage by design.
+template <typename T, int BN, int TH, int NWS, int MODE = CONV3, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
     using Cfg = HaloCfg<T, BN, TH, NWS, MODE>;
+    constexpr int ko = DBG;
     constexpr int NT = Cfg::NT, KW = Cfg::KW;
     constexpr int EPC = 16 / sizeof(T), BKE = 128 / sizeof(T);
     constexpr int TW = Cfg::TW, PW = Cfg::PW, PROWS = Cfg::PROWS;
@@ -198,12 +203,27 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
 #pragma unroll
             for (int s = 0; s < SG; ++s) {
                 const unsigned ks = (unsigned)((g0 + s) << 5);
+                if (DBG && (ko & 8)) {
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) af[s][i] = make_uint4(ks, wo, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) bf[s][j] = make_uint4(ks, po[j], 0, 0);
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < TN; ++i) af[s][i] = *(const uint4*)(smem + (wo ^ ks) + i * 32 * 128);
 #pragma unroll
                 for (int j = 0; j < TM; ++j) bf[s][j] = *(const uint4*)(smem + (po[j] ^ ks));
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (DBG && (ko & 2)) {                               // (keep the fragments alive without the matrix pipe)
+#pragma unroll
+                for (int s = 0; s < SG; ++s)
+#pragma unroll
+                    for (int i = 0; i < TN; ++i)
+#pragma unroll
+                        for (int j = 0; j < TM; ++j) acc[i][j][s] += __uint_as_float(af[s][i].x ^ bf[s][j].y);
+            } else
 #pragma unroll
             for (int s = 0; s < SG; ++s) {
 #pragma unroll
@@ -257,21 +277,22 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
             const int wt = tap + AHEAD;                          // weights requested now (compile-time position)
             const bool more = wt < NT || hasnext;
             int stn = st + AHEAD; if (stn >= NWS) stn -= NWS;
-            if (wt < NT) request_w(woffA + (unsigned)wt * w_tap_b, roomA, stn);
+            if (DBG && (ko & 4)) {}
+            else if (wt < NT) request_w(woffA + (unsigned)wt * w_tap_b, roomA, stn);
             else if (hasnext) request_w(woffB + (unsigned)(wt - NT) * w_tap_b, roomB, stn);
             compute(tap / KW, tap % KW, st, kv);
             if (tap == NT - 1 && hasnext) {
                 // every wave has finished reading the patch before it is overwritten
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                issue_patch(cc + 1);
+                if (!(DBG && (ko & 16))) issue_patch(cc + 1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
                 if (AHEAD == 2 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            __builtin_amdgcn_s_barrier();
+            if (!(DBG && (ko & 64))) __builtin_amdgcn_s_barrier();
             if (++st == NWS) st = 0;
         }
         woffA = woffB; roomA = roomB;
@@ -279,6 +300,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
 
     // --- epilogue: bias -> LDS, tile -> LDS, coalesced 16-byte row stores ------------------
     constexpr int OROW = Cfg::OROW;
+    if (DBG && (ko & 32)) {                                      // no epilogue: one never-taken store keeps the accumulators live
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 1.2345e-30f) *(float*)a.out = sacc;
+        return;
+    }
     float* sbias = (float*)(smem + BM * OROW);
     if (tid < BN) {                                              // (requested at kernel entry: no load latency here)
         sbias[tid] = (a.bias && early_ok) ? early_bias_raw : 0.f;
@@ -412,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
                     if (!(__uint_as_float(mk.w) > 0.f)) val.w = 0;
                 }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(val, rso, off, 0, 0);
+            if (!(DBG && (ko & 1))) __builtin_amdgcn_raw_buffer_store_b128(val, rso, off, 0, 0);
         }
         if (a.pooled) {  // second output: 2x2 max pooling of the tile (TH and TW even, tile origin even), from the staging tile
             constexpr int PW2 = TW / 2, PPIX = BM / 4;
@@ -1063,10 +1095,10 @@ int launch_halo8_cfg_n(const ConvArgs& a_in, hipStream_t st) {
     return launch_ok();
 }
 
-template <typename T, int BN, int TH, int NWS, int MODE = CONV3>
+template <typename T, int BN, int TH, int NWS, int MODE = CONV3, int DBG = 0>
 int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
     using Cfg = HaloCfg<T, BN, TH, NWS, MODE>;
-    auto kern = conv_halo_kernel<T, BN, TH, NWS, MODE>;
+    auto kern = conv_halo_kernel<T, BN, TH, NWS, MODE, DBG>;
     ConvArgs a = a_in;
     if (a.w_elems <= 0) a.w_elems = (Cfg::NT - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
     static unsigned long long attr_set = 0;
@@ -1156,6 +1188,19 @@ int try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
     const long tiles4 = (long)a.B * cdiv(a.Ho, 4) * cdiv(a.Wo, 32);
     const bool narrow = a.Cout > 64 && tiles4 * cdiv(a.Cout, 128) < bn64_below;
     if (dtype == MPU_BF16) {
+#ifdef MPU_HALO_KNOCKOUT_BUILD
+        static int knock = -1;                                   // dev aid: knock-out instantiations of the predict kernel
+        if (knock < 0) { const char* e = getenv("MPU_HALO_KNOCKOUT"); knock = e ? atoi(e) : 0; }
+        if (a.Cout > 64 && !narrow && tall128 && knock) {
+            switch (knock) {
+#define MPU_KO(V) case V: rc = launch_halo_cfg<bf16_t, 128, 8, 2, CONV3, V>(a, st); break;
+                MPU_KO(1) MPU_KO(2) MPU_KO(4) MPU_KO(8) MPU_KO(10) MPU_KO(16) MPU_KO(20) MPU_KO(32) MPU_KO(33) MPU_KO(64) MPU_KO(30) MPU_KO(62)
+#undef MPU_KO
+                default: return fail(MPU_EINVAL, "%s", "MPU_HALO_KNOCKOUT: mask not instantiated");
+            }
+            return rc ? rc : 1;
+        }
+#endif
         if (a.Cout > 64 && !narrow) rc = tall128 ? launch_halo_cfg<bf16_t, 128, 8, 2>(a, st)
                                                  : launch_halo_cfg<bf16_t, 128, 4, 3>(a, st);
         else rc = tall ? launch_halo_cfg<bf16_t, 64, 8, 3>(a, st) : launch_halo_cfg<bf16_t, 64, 4, 3>(a, st);

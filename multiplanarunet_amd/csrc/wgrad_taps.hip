@@ -120,8 +120,15 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
     const unsigned ldsZ = lds0 + NXR * XROWB;
 
     // ---- DMA: piece q of a step's group: q < 5: 8 pixels of the new X row; q >= 5: 8 pixels of the dZ row.
-    // 128-byte pixel rows; the 64-byte granule of a row is XOR-ed with (pixel>>1)&1 so that the four k-rows
-    // of a transpose read fall in four different bank groups.
+    // 128-byte pixel rows, 16-byte slots permuted per pixel (swz below) so that a transposing fragment read is free of
+    // bank conflicts. One ds_read_b64_tr_b16 is serviced in two groups of 32 lanes; a group reads 32 contiguous bytes (this
+    // wave's 16 channels) of EIGHT pixels: c0 .. c0+3 (lane bits 2-3) and c0+8 .. c0+11 (lane bit 4; up-conv: c, c+1(,c+2)
+    // and c+4 ..). The 64 banks span 256 bytes = 8 such 32-byte blocks, and the block of pixel c is
+    // 4 (c & 1) + (wave ^ swizzle bits). Round 3 flipped only the 64-byte granule by bit 1 of c: pixels c and c+8 (up-conv:
+    // c and c+4) shared their banks -- a 2-way conflict on every fragment read, SQ_LDS_BANK_CONFLICT / SQ_INSTS_LDS = 1.9
+    // (profiles/r03b_conv_pmc_cfg1_shapes.txt). Now the 32-byte granule is flipped as well, by bit 3 of c
+    // (bit 2 for the low-resolution up-conv rows): the eight pixels of a group take the eight blocks once.
+    auto swz = [](int c, bool lowres) { return (((c >> 1) & 1) << 2) | (((c >> (lowres ? 2 : 3)) & 1) << 1); };
     const int dpx = lane >> 3, dsl = lane & 7;
     // per-lane parts of the request offsets are fixed for the whole strip (column, channel chunk, their validity);
     // a request then costs a scalar row base + one add instead of ~20 integer instructions per piece and step
@@ -131,13 +138,13 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
         const int q = wave + 4 * k;
         const int c = q * 8 + dpx;
         const int ix = MODE == UPCONV2 ? x0 / 2 + c : x0 - 1 + c;
-        const int ch = (dsl ^ (((c >> 1) & 1) << 2)) * 8;
+        const int ch = (dsl ^ swz(c, MODE == UPCONV2)) * 8;
         const bool v = q < NXP && c < (MODE == UPCONV2 ? 17 : 34) && (unsigned)ix < (unsigned)Wi && cs0 + ch < Cs;
         xlane[k] = v ? (unsigned)((ix * Cs + cs0 + ch) * 2) : OOB;
     }
     {
         const int c = wave * 8 + dpx, x = x0 + c;
-        const int ch = (dsl ^ (((c >> 1) & 1) << 2)) * 8;
+        const int ch = (dsl ^ swz(c, false)) * 8;
         zlane = (x < W && co0 + ch < a.Cout) ? (unsigned)((x * a.Cout + co0 + ch) * 2) : OOB;
     }
     auto issue_x = [&](int r) {                                  // staged X row r of this strip
@@ -187,7 +194,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
         for (int h = 0; h < 2; ++h) {
             const int cu = kx + 8 * g + (i >> 2) + 4 * h;        // (upsampled) pixel column of this k-row
             const int c = MODE == UPCONV2 ? cu >> 1 : cu;        // staged pixel column
-            const int slot16 = (wave * 2 + ((i & 3) >> 1)) ^ (((c >> 1) & 1) << 2);
+            const int slot16 = (wave * 2 + ((i & 3) >> 1)) ^ swz(c, MODE == UPCONV2);
             offA[kx][h] = c * 128 + (slot16 << 4) + (i & 1) * 8;
         }
     int offB[4][2];                                              // dZ: per 16-channel block and half
@@ -196,7 +203,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int c = 8 * g + (i >> 2) + 4 * h;
-            const int slot16 = (cb * 2 + ((i & 3) >> 1)) ^ (((c >> 1) & 1) << 2);
+            const int slot16 = (cb * 2 + ((i & 3) >> 1)) ^ swz(c, false);
             offB[cb][h] = c * 128 + (slot16 << 4) + (i & 1) * 8;
         }
 

@@ -103,9 +103,10 @@ class DataParallelTrainer:
         self.overlap = can if overlap is None else (bool(overlap) and can)
         self.ready_events = None
         self.buckets = []                          # (point index, lo, hi) in the order the backward pass completes them
-        if self.overlap:
-            pts = model.grad_ready_points()
+        if hasattr(model, "grad_ready_points"):    # the same bucket sequence with and without overlap (and on gloo / CPU:
+            pts = model.grad_ready_points()        # the world-8 test runs exactly the collectives an 8-GPU step issues)
             self.buckets = plan_buckets(pts, model.grads.numel(), bucket_bytes)
+        if self.overlap:
             self.ready_events = [None] * len(pts)
             for k, _, _ in self.buckets:
                 ev = torch.cuda.Event()
@@ -130,7 +131,12 @@ class DataParallelTrainer:
             if timing:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            allreduce_sum_(grads, self.bucket_bytes)
+            if self.buckets and self.buckets[0][2] == grads.numel():
+                works = [dist.all_reduce(grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True) for _, lo, hi in self.buckets]
+                for w in works:
+                    w.wait()
+            else:
+                allreduce_sum_(grads, self.bucket_bytes)
             if timing:
                 e1.record()
                 self._timed.append((e_bwd, [(e0, e1)]))

@@ -108,3 +108,156 @@ def test_gloo_world2_collectives():
     assert sorted(r[0] for r in res) == [0, 1]
     for r in res:
         assert r[1] and r[2] and r[3], r
+
+
+# --------------------------------------------------------------------------- #
+# world size 8: the WHOLE sharded predict and the bucketed gradient all-reduce with eight gloo
+# ranks on CPU. The HIP kernels of the product are replaced by the oracle's NumPy restatements (test infrastructure),
+# so what runs is the product's orchestration: work items, the OOB owner, ragged X slabs, both exchanges.
+# --------------------------------------------------------------------------- #
+def _toy_problem():
+    rng = np.random.RandomState(5)
+    X, Y, Z, C, K, V, dim = 13, 11, 9, 1, 3, 3, 12
+    image = rng.rand(X, Y, Z, C).astype(np.float32)
+    affine = np.diag([1.0, 1.1, 0.9, 1.0])
+    views = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.2], [0.3, 0.2, 1.0]])
+    views /= np.linalg.norm(views, axis=1, keepdims=True)
+    W = rng.rand(V, K).astype(np.float32) + 0.5
+    b = (rng.rand(1, K).astype(np.float32) - 0.5) * 0.1
+    A = rng.randn(C, K).astype(np.float32) * 3
+    return image, affine, views, W, b, A, dim, 14.0, K
+
+
+def _toy_predict(A):
+    def f(Xs):                                             # [P,d,d,C] -> softmax over a fixed per-pixel linear map
+        z = np.asarray(Xs, np.float32) @ A
+        e = np.exp(z - z.max(-1, keepdims=True))
+        return (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    return f
+
+
+def _install_oracle_standins(monkey_targets, image, affine):
+    """Replace the HIP-backed functions of multiplanarunet_amd.interpolation by oracle restatements (CPU)."""
+    from oracle import geometry as G
+    I = monkey_targets
+    vg = G.voxel_grid_real_space(image.shape[:3], affine)
+
+    def sample_view(volume, geom, want_labels=True, out=None):
+        planes = []
+        for off in geom.offsets:
+            grid, _g, _ib = G.sample_plane_at(geom.view, geom.dim, geom.span, off)
+            im, _ = G.view_interpolate(image, None, affine, 0.0, 0, grid)
+            planes.append(im)
+        return torch.tensor(np.stack(planes, 0)), None
+
+    def nearest_idx(grid, inv_basis):
+        pts = np.stack([vg[i].ravel() for i in range(3)], axis=1)
+        pts = inv_basis.dot(pts.T).T
+        idx, _dist, oob = G.rgi_find_indices(pts.T, grid)
+        res = []
+        for i, yi, g in zip(idx, _dist, grid):
+            res.append(np.where(yi <= .5, i, i + 1))
+        return res, oob
+
+    def map_accumulate(volume, pred_chunk, grid, inv_basis, Wv, p_lo, p_hi, owns_oob, z):
+        (i0, i1, i2), oob = nearest_idx(grid, inv_basis)
+        K = pred_chunk.shape[-1]
+        pc = np.asarray(pred_chunk)                        # [p_hi - p_lo, d, d, K]; full view = [P][row g0][col g1]
+        zz = z.numpy().reshape(-1, K)
+        Wn = np.asarray(Wv, np.float32).reshape(K)
+        mine = (~oob) & (i2 >= p_lo) & (i2 < p_hi)
+        zz[mine] += Wn * pc[i2[mine] - p_lo, i0[mine], i1[mine]]
+        if owns_oob:
+            fill = np.zeros(K, np.float32); fill[0] = 1.0
+            zz[oob] += Wn * fill
+        return z
+
+    def fusion_finalize(z, b=None, sum_fusion=False, want_probs=True):
+        zz = z.numpy() + (0 if sum_fusion else np.asarray(b, np.float32).reshape(-1))
+        return None, torch.tensor(zz.argmax(-1).astype(np.uint8))
+
+    def map_real_space_pred(pred, grid, inv_basis, volume, method="nearest"):
+        return torch.tensor(G.map_real_space_pred(np.asarray(pred), grid, inv_basis, vg))
+
+    I.sample_view, I.map_accumulate, I.fusion_finalize, I.map_real_space_pred = \
+        sample_view, map_accumulate, fusion_finalize, map_real_space_pred
+
+
+def _worker8(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    D.init_from_env("gloo")
+    from multiplanarunet_amd import interpolation as I
+    from oracle import geometry as G
+    image, affine, views, W, b, A, dim, span, K = _toy_problem()
+    _install_oracle_standins(I, image, affine)
+    f = _toy_predict(A)
+
+    class Vol:
+        device = torch.device("cpu")
+        n_channels = image.shape[-1]
+    vol = Vol(); vol.image = torch.tensor(image)
+
+    class Model:
+        n_classes = K
+        def predict(self, Xs, batch_size=None):
+            return torch.tensor(f(Xs.numpy()))
+
+    class Fusion:
+        def predict(self, x, batch_size=None):             # FusionLayer: softmax(sum_v W_v x_v + b)
+            z = (x.numpy() * W[None]).sum(1) + b
+            e = np.exp(z - z.max(-1, keepdims=True))
+            return torch.tensor(e / e.sum(-1, keepdims=True))
+    fus = Fusion(); fus.W = torch.tensor(W); fus.b = torch.tensor(b)
+    # single-process oracle pipeline (every rank computes it: cheap at this size)
+    merged, _, _ = G.multi_view_predict(image, affine, views, dim, span, f, W, b)
+    ref = merged.argmax(-1).astype(np.uint8)
+    ok = {}
+    for ex in ("reduce_scatter", "all_gather"):
+        t = {}
+        out = D.multi_view_predict_sharded(Model(), vol, views, dim, span, fusion_model=fus, exchange=ex, timings=t)
+        ok[ex] = bool(np.array_equal(out.numpy(), ref)) and out.shape == ref.shape
+        ok[ex + "_items"] = t.get("work_items", -1)
+    out = D.multi_view_predict_sharded(Model(), vol, views, dim, span, sum_fusion=True, exchange="reduce_scatter")
+    ms, _, _ = G.multi_view_predict(image, affine, views, dim, span, f, W, b, sum_fusion=True)
+    ok["sum_fusion"] = bool(np.array_equal(out.numpy(), ms.argmax(-1).astype(np.uint8)))
+    # the bucketed gradient all-reduce with the configs[1] ready points scaled down (three buckets, as on the GPU)
+    class M:
+        pass
+    m = M()
+    n = 31046
+    m.params = torch.full((16,), float(rank)); m.bn_state = torch.zeros(4); m._repack = lambda: None
+    m.grads = torch.zeros(n)
+    m.grad_ready_points = lambda: [31030, 30900, 28000, 20000, 12000, 4700, 1200, 300, 40, 0]
+    tr = D.DataParallelTrainer(m, bucket_bytes=32 << 10)
+    ok["buckets"] = [x[0] for x in tr.buckets] == [3, 5, 9] and not tr.overlap
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    m._grad_hook(g)
+    ok["allreduce"] = bool(torch.equal(g, torch.arange(n, dtype=torch.float32) * 36.0)) and bool((m.params == 0).all())
+    # ragged reduce-scatter (padded layout) + label all-gather at world 8
+    for Xr in (13, 8, 5, 1):
+        zr = torch.ones((Xr, 2, 3)) * (rank + 1) + torch.arange(Xr).reshape(Xr, 1, 1)
+        zp, (lo, hi) = D.reduce_scatter_slabs(zr.clone(), force_pad=True)
+        exp = (torch.ones((Xr, 2, 3)) * 36 + 8 * torch.arange(Xr).reshape(Xr, 1, 1))[lo:hi]
+        full = D.all_gather_slabs(zp[..., 0].contiguous(), Xr)
+        ok["rs%d" % Xr] = bool(torch.equal(zp, exp)) and bool(torch.equal(full, (36 + 8 * torch.arange(Xr)).reshape(Xr, 1).expand(Xr, 2).float()))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_gloo_world8_sharded_predict_and_bucketed_allreduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(r[0] for r in res) == list(range(8))
+    for rank, ok in res:
+        assert all(v for k, v in ok.items() if not k.endswith("_items")), (rank, ok)
+    items = sorted(ok["reduce_scatter_items"] for _, ok in res)
+    assert items[0] >= 1 and sum(items) == 24            # 3 views x 8 chunks dealt over 8 ranks
