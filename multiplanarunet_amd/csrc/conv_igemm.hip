@@ -727,6 +727,8 @@ int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
             if (c != 0) { note("c8"); return c < 0 ? c : MPU_OK; }
             const int w = try_conv_ws(dtype, mode, a, st);
             if (w != 0) { note("ws"); return w < 0 ? w : MPU_OK; }
+            const int x = try_conv_halo16(dtype, mode, a, st);
+            if (x != 0) { note("halo16"); return x < 0 ? x : MPU_OK; }
             const int h = try_conv_halo(dtype, mode, a, st);
             if (h != 0) { note(h == 2 ? "halo8" : "halo"); return h < 0 ? h : MPU_OK; }
         }

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void map_fuse_kernel(FuseArgs a) {
 // half-integer tie, an axis end). |u - u_exact| is bounded by compose_view's err (it must be < GEOM_TAU / 4, else
 // the view is not eligible), so a lookup that is not risky equals the exact one. Risky voxels (~1e-7 of them) are
 // appended to a work list and recomputed from scratch by map_fuse_fixup_kernel with the exact search.
-struct AffView { double M[9], t[3]; const float* pred; int dim, P; };
+struct AffView { double M[9], t[3]; const float* pred; int dim, P; int S[3], _pad; };   // S: fixed-point z step (FX kernels)
 struct FuseFastArgs {
     AffView v[MAX_VIEWS]; int V, X, Y, Z;
     const float* W; const float* b; int sum_fusion;
@@ -514,8 +514,22 @@ struct FuseFastArgs {
     int morton, px2, py2;        // brick columns (x, y) in Morton order (log2 of the padded column grid), z fastest
 };
 
-template <int K, int CFG>
+// FX (round 4, CFG 2 only): the index coordinates of a lane's four consecutive z voxels in 32-bit FIXED POINT. Only a rounded
+// index and three range / tie decisions are needed per axis, not a value: voxel 0's coordinate u0 comes from the fp64 chain
+// as before, is truncated to Q11.20 (FP0 = trunc(u0 * 2^20), clamped to +-1.5 * 2^30), and voxels 1..3 add the host-rounded
+// step S = rint(M_z * 2^20). Error against the fp64 coordinate: < 2^-20 (truncation) + 3 * 2^-21 (steps) = 2.4e-6 index
+// units. A decision of the exact procedure changes only at multiples of 0.5 (ties at half-integers; the range limits 0 and
+// n-1 are integers), so a voxel whose fixed-point coordinate is farther than FX_T * 2^-20 = 1.5e-5 from every multiple of
+// 0.5 on all three axes has the same rounded index and the same in / out answer: per axis and voxel one add (position), one
+// unsigned compare (range), add + shift (rounded index) and one shift-add (distance to the 0.5 lattice; min3 + one compare
+// per voxel) -- ~20 integer instructions per voxel and view where the fp64 form below spends ~33 fp64 ones (half rate).
+// Lanes inside the band (1.8e-4 of the lookups) recompute THAT view's lookup with the fp64 form in a divergent branch;
+// what that flags (|u - lattice| < GEOM_TAU, ~1e-7) goes to the exact fix-up as before. Host-side eligibility: every
+// axis <= 1024 nodes and |M_z| <= 8 (compose_view fills S).
+constexpr int FX_T = 16, FX_SH = 20;
+template <int K, int CFG, bool FX = false>
 __global__ __launch_bounds__(256) void map_fuse_fast_kernel(FuseFastArgs a) {
+    static_assert(!FX || CFG == 2, "fixed-point screening: the 4-consecutive-z lane layout");
     // lanes: 16 along z, LY along y, the rest along x; a thread owns FZ voxels strided along z (CFG 0: brick
     // 4x4x64) or along x (CFG 1: brick 8x8x16)
     // CFG 2: a WAVE covers a 4x4x16 block, lane (tx, ty, tz) owns the 4 consecutive voxels z = 4 tz .. 4 tz + 3; the 4
@@ -595,8 +609,8 @@ __global__ __launch_bounds__(256) void map_fuse_fast_kernel(FuseFastArgs a) {
 #pragma unroll
         for (int k = 0; k < K; ++k) wk[k] = a.sum_fusion ? 1.f : a.W[v * K + k];
         unsigned off[FZ]; bool out[FZ];
-#pragma unroll
-        for (int u = 0; u < FZ; ++u) {
+        // one lookup in fp64 (the round-2 form): rounded indices, sure-out and "within GEOM_TAU of a decision" flags
+        auto lookup64 = [&](int u, unsigned& offu, bool& outu) {
             int n[3]; bool o = false, rk = false;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -609,9 +623,45 @@ __global__ __launch_bounds__(256) void map_fuse_fast_kernel(FuseFastArgs a) {
                 o |= sure_out; rk |= !(in | sure_out);
                 n[r] = (int)rr;
             }
-            out[u] = o;
+            outu = o;
             risky |= rk ? (1u << u) : 0u;
-            off[u] = (o | rk) ? 0u : (((unsigned)n[2] * (unsigned)w.dim + (unsigned)n[0]) * (unsigned)w.dim + (unsigned)n[1]) * K;
+            offu = (o | rk) ? 0u : (((unsigned)n[2] * (unsigned)w.dim + (unsigned)n[0]) * (unsigned)w.dim + (unsigned)n[1]) * K;
+        };
+        if constexpr (FX) {
+            constexpr int LIMC = 3 << 29;                            // clamp: 1.5 * 2^30 (+ 3 steps of <= 2^23 stays below 2^31)
+            int fp0[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double u0 = fma(w.M[3 * r + OWN], co[0], base[r]);
+                const int q = (int)(u0 * (double)(1 << FX_SH));      // v_cvt_i32_f64: truncates, saturates
+                fp0[r] = q < -LIMC ? -LIMC : (q > LIMC ? LIMC : q);
+            }
+            const unsigned lim[3] = {(unsigned)(w.dim - 1) << FX_SH, (unsigned)(w.dim - 1) << FX_SH, (unsigned)(w.P - 1) << FX_SH};
+            unsigned band = 0;
+#pragma unroll
+            for (int u = 0; u < FZ; ++u) {
+                int n[3]; bool in = true; unsigned qmin = 0xffffffffu;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int fp = fp0[r] + u * w.S[r];
+                    in &= (unsigned)fp < lim[r];
+                    n[r] = (fp + (1 << (FX_SH - 1))) >> FX_SH;
+                    const unsigned q = ((unsigned)fp << (32 - (FX_SH - 1))) + ((unsigned)FX_T << (32 - (FX_SH - 1)));
+                    qmin = q < qmin ? q : qmin;
+                }
+                const bool near = qmin < ((unsigned)(2 * FX_T) << (32 - (FX_SH - 1)));
+                band |= near ? (1u << u) : 0u;
+                out[u] = !in;
+                off[u] = (!in | near) ? 0u : (((unsigned)n[2] * (unsigned)w.dim + (unsigned)n[0]) * (unsigned)w.dim + (unsigned)n[1]) * K;
+            }
+            if (band) {                                              // ~2e-4 of the lookups: this view's fp64 form for those voxels
+#pragma unroll
+                for (int u = 0; u < FZ; ++u)
+                    if ((band >> u) & 1u) lookup64(u, off[u], out[u]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < FZ; ++u) lookup64(u, off[u], out[u]);
         }
 #pragma unroll
         for (int u = 0; u < FZ; ++u) {
@@ -1013,6 +1063,15 @@ static bool compose_view(const GridDev& g, const ViewDev& v, int K, AffView& o) 
         if (!isfinite(o.t[r]) || !isfinite(o.M[3 * r]) || !isfinite(o.M[3 * r + 1]) || !isfinite(o.M[3 * r + 2])) return false;
     }
     o.pred = v.pred; o.dim = v.dim; o.P = v.P;
+    for (int r = 0; r < 3; ++r) o.S[r] = (int)llrint(o.M[3 * r + 2] * 1048576.0 < -2147483000.0 ? -2147483000.0
+                                                     : (o.M[3 * r + 2] * 1048576.0 > 2147483000.0 ? 2147483000.0 : o.M[3 * r + 2] * 1048576.0));
+    o._pad = 0;
+    return true;
+}
+// fixed-point screening (map_fuse_fast_kernel<K, 2, true>): every axis <= 1024 nodes, z step of every axis at most 8 index units
+static bool fx_eligible(const AffView& o) {
+    if (o.dim > 1024 || o.P > 1024) return false;
+    for (int r = 0; r < 3; ++r) if (!(fabs(o.M[3 * r + 2]) <= 8.0)) return false;
     return true;
 }
 
@@ -1244,12 +1303,17 @@ int mpu_map_fuse_views(const mpu_voxel_grid* grid, const mpu_view_pred* views, i
         }
         f.nblk8 = (unsigned)((nblk + 7) / 8);
         const dim3 g(f.nblk8 * 8u), b(256);
-        if (cfg == 2)      { MPU_DISPATCH_K(n_classes, (map_fuse_fast_kernel<KK, 2><<<g, b, 0, st>>>(f))); }
+        static int fx_on = -1;                                   // MPU_FUSE_FX=0: the fp64 index arithmetic of round 2 (A/B, equality test)
+        if (fx_on < 0) { const char* e = getenv("MPU_FUSE_FX"); fx_on = (e && e[0] == '0') ? 0 : 1; }
+        bool fx = fx_on && cfg == 2;
+        for (int v = 0; fx && v < n_views; ++v) fx = fx_eligible(f.v[v]);
+        if (fx)            { MPU_DISPATCH_K(n_classes, (map_fuse_fast_kernel<KK, 2, true><<<g, b, 0, st>>>(f))); }
+        else if (cfg == 2) { MPU_DISPATCH_K(n_classes, (map_fuse_fast_kernel<KK, 2><<<g, b, 0, st>>>(f))); }
         else if (cfg == 1) { MPU_DISPATCH_K(n_classes, (map_fuse_fast_kernel<KK, 1><<<g, b, 0, st>>>(f))); }
         else               { MPU_DISPATCH_K(n_classes, (map_fuse_fast_kernel<KK, 0><<<g, b, 0, st>>>(f))); }
         { const int rc_ = launch_ok(); if (rc_) return rc_; }
         MPU_DISPATCH_K(n_classes, (map_fuse_fixup_kernel<KK><<<dim3(256), dim3(256), 0, st>>>(a, f.list, f.count, f.cap, nxt)));
-        if (sched_log_on()) sched_note("map_fuse fast views=%d K=%d brick=%d", n_views, n_classes, cfg);
+        if (sched_log_on()) sched_note("map_fuse fast views=%d K=%d brick=%d fx=%d", n_views, n_classes, cfg, fx ? 1 : 0);
         const int rc_ = launch_ok();
         guard.done = rc_ == MPU_OK;
         return rc_;

@@ -87,6 +87,7 @@ const char* last_glds_schedule();               // "glds" or "pipe": what the la
 int  try_conv_c8(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // <= 8 input channels: first layer (conv_c8.hip)
 int  try_conv_ws(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // register-stationary weights, persistent (conv_ws.hip)
 int  try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st);     // LDS-resident patch variant (conv_halo.hip)
+int  try_conv_halo16(int dtype, int mode, const ConvArgs& a, hipStream_t st);   // ... 16-row tiles, staggered halves: large grids (conv_halo16.hip)
 // grouped: the job will run inside a grouped launch (WgradGroup): it need not fill the chip on its own, so it takes
 // about half the workgroups (K splits / pixel strips) of a stand-alone launch -- half the fp32 partial copies
 long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out, bool grouped = false);

@@ -111,6 +111,60 @@ def test_halo8_double_buffered_patch_schedule(case):
     assert conv and conv[0] == "halo8", conv                    # the forward launch of the case took the new schedule
 
 
+# Large grids of 128-channel tiles: the 16-row staggered kernel (conv_halo16, round 4). The first case reaches the
+# dispatcher's grid bound (768 tiles) at its real size; the others run in a subprocess with MPU_HALO16_MIN=1 (read once
+# per process) so that small shapes exercise the schedule: chunk boundaries (single-buffered patch reload), concat sources,
+# channel tails (k-step guards), ragged W / N tiles, one-tile grids.
+HALO16_BIG = (CONV3, 12, 128, 128, 16, 0, 256)
+HALO16_CASES = [
+    # mode,   B, H,  W,  C0,  C1,  Cout
+    (CONV3,   2, 32, 64, 128, 0, 128),      # two full chunks: one patch reload
+    (CONV3,   1, 16, 40, 72, 0, 136),       # ragged W tile, channel tail (64 + 8), ragged N (two n-tiles)
+    (CONV3,   2, 48, 32, 64, 64, 256),      # concat: the second chunk comes from the second source
+    (CONV3,   1, 32, 96, 256, 0, 128),      # four chunks: three reloads
+    (CONV3,   3, 16, 32, 8, 0, 72),         # one k-step of data, 72 of 128 channels
+    (CONV3,   1, 16, 32, 200, 0, 128),      # chunks 64 + 64 + 64 + 8
+]
+
+
+def _schedules_of(fn):
+    import ctypes as C
+    from multiplanarunet_amd import _lib
+    lib = _lib.load()
+    lib.mpu_schedule_log_enable(1)
+    try:
+        fn()
+        n = lib.mpu_schedule_log_read(None, 0)
+        buf = C.create_string_buffer(int(n) + 1)
+        lib.mpu_schedule_log_read(buf, n + 1)
+    finally:
+        lib.mpu_schedule_log_enable(0)
+    return [l.split()[1] for l in buf.value.decode().splitlines() if l.startswith("conv ")]
+
+
+def test_halo16_at_its_real_grid_size():
+    conv = _schedules_of(lambda: _run_case(HALO16_BIG, torch.bfloat16))
+    assert conv and conv[0] == "halo16", conv
+
+
+@pytest.mark.parametrize("case", HALO16_CASES)
+def test_halo16_cases(case):
+    """(meaningful under MPU_HALO16_MIN=1: test_halo16_small_shapes_subprocess runs it that way and asserts the schedule)"""
+    import os
+    conv = _schedules_of(lambda: _run_case(case, torch.bfloat16))
+    if os.environ.get("MPU_HALO16_MIN") == "1":
+        assert conv and conv[0] == "halo16", conv
+
+
+def test_halo16_small_shapes_subprocess():
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_conv.py"), "-x", "-q", "-k",
+                        "halo16_cases or forward_dgrad_wgrad"], env=dict(os.environ, MPU_HALO16_MIN="1"),
+                       capture_output=True, text=True, cwd=os.path.dirname(here))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("case", DEEP_CASES)
 def test_deep_level_layers_split_k_schedule(case):
     """bf16, with the split-K workspace (the path mpu_unet_forward / backward take at the deep levels)."""

@@ -154,11 +154,21 @@ def test_cfg1_bf16_step_every_conv_launch_against_fp64_on_its_own_inputs():
 
     cb = _lib.LAUNCH_TAP_FN(on_launch)
     _lib.call("mpu_unet_set_launch_tap", m._h, C.cast(cb, C.c_void_p), None)
+    lib.mpu_schedule_log_enable(1)
     try:
         m.forward_backward(x, y, sw)
         torch.cuda.synchronize()
+        nlog = lib.mpu_schedule_log_read(None, 0)
+        lbuf = C.create_string_buffer(int(nlog) + 1)
+        lib.mpu_schedule_log_read(lbuf, nlog + 1)
     finally:
+        lib.mpu_schedule_log_enable(0)
         _lib.call("mpu_unet_set_launch_tap", m._h, None, None)
+    import os
+    n16 = sum(1 for l in lbuf.value.decode().splitlines() if l.startswith("conv halo16"))
+    if os.environ.get("MPU_EXPECT_HALO16") == "1":
+        assert n16 >= 8, lbuf.value.decode()
+        print("replay: %d launches on conv_halo16" % n16)
     g = m.grads.cpu().numpy().astype(np.float64)
 
     assert len(fwd_err) == 22 and len(dg_err) == 25 and len(wg_ref) == 22, (len(fwd_err), len(dg_err), len(wg_ref))
@@ -177,3 +187,16 @@ def test_cfg1_bf16_step_every_conv_launch_against_fp64_on_its_own_inputs():
         worst_w = max(worst_w, e, eb)
         assert e <= 2e-3 and eb <= 2e-3, ("wgrad", ci, e, eb)
     print("replay: weight / bias gradients of the 22 layers: worst rel-to-max error %.3g" % worst_w)
+
+
+def test_replay_with_the_16_row_staggered_kernel_subprocess():
+    """The same teacher-forced replay with MPU_HALO16_MIN=1 (read once per process): the level-1 / level-2 layers of the
+    step then run on conv_halo16 (16-row tiles, staggered halves) -- forward with fused BatchNorm statistics, data
+    gradients with the ReLU mask and the BatchNorm-backward sums -- and every launch is again pinned against the fp64
+    convolution of its own inputs."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_replay.py"), "-x", "-q", "-s", "-k",
+                        "every_conv_launch"], env=dict(os.environ, MPU_HALO16_MIN="1", MPU_EXPECT_HALO16="1"),
+                       capture_output=True, text=True, cwd=os.path.dirname(here))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
