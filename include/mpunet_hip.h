@@ -406,13 +406,27 @@ int mpu_debug_stamps_read(uint64_t* host_out, int32_t n);
  * (out = conv^T(dz) restricted to input channels [n_off, n_off + n_cnt), times the ReLU mask 1[mask > 0] when mask
  * is set), 2 weight gradient (x = in0|in1, dz; the result lands in the flat gradient buffer at float offset w_off
  * once the backward pass has returned). H, W = resolution of the launch's OUTPUT (kind 0/1) or of dz (kind 2).
+ * Round 4: the NON-convolution launches of the step report too (their inputs and outputs are final when the callback runs):
+ *   kind 3  BatchNormalization forward, training (mpunet/models/unet.py:127,144,165,176): in0 = x [B,H,W,C0], out = y
+ *           (= gamma * xhat + beta), mask = the 2x2 max-pooled y of an encoder level (or NULL), aux0 / aux1 = batch mean /
+ *           1/sqrt(var + eps) (f32 [C0]), w_off / b_off = float offsets of gamma / beta in the flat parameter buffer;
+ *   kind 4  BatchNormalization backward: in0 = dn, in1 = x (the layer's post-ReLU input), out = dz = 1[x > 0] * d(x),
+ *           aux0 / aux1 = saved mean / invstd; dgamma / dbeta land at w_off / b_off of the flat GRADIENT buffer;
+ *   kind 5  MaxPooling2D backward + skip add: in0 = n (the level's BN output), in1 = dskip, dz = dp (gradient of the pooled
+ *           tensor [B,H/2,W/2,C0]), out = dn = dskip + unpool(dp) (routed to the FIRST maximum of each window);
+ *   kind 6  1x1 head forward: in0 = n [B,H,W,C0], out = probabilities f32 [B,H,W,Cout] (softmax of n @ Wh + bh; Wh at w_off
+ *           with row stride Cout, bh at b_off);
+ *   kind 7  head backward (Keras sparse CE on clipped probabilities, sum gradient): in0 = n, in1 = probabilities (f32),
+ *           dz = labels (u8 [B,H*W]), mask = per-image sample weights (f32 [B]) or NULL, out = dn [B,H,W,C0]; dWh / dbh land
+ *           at w_off / b_off of the gradient buffer.
  * The callback runs on the calling thread; NULL removes the tap. Not for use under graph capture. */
 typedef struct mpu_launch_info {
-    int32_t kind, conv_index, mode, dtype;      /* mode: 0 3x3, 1 up-conv 2x2, 3 1x1 (the LAYER's mode) */
+    int32_t kind, conv_index, mode, dtype;      /* mode: 0 3x3, 1 up-conv 2x2, 3 1x1 (the LAYER's mode); kinds >= 3: conv_index = BN index */
     int32_t B, H, W, C0, C1, Cout;              /* C0/C1: channels of in0/in1 (kind 1: C0 = channels of dz) */
     int32_t n_off, n_cnt, relu, _pad;
     const void* in0; const void* in1; const void* dz; const void* mask; const void* out;
     int64_t w_off, b_off;                       /* float offsets of the layer's kernel / bias in the flat buffers */
+    const void* aux0; const void* aux1;         /* kinds 3, 4: batch mean, 1/sqrt(var + eps) */
 } mpu_launch_info;
 typedef void (*mpu_launch_tap_fn)(void* user, const mpu_launch_info* info);
 int mpu_unet_set_launch_tap(mpu_unet* m, mpu_launch_tap_fn fn, void* user);

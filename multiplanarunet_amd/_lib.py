@@ -150,7 +150,7 @@ class LaunchInfo(C.Structure):
                 ("B", i32), ("H", i32), ("W", i32), ("C0", i32), ("C1", i32), ("Cout", i32),
                 ("n_off", i32), ("n_cnt", i32), ("relu", i32), ("_pad", i32),
                 ("in0", c_p), ("in1", c_p), ("dz", c_p), ("mask", c_p), ("out", c_p),
-                ("w_off", i64), ("b_off", i64)]
+                ("w_off", i64), ("b_off", i64), ("aux0", c_p), ("aux1", c_p)]
 
 
 LAUNCH_TAP_FN = C.CFUNCTYPE(None, c_p, C.POINTER(LaunchInfo))

@@ -12,17 +12,21 @@
 // matrix pipe per wave) against 20 fragment reads in the load phase + 4 in the compute phase, so the compute phase is the
 // longer one and the load phase of the other half hides beside it.
 //
-// Schedule (g = running tap index, stage = g & 3; waves 4-7 start one barrier late):
-//   L(g): read the tap's pixel fragments of all four k-steps and the weight fragments of k-steps 0-1 into registers;
-//         request the weights of tap g+2 into stage (g+2) & 3; counted vmcnt (tap g+1 has landed); lgkmcnt(0); barrier
-//   C(g): 8 MFMAs of k-step 0 | read weight fragments of k-step 2 | 8 MFMAs k-step 1 | read k-step 3 | 16 MFMAs; barrier
-//   interval:   I0    I1    I2    I3 ...        stage g is read in I(2g) .. I(2g+2); its next occupant, tap g+4, is
-//   waves 0-3:  L(0)  C(0)  L(1)  C(1)          requested in L(g+2) = I(2g+4) / I(2g+5): two barriers later.
-//   waves 4-7:   -    L(0)  C(0)  L(1)
-// The halo patch (18 x 34 pixels x 64 channels = 77 KB) is SINGLE-buffered (two of them do not fit beside four weight
-// stages): all its readers sit in load phases, so at a chunk boundary the second half's L(8) is the last reader, both halves
-// request their pieces of the next chunk's patch right behind that barrier (the first half before idling one interval, the
-// second half in front of its C(8)), and the schedule slips by ONE interval per 64-channel chunk (~9 % of a chunk).
+// Schedule. The reduction runs over ITEMS (32-channel chunk, tap): 16 MFMAs per wave each; an INTERVAL is two consecutive
+// items (32 MFMAs per wave), a BLOCK two chunk32s A | B = 18 items = 9 intervals (iv 0..3: A taps (0,1) (2,3) (4,5) (6,7);
+// iv 4: (A, 8) (B, 0); iv 5..8: B taps (1,2) .. (7,8)) -- unrolled, so every tap position, patch buffer and counted wait is
+// a compile-time constant. Waves 4-7 start one barrier late:
+//   L(iv): read the pixel fragments of both items and the weight fragments of item 0 (20 reads); request the weights of
+//          interval iv+3 (stage + 3 of five) and this interval's share of the patch prefetch; counted vmcnt; barrier
+//   C(iv): 8 MFMAs | read item 1's weight fragments (k-step 0) | 8 MFMAs | read (k-step 1) | 16 MFMAs; barrier
+// Patch: TWO 32-channel half patches (18 x 34 pixels x 64 bytes = 39 KB each): buffer 0 holds chunk A, buffer 1 chunk B. All
+// patch readers sit in load phases. B of a block is requested in L(0..2) (2 + 2 + 1 pieces per wave) and forced by the
+// strict wait of L(3) (first reader: iv 4); A of the NEXT block is requested in L(5..7) -- buffer 0's last reader is iv 4 --
+// and forced by L(8). So the activation stream is spread over the whole block instead of arriving as one exposed burst per
+// chunk: version 1 of this kernel (64-channel single-buffered patch) stalled 13-15 k cycles at every chunk boundary, the
+// whole chip waiting on HBM in lockstep (stamps, gpurun R4e: profiles/r04b_halo16_stamps.txt).
+// In-order DMA queue of a wave behind the weights W(iv+1) that L(iv) must see landed: P(iv-2) W(iv+2) P(iv-1) W(iv+3) P(iv)
+// with |W| = 2, |P| = {2,2,1,0,0,2,2,1,0}: allowed in flight = {6,8,9,2*,4,6,8,9,2*} (* strict: also forces the patch pieces).
 // Epilogue: as conv_halo8 (bias / ReLU / folded-BN affine, staged tile, coalesced stores, ReLU mask, BN statistics of
 // both passes, fused 2x2 max pooling) on the 512-pixel tile.
 #include <stdlib.h>
@@ -54,36 +58,40 @@ __device__ __forceinline__ void x_mma(const uint4& a, const uint4& b, f32x16& c)
 
 struct Halo16Cfg {
     static constexpr int NT = 9, KW = 3, BN = 128, TH = 16, TW = 32, PW = TW + 2, PH = TH + 2;
-    static constexpr int PROWS = (PH * PW + 7) / 8 * 8;          // 616 patch rows (612 used)
-    static constexpr int PATCH = PROWS * 128;
-    static constexpr int WSTAGE = BN * 128, NWS = 4;
+    static constexpr int PROWS = (PH * PW + 15) / 16 * 16;       // 624 patch rows of 64 bytes (612 used): 39 DMA pieces
+    static constexpr int PBUF = PROWS * 64;                      // one 32-channel half patch
+    static constexpr int WSTAGE = 2 * BN * 64, NWS = 5;          // a stage = the two items of an interval; requests three intervals ahead
     static constexpr int BM = TH * TW;
     static constexpr int OROW = BN * 2 + 16;
     static constexpr int EPI = BM * OROW;
-    static constexpr int MAIN = PATCH + NWS * WSTAGE;
+    static constexpr int MAIN = 2 * PBUF + NWS * WSTAGE;
     static constexpr int CONSTS = MAIN > EPI ? MAIN : EPI;       // bias / folded-BN scale / shift of the tile's channels: NOT aliased
     static constexpr int SMEM = CONSTS + 3 * BN * 4;
 };
 static_assert(Halo16Cfg::SMEM <= 160 * 1024, "LDS");
 
-// FULL: every chunk holds 64 channels (C0, C1 multiples of 64): no k-step guards in the stream
-template <bool FULL>
+// STAMP (dev aid, MPU_STAMPS=1): s_memtime stamps of wave 0 of every 8th workgroup at the phase boundaries
+template <bool STAMP>
 __global__ __launch_bounds__(512, 2) void conv_halo16_kernel(ConvArgs a) {
     typedef bf16_t T;
     using Cfg = Halo16Cfg;
     constexpr int NT = Cfg::NT, KW = Cfg::KW, BN = Cfg::BN, TH = Cfg::TH;
-    constexpr int EPC = 8, BKE = 64, NW = 8, NTHR = 512;
+    constexpr int EPC = 8, BKE = 32, NW = 8, NTHR = 512;
     constexpr int TW = Cfg::TW, PW = Cfg::PW, PROWS = Cfg::PROWS;
     constexpr int TN = 2, TM = 4;                                // wave tile: 2 x 32 channels, 4 rows of 32 pixels
-    constexpr int NPP = PROWS / 8;                               // 77 patch DMA pieces
-    constexpr int NPW = (NPP + NW - 1) / NW;                     // 10 per wave (the last one of waves 5-7 repeats a piece)
-    constexpr int GW = BN / (8 * NW);                            // 2 weight DMA pieces per wave and stage
+    constexpr int NPP = PROWS / 16;                              // 39 patch DMA pieces per chunk32
+    constexpr int NPW = (NPP + NW - 1) / NW;                     // 5 per wave (wave 7 repeats its fourth)
     constexpr int BM = Cfg::BM;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wm = wave >> 1;                     // 2 x 4 waves; waves w and w + 4 share a SIMD
+    // (a.dbg = first workgroup of the sampled window of 256: MPU_STAMPS_FIRST, default 0 = the first round)
+    const unsigned sblk = blockIdx.x - (unsigned)a.dbg;
+    unsigned long long* stamps = (STAMP && a.dbg_buf && (sblk & 7) == 0 && (sblk >> 3) < 32 && tid == 0)
+                                     ? a.dbg_buf + (sblk >> 3) * 16 : nullptr;
+    if (STAMP && stamps) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[14] = __builtin_amdgcn_s_memrealtime(); }
     const int H = a.Ho, W = a.Wo;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int tiles_n = (a.Cout + BN - 1) / BN;
@@ -91,15 +99,15 @@ __global__ __launch_bounds__(512, 2) void conv_halo16_kernel(ConvArgs a) {
     const int n0 = (t % tiles_n) * BN; t /= tiles_n;
     const int x0 = (t % tiles_x) * TW; t /= tiles_x;
     const int y0 = (t % tiles_y) * TH; const int b = t / tiles_y;
-    const int nch0 = (a.C0 + BKE - 1) / BKE, nch1 = (a.C1 + BKE - 1) / BKE;
-    const int nchunks = nch0 + nch1;
+    const int nc0 = a.C0 / BKE, nc1 = a.C1 / BKE;                // chunk32s per source (the launcher requires multiples of 32 and an even total)
+    const int nblocks = (nc0 + nc1) / 2;
     constexpr unsigned OOB = 0xfffffff0u;
     const long npix = (long)a.B * H * W;
     const i32x4 rs0 = x_make_rsrc(a.in0, npix * a.C0 * 2L);
     const i32x4 rs1 = x_make_rsrc(a.in1 ? a.in1 : a.in0, a.in1 ? npix * a.C1 * 2L : 0);
     const i32x4 rsw = x_make_rsrc(a.w, a.w_elems * 2L);
     const unsigned lds0 = (unsigned)(uintptr_t)smem;
-    const unsigned ldsW = lds0 + Cfg::PATCH;
+    const unsigned ldsW = lds0 + 2 * Cfg::PBUF;
 
     // epilogue constants of the tile's channels -> their own LDS rows, now (no register held over the main loop, no
     // exposed global load in front of the epilogue)
@@ -112,53 +120,39 @@ __global__ __launch_bounds__(512, 2) void conv_halo16_kernel(ConvArgs a) {
         sbias[2 * BN + tid] = (a.post_scale && nv) ? a.post_shift[e] : 0.f;
     }
 
-    // --- per-lane DMA roles -------------------------------------------------------------
-    const int lrow = lane >> 3, slot = lane & 7;
-    // Patch pieces of this wave: wave, wave + 8, ...; piece q covers patch rows 8 q .. 8 q + 7, this lane row lrow of it. The
-    // pixel of piece k + 1 lies 64 patch rows behind that of piece k: (py, px) advance by (1, 30) with one carry --
-    // recomputed at every chunk (ten pieces per ~21 k cycles) instead of held in 20 registers beside 128 accumulators.
-    auto issue_patch = [&](int cc) {
-        const bool s1 = cc >= nch0;
-        const int cbase = (s1 ? cc - nch0 : cc) * BKE, Cs = s1 ? a.C1 : a.C0;
+    // --- per-lane DMA roles (64-byte rows: a 1-KB piece = 16 rows x 4 slots of 16 bytes) ----------------------
+    const int drow = lane >> 2, dslot = lane & 3;
+    // chunk32 c: source, first channel inside the source, byte offset of its channels inside a packed weight row
+    auto chunk_src = [&](int c, bool& s1, int& cbase, int& Cs) { s1 = c >= nc0; cbase = (s1 ? c - nc0 : c) * BKE; Cs = s1 ? a.C1 : a.C0; };
+    auto chunk_woff = [&](int c) { const bool s1 = c >= nc0; return (unsigned)(((s1 ? a.C0 : 0) + (s1 ? c - nc0 : c) * BKE) * 2); };
+    // patch piece k (0..4) of this wave for chunk32 c into buffer pb: rows 16 (wave + 8 k) .. + 15, this lane row drow
+    auto issue_patch_piece = [&](int c, int pb, int k) {
+        bool s1; int cbase, Cs; chunk_src(c, s1, cbase, Cs);
         i32x4 qrs;
         qrs.x = s1 ? rs1.x : rs0.x; qrs.y = s1 ? rs1.y : rs0.y; qrs.z = s1 ? rs1.z : rs0.z; qrs.w = rs0.w;
-        const bool tail = Cs - cbase < BKE;
-        int pr = wave * 8 + lrow;
-        int py = pr / PW, px = pr - py * PW;
-#pragma unroll
-        for (int k = 0; k < NPW; ++k) {
-            const bool dup = wave + NW * k >= NPP;               // (wave-uniform, only k = NPW - 1): the wave's previous piece again
-            if (dup) { pr -= 64; px -= 30; py -= 1; if (px < 0) { px += PW; py -= 1; } }
-            const int iy = y0 + py - 1, ix = x0 + px - 1;
-            const bool v = pr < Cfg::PH * PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const int pix = v ? (b * H + iy) * W + ix : (int)npix;   // padding: the first pixel beyond the tensor
-            const int ch = cbase + ((slot ^ ((pr >> 1) & 7)) * EPC);
-            unsigned off = (unsigned)((pix * Cs + ch) * 2);
-            if (tail) off = ch < Cs ? off : OOB;
-            const int piece = __builtin_amdgcn_readfirstlane(dup ? wave + NW * (k - 1) : wave + NW * k);
-            x_dma16(qrs, off, lds0 + piece * 1024);
-            pr += 64; px += 30; py += 1; if (px >= PW) { px -= PW; py += 1; }
-        }
+        int q = wave + NW * k;
+        if (q >= NPP) q -= NW;                                   // (wave 7, k = 4) the wave's previous piece again: same bytes, same place
+        const int pr = q * 16 + drow;
+        const int py = pr / PW, px = pr - py * PW;
+        const int iy = y0 + py - 1, ix = x0 + px - 1;
+        const bool v = pr < Cfg::PH * PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const int pix = v ? (b * H + iy) * W + ix : (int)npix;   // padding: the first pixel beyond the tensor
+        const int ch = cbase + ((dslot ^ ((pr >> 2) & 3)) * EPC);
+        const unsigned off = (unsigned)((pix * Cs + ch) * 2);
+        x_dma16(qrs, off, lds0 + pb * Cfg::PBUF + __builtin_amdgcn_readfirstlane(q) * 1024);
     };
-    unsigned wpo[GW]; int wch[GW];
-#pragma unroll
-    for (int g = 0; g < GW; ++g) {
-        const int rl = wave * (BN / NW) + g * 8 + lrow;
+    // weights of one interval = two items (chunk32, tap): 128 rows x 64 bytes each; this wave's piece of an item = rows
+    // 16 wave .. + 15
+    unsigned wpo;
+    {
+        const int rl = wave * 16 + drow;
         const int n = n0 + rl;
-        wch[g] = (slot ^ ((rl >> 1) & 7)) * EPC;
-        wpo[g] = n < a.Cout ? (unsigned)((long)n * a.w_row_stride * 2L) + (unsigned)(wch[g] * 2) : X_POISON;
+        wpo = n < a.Cout ? (unsigned)((long)n * a.w_row_stride * 2L) + (unsigned)(((dslot ^ ((rl >> 2) & 3)) * EPC) * 2) : X_POISON;
     }
-    auto chunk_woff = [&](int c_) { const bool s1 = c_ >= nch0; return (unsigned)(((s1 ? a.C0 : 0) + (s1 ? c_ - nch0 : c_) * BKE) * 2); };
-    auto chunk_room = [&](int c_) { const bool s1 = c_ >= nch0; return (s1 ? a.C1 : a.C0) - (s1 ? c_ - nch0 : c_) * BKE; };
-    auto request_w = [&](unsigned soff, int room, int stage) {   // weights of one tap: GW pieces per wave
-        const unsigned dst = ldsW + stage * Cfg::WSTAGE + wave * (BN / NW) * 128;
-        if (FULL || room >= BKE) {
-#pragma unroll
-            for (int g = 0; g < GW; ++g) x_dma16(rsw, wpo[g] + soff, dst + g * 8 * 128);
-        } else {
-#pragma unroll
-            for (int g = 0; g < GW; ++g) x_dma16(rsw, wch[g] < room ? wpo[g] + soff : X_POISON, dst + g * 8 * 128);
-        }
+    const unsigned w_tap_b = (unsigned)(a.w_tap_stride * 2L);
+    auto request_item = [&](int c, int tap, int stage, int slot2) {
+        const unsigned soff = (unsigned)tap * w_tap_b + chunk_woff(c);
+        x_dma16(rsw, wpo + soff, ldsW + stage * Cfg::WSTAGE + slot2 * (Cfg::WSTAGE / 2) + wave * 1024);
     };
 
     f32x16 acc[TN][TM];
@@ -169,127 +163,136 @@ __global__ __launch_bounds__(512, 2) void conv_halo16_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int fsw = ((lane & 31) >> 1) & 7, fh = lane >> 5;
+    const int fh = lane >> 5, l31v = lane & 31;
     const bool second = wave >= 4;
-    const unsigned w_tap_b = (unsigned)(a.w_tap_stride * 2L);
-    unsigned woffA = chunk_woff(0); int roomA = chunk_room(0);
-    issue_patch(0);
-    request_w(woffA, roomA, 0);
-    request_w(woffA + w_tap_b, roomA, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory");    // patch + tap 0 landed (tap 1 may be in flight)
-    __builtin_amdgcn_s_barrier();
-    if (second) __builtin_amdgcn_s_barrier();                    // one phase behind
-    // weight-fragment offset of this lane inside a stage at k-step 0 (k-step s flips bits 5-6 of the swizzled slot: ^ s << 5)
-    const unsigned wlane = (unsigned)(Cfg::PATCH + (wn * 64 + (lane & 31)) * 128) + (unsigned)((fh ^ fsw) << 4);
-    const int prow0 = (wm * TM) * PW + (lane & 31);              // patch row of the lane's pixel in tile row wm * 4, tap (0, 0)
-    unsigned stb = 0;                                            // byte offset of the current weight stage
-    for (int cc = 0; cc < nchunks; ++cc) {
-        const bool hasnext = cc + 1 < nchunks;
-        const int kv = (FULL || roomA >= BKE) ? 4 : (roomA + 15) / 16;   // k-steps of 16 channels that hold data (a tail chunk: fewer)
-        const unsigned woffB = hasnext ? chunk_woff(cc + 1) : 0u;
-        const int roomB = hasnext ? chunk_room(cc + 1) : 0;
+    // block = two chunk32s A (even, patch buffer 0) and B (odd, buffer 1) = 18 items (chunk, tap) = 9 intervals of two items:
+    //   iv 0..3: (A, 2 iv), (A, 2 iv + 1)    iv 4: (A, 8), (B, 0)    iv 5..8: (B, 2 iv - 9), (B, 2 iv - 8)
+    auto item_is_b = [](int iv, int which) { return iv > 4 || (iv == 4 && which == 1); };
+    auto item_tap = [](int iv, int which) { return iv < 4 ? 2 * iv + which : (iv == 4 ? (which ? 0 : 8) : 2 * iv - 9 + which); };
+    // request the weights of interval (blk, iv) -- iv may run past 8 into the next block -- into stage stg
+    auto request_interval = [&](int blk, int iv, int stg) {
+        if (iv >= 9) { iv -= 9; ++blk; }
+        request_item(2 * blk + (item_is_b(iv, 0) ? 1 : 0), item_tap(iv, 0), stg, 0);
+        request_item(2 * blk + (item_is_b(iv, 1) ? 1 : 0), item_tap(iv, 1), stg, 1);
+    };
+    // prologue: chunk A of block 0 (5 pieces per wave), the weights of intervals 0, 1, 2
 #pragma unroll
-        for (int tap = 0; tap < NT; ++tap) {
-            const int ky = tap / KW, kx = tap % KW;              // (compile-time)
-            // ---- L: the tap's pixel fragments (all k-steps) and the weight fragments of k-steps 0, 1
+    for (int k = 0; k < NPW; ++k) issue_patch_piece(0, 0, k);
+    request_interval(0, 0, 0);
+    request_interval(0, 1, 1);
+    request_interval(0, 2, 2);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            // patch A + interval 0 landed (intervals 1, 2 may be in flight)
+    __builtin_amdgcn_s_barrier();
+    if (STAMP && stamps) stamps[1] = __builtin_amdgcn_s_memtime();
+    if (second) __builtin_amdgcn_s_barrier();                    // one phase behind
+    // fragment offsets of this lane at k-step 0 (k-step 1: ^ 32): weights inside an item's 8-KB half stage, pixels by patch row
+    const unsigned wlane = (unsigned)(2 * Cfg::PBUF + (wn * 64 + l31v) * 64) + (unsigned)((fh ^ ((l31v >> 2) & 3)) << 4);
+    const int prow0 = (wm * TM) * PW + l31v;                     // patch row of the lane's pixel in tile row wm * 4, tap (0, 0)
+    unsigned stb = 0;                                            // byte offset of the current weight stage
+    for (int blk = 0; blk < nblocks; ++blk) {
+        const bool lastb = blk + 1 >= nblocks;
+#pragma unroll
+        for (int iv = 0; iv < 9; ++iv) {
+            // ---- L: the pixel fragments of both items and the weight fragments of item 0
+            const bool sh = STAMP && stamps && blk == 0 && iv == 1;
+            if (STAMP && stamps && blk == 0 && iv == 2) stamps[12] = __builtin_amdgcn_s_memtime();
+            if (sh) stamps[8] = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_setprio(1);
             int l31 = prow0;
-            asm volatile("" : "+v"(l31));                        // (keeps the nine taps' addresses from being hoisted into registers)
-            unsigned po[TM];
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-                const int prow = l31 + (j + ky) * PW + kx;
-                po[j] = (unsigned)(prow * 128) + (unsigned)((fh ^ ((prow >> 1) & 7)) << 4);
-            }
+            asm volatile("" : "+v"(l31));                        // (keeps the nine intervals' addresses from being hoisted into registers)
             const unsigned wst = wlane + stb;
-            uint4 fa[4][TN], fb[4][TM];
+            uint4 fa[2][2][TN], fb[2][2][TM];                    // [item][k-step][block]
 #pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) {
-                if (s_ > 0 && s_ >= kv) break;                   // (workgroup-uniform)
-                const unsigned ks = (unsigned)(s_ << 5);
-                if (s_ < 2) {
+            for (int it = 0; it < 2; ++it) {
+                const int tap = item_tap(iv, it), ky = tap / KW, kx = tap % KW;
+                const unsigned pbo = item_is_b(iv, it) ? (unsigned)Cfg::PBUF : 0u;
+                unsigned po[TM];
 #pragma unroll
-                    for (int i = 0; i < TN; ++i) fa[s_][i] = *(const uint4*)(smem + (wst ^ ks) + i * 32 * 128);
+                for (int j = 0; j < TM; ++j) {
+                    const int prow = l31 + (j + ky) * PW + kx;
+                    po[j] = pbo + (unsigned)(prow * 64) + (unsigned)((fh ^ ((prow >> 2) & 3)) << 4);
                 }
 #pragma unroll
-                for (int j = 0; j < TM; ++j) fb[s_][j] = *(const uint4*)(smem + (po[j] ^ ks));
+                for (int ks = 0; ks < 2; ++ks) {
+                    if (it == 0) {
+#pragma unroll
+                        for (int i = 0; i < TN; ++i) fa[0][ks][i] = *(const uint4*)(smem + (wst ^ (unsigned)(ks << 5)) + i * 32 * 64);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) fb[it][ks][j] = *(const uint4*)(smem + (po[j] ^ (unsigned)(ks << 5)));
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
-            {   // weights two taps ahead (of this chunk, or the first taps of the next one) into stage + 2
-                const int wt = tap + 2;
-                const bool req = wt < NT || hasnext;
-                const int stn = (int)(((stb >> 14) + 2) & 3);
-                if (wt < NT) request_w(woffA + (unsigned)wt * w_tap_b, roomA, stn);
-                else if (hasnext) request_w(woffB + (unsigned)(wt - NT) * w_tap_b, roomB, stn);
+            if (sh) stamps[13] = __builtin_amdgcn_s_memtime();
+            {   // DMA requests: the weights of the interval three ahead (stage + 3), then this interval's share of the patch
+                // prefetch: iv 0..2 -> chunk B of this block into buffer 1, iv 5..7 -> chunk A of the next block into buffer 0
+                const bool wreq = iv + 3 < 9 || !lastb;
+                int stn = (int)(stb >> 14) + 3; if (stn >= Cfg::NWS) stn -= Cfg::NWS;
+                if (wreq) request_interval(blk, iv + 3, stn);
+                constexpr int pk0[9] = {0, 2, 4, 5, 5, 0, 2, 4, 5}, pk1[9] = {2, 4, 5, 5, 5, 2, 4, 5, 5};
+                if (iv <= 2) {
+#pragma unroll
+                    for (int k = pk0[iv]; k < pk1[iv]; ++k) issue_patch_piece(2 * blk + 1, 1, k);
+                } else if (iv >= 5 && iv <= 7 && !lastb) {
+#pragma unroll
+                    for (int k = pk0[iv]; k < pk1[iv]; ++k) issue_patch_piece(2 * blk + 2, 0, k);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                // tap g + 1 has landed; only the stage requested just now may stay in flight
-                if (req) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GW) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // The weights of interval iv + 1 have landed (in-order queue: everything requested before them too); allowed
+                // in flight behind them: see the table in the header comment. iv 3 / iv 8 also force the patch pieces
+                // (buffer 1 is read from iv 4 on, buffer 0 from the next block's iv 0 on).
+                if (!lastb || iv <= 4) {
+                    constexpr int allow[9] = {6, 8, 9, 2, 4, 6, 8, 9, 2};
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allow[iv]) : "memory");
+                } else {
+                    constexpr int allow_last[9] = {0, 0, 0, 0, 0, 4, 2, 0, 0};
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allow_last[iv]) : "memory");
+                }
             }
+            if (sh) stamps[9] = __builtin_amdgcn_s_memtime();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (sh) stamps[10] = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
-            // ---- C: the tap's MFMAs; the weight fragments of k-steps 2, 3 are read under them
-            const bool reload = tap == NT - 1 && hasnext;        // chunk boundary (see the header): the patch is dead behind the
-            if (reload && second) issue_patch(cc + 1);           // barrier that closed the second half's L(8)
+            if (sh) stamps[11] = __builtin_amdgcn_s_memtime();
+            // ---- C: the 32 MFMAs of the two items; item 1's weight fragments are read under item 0's MFMAs
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) x_mma(fa[0][i], fb[0][j], acc[i][j]);
+                for (int j = 0; j < TM; ++j) x_mma(fa[0][0][i], fb[0][0][j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
-            if (kv > 2) {
 #pragma unroll
-                for (int i = 0; i < TN; ++i) fa[2][i] = *(const uint4*)(smem + (wst ^ (2u << 5)) + i * 32 * 128);
-            }
+            for (int i = 0; i < TN; ++i) fa[1][0][i] = *(const uint4*)(smem + wst + (Cfg::WSTAGE / 2) + i * 32 * 64);
             __builtin_amdgcn_sched_barrier(0);
-            if (kv > 1) {
 #pragma unroll
-                for (int i = 0; i < TN; ++i)
+            for (int i = 0; i < TN; ++i)
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) x_mma(fa[1][i], fb[1][j], acc[i][j]);
-            }
+                for (int j = 0; j < TM; ++j) x_mma(fa[0][1][i], fb[0][1][j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
-            if (kv > 3) {
 #pragma unroll
-                for (int i = 0; i < TN; ++i) fa[3][i] = *(const uint4*)(smem + (wst ^ (3u << 5)) + i * 32 * 128);
-            }
+            for (int i = 0; i < TN; ++i) fa[1][1][i] = *(const uint4*)(smem + (wst ^ 32u) + (Cfg::WSTAGE / 2) + i * 32 * 64);
             __builtin_amdgcn_sched_barrier(0);
-            if (kv > 2) {
-                if (kv > 3) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN) : "memory");   // k-step 2's fragments (k-step 3's may be in flight)
-                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN) : "memory");     // item 1 k-step 0 (k-step 1 may be in flight)
 #pragma unroll
-                for (int i = 0; i < TN; ++i)
+            for (int i = 0; i < TN; ++i)
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) x_mma(fa[2][i], fb[2][j], acc[i][j]);
-            }
+                for (int j = 0; j < TM; ++j) x_mma(fa[1][0][i], fb[1][0][j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
-            if (kv > 3) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int i = 0; i < TN; ++i)
+            for (int i = 0; i < TN; ++i)
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) x_mma(fa[3][i], fb[3][j], acc[i][j]);
-            }
+                for (int j = 0; j < TM; ++j) x_mma(fa[1][1][i], fb[1][1][j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
-            if (reload) {
-                // second half: its pieces were requested in front of this C(8); first half: one interval of its own for
-                // them (behind the barrier that closes [first: C(8) | second: L(8)]). The barrier that closes
-                // [first: reload | second: C(8)] makes the whole patch visible; the second half then idles one interval
-                // so that the halves stay one phase apart.
-                if (second) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (!second) { issue_patch(cc + 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-                __builtin_amdgcn_s_barrier();
-            } else {
-                __builtin_amdgcn_s_barrier();
-            }
-            stb = (stb + Cfg::WSTAGE) & (4 * Cfg::WSTAGE - 1);
+            if (sh) stamps[7] = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            stb += Cfg::WSTAGE; if (stb == Cfg::NWS * Cfg::WSTAGE) stb = 0;
         }
-        woffA = woffB; roomA = roomB;
     }
     if (!second) __builtin_amdgcn_s_barrier();                   // the second half's last compute phase
     __builtin_amdgcn_s_setprio(0);
+    if (STAMP && stamps) stamps[2] = __builtin_amdgcn_s_memtime();
 
     // --- epilogue: as conv_halo8, on the 512-pixel tile -------------------------------------------
     constexpr int OROW = Cfg::OROW;
@@ -328,6 +331,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo16_kernel(ConvArgs a) {
         }
     }
     __syncthreads();
+    if (STAMP && stamps) stamps[3] = __builtin_amdgcn_s_memtime();
     {
         // thread = (16-byte channel piece c, pixel r0 of a tile row); a pass covers one 32-pixel row of the tile
         constexpr int CPRO = BN * 2 / 16, RPI = NTHR / CPRO, NIT = BM / RPI;
@@ -436,13 +440,22 @@ __global__ __launch_bounds__(512, 2) void conv_halo16_kernel(ConvArgs a) {
             }
         }
     }
+    if (STAMP && stamps) {
+        stamps[4] = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamps[5] = __builtin_amdgcn_s_memtime();
+        stamps[15] = __builtin_amdgcn_s_memrealtime();
+        stamps[6] = (unsigned long long)(nblocks * 9);
+    }
 }
 
 int launch_halo16(const ConvArgs& a_in, hipStream_t st) {
     using Cfg = Halo16Cfg;
-    const bool full = a_in.C0 % 64 == 0 && a_in.C1 % 64 == 0;
-    auto kern = full ? conv_halo16_kernel<true> : conv_halo16_kernel<false>;
+    unsigned long long* sbuf = stamp_buffer();                  // MPU_STAMPS=1: the instrumented instantiation
+    auto kern = sbuf ? conv_halo16_kernel<true> : conv_halo16_kernel<false>;
     ConvArgs a = a_in;
+    a.dbg_buf = sbuf;
+    { static int first = -1; if (first < 0) { const char* e = getenv("MPU_STAMPS_FIRST"); first = e ? atoi(e) : 0; } a.dbg = first; }
     if (a.w_elems <= 0) a.w_elems = (Cfg::NT - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
     static unsigned long long attr_set = 0;
     if (first_use_on_device(attr_set)) {
@@ -472,12 +485,18 @@ int launch_halo16(const ConvArgs& a_in, hipStream_t st) {
 // 3 = launched, 0 = shape not suited (the caller falls back to conv_halo), < 0 = error.
 // Large grids of 128-channel tiles on 16-row x 32-pixel pixel tiles: predict batches, the configs[3] train step.
 int try_conv_halo16(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
+    // OFF by default (MPU_HALO16=1 enables): on predict-size layers it ties with the 4-wave two-workgroups-per-CU kernel
+    // (gpurun R4e/R4f: 128 -> 128 @ 138 x 128^2: 799 vs 770 us; 256 -> 256 @ 64^2: 587 vs 606; 256 -> 128: 1164 vs 1150) although
+    // its main loop keeps the matrix pipe 82 % busy: the chip clocks at ~1.52 GHz under it (s_memtime / s_memrealtime in the
+    // kernel), and prologue + epilogue (15 % + 18 % of a workgroup's life) are exposed with one workgroup per CU. DESIGN section 5.
     static int on = -1; static long min_tiles = 768;
     if (on < 0) {
-        const char* e = getenv("MPU_HALO16"); on = (e && e[0] == '0') ? 0 : 1;
+        const char* e = getenv("MPU_HALO16"); on = (e && e[0] == '1') ? 1 : 0;
         const char* m = getenv("MPU_HALO16_MIN"); if (m) min_tiles = atol(m);
     }
     if (!on || dtype != MPU_BF16 || mode != CONV3 || a.Cout <= 64 || a.Wo < 32 || (a.Ho & 15) || a.head_w) return 0;
+    // 32-channel chunks, two per block: sources that are multiples of 32 channels, an even number of chunks in total
+    if ((a.C0 & 31) || (a.C1 & 31) || (((a.C0 + a.C1) >> 5) & 1)) return 0;
     const long tiles = (long)a.B * (a.Ho / 16) * cdiv(a.Wo, 32) * cdiv(a.Cout, 128);
     if (tiles < min_tiles) return 0;
     const int rc = launch_halo16(a, st);

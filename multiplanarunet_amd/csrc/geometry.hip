@@ -706,11 +706,11 @@ __global__ __launch_bounds__(256) void map_fuse_fast_kernel(FuseFastArgs a) {
 }
 
 // exact recomputation of the voxels on the work list (all voxels if the list overflowed). The list is short and the exact
-// search long, so the kernel's time is the latency of ONE voxel: a workgroup takes 64 voxels (lane = voxel), its four
-// waves look up the views w, w + 4, ... (a wave-uniform view: its parameters stay scalar loads), and wave 0 then
+// search long, so the kernel's time is the latency of ONE voxel: a workgroup takes 64 voxels (lane = voxel), its eight
+// waves look up the views w, w + 8, ... (a wave-uniform view: its parameters stay scalar loads), and wave 0 then
 // accumulates the views in order, as the fused kernels do.
 template <int K>
-__global__ __launch_bounds__(256) void map_fuse_fixup_kernel(FuseArgs a, const unsigned* list, const unsigned* count, unsigned cap,
+__global__ __launch_bounds__(512) void map_fuse_fixup_kernel(FuseArgs a, const unsigned* list, const unsigned* count, unsigned cap,
                                                              unsigned* next_count) {
     __shared__ float xs[MAX_VIEWS][K][64];
     const GridDev& g = a.grid;
@@ -727,8 +727,8 @@ __global__ __launch_bounds__(256) void map_fuse_fixup_kernel(FuseArgs a, const u
         const int vz = (int)(t % g.Z), vy = (int)((t / g.Z) % g.Y), vx = (int)(t / ((long)g.Z * g.Y));
         double rx, ry, rz;
         voxel_real(g, vx, vy, vz, rx, ry, rz);
-        for (int v = wave; v < a.V; v += 4) {
-            const ViewDev& vw = a.views[v];
+        for (int v = wave; v < a.V; v += 8) {                                         // (eight waves: six views = one round;
+            const ViewDev& vw = a.views[v];                                           //  round 3 ran two rounds on four waves)
             int pl;
             const long o = live ? view_lookup(vw, rx, ry, rz, K, pl) : -1;
 #pragma unroll
@@ -1312,7 +1312,7 @@ int mpu_map_fuse_views(const mpu_voxel_grid* grid, const mpu_view_pred* views, i
         else if (cfg == 1) { MPU_DISPATCH_K(n_classes, (map_fuse_fast_kernel<KK, 1><<<g, b, 0, st>>>(f))); }
         else               { MPU_DISPATCH_K(n_classes, (map_fuse_fast_kernel<KK, 0><<<g, b, 0, st>>>(f))); }
         { const int rc_ = launch_ok(); if (rc_) return rc_; }
-        MPU_DISPATCH_K(n_classes, (map_fuse_fixup_kernel<KK><<<dim3(256), dim3(256), 0, st>>>(a, f.list, f.count, f.cap, nxt)));
+        MPU_DISPATCH_K(n_classes, (map_fuse_fixup_kernel<KK><<<dim3(256), dim3(512), 0, st>>>(a, f.list, f.count, f.cap, nxt)));
         if (sched_log_on()) sched_note("map_fuse fast views=%d K=%d brick=%d fx=%d", n_views, n_classes, cfg, fx ? 1 : 0);
         const int rc_ = launch_ok();
         guard.done = rc_ == MPU_OK;

@@ -311,6 +311,18 @@ int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* 
     return launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st, q, (r.group && q) ? &r.grp : nullptr);
 }
 
+// test aid: report a non-convolution launch to the tap (kinds 3-7 of mpu_launch_info)
+void tap_aux(const Run& r, int kind, int index, int lvl, int C0, int Cout, const void* in0, const void* in1, const void* dz,
+             const void* mask, const void* out, long w_off, long b_off, const void* aux0 = nullptr, const void* aux1 = nullptr) {
+    if (!r.m->tap) return;
+    mpu_launch_info li{};
+    li.kind = kind; li.conv_index = index; li.mode = 0; li.dtype = r.m->cfg.dtype;
+    li.B = r.B; li.H = r.m->cfg.H >> lvl; li.W = r.m->cfg.W >> lvl; li.C0 = C0; li.C1 = 0; li.Cout = Cout;
+    li.in0 = in0; li.in1 = in1; li.dz = dz; li.mask = mask; li.out = out; li.w_off = w_off; li.b_off = b_off;
+    li.aux0 = aux0; li.aux1 = aux1;
+    r.m->tap(r.m->tap_user, &li);
+}
+
 int bn_fwd(const Run& r, const BN& b, const void* x, int lvl, int training, void* y, void* pooled, int stats_rows = 0) {
     const int H = r.m->cfg.H >> lvl, W = r.m->cfg.W >> lvl;
     const long M = (long)r.B * H * W;
@@ -323,15 +335,19 @@ int bn_fwd(const Run& r, const BN& b, const void* x, int lvl, int training, void
         rc = launch_bn_infer_coeffs(r.params + b.g, r.params + b.b, r.state + b.mm, r.state + b.mv, b.C, BN_EPS,
                                     r.stat(b, 2), r.stat(b, 3), r.st);
     if (rc) return rc;
-    return launch_bn_apply(r.m->cfg.dtype, x, r.B, H, W, b.C, r.stat(b, 2), r.stat(b, 3), y, pooled, r.st);
+    rc = launch_bn_apply(r.m->cfg.dtype, x, r.B, H, W, b.C, r.stat(b, 2), r.stat(b, 3), y, pooled, r.st);
+    if (!rc && training) tap_aux(r, 3, (int)(&b - &r.m->bn[0]), lvl, b.C, b.C, x, nullptr, nullptr, pooled, y, b.g, b.b, r.stat(b, 0), r.stat(b, 1));
+    return rc;
 }
 
 int bn_bwd(const Run& r, const BN& b, const void* dn, const void* x, int lvl, void* dz, int ready_rows = 0,
            int ready_colmajor = 0) {
     const long M = (long)r.B * (r.m->cfg.H >> lvl) * (r.m->cfg.W >> lvl);
-    return launch_bn_backward(r.m->cfg.dtype, dn, x, M, b.C, (float*)r.at(r.P.partial), r.params + b.g, r.stat(b, 0),
-                              r.stat(b, 1), r.grads + b.g, r.grads + b.b, (float*)r.at(r.P.coeffs), dz, ready_rows,
-                              ready_colmajor, r.st);
+    const int rc = launch_bn_backward(r.m->cfg.dtype, dn, x, M, b.C, (float*)r.at(r.P.partial), r.params + b.g, r.stat(b, 0),
+                                      r.stat(b, 1), r.grads + b.g, r.grads + b.b, (float*)r.at(r.P.coeffs), dz, ready_rows,
+                                      ready_colmajor, r.st);
+    if (!rc) tap_aux(r, 4, (int)(&b - &r.m->bn[0]), lvl, b.C, b.C, dn, x, nullptr, nullptr, dz, b.g, b.b, r.stat(b, 0), r.stat(b, 1));
+    return rc;
 }
 
 #define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
@@ -419,6 +435,7 @@ int run_forward(const Run& r, const float* d_x, int training, float* d_out) {
     float* out = d_out ? d_out : (float*)r.at(P.probs);
     RC(launch_head_forward(m->cfg.dtype, prev, M0, m->head_C, m->cfg.n_classes, r.params + m->head_w,
                            m->cfg.n_classes, r.params + m->head_b, m->cfg.softmax, out, r.st));
+    tap_aux(r, 6, -1, 0, m->head_C, m->cfg.n_classes, prev, nullptr, nullptr, nullptr, out, m->head_w, m->head_b);
     if (training && d_out)     // keep a copy for the backward pass
         MPU_CHECK_HIP(hipMemcpyAsync(r.at(P.probs), d_out, M0 * m->cfg.n_classes * 4, hipMemcpyDeviceToDevice, r.st));
     return MPU_OK;
@@ -445,6 +462,7 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
     RC(launch_head_backward(dt, last, (const float*)r.at(P.probs), d_y, d_sw, M0, (long)m->cfg.H * m->cfg.W,
                             m->head_C, m->cfg.n_classes, r.params + m->head_w, m->cfg.n_classes,
                             (float*)r.at(P.partial), gA, r.grads + m->head_w, r.grads + m->head_b, d_loss, r.st));
+    tap_aux(r, 7, -1, 0, m->head_C, m->cfg.n_classes, last, r.at(P.probs), d_y, d_sw, gA, m->head_w, m->head_b);
     int point = 0;
     RC(mark_ready(r, point++));                                                            // head
     // (weight gradients on a side stream next to the data gradients were measured twice -- 3.08 vs 3.03 ms in round 2 --
@@ -494,6 +512,7 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
         RC(launch_maxpool_bwd_add_stats(dt, r.at(P.n[i]), r.at(P.dskip[i]), gB, r.B, H, W, m->F[i], gA, r.at(P.c2[i]),
                                         r.stat(eb, 0), r.stat(eb, 1), (float*)r.at(P.partial), P.partial_floats, &bwd_rows,
                                         r.st));
+        tap_aux(r, 5, m->enc_bn(i), i, m->F[i], m->F[i], r.at(P.n[i]), r.at(P.dskip[i]), gB, nullptr, gA, 0, 0);
         RC(bn_bwd(r, eb, gA, r.at(P.c2[i]), i, DZ(i2), bwd_rows));
         RC(conv_wgrad(r, c2, r.at(P.c1[i]), m->F[i], nullptr, 0, DZ(i2), i));
         RC(conv_dgrad(r, c2, DZ(i2), r.at(P.c1[i]), DZ(i1), i, 0, m->F[i]));

@@ -115,15 +115,16 @@ def test_halo8_double_buffered_patch_schedule(case):
 # dispatcher's grid bound (768 tiles) at its real size; the others run in a subprocess with MPU_HALO16_MIN=1 (read once
 # per process) so that small shapes exercise the schedule: chunk boundaries (single-buffered patch reload), concat sources,
 # channel tails (k-step guards), ragged W / N tiles, one-tile grids.
-HALO16_BIG = (CONV3, 12, 128, 128, 16, 0, 256)
+HALO16_BIG = (CONV3, 12, 128, 128, 64, 0, 256)
 HALO16_CASES = [
-    # mode,   B, H,  W,  C0,  C1,  Cout
-    (CONV3,   2, 32, 64, 128, 0, 128),      # two full chunks: one patch reload
-    (CONV3,   1, 16, 40, 72, 0, 136),       # ragged W tile, channel tail (64 + 8), ragged N (two n-tiles)
-    (CONV3,   2, 48, 32, 64, 64, 256),      # concat: the second chunk comes from the second source
-    (CONV3,   1, 32, 96, 256, 0, 128),      # four chunks: three reloads
-    (CONV3,   3, 16, 32, 8, 0, 72),         # one k-step of data, 72 of 128 channels
-    (CONV3,   1, 16, 32, 200, 0, 128),      # chunks 64 + 64 + 64 + 8
+    # mode,   B, H,  W,  C0,  C1,  Cout          (sources in multiples of 32 channels, an even number of 32-channel chunks)
+    (CONV3,   2, 32, 64, 128, 0, 128),      # two blocks: patch prefetch of the next block's chunk A
+    (CONV3,   1, 16, 40, 64, 0, 136),       # one block; ragged W tile, ragged N (two n-tiles)
+    (CONV3,   2, 48, 32, 64, 64, 256),      # concat: the second block comes from the second source
+    (CONV3,   1, 32, 96, 256, 0, 128),      # four blocks
+    (CONV3,   3, 16, 32, 32, 32, 72),       # ONE block whose chunk B is the second source; 72 of 128 channels
+    (CONV3,   1, 16, 32, 96, 32, 128),      # three chunks of source 0 + one of source 1: a block that straddles the sources
+    (CONV3,   1, 16, 32, 192, 0, 128),      # three blocks
 ]
 
 
@@ -142,25 +143,22 @@ def _schedules_of(fn):
     return [l.split()[1] for l in buf.value.decode().splitlines() if l.startswith("conv ")]
 
 
-def test_halo16_at_its_real_grid_size():
-    conv = _schedules_of(lambda: _run_case(HALO16_BIG, torch.bfloat16))
-    assert conv and conv[0] == "halo16", conv
-
-
-@pytest.mark.parametrize("case", HALO16_CASES)
+@pytest.mark.parametrize("case", HALO16_CASES + [HALO16_BIG])
 def test_halo16_cases(case):
-    """(meaningful under MPU_HALO16_MIN=1: test_halo16_small_shapes_subprocess runs it that way and asserts the schedule)"""
+    """(meaningful under MPU_HALO16=1 MPU_HALO16_MIN=1: test_halo16_subprocess runs it that way and asserts the schedule)"""
     import os
     conv = _schedules_of(lambda: _run_case(case, torch.bfloat16))
-    if os.environ.get("MPU_HALO16_MIN") == "1":
+    if os.environ.get("MPU_HALO16") == "1":
         assert conv and conv[0] == "halo16", conv
 
 
-def test_halo16_small_shapes_subprocess():
+def test_halo16_subprocess():
+    """conv_halo16 is an opt-in schedule (MPU_HALO16=1, read once per process): its cases -- and the whole layer suite, with
+    the grid bound lowered so that every eligible small shape takes it -- in a fresh interpreter."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_conv.py"), "-x", "-q", "-k",
-                        "halo16_cases or forward_dgrad_wgrad"], env=dict(os.environ, MPU_HALO16_MIN="1"),
+                        "halo16_cases or forward_dgrad_wgrad"], env=dict(os.environ, MPU_HALO16="1", MPU_HALO16_MIN="1"),
                        capture_output=True, text=True, cwd=os.path.dirname(here))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 

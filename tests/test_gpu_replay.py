@@ -130,7 +130,7 @@ def test_cfg1_bf16_step_every_conv_launch_against_fp64_on_its_own_inputs():
                 ref = ref * (_d2h_bf16(hip, li.mask, (B, li.H, li.W, li.n_cnt))[:CMP] > 0)
             got = _d2h_bf16(hip, li.out, (B, li.H, li.W, li.n_cnt))[:CMP]
             dg_err.append((li.conv_index, li.n_off, float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)), ref.shape))
-        else:
+        elif li.kind == 2:
             # weight gradient: reference from the launch's x and dz (whole batch; fp32 mkldnn convolutions per chunk of
             # 4 images, chunk results accumulated in fp64: the chunk error ~1e-6 is far below the 2e-3 bound)
             xin = _d2h_bf16(hip, li.in0, (B, Hi, Wi, li.C0))
@@ -190,13 +190,158 @@ def test_cfg1_bf16_step_every_conv_launch_against_fp64_on_its_own_inputs():
 
 
 def test_replay_with_the_16_row_staggered_kernel_subprocess():
-    """The same teacher-forced replay with MPU_HALO16_MIN=1 (read once per process): the level-1 / level-2 layers of the
+    """The same teacher-forced replay with MPU_HALO16=1 MPU_HALO16_MIN=1 (opt-in schedule, read once per process): the level-1 / level-2 layers of the
     step then run on conv_halo16 (16-row tiles, staggered halves) -- forward with fused BatchNorm statistics, data
     gradients with the ReLU mask and the BatchNorm-backward sums -- and every launch is again pinned against the fp64
     convolution of its own inputs."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_replay.py"), "-x", "-q", "-s", "-k",
-                        "every_conv_launch"], env=dict(os.environ, MPU_HALO16_MIN="1", MPU_EXPECT_HALO16="1"),
+                        "every_conv_launch"], env=dict(os.environ, MPU_HALO16="1", MPU_HALO16_MIN="1", MPU_EXPECT_HALO16="1"),
                        capture_output=True, text=True, cwd=os.path.dirname(here))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def _d2h_f32(hip, dptr, shape):
+    n = int(np.prod(shape))
+    host = np.empty(n, np.float32)
+    rc = hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), C.c_size_t(4 * n), C.c_int(2))
+    assert rc == 0, rc
+    return host.reshape(shape).astype(np.float64)
+
+
+def _d2h_u8(hip, dptr, shape):
+    n = int(np.prod(shape))
+    host = np.empty(n, np.uint8)
+    rc = hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), C.c_size_t(n), C.c_int(2))
+    assert rc == 0, rc
+    return host.reshape(shape)
+
+
+def test_cfg1_bf16_step_every_non_conv_launch_against_fp64_on_its_own_inputs():
+    """the launch tap also reports the BatchNormalization forward / backward launches, the max-pool
+    backward + skip add, the 1x1 head forward and the head backward of the benchmarked bf16 step; each is recomputed in fp64
+    (NumPy / torch-CPU) from exactly the tensors the launch read and compared with what it stored. Tolerances: bf16 tensors
+    1.2e-2 of the tensor max (one rounding of the stored value is 2^-9 relative; BatchNorm-backward outputs are differences
+    of O(1) terms), fp32 reductions (batch statistics, dgamma / dbeta, head weight / bias gradients) 2e-3 of the tensor max,
+    probabilities 2e-5 absolute."""
+    from multiplanarunet_amd import _lib
+    from multiplanarunet_amd.unet import UNet
+    from oracle import unet_ref as U
+    hip = _hip()
+    B, dim, K = 16, 128, 3
+    w0 = U.init_weights(K, 1, 4, 1, seed=41)
+    rng = np.random.RandomState(42)
+    for k in w0:
+        v = k.split("/")[1]
+        if v == "bias":
+            w0[k] = rng.uniform(-.1, .1, w0[k].shape).astype(np.float32)
+        elif v == "gamma":
+            w0[k] = rng.uniform(.5, 1.5, w0[k].shape).astype(np.float32)
+            w0[k][0] = -0.8                                  # a negative gamma: the pooling must follow the affine
+        elif v == "beta":
+            w0[k] = rng.uniform(-.3, .3, w0[k].shape).astype(np.float32)
+    x = rng.randn(B, dim, dim, 1).astype(np.float32)
+    y = (rng.randint(0, K, (B, dim, dim)) * (rng.rand(B, dim, dim) < 0.5)).astype(np.uint8).reshape(B, -1, 1)
+    sw = np.where(np.arange(B) % 3 == 0, 0.33, 1.0).astype(np.float32)
+    m = UNet(n_classes=K, dim=dim, n_channels=1, depth=4, complexity_factor=1, flatten_output=True, dtype="bf16",
+             logger=quiet)
+    m.set_weights_dict(w0)
+    params = m.params.cpu().numpy().astype(np.float64)
+    EPS = 1e-3
+    rel = lambda got, ref: float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+    seen = {3: 0, 4: 0, 5: 0, 6: 0, 7: 0}
+    worst = {3: 0.0, 4: 0.0, 5: 0.0, 6: 0.0, 7: 0.0}
+    later = []                                             # (kind, w_off, b_off, ref at w_off, ref at b_off): gradients read after the pass
+
+    def on_launch(_user, pinfo):
+        li = pinfo.contents
+        if li.kind < 3:
+            return
+        torch.cuda.synchronize()
+        seen[li.kind] += 1
+        H, W, Cc = li.H, li.W, li.C0
+        if li.kind == 3:
+            xx = _d2h_bf16(hip, li.in0, (B, H, W, Cc))
+            got = _d2h_bf16(hip, li.out, (B, H, W, Cc))
+            mean_d, inv_d = _d2h_f32(hip, li.aux0, (Cc,)), _d2h_f32(hip, li.aux1, (Cc,))
+            g, bt = params[li.w_off:li.w_off + Cc], params[li.b_off:li.b_off + Cc]
+            mu = xx.mean((0, 1, 2)); var = xx.var((0, 1, 2))
+            inv = 1.0 / np.sqrt(var + EPS)
+            e_stat = max(rel(mean_d, mu), rel(inv_d, inv))
+            assert e_stat <= 1e-4, ("bn fwd statistics", li.conv_index, e_stat)
+            ref = (xx - mu) * inv * g + bt
+            e = rel(got, ref)
+            assert e <= 1.2e-2, ("bn fwd", li.conv_index, e)
+            worst[3] = max(worst[3], e)
+            if li.mask:                                      # pooled = 2x2 max of the STORED (rounded) output, exactly
+                pg = _d2h_bf16(hip, li.mask, (B, H // 2, W // 2, Cc))
+                pr = got.reshape(B, H // 2, 2, W // 2, 2, Cc).max((2, 4))
+                assert np.array_equal(pg, pr), ("bn fwd pooled", li.conv_index)
+        elif li.kind == 4:
+            dn = _d2h_bf16(hip, li.in0, (B, H, W, Cc)); xx = _d2h_bf16(hip, li.in1, (B, H, W, Cc))
+            got = _d2h_bf16(hip, li.out, (B, H, W, Cc))
+            mean_d, inv_d = _d2h_f32(hip, li.aux0, (Cc,)), _d2h_f32(hip, li.aux1, (Cc,))
+            g = params[li.w_off:li.w_off + Cc]
+            xh = (xx - mean_d) * inv_d
+            M = float(B * H * W)
+            dbeta = dn.sum((0, 1, 2)); dgamma = (dn * xh).sum((0, 1, 2))
+            dxx = g * inv_d * (dn - dbeta / M - xh * dgamma / M)
+            ref = np.where(xx > 0, dxx, 0.0)
+            e = rel(got, ref)
+            assert e <= 1.2e-2, ("bn bwd dz", li.conv_index, e)
+            worst[4] = max(worst[4], e)
+            later.append((4, li.w_off, li.b_off, dgamma, dbeta))
+        elif li.kind == 5:
+            n_ = _d2h_bf16(hip, li.in0, (B, H, W, Cc)); ds = _d2h_bf16(hip, li.in1, (B, H, W, Cc))
+            dp = _d2h_bf16(hip, li.dz, (B, H // 2, W // 2, Cc))
+            got = _d2h_bf16(hip, li.out, (B, H, W, Cc))
+            win = n_.reshape(B, H // 2, 2, W // 2, 2, Cc).transpose(0, 1, 3, 5, 2, 4).reshape(B, H // 2, W // 2, Cc, 4)
+            first = win.argmax(-1)                           # np.argmax: the FIRST maximum, row-major inside the window
+            routed = np.zeros_like(win)
+            np.put_along_axis(routed, first[..., None], dp[..., None], -1)
+            routed = routed.reshape(B, H // 2, W // 2, Cc, 2, 2).transpose(0, 1, 4, 2, 5, 3).reshape(B, H, W, Cc)
+            ref = ds + routed
+            e = float((np.abs(got - ref) / (np.abs(ref) + 1e-6 * np.abs(ref).max())).max())
+            assert e <= 2.0 ** -8, ("maxpool bwd + skip", li.conv_index, e)        # one bf16 rounding of an exact sum
+            worst[5] = max(worst[5], e)
+        elif li.kind == 6:
+            n_ = _d2h_bf16(hip, li.in0, (B, H, W, Cc))
+            got = _d2h_f32(hip, li.out, (B, H, W, li.Cout))
+            Wh = params[li.w_off:li.w_off + Cc * li.Cout].reshape(Cc, li.Cout); bh = params[li.b_off:li.b_off + li.Cout]
+            z = n_ @ Wh + bh
+            ez = np.exp(z - z.max(-1, keepdims=True))
+            ref = ez / ez.sum(-1, keepdims=True)
+            e = float(np.abs(got - ref).max())
+            assert e <= 2e-5, ("head fwd", e)
+            worst[6] = max(worst[6], e)
+        elif li.kind == 7:
+            n_ = torch.tensor(_d2h_bf16(hip, li.in0, (B, H, W, Cc)), requires_grad=True)
+            yy = torch.tensor(_d2h_u8(hip, li.dz, (B, H, W)).astype(np.int64))
+            ww = torch.tensor(_d2h_f32(hip, li.mask, (B,)) if li.mask else np.ones(B))
+            Wh = torch.tensor(params[li.w_off:li.w_off + Cc * li.Cout].reshape(Cc, li.Cout), requires_grad=True)
+            bh = torch.tensor(params[li.b_off:li.b_off + li.Cout], requires_grad=True)
+            probs = torch.softmax(n_ @ Wh + bh, -1)
+            U.keras_sparse_ce(probs, yy, ww).sum().backward()
+            got = _d2h_bf16(hip, li.out, (B, H, W, Cc))
+            e = rel(got, n_.grad.numpy())
+            assert e <= 1.2e-2, ("head bwd dn", e)
+            worst[7] = max(worst[7], e)
+            later.append((7, li.w_off, li.b_off, Wh.grad.numpy().ravel(), bh.grad.numpy()))
+
+    cb = _lib.LAUNCH_TAP_FN(on_launch)
+    _lib.call("mpu_unet_set_launch_tap", m._h, C.cast(cb, C.c_void_p), None)
+    try:
+        m.forward_backward(x, y, sw)
+        torch.cuda.synchronize()
+    finally:
+        _lib.call("mpu_unet_set_launch_tap", m._h, None, None)
+    g = m.grads.cpu().numpy().astype(np.float64)
+    assert seen == {3: 13, 4: 13, 5: 4, 6: 1, 7: 1}, seen
+    worst_red = 0.0
+    for kind, w_off, b_off, rw, rb in later:
+        ew, eb = rel(g[w_off:w_off + rw.size], rw), rel(g[b_off:b_off + rb.size], rb)
+        worst_red = max(worst_red, ew, eb)
+        assert ew <= 2e-3 and eb <= 2e-3, (kind, w_off, ew, eb)
+    print("replay (non-conv): bn fwd %.3g, bn bwd %.3g, pool bwd %.3g, head fwd %.3g (abs), head bwd %.3g; fp32 reductions %.3g"
+          % (worst[3], worst[4], worst[5], worst[6], worst[7], worst_red))
