@@ -267,6 +267,9 @@ def main():
                 out["comm"] = comm
         if dt_eager is not None:
             out["ms_per_step_eager_with_events"] = round(dt_eager / args.steps * 1e3, 4)
+        if world == 1 and not args.no_peaks:
+            # what the step's cycle counts are worth in time: the chip does not hold its 2.4 GHz maximum under these kernels
+            out["shader_clock_mhz_during_step"] = clock_during(lambda: [run() for _ in range(14)], device)
         traffic = {}
         try:   # HBM bytes per launch from the rocprofv3 PMC passes of this round (profiles/, see its note)
             tfile = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic_pmc.json"))[-1]
@@ -355,6 +358,8 @@ def bench_predict(device, quiet, D=256, V=6, K=3, reps=5, batch=None, C=1):
         runs.append((time.perf_counter() - t0, t))
     runs.sort(key=lambda r: r[0])
     best, tim = runs[len(runs) // 2]
+    clk = clock_during(lambda: multi_view_predict(model, vol, views, D, float(D), fm, batch_size=batch, want_probs=False),
+                       device, n=400, naps=16)
     hist = torch.bincount(labels.reshape(-1).long(), minlength=K).tolist()          # correctness guard of the leg
     if sum(hist) != D ** 3 or len(hist) != K or sum(1 for h in hist if h > 0) < 2:
         raise SystemExit("bench.py predict guard failed: label histogram %r" % (hist,))
@@ -379,6 +384,7 @@ def bench_predict(device, quiet, D=256, V=6, K=3, reps=5, batch=None, C=1):
     return {"metric": "voxels/sec (6-view predict+fuse)", "value": round(D ** 3 / best, 1), "unit": "voxels/s",
             "volume": "%d^3x%d" % (D, C), "views": V, "classes": K, "planes_per_view": P, "seconds": round(best, 4),
             "reps": reps, "statistic": "median", "seconds_all": [round(r[0], 4) for r in runs],
+            "shader_clock_mhz_during_predict": clk,
             "sample_ms": round(tim["sample_ms"], 2), "unet_ms": round(tim["unet_ms"], 2),
             "map_fuse_ms": round(tim["map_fuse_ms"], 3),
             "unet_tflops_algorithmic": round(gflop / tim["unet_ms"], 1),
@@ -483,6 +489,24 @@ def cpu_baseline_predict(D=64, V=6, K=3):
                       "restatement, threads as NumPy/torch choose; U-Net = torch-CPU fp32)" % (D, V, D + 20, D, D)}
 
 
+def clock_during(fn, device, n=400, naps=6):
+    """Effective shader clock (MHz) while fn()'s kernels run: one sampler wave on a side stream (mpu_probe_clock) records
+    (shader cycles, 100-MHz ticks) pairs; fn must keep the GPU busy for longer than the sampler (~n * naps * 8 k cycles)."""
+    from multiplanarunet_amd import _lib
+    lib = _lib.load()
+    buf = torch.zeros(2 * n, dtype=torch.int64, device=device)
+    side = torch.cuda.Stream(device=device)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        _lib.check(lib.mpu_probe_clock(_lib.ptr(buf), n, naps, _lib.stream_ptr()), "mpu_probe_clock")
+    fn()
+    torch.cuda.synchronize()
+    s = buf.cpu().numpy().reshape(n, 2)
+    lo, hi = n // 8, n - 1                                        # (skip the ramp at the start)
+    dt = float(s[hi, 1] - s[lo, 1])
+    return round(float(s[hi, 0] - s[lo, 0]) / dt * 100.0, 0) if dt > 0 else None
+
+
 def measured_peaks(device):
     """MFMA and HBM peaks measured on this box, quoted next to the spec values."""
     import ctypes as C
@@ -502,6 +526,18 @@ def measured_peaks(device):
             lib.mpu_probe_mfma_bf16(blocks, 2000, _lib.ptr(sink), C.byref(fl), st)
         e1.record(); torch.cuda.synchronize()
         best = max(best, 3 * fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    # the same loop on pseudo-random operands: the rate (and clock) the part sustains under its power limit on real data
+    blocks = ncu * 4
+    lib.mpu_probe_mfma_bf16_random(blocks, 2000, _lib.ptr(sink), C.byref(fl), st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(6):
+        lib.mpu_probe_mfma_bf16_random(blocks, 2000, _lib.ptr(sink), C.byref(fl), st)
+    e1.record(); torch.cuda.synchronize()
+    best_rand = 6 * fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    clk_rand = clock_during(lambda: [lib.mpu_probe_mfma_bf16_random(blocks, 2000, _lib.ptr(sink), C.byref(fl), st) for _ in range(12)],
+                            device, n=200, naps=4)
     n = 1 << 28                                                   # 3 x 1 GiB arrays: far beyond the 256 MB Infinity Cache
     a = torch.empty(n, device=device); b = torch.ones(n, device=device); c = torch.ones(n, device=device)
     lib.mpu_probe_stream_triad(_lib.ptr(a), _lib.ptr(b), _lib.ptr(c), n, st)
@@ -512,8 +548,12 @@ def measured_peaks(device):
         lib.mpu_probe_stream_triad(_lib.ptr(a), _lib.ptr(b), _lib.ptr(c), n, st)
     e1.record(); torch.cuda.synchronize()
     triad = 5 * 12.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    clk_triad = clock_during(lambda: [lib.mpu_probe_stream_triad(_lib.ptr(a), _lib.ptr(b), _lib.ptr(c), n, st) for _ in range(6)], device, n=200, naps=4)
     del a, b, c
+    clk_mfma = clock_during(lambda: [lib.mpu_probe_mfma_bf16(ncu * 4, 2000, _lib.ptr(sink), C.byref(fl), st) for _ in range(12)], device, n=200, naps=4)
     return {"mfma_bf16_tflops": round(best, 1), "mfma_bf16_spec_tflops": PEAK_BF16_TFLOPS,
+            "mfma_bf16_tflops_random_operands": round(best_rand, 1), "shader_clock_mhz_during_random_mfma_probe": clk_rand,
+            "shader_clock_mhz_during_mfma_probe": clk_mfma, "shader_clock_mhz_during_triad": clk_triad, "shader_clock_mhz_max": 2400,
             "stream_triad_GBs": round(triad, 1), "hbm_spec_GBs": PEAK_HBM_GBS, "compute_units": ncu,
             "note": "in-house probes under this box's power / clock state (non-zero operands; 2 reads + 1 write): they sit "
                     "10-20 % below the guide's best micro-benchmarks (2495 TFLOP/s, 6.29 TB/s copy) and are NOT used as "

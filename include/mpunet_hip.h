@@ -378,11 +378,17 @@ int mpu_geometry_check_cell_division(const mpu_axis* axis, int64_t count, uint64
  * independent v_mfma_f32_32x32x16_bf16 (no memory traffic); *flops = FLOPs executed. mpu_probe_stream_triad:
  * a = b + 1.5 c over n floats (n % 4 == 0), 12 * n bytes of HBM traffic. */
 int mpu_probe_mfma_bf16(int32_t blocks, int32_t iters, float* d_sink, double* flops, void* stream);
+/* the same loop on pseudo-random bf16 operands: the matrix rate the part sustains under its POWER limit on real data */
+int mpu_probe_mfma_bf16_random(int32_t blocks, int32_t iters, float* d_sink, double* flops, void* stream);
 int mpu_probe_stream_triad(float* d_a, const float* d_b, const float* d_c, int64_t n, void* stream);
 /* out[i] = x[3i] + x[3i+1] + x[3i+2]: 12 contiguous bytes per lane, 12 n bytes read exactly once -- the access width of
  * the fused back-mapping's K = 3 gathers; calibrates rocprofv3's FETCH_SIZE for that width (MI355X_MICROARCH.md: the
  * gfx950 x2 correction is established for 16-byte accesses only). */
 int mpu_probe_gather12(const float* d_x, float* d_out, int64_t n, void* stream);
+/* Shader-clock sampler (measurement aid): ONE wave writes n pairs (s_memtime = shader cycles, s_memrealtime = 100-MHz ticks)
+ * into d_samples [2 n] u64, about naps x 8 k cycles apart. Launch it on a side stream next to the work of interest; the
+ * effective clock of a window is d(cycles) / d(ticks) x 100 MHz. bench.py reports it for its timed regions. */
+int mpu_probe_clock(uint64_t* d_samples, int32_t n, int32_t naps, void* stream);
 
 /* Test aid (no reference counterpart): when enabled, every convolution / weight-gradient launch appends one text
  * line naming the kernel schedule the dispatcher chose for the layer shape ("conv halo mode=0 B=.. H=.. W=.. Cin=..

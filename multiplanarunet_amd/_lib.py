@@ -133,8 +133,10 @@ _SIGS = {
     "mpu_geometry_set_fast_path": (C.c_int, [i32]),
     "mpu_geometry_check_cell_division": (C.c_int, [C.POINTER(Axis), i64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "mpu_probe_mfma_bf16": (C.c_int, [i32, i32, c_p, C.POINTER(f64), c_p]),
+    "mpu_probe_mfma_bf16_random": (C.c_int, [i32, i32, c_p, C.POINTER(f64), c_p]),
     "mpu_probe_stream_triad": (C.c_int, [c_p, c_p, c_p, i64, c_p]),
     "mpu_probe_gather12": (C.c_int, [c_p, c_p, i64, c_p]),
+    "mpu_probe_clock": (C.c_int, [c_p, i32, i32, c_p]),
     "mpu_schedule_log_enable": (C.c_int, [i32]),
     "mpu_schedule_log_read": (i64, [C.c_char_p, i64]),
     "mpu_conv2d_wgrad": (C.c_int, [i32, i32, c_p, i32, c_p, i32, c_p, i32, i32, i32, i32, c_p, c_p, c_p]),

@@ -33,6 +33,48 @@ __global__ __launch_bounds__(256) void probe_mfma_kernel(int iters, float* sink)
     if (s == 12345.678f) sink[0] = s;            // keeps the accumulators alive; never true
 }
 
+// The same loop with RANDOM operands (round 4): four A and four B fragments of pseudo-random bf16 values (random sign and
+// mantissa, exponents 2^-2 .. 2^1) rotate through the MFMAs, so consecutive instructions present different bits to the
+// multiplier arrays -- as a convolution on real activations does. The constant-operand probe above barely toggles the
+// datapath and holds ~2.2 GHz; under random operands the part is POWER-limited and clocks far lower (clock sampler:
+// mpu_probe_clock), which is the ceiling a real MFMA kernel works under.
+__global__ __launch_bounds__(256) void probe_mfma_random_kernel(int iters, float* sink) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    s16x8 a[4], b[4];
+    unsigned h = (unsigned)(threadIdx.x * 2654435761u) ^ (unsigned)(blockIdx.x * 40503u + 12345u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            h = h * 1664525u + 1013904223u;
+            a[k][j] = (short)(((h >> 16) & 0x807f) | (0x3e80 + ((h >> 8) & 0x3) * 0x80));
+            h = h * 1664525u + 1013904223u;
+            b[k][j] = (short)(((h >> 16) & 0x807f) | (0x3e80 + ((h >> 8) & 0x3) * 0x80));
+        }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i + u) & 3], b[(i + 2 * u + 1) & 3], acc[i], 0, 0, 0);
+        if ((it & 63) == 63) {                   // keep the sums finite: damp the accumulators now and then
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] *= 0.0009765625f;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 12345.678f) sink[0] = s;
+}
+
 // a[i] = b[i] + s * c[i], 16 bytes per lane: 2 reads + 1 write per element
 __global__ __launch_bounds__(256) void probe_triad_kernel(float4* __restrict__ a, const float4* __restrict__ b,
                                                           const float4* __restrict__ c, long n4, float s) {
@@ -54,12 +96,32 @@ __global__ __launch_bounds__(256) void probe_gather12_kernel(const float* __rest
     }
 }
 
+// One wave samples the shader clock while other kernels run: (s_memtime, s_memrealtime) pairs `naps` x s_sleep 127 apart
+// (s_memrealtime ticks at a constant 100 MHz; s_memtime counts shader cycles). Round 4: under the dense MFMA + LDS
+// kernels this part runs well below its 2.4 GHz maximum (1.5 GHz inside conv_halo16), so a cycle count is not a time.
+__global__ __launch_bounds__(64) void probe_clock_kernel(unsigned long long* out, int n, int naps) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < n; ++i) {
+        out[2 * i] = __builtin_amdgcn_s_memtime();
+        out[2 * i + 1] = __builtin_amdgcn_s_memrealtime();
+        for (int k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+}
+
 }  // namespace
 }  // namespace mpu
 
 using namespace mpu;
 
 extern "C" {
+
+// n (shader cycles, 100-MHz ticks) pairs into d_samples [2 n] u64, about naps x 8 k cycles apart; launch it on a SIDE stream
+// next to the work whose clock is wanted.
+int mpu_probe_clock(uint64_t* d_samples, int32_t n, int32_t naps, void* stream) {
+    MPU_REQUIRE(d_samples && n > 0 && naps >= 0, "mpu_probe_clock: bad argument");
+    probe_clock_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>((unsigned long long*)d_samples, n, naps);
+    return launch_ok();
+}
 
 // 12 n bytes read (each once, 12 per lane), 4 n written.
 int mpu_probe_gather12(const float* d_x, float* d_out, int64_t n, void* stream) {
@@ -73,6 +135,14 @@ int mpu_probe_gather12(const float* d_x, float* d_out, int64_t n, void* stream) 
 int mpu_probe_mfma_bf16(int32_t blocks, int32_t iters, float* d_sink, double* flops, void* stream) {
     MPU_REQUIRE(blocks > 0 && iters > 0 && d_sink, "mpu_probe_mfma_bf16: bad argument");
     probe_mfma_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(iters, d_sink);
+    if (flops) *flops = (double)blocks * 4.0 * iters * 8.0 * 2.0 * 32 * 32 * 16;
+    return launch_ok();
+}
+
+// ... with pseudo-random bf16 operands (see probe_mfma_random_kernel): the power-limited ceiling of real data
+int mpu_probe_mfma_bf16_random(int32_t blocks, int32_t iters, float* d_sink, double* flops, void* stream) {
+    MPU_REQUIRE(blocks > 0 && iters > 0 && d_sink, "mpu_probe_mfma_bf16_random: bad argument");
+    probe_mfma_random_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(iters, d_sink);
     if (flops) *flops = (double)blocks * 4.0 * iters * 8.0 * 2.0 * 32 * 32 * 16;
     return launch_ok();
 }

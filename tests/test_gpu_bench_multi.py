@@ -16,10 +16,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, port):
+def _run(extra, port, nproc=2):
     env = dict(os.environ, MPU_SHARE_GPU="1", MPU_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + extra
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -52,3 +52,12 @@ def test_bench_two_ranks_config3_strong_scaling_and_config4_sharded_predict():
     assert d["unit"] == "voxels/s" and d["n_gpus"] == 2 and "configs[4]" in d["config"]["workload"]
     pf = d["predict_fuse"]
     assert pf["volume"] == "64^3x2" and pf["classes"] == 5 and pf["exchanges"]["reduce_scatter"]["value"] == d["value"]
+
+
+def test_bench_four_ranks_config3_eight_slices_per_rank():
+    """four ranks (sharing the test box's GPU over gloo) on configs[3] -- 8 slices of 256 x 256 per rank, the
+    three-bucket overlapped all-reduce with the weight-gradient groups flushed at the bucket boundaries."""
+    d = _run(["--config", "3", "--steps", "2", "--warmup", "1", "--no-predict", "--no-cpu-baseline", "--no-peaks"], 29617, nproc=4)
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["config"]["global_batch"] == 32 and d["config"]["slices_per_gpu"] == 8
+    c = d["comm"]
+    assert c["buckets"] == 3 and c["comm_ms_per_step"] > 0 and d["guard"]["finite"] and d["guard"]["decreasing"]

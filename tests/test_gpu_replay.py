@@ -62,12 +62,27 @@ def _layer_forward(mode, x_nhwc, w_hwio, bias):
 
 
 def test_cfg1_bf16_step_every_conv_launch_against_fp64_on_its_own_inputs():
+    _replay_conv_launches(16, 128, 1)
+
+
+def test_default_yaml_network_cf2_every_conv_launch_against_fp64():
+    """the same replay on the default project YAML's network (complexity_factor 2: 90 / 181 / 362 / 724 /
+    1448 filters, every layer with channel tails; the concat weight gradients run as one job per source), B = 8 of 128 x 128."""
+    _replay_conv_launches(8, 128, 2)
+
+
+def test_configs3_per_gpu_share_every_conv_launch_against_fp64():
+    """... and on one configs[3]-shaped step: 4 slices of 256 x 256 (the per-GPU share of the global batch 32 at N = 8)."""
+    _replay_conv_launches(4, 256, 1)
+
+
+def _replay_conv_launches(B, dim, cf):
     from multiplanarunet_amd import _lib
     from multiplanarunet_amd.unet import UNet
     from oracle import unet_ref as U
     hip = _hip()
-    B, dim, K = 16, 128, 3
-    w0 = U.init_weights(K, 1, 4, 1, seed=31)
+    K = 3
+    w0 = U.init_weights(K, 1, 4, cf, seed=31)
     rng = np.random.RandomState(32)
     for k in w0:
         v = k.split("/")[1]
@@ -81,7 +96,7 @@ def test_cfg1_bf16_step_every_conv_launch_against_fp64_on_its_own_inputs():
     x = rng.randn(B, dim, dim, 1).astype(np.float32)
     y = (rng.randint(0, K, (B, dim, dim)) * (rng.rand(B, dim, dim) < 0.5)).astype(np.uint8).reshape(B, -1, 1)
     sw = np.where(np.arange(B) % 3 == 0, 0.33, 1.0).astype(np.float32)
-    m = UNet(n_classes=K, dim=dim, n_channels=1, depth=4, complexity_factor=1, flatten_output=True, dtype="bf16",
+    m = UNet(n_classes=K, dim=dim, n_channels=1, depth=4, complexity_factor=cf, flatten_output=True, dtype="bf16",
              logger=quiet)
     m.set_weights_dict(w0)
     params = m.params.cpu().numpy()
@@ -197,7 +212,7 @@ def test_replay_with_the_16_row_staggered_kernel_subprocess():
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_replay.py"), "-x", "-q", "-s", "-k",
-                        "every_conv_launch"], env=dict(os.environ, MPU_HALO16="1", MPU_HALO16_MIN="1", MPU_EXPECT_HALO16="1"),
+                        "cfg1_bf16_step_every_conv_launch"], env=dict(os.environ, MPU_HALO16="1", MPU_HALO16_MIN="1", MPU_EXPECT_HALO16="1"),
                        capture_output=True, text=True, cwd=os.path.dirname(here))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
