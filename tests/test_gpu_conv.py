@@ -163,6 +163,44 @@ def test_halo16_subprocess():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+UPQ_CASES = [
+    # B, Ho, Wo,  Cin, Cout      (output size; the low-resolution input is Ho/2 x Wo/2)
+    (2, 16, 64, 64, 128),        # one low-resolution tile row, one chunk
+    (1, 32, 96, 72, 40),         # channel tail (64 + 8), 64-channel tile variant with ragged N, three tile columns
+    (3, 18, 66, 64, 64),         # 9 x 33 low-resolution pixels: ragged tiles both ways, far-edge zero padding inside a tile
+    (1, 64, 128, 256, 136),      # four chunks (patch reloads), two n-tiles
+    (2, 48, 64, 128, 128),       # three tile rows
+]
+
+
+@pytest.mark.parametrize("case", UPQ_CASES)
+def test_tap_combined_upconv_inference_form(case):
+    """conv_halo UPQ (round 4): UpSampling2D(2) + Conv2D(2x2, SAME) with the kernel taps combined per output-pixel parity
+    class (9 MFMA taps per output quad instead of 16; weights summed in fp32 and rounded ONCE, so the result differs from the
+    four-tap evaluation by one bf16 rounding of a weight) against the fp64 reference of the layer, through the C-ABI
+    (mpu_conv2d_pack_weights / mpu_conv2d_igemm mode 4)."""
+    from multiplanarunet_amd import ops
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = rnd(torch.randn(B, H // 2, W // 2, Cin, generator=g), torch.bfloat16)
+    w = rnd(torch.randn(2, 2, Cin, Cout, generator=g) / np.sqrt(4 * Cin), torch.bfloat16)
+    b = torch.randn(Cout, generator=g).to(torch.float64) * 0.1
+    ref = torch.relu(ref_forward(UPCONV2, x, w, b))
+    wq = ops.pack_weights_upq(w.to("cuda", torch.float32))
+    conv = _schedules_of(lambda: None)
+    got = {}
+    def run():
+        got["y"] = ops.conv2d(ops.UPQ, x.to("cuda", torch.bfloat16), wq, Cout, (H, W), bias=b.to("cuda", torch.float32), relu=True)
+    conv = _schedules_of(run)
+    assert conv == ["halo-upq"], conv
+    rt, at = tol(torch.bfloat16, ref)
+    np.testing.assert_allclose(got["y"].cpu().double().numpy(), ref.numpy(), rtol=rt, atol=at)
+    # ... and it agrees with the four-tap kernel on the same operands to the same tolerance
+    wf, _ = ops.pack_weights(w.to("cuda", torch.float32), UPCONV2, torch.bfloat16)
+    y4 = ops.conv2d(UPCONV2, x.to("cuda", torch.bfloat16), wf, Cout, (H, W), bias=b.to("cuda", torch.float32), relu=True)
+    np.testing.assert_allclose(got["y"].cpu().double().numpy(), y4.cpu().double().numpy(), rtol=rt, atol=at)
+
+
 @pytest.mark.parametrize("case", DEEP_CASES)
 def test_deep_level_layers_split_k_schedule(case):
     """bf16, with the split-K workspace (the path mpu_unet_forward / backward take at the deep levels)."""
