@@ -306,7 +306,12 @@ int mpu_adam_step_device_counter(float* d_params, const float* d_grads, float* d
  * NULL; sizes: fwd taps*Cin*Cout elements, dgrad 9*Cin*Cout elements.
  * mpu_conv2d_igemm computes out[m][n] = act(sum_k in[m@tap][k] w[tap][n][k] + bias[n])
  * (* (mask[m][n] > 0) when d_mask is given) over the channel-concatenation of
- * in0 and in1. */
+ * in0 and in1.
+ * mode 4 (bf16, forward only): the up-convolution (mode 1) on TAP-COMBINED weights -- mpu_conv2d_pack_weights(mode 4) writes
+ * 9*Cin*Cout elements [9][Cout][Cin] to d_w_fwd (d_w_dgrad ignored), mpu_conv2d_igemm(mode 4) takes them as d_w_packed
+ * (w_tap_stride = Cin*Cout, one source, no mask, output at least 16 x 64) and evaluates UpSampling2D(2) + Conv2D(2x2, SAME)
+ * (mpunet/models/unet.py:148-160) as four parity-class convolutions on the low-resolution grid: 9 instead of 16 MFMA
+ * taps per output quad; the weights of taps that read the same low-resolution pixel are summed in fp32 and rounded once. */
 int mpu_conv2d_pack_weights(int32_t dtype, int32_t mode, const float* d_w, int32_t Cin, int32_t Cout,
                             void* d_w_fwd, void* d_w_dgrad, void* stream);
 int mpu_conv2d_igemm(int32_t dtype, int32_t mode, const void* d_in0, int32_t C0,

@@ -1125,7 +1125,10 @@ __device__ __forceinline__ void wgrad_glds_body(const WgradArgs& a, const unsign
     //   * otherwise the coordinates are decoded from the pixel index with multiply-high divisions (exact for
     //     M * max(Wo, Ho) < 2^32: wgrad_glds_supported).
     // dZ rows beyond the chunk's end are zero (dZ descriptor bounded to mend), so the X side needs no `m < mend` test:
-    // whatever it fetches for those rows is multiplied by zero.
+    // whatever it fetches for those rows is multiplied by zero. ASSUMPTION: the X rows of the neighbouring chunk
+    // are FINITE -- 0 * Inf / 0 * NaN would put a NaN into this chunk's partials although the offending activation belongs
+    // to the next chunk. Activations only stop being finite after an overflow upstream, which bench.py's guard and the
+    // loss already report; when localising such a NaN remember that it may sit one K chunk (mchunk pixels) further on.
     int xm[NPX], xox[NPX], xoy[NPX], xb[NPX];
     const unsigned magic_w = 0xffffffffu / (unsigned)a.Wo + 1u, magic_h = 0xffffffffu / (unsigned)a.Ho + 1u;   // ceil(2^32 / d)
     auto decode = [&](int g) {
