@@ -144,7 +144,7 @@ int launch_c8(const ConvArgs& a_in, hipStream_t st) {
     const long tiles = (long)a.B * tx * ty;
     if (tiles >= (1L << 31)) return fail(MPU_EUNSUPPORTED, "%s", "conv: too many tiles");
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * 9 * a.C0, st);
-    conv_c8_kernel<NB><<<dim3((unsigned)tiles), dim3(256), 0, st>>>(a, tx, ty, rows / 4);
+    launch_k(conv_c8_kernel<NB>, dim3((unsigned)tiles), dim3(256), 0, st, a, tx, ty, rows / 4);
     if (prof_on()) prof_end(st);
     return launch_ok();
 }

@@ -510,15 +510,15 @@ static int launch_splitk_finish(const ConvArgs& a, int ks, long M, hipStream_t s
         if (blocks * 2 * a.Cout > a.stats_cap) blocks = a.stats_cap / (2 * a.Cout);
         *a.stats_rows = (int)blocks;
         if (a.bn_x)
-            splitk_finish_kernel<T, 2><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
+            launch_k(splitk_finish_kernel<T, 2>, (unsigned)blocks, 256, 0, st, a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
                                                                          a.relu, a.post_scale, a.post_shift, (T*)a.out, a.stats,
                                                                          (const T*)a.bn_x, a.bn_mean, a.bn_invstd);
         else
-            splitk_finish_kernel<T, 1><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
+            launch_k(splitk_finish_kernel<T, 1>, (unsigned)blocks, 256, 0, st, a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
                                                                          a.relu, a.post_scale, a.post_shift, (T*)a.out, a.stats,
                                                                          nullptr, nullptr, nullptr);
     } else {
-        splitk_finish_kernel<T, 0><<<(unsigned)blocks, 256, 0, st>>>(a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
+        launch_k(splitk_finish_kernel<T, 0>, (unsigned)blocks, 256, 0, st, a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
                                                                      a.relu, a.post_scale, a.post_shift, (T*)a.out, nullptr,
                                                                      nullptr, nullptr, nullptr);
     }
@@ -548,7 +548,7 @@ static int launch_glds_cfg(const ConvArgs& a_in, hipStream_t st) {
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * NT * (a.C0 + a.C1), st);
     const int ks = a.ksplit > 1 ? a.ksplit : 1;
     a.ksplit = ks;
-    kern<<<dim3((unsigned)tiles, ks), dim3(256), Cfg::SMEM, st>>>(a);
+    launch_k(kern, dim3((unsigned)tiles, ks), dim3(256), Cfg::SMEM, st, a);
     int rc = launch_ok();
     if (!rc && ks > 1) rc = launch_splitk_finish<T>(a, ks, M, st);
     if (prof_on()) prof_end(st);
@@ -923,7 +923,7 @@ static int launch_pipe(const ConvArgs& a_in, int ks, hipStream_t st) {
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * NT * (a.C0 + a.C1), st);
     a.ksplit = ks > 1 ? ks : 1;
     const unsigned mw = (unsigned)(((1UL << 32) + a.Wo - 1) / a.Wo), mh = (unsigned)(((1UL << 32) + a.Ho - 1) / a.Ho);
-    kern<<<dim3((unsigned)((long)tiles_m * tiles_n * a.ksplit)), dim3(512), PipeCfg::SMEM, st>>>(a, tiles_m, tiles_n, mw, mh);
+    launch_k(kern, dim3((unsigned)((long)tiles_m * tiles_n * a.ksplit)), dim3(512), PipeCfg::SMEM, st, a, tiles_m, tiles_n, mw, mh);
     int rc = launch_ok();
     if (!rc && a.ksplit > 1) rc = launch_splitk_finish<bf16_t>(a, a.ksplit, M, st);
     if (prof_on()) prof_end(st);
@@ -1364,12 +1364,12 @@ static int try_wgrad_glds_mode(const WgradArgs& a, hipStream_t st) {
         if constexpr (sizeof(T) == 2) {
             const long units = (long)a.ksplit * cdiv(Cin, 128) * cdiv(a.Cout, 128);
             const long g = 8 * ((units + 7) / 8) * ntaps;
-            wgrad_glds_kernel<T, MODE, 128, 128><<<dim3((unsigned)g), dim3(256), 0, st>>>(a);
+            launch_k(wgrad_glds_kernel<T, MODE, 128, 128>, dim3((unsigned)g), dim3(256), 0, st, a);
         }
     } else {
         const long units = (long)a.ksplit * cdiv(Cin, 64) * cdiv(a.Cout, 64);
         const long g = 8 * ((units + 7) / 8) * ntaps;
-        wgrad_glds_kernel<T, MODE, 64, 64><<<dim3((unsigned)g), dim3(256), 0, st>>>(a);
+        launch_k(wgrad_glds_kernel<T, MODE, 64, 64>, dim3((unsigned)g), dim3(256), 0, st, a);
     }
     int rc = launch_ok();
     return rc ? rc : 1;
@@ -1396,7 +1396,7 @@ int launch_wgrad_glds_group(int dtype, const GldsGroupJob* jobs, int n, hipStrea
         if (g <= 0) return fail(MPU_EINVAL, "%s", "wgrad_glds group: job is not on the grouped variant");
         grid += g;
     }
-    wgrad_glds_group_kernel<<<dim3((unsigned)grid), dim3(256), 0, st>>>(t);
+    launch_k(wgrad_glds_group_kernel, dim3((unsigned)grid), dim3(256), 0, st, t);
     return launch_ok();
 }
 

@@ -1105,7 +1105,7 @@ int launch_halo8_cfg_n(const ConvArgs& a_in, hipStream_t st) {
     a.dbg_buf = stamp_buffer();
     a.dbg = 2;                                                   // (SCHED 2: s_setprio 1 in the load phase, as SCHED 1 has it compiled in)
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);
-    kern<<<dim3((unsigned)tiles), dim3(512), Cfg::SMEM, st>>>(a);
+    launch_k(kern, dim3((unsigned)tiles), dim3(512), Cfg::SMEM, st, a);
     if (prof_on()) prof_end(st);
     return launch_ok();
 }
@@ -1136,7 +1136,7 @@ int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st, bool timed = true) {
     if (a.pooled && a.pooled_done && MODE == CONV3 && !a.mask && !(a.Ho & 1) && !(a.Wo & 1) && TH % 2 == 0) *a.pooled_done = 1;
     else a.pooled = nullptr;
     if (timed && prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);
-    kern<<<dim3((unsigned)tiles), dim3(256), Cfg::SMEM, st>>>(a);
+    launch_k(kern, dim3((unsigned)tiles), dim3(256), Cfg::SMEM, st, a);
     if (timed && prof_on()) prof_end(st);
     return launch_ok();
 }

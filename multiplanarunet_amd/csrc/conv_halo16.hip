@@ -475,7 +475,7 @@ int launch_halo16(const ConvArgs& a_in, hipStream_t st) {
     if (a.pooled && a.pooled_done && !a.mask && !(a.Ho & 1) && !(a.Wo & 1)) *a.pooled_done = 1;
     else a.pooled = nullptr;
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);
-    kern<<<dim3((unsigned)tiles), dim3(512), Cfg::SMEM, st>>>(a);
+    launch_k(kern, dim3((unsigned)tiles), dim3(512), Cfg::SMEM, st, a);
     if (prof_on()) prof_end(st);
     return launch_ok();
 }

@@ -627,7 +627,7 @@ int flush_wgrad_reduces(ReduceQueue& q, hipStream_t st) {
     if (q.njobs == 0) return MPU_OK;
     ReduceTable t; t.njobs = q.njobs; t._pad = 0;
     for (int k = 0; k < q.njobs; ++k) t.job[k] = q.job[k];
-    wgrad_reduce_all_kernel<<<dim3((unsigned)q.nblocks), dim3(256), 0, st>>>(t);
+    launch_k(wgrad_reduce_all_kernel, dim3((unsigned)q.nblocks), dim3(256), 0, st, t);
     q.njobs = 0; q.nblocks = 0;
     return launch_ok();
 }
@@ -690,7 +690,7 @@ static int launch_conv_cfg(const ConvArgs& a_in, hipStream_t st) {
         const int taps = MODE == UPCONV2 ? 4 : (MODE == CONV1 ? 1 : 9);
         prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * taps * (a.C0 + a.C1), st);
     }
-    kern<<<dim3((unsigned)tiles), dim3(256), SMEM, st>>>(a);
+    launch_k(kern, dim3((unsigned)tiles), dim3(256), SMEM, st, a);
     if (prof_on()) prof_end(st);
     return launch_ok();
 }
@@ -874,12 +874,12 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue
         if (Cin >= 128 && a.Cout >= 128) {
             big = true;
             dim3 g((unsigned)(cdiv(Cin, 128) * cdiv(a.Cout, 128)), ntaps, a.ksplit);
-            wgrad_igemm_kernel<T, MODE, 128, 128><<<g, dim3(256), 0, st>>>(a);
+            launch_k(wgrad_igemm_kernel<T, MODE, 128, 128>, g, dim3(256), 0, st, a);
         }
     }
     if (!big) {
         dim3 g((unsigned)(cdiv(Cin, 64) * cdiv(a.Cout, 64)), ntaps, a.ksplit);
-        wgrad_igemm_kernel<T, MODE, 64, 64><<<g, dim3(256), 0, st>>>(a);
+        launch_k(wgrad_igemm_kernel<T, MODE, 64, 64>, g, dim3(256), 0, st, a);
     }
     if (prof_on() && !deferred) prof_end(st);
     int rc = launch_ok();
@@ -912,9 +912,9 @@ static int launch_wgrad_mode(WgradArgs a, float* dW, hipStream_t st, ReduceQueue
     }
     if (a.ksplit == 1 && !strided) return db_blocks ? launch_colsum_finalize(a.db_partial, f.nshare, a.Cout, a.db, st) : MPU_OK;
     if (kl4)
-        wgrad_reduce_kl4_kernel<<<dim3((unsigned)(f.main_blocks + db_blocks)), dim3(256), 0, st>>>(a.partial, a.ksplit, n, dW, f);
+        launch_k(wgrad_reduce_kl4_kernel, dim3((unsigned)(f.main_blocks + db_blocks)), dim3(256), 0, st, a.partial, a.ksplit, n, dW, f);
     else
-        wgrad_reduce_kernel<<<dim3((unsigned)(f.main_blocks + db_blocks)), dim3(256), 0, st>>>(a.partial, a.ksplit, n, dW, f);
+        launch_k(wgrad_reduce_kernel, dim3((unsigned)(f.main_blocks + db_blocks)), dim3(256), 0, st, a.partial, a.ksplit, n, dW, f);
     return launch_ok();
 }
 

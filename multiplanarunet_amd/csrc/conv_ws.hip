@@ -394,7 +394,7 @@ int launch_ws(const ConvArgs& a_in, hipStream_t st) {
     else a.pooled = nullptr;
     if (HEAD) *a.head_done = 1;
     else a.head_partial = nullptr;
-    kern<<<dim3((unsigned)grid), dim3(256), Cfg::SMEM, st>>>(a, (int)tiles, mx, my);
+    launch_k(kern, dim3((unsigned)grid), dim3(256), Cfg::SMEM, st, a, (int)tiles, mx, my);
     if (prof_on()) prof_end(st);
     return launch_ok();
 }

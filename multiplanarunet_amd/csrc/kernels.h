@@ -79,8 +79,20 @@ unsigned long long* stamp_buffer();
 // ---- profile.hip: optional per-launch HIP-event timing of the MFMA kernels ----
 enum { PROF_CONV = 0, PROF_WGRAD = 1, PROF_KINDS = 2 };
 bool prof_on();
-void prof_begin(int kind, double flops, hipStream_t st);
+void prof_begin(int kind, double flops, hipStream_t st);   // opens a timing scope (one "launch": one or more kernels)
 void prof_end(hipStream_t st);
+hipEvent_t prof_start_event();                  // the open scope's start event, ONCE (its first kernel); nullptr otherwise
+hipEvent_t prof_stop_event();                   // the open scope's stop event (every kernel re-binds it); nullptr when no scope is open
+// Kernel launch of the timed families. Inside an open scope the dispatch itself carries the scope's events
+// (hipExtLaunchKernel: start / stop time stamps of the dispatch packet, which is what rocprofv3 reports), instead of two
+// hipEventRecord marker packets around it (those add ~2 us of dispatch latency to every ~30-us kernel).
+template <typename... KA, typename... A>
+inline void launch_k(void (*kern)(KA...), dim3 grid, dim3 block, unsigned shmem, hipStream_t st, A... args) {
+    if (hipEvent_t stop = prof_stop_event())
+        hipExtLaunchKernelGGL(kern, grid, block, shmem, st, prof_start_event(), stop, 0u, static_cast<KA>(args)...);
+    else
+        kern<<<grid, block, shmem, st>>>(static_cast<KA>(args)...);
+}
 bool sched_log_on();                            // schedule log (mpu_schedule_log_*): one line per conv / wgrad launch
 void sched_note(const char* fmt, ...);
 

@@ -19,12 +19,40 @@ hipEvent_t take_event() {
 }  // namespace
 
 bool prof_on() { return g_on; }
-void prof_begin(int kind, double flops, hipStream_t st) {
-    Rec r; r.a = take_event(); r.b = take_event(); r.kind = kind; r.flops = flops;
-    (void)hipEventRecord(r.a, st);
-    g_recs.push_back(r);
+// A scope times one "launch" of a family (a convolution with its split-K finish, the four launches of a tap-combined
+// up-convolution, ...): launch_k (kernels.h) binds the start event to the scope's first dispatch and the stop event to
+// every dispatch, so the pair spans first-kernel start .. last-kernel end. MPU_PROF_MARKERS=1: the round-1..3 form
+// (hipEventRecord markers around the launches), kept for comparison.
+namespace {
+bool g_open = false, g_first = false;
+int g_markers = -1;
+bool markers() {
+    if (g_markers < 0) { const char* e = getenv("MPU_PROF_MARKERS"); g_markers = (e && e[0] == '1') ? 1 : 0; }
+    return g_markers == 1;
 }
-void prof_end(hipStream_t st) { (void)hipEventRecord(g_recs.back().b, st); }
+void drop_open_scope() {                        // a scope that never saw a kernel (error return between begin and launch)
+    if (!g_open) return;
+    g_open = false;
+    if (g_first && !g_recs.empty()) { g_pool.push_back(g_recs.back().a); g_pool.push_back(g_recs.back().b); g_recs.pop_back(); }
+}
+}  // namespace
+void prof_begin(int kind, double flops, hipStream_t st) {
+    drop_open_scope();
+    Rec r; r.a = take_event(); r.b = take_event(); r.kind = kind; r.flops = flops;
+    g_recs.push_back(r);
+    if (markers()) { (void)hipEventRecord(r.a, st); return; }
+    g_open = true; g_first = true;
+}
+void prof_end(hipStream_t st) {
+    if (markers()) { if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().b, st); return; }
+    drop_open_scope();
+}
+hipEvent_t prof_start_event() {
+    if (!g_open || !g_first) return nullptr;
+    g_first = false;
+    return g_recs.back().a;
+}
+hipEvent_t prof_stop_event() { return g_open ? g_recs.back().b : nullptr; }
 
 // ---- schedule log: which kernel schedule each conv / wgrad launch took (tests assert the intended dispatch) ----
 namespace { bool g_sched_on = false; std::string g_sched; }
@@ -67,6 +95,7 @@ int mpu_debug_stamps_read(uint64_t* host_out, int32_t n) {
 int mpu_profile_enable(int32_t on) {
     for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
     g_recs.clear();
+    g_open = g_first = false;
     g_on = on != 0;
     return MPU_OK;
 }

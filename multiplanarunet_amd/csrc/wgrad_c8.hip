@@ -194,17 +194,17 @@ int try_wgrad_c8(int dtype, int mode, const WgradArgs& a, float* dW, hipStream_t
     if (M * 16L >= (1L << 31) || M * a.Cout * 2L >= (1L << 31)) return 0;   // 32-bit buffer offsets
     if (prof_on()) prof_begin(PROF_WGRAD, a.flops > 0 ? a.flops : 2.0 * M * 9 * a.C0 * a.Cout, st);
     if (a.c0_logical == 1)
-        wgrad_c8_kernel_1<<<dim3((unsigned)wgs), dim3(256), 0, st>>>((const bf16_t*)a.x0, (const bf16_t*)a.dz, a.Ho, a.Wo,
+        launch_k(wgrad_c8_kernel_1, dim3((unsigned)wgs), dim3(256), 0, st, (const bf16_t*)a.x0, (const bf16_t*)a.dz, a.Ho, a.Wo,
                                                                       a.Cout, R, strips, a.partial);
     else
-        wgrad_c8_kernel_2<<<dim3((unsigned)wgs), dim3(256), 0, st>>>((const bf16_t*)a.x0, (const bf16_t*)a.dz, a.Ho, a.Wo,
+        launch_k(wgrad_c8_kernel_2, dim3((unsigned)wgs), dim3(256), 0, st, (const bf16_t*)a.x0, (const bf16_t*)a.dz, a.Ho, a.Wo,
                                                                       a.Cout, R, strips, a.partial);
     if (prof_on()) prof_end(st);
     int rc = launch_ok();
     if (rc) return rc;
     const int ncol = 9 * a.c0_logical * a.Cout + a.Cout;
     const int sum_blocks = cdiv(ncol, FIN_COLS), npad = 9 * (8 - a.c0_logical) * a.Cout;
-    wgrad_c8_finalize_kernel<<<sum_blocks + cdiv(npad, 256), 256, 0, st>>>(a.partial, (int)wgs, a.c0_logical, a.Cout,
+    launch_k(wgrad_c8_finalize_kernel, sum_blocks + cdiv(npad, 256), 256, 0, st, a.partial, (int)wgs, a.c0_logical, a.Cout,
                                                                           sum_blocks, dW, a.db);
     rc = launch_ok();
     return rc ? rc : 1;

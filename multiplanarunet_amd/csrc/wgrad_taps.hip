@@ -552,11 +552,11 @@ int launch_wgrad_taps(int mode, const WgradArgs& a_in, const TapsPlan& p, hipStr
     const int grid = wgrad_taps_grid(mode, a, p);
     { const int rc = taps_attrs(); if (rc) return rc; }
     if (taps_stag() && !a.dbg_buf) {                             // (the stamps live in the lockstep variant)
-        if (mode == UPCONV2) wgrad_taps_kernel<UPCONV2, true><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(a, p);
-        else wgrad_taps_kernel<CONV3, true><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(a, p);
+        if (mode == UPCONV2) launch_k(wgrad_taps_kernel<UPCONV2, true>, dim3((unsigned)grid), dim3(512), TAPS_SMEM, st, a, p);
+        else launch_k(wgrad_taps_kernel<CONV3, true>, dim3((unsigned)grid), dim3(512), TAPS_SMEM, st, a, p);
     } else {
-        if (mode == UPCONV2) wgrad_taps_kernel<UPCONV2, false><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(a, p);
-        else wgrad_taps_kernel<CONV3, false><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(a, p);
+        if (mode == UPCONV2) launch_k(wgrad_taps_kernel<UPCONV2, false>, dim3((unsigned)grid), dim3(512), TAPS_SMEM, st, a, p);
+        else launch_k(wgrad_taps_kernel<CONV3, false>, dim3((unsigned)grid), dim3(512), TAPS_SMEM, st, a, p);
     }
     return launch_ok();
 }
@@ -578,8 +578,8 @@ int launch_wgrad_taps_group(const TapsGroupJob* jobs, int n, hipStream_t st) {
         t.job[k].blk_begin = grid;
         grid += wgrad_taps_grid(t.job[k].mode, t.job[k].a, t.job[k].p);      // a multiple of 8: the XCD decode of every job stays aligned
     }
-    if (taps_stag()) wgrad_taps_group_kernel<true><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(t);
-    else wgrad_taps_group_kernel<false><<<dim3((unsigned)grid), dim3(512), TAPS_SMEM, st>>>(t);
+    if (taps_stag()) launch_k(wgrad_taps_group_kernel<true>, dim3((unsigned)grid), dim3(512), TAPS_SMEM, st, t);
+    else launch_k(wgrad_taps_group_kernel<false>, dim3((unsigned)grid), dim3(512), TAPS_SMEM, st, t);
     return launch_ok();
 }
 
