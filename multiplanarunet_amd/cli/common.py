@@ -3,7 +3,9 @@ import os
 import numpy as np
 import yaml
 
-from ..data import list_volume_files, load_volume_file, as_volume, make_toy_volume, random_views, audit_dim_and_span
+from ..data import (list_volume_files, load_volume_file, load_label_file, as_volume, make_toy_volume, random_views,
+                    audit_dim_and_span)
+from ..nifti import volume_identifier
 
 DEFAULT_HPARAMS = {
     "train_data": {"base_dir": None, "img_subdir": "images", "label_subdir": "labels", "bg_class": 0},
@@ -57,12 +59,12 @@ def load_dataset(cfg, project_dir, hp, device, synthetic=0, seed=0, need_labels=
         if lab is None:
             lp = os.path.join(base, cfg.get("label_subdir", "labels"), os.path.basename(path))
             if os.path.exists(lp):
-                with np.load(lp) as z:
-                    lab = z["labels"] if "labels" in z.files else z[z.files[0]]
+                lab = load_label_file(lp)
         if lab is None and need_labels:
             raise ValueError("no labels for %s" % path)
-        ident = os.path.splitext(os.path.basename(path))[0]
+        ident = volume_identifier(path)
         vols.append(as_volume(img, lab, aff, fit.get("bg_value"), fit.get("scaler"), device, ident))
+        vols[-1].source_path = path                    # (`mp predict` writes <id>_PRED.nii.gz for NIfTI inputs)
     return vols
 
 

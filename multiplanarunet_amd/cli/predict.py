@@ -1,7 +1,8 @@
 """
 `mp predict` on MI355X: flags / project layout of mpunet/bin/predict.py:19-78,433-470; the 6-view
 loop, back-mapping and fusion run in multiplanarunet_amd.predict (distributed: plane-sharded).
-Outputs <out_dir>/nii_files/<id>_PRED.npz (labels + affine; NIfTI writing needs nibabel).
+Outputs <out_dir>/nii_files/<id>_PRED.nii.gz for NIfTI inputs (mpunet/bin/predict.py:90-117; native writer, nifti.py) and
+<id>_PRED.npz (labels + affine) for .npz / synthetic volumes; --out_format forces one of them.
 """
 import os
 from argparse import ArgumentParser
@@ -15,8 +16,10 @@ from .common import (validate_project_dir, load_hparams, load_dataset, require_a
 def get_argparser():
     p = ArgumentParser(description="Predict using a mpunet model (MI355X hot path).")
     p.add_argument("--project_dir", type=str, default="./")
-    p.add_argument("-f", help="Predict on a single file (.npz)")
-    p.add_argument("-l", help="Optional single label file (.npz) to use with -f")
+    p.add_argument("-f", help="Predict on a single file (.nii / .nii.gz / .npz)")
+    p.add_argument("-l", help="Optional single label file (.nii / .nii.gz / .npz) to use with -f")
+    p.add_argument("--out_format", default="auto", choices=("auto", "nii", "npz"),
+                   help="auto: <id>_PRED.nii.gz for NIfTI inputs, <id>_PRED.npz otherwise")
     p.add_argument("--dataset", type=str, default="test")
     p.add_argument("--out_dir", type=str, default="predictions")
     p.add_argument("--num_GPUs", type=int, default=1)
@@ -47,7 +50,9 @@ def run(args):
     from ..fusion_model import FusionModel
     from ..predict import multi_view_predict
     from ..interpolation import dice_all
-    from ..data import load_volume_file, as_volume
+    from ..data import load_volume_file, load_label_file, as_volume
+    from ..nifti import volume_identifier
+    from ..formats import save_nifti
     project_dir = os.path.abspath(args.project_dir)
     validate_project_dir(project_dir)
     for req in ("views.npz", "model"):
@@ -62,10 +67,9 @@ def run(args):
     if args.f:
         img, lab, aff = load_volume_file(args.f)
         if args.l:
-            with np.load(args.l) as z:
-                lab = z["labels"] if "labels" in z.files else z[z.files[0]]
-        vols = [as_volume(img, lab, aff, fit.get("bg_value"), fit.get("scaler"), device,
-                          os.path.splitext(os.path.basename(args.f))[0])]
+            lab = load_label_file(args.l)
+        vols = [as_volume(img, lab, aff, fit.get("bg_value"), fit.get("scaler"), device, volume_identifier(args.f))]
+        vols[0].source_path = args.f
     else:
         key = "val_data" if args.on_val else args.dataset.replace("_data", "") + "_data"
         vols = load_dataset(hp[key], project_dir, hp, device, args.synthetic, seed=5000, need_labels=False)
@@ -94,7 +98,9 @@ def run(args):
         os.makedirs(nii, exist_ok=True)
     results = {}
     for v in vols:
-        dst = os.path.join(nii, "%s_PRED.npz" % v.identifier)
+        src = str(getattr(v, "source_path", "") or "")
+        as_nii = args.out_format == "nii" or (args.out_format == "auto" and src.endswith((".nii", ".nii.gz")))
+        dst = os.path.join(nii, "%s_PRED.%s" % (v.identifier, "nii.gz" if as_nii else "npz"))
         if os.path.exists(dst) and args.continue_:
             continue
         if os.path.exists(dst) and not args.overwrite:
@@ -108,10 +114,14 @@ def run(args):
                                                sum_fusion=args.sum_fusion, batch_size=None,
                                                want_probs=args.no_argmax)
         if rank == 0:
-            out = {"labels": labels.cpu().numpy(), "affine": v.affine}
-            if args.no_argmax and probs is not None:
-                out["probs"] = probs.cpu().numpy()
-            np.savez_compressed(dst, **out)
+            if as_nii:                                # the label map, or with --no_argmax the fused [X,Y,Z,K] probabilities
+                pred = probs.cpu().numpy() if (args.no_argmax and probs is not None) else labels.cpu().numpy().astype(np.uint8)
+                save_nifti(dst, pred, v.affine)
+            else:
+                out = {"labels": labels.cpu().numpy(), "affine": v.affine}
+                if args.no_argmax and probs is not None:
+                    out["probs"] = probs.cpu().numpy()
+                np.savez_compressed(dst, **out)
             if v.labels is not None and not args.no_eval:
                 d = dice_all(v.labels, labels, n_classes=build["n_classes"], ignore_zero=True)
                 results[v.identifier] = d

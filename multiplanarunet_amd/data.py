@@ -8,8 +8,8 @@ Reference behaviour restated here:
   fg balancing .............. mpunet/sequences/isotrophic_live_view_sequence.py:98-128
   random views .............. mpunet/interpolation/sample_grid.py:133-173
   views.npz / dim / span .... mpunet/preprocessing/data_preparation_funcs.py:116-154, mpunet/image/auditor.py:108-112,199-209
-NIfTI I/O (nibabel) is outside the path and not available here: volumes are .npz files with keys
-`image` [X,Y,Z(,C)], optional `labels` [X,Y,Z], optional `affine` [4,4].
+Volume files: NIfTI-1 (.nii / .nii.gz, read natively -- nifti.py) as in a reference project folder, or .npz files with
+keys `image` [X,Y,Z(,C)], optional `labels` [X,Y,Z], optional `affine` [4,4].
 """
 import os
 import numpy as np
@@ -20,7 +20,7 @@ from .interpolation import Volume, ViewGeometry, sample_view
 
 def load_volume_file(path):
     if path.endswith((".nii", ".nii.gz")):
-        from .formats import load_nifti                      # needs nibabel (import-guarded adapter)
+        from .formats import load_nifti
         img, aff = load_nifti(path)
         return img, None, aff
     with np.load(path) as z:
@@ -31,6 +31,15 @@ def load_volume_file(path):
     if img.ndim == 3:
         img = img[..., None]
     return img.astype(np.float32), d.get("labels"), d.get("affine", np.eye(4))
+
+
+def load_label_file(path):
+    """Label volume [X,Y,Z] u8 of a NIfTI or .npz file (key `labels`, else the first array)."""
+    if path.endswith((".nii", ".nii.gz")):
+        from .formats import load_nifti_labels
+        return load_nifti_labels(path)
+    with np.load(path) as z:
+        return z["labels"] if "labels" in z.files else z[z.files[0]]
 
 
 def list_volume_files(base_dir, img_subdir="images"):

@@ -1,14 +1,15 @@
 """
 On-disk formats of a reference mpunet project, as OPTIONAL adapters: the accelerated path
-itself only needs name-keyed arrays, so everything here degrades to a clear ImportError when h5py / nibabel
-are not installed (they are absent from the build image; nothing on the hot path imports this module).
+itself only needs name-keyed arrays. NIfTI volumes are read and written natively (nifti.py: numpy + gzip, no nibabel);
+Keras .h5 weight files degrade to a clear ImportError when h5py is not installed (it is absent from the build image;
+the .npz mirror is what this build writes). Nothing on the hot path imports this module.
 
   Keras weights  .h5 ... model.save_weights / load_weights(by_name=True) of tf.keras 2.3
                          (mpunet/models/model_init.py:31,56, mpunet/callbacks/mcp_clean.py:57):
                          root attr `layer_names`; per layer a group with attr `weight_names`
                          ("<layer>/<var>:0") and one dataset per weight at <layer>/<layer>/<var>:0.
                          Kernels HWIO, BatchNormalization [gamma, beta, moving_mean, moving_variance].
-  Volumes  .nii/.nii.gz  mpunet/image/image_pair.py:164-198 (nibabel get_fdata, affine), predictions
+  Volumes  .nii/.nii.gz  mpunet/image/image_pair.py:164-198 (get_fdata, affine), predictions
                          <id>_PRED.nii.gz (mpunet/bin/predict.py:90-117).
   Checkpoint names ..... "@epoch_{epoch:02d}_val_dice_{val_dice:.5f}.h5", best one chosen by get_best_model
                          (mpunet/utils/utils.py:88-110).
@@ -89,29 +90,30 @@ def load_keras_h5(path):
     return out
 
 
-def _nib():
-    try:
-        import nibabel
-        return nibabel
-    except ImportError as e:
-        raise ImportError("NIfTI files need nibabel (pip install nibabel); without it use .npz volumes "
-                          "(image [X,Y,Z,C] f32, labels [X,Y,Z] u8, affine 4x4)") from e
-
-
-def load_nifti(path):
-    """(image f32 [X,Y,Z,C], affine) as ImagePair does (mpunet/image/image_pair.py:164-198)."""
-    nib = _nib()
-    obj = nib.load(path)
-    img = np.asarray(obj.get_fdata(caching="unchanged"), np.float32)
+def load_nifti(path, dtype=np.float32):
+    """(image [X,Y,Z,C] as `dtype`, affine) as ImagePair does (mpunet/image/image_pair.py:164-198): get_fdata with the
+    header's intensity scaling, a channel axis added to 3-D data. Native reader (nifti.py), no nibabel."""
+    from .nifti import read_nifti
+    img, aff, _ = read_nifti(path, dtype=dtype)
     if img.ndim == 3:
         img = img[..., None]
-    return img, np.asarray(obj.affine, np.float64)
+    return img, aff
+
+
+def load_nifti_labels(path, dtype=np.uint8):
+    """labels_obj.get_fdata().astype(uint8) (image_pair.py:189-197); a trailing singleton axis is dropped."""
+    from .nifti import read_nifti
+    lab, _, _ = read_nifti(path, dtype=np.float64)
+    lab = lab.astype(dtype)
+    if lab.ndim == 4 and lab.shape[-1] == 1:
+        lab = lab[..., 0]
+    return lab
 
 
 def save_nifti(path, volume, affine):
-    """<id>_PRED.nii.gz (mpunet/bin/predict.py:90-117)."""
-    nib = _nib()
-    nib.save(nib.Nifti1Image(np.asarray(volume), affine=np.asarray(affine, np.float64)), path)
+    """<id>_PRED.nii.gz (mpunet/bin/predict.py:90-117): nib.save(nib.Nifti1Image(volume, affine), path)."""
+    from .nifti import write_nifti
+    write_nifti(path, np.asarray(volume), np.asarray(affine, np.float64))
 
 
 def get_best_model(model_dir, extensions=(".h5", ".npz")):

@@ -1,5 +1,5 @@
 """On-disk formats: the Keras name list of Appendix B, checkpoint selection, and the optional
-h5py / nibabel adapters (round trips run only where those packages exist)."""
+h5py adapter (its round trip runs only where h5py exists); NIfTI is native -- tests/test_nifti_host.py."""
 import os
 import numpy as np
 import pytest
@@ -75,11 +75,6 @@ def test_missing_optional_packages_fail_loudly(tmp_path):
             F.load_keras_h5(str(tmp_path / "x.h5"))
         with pytest.raises(ImportError, match="h5py"):
             _model().save_weights(str(tmp_path / "x.h5"))
-    try:
-        import nibabel  # noqa: F401
-    except ImportError:
-        with pytest.raises(ImportError, match="nibabel"):
-            F.load_nifti(str(tmp_path / "x.nii.gz"))
 
 
 def test_keras_h5_round_trip(tmp_path):
@@ -98,7 +93,6 @@ def test_keras_h5_round_trip(tmp_path):
 
 
 def test_nifti_round_trip(tmp_path):
-    pytest.importorskip("nibabel")
     lab = (np.arange(4 * 5 * 6).reshape(4, 5, 6) % 3).astype(np.uint8)
     aff = np.diag([1.0, 0.8, 1.5, 1.0])
     p = str(tmp_path / "x_PRED.nii.gz")

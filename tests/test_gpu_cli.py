@@ -45,3 +45,20 @@ def test_mp_train_then_predict_synthetic(tmp_path):
     assert float(res2[1].split(",")[1]) > 0.5, res2
     with pytest.raises(OSError):
         mp.entry_func(["train_fusion", "--project_dir", str(proj), "--synthetic", "1"])       # exists, no --overwrite
+    # the same volume as a NIfTI file (native reader / writer, multiplanarunet_amd/nifti.py): identical label map, written
+    # as <id>_PRED.nii.gz with the input's affine (mpunet/bin/predict.py:90-117)
+    from multiplanarunet_amd.data import make_toy_volume
+    from multiplanarunet_amd.formats import save_nifti
+    from multiplanarunet_amd.nifti import read_nifti
+    img, lab_true, aff = make_toy_volume(64, 5000)
+    save_nifti(str(tmp_path / "toy_5000.v1.nii.gz"), img[..., 0], aff)
+    save_nifti(str(tmp_path / "toy_5000_labels.nii.gz"), lab_true, aff)
+    lab_npz = np.load(out)["labels"]
+    mp.entry_func(["predict", "--project_dir", str(proj), "-f", str(tmp_path / "toy_5000.v1.nii.gz"),
+                   "-l", str(tmp_path / "toy_5000_labels.nii.gz"), "--out_dir", "predictions_nii"])
+    pred, aff2, hdr = read_nifti(str(proj / "predictions_nii" / "nii_files" / "toy_5000_PRED.nii.gz"), scaled=False)
+    assert pred.dtype == np.uint8 and pred.shape == (64, 64, 64)
+    np.testing.assert_array_equal(aff2, aff)
+    np.testing.assert_array_equal(pred, lab_npz)
+    res3 = (proj / "predictions_nii" / "csv" / "results.csv").read_text().splitlines()
+    assert res3[1].startswith("toy_5000,") and res3[1].split(",")[1] == res2[1].split(",")[1], (res3, res2)
