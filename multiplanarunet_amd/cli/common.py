@@ -272,9 +272,10 @@ def init_callback_objects(callbacks, project_dir, logger=None, have_h5py=None):
     Relative paths are relative to the project folder (the reference chdirs into it, bin/train.py:330)."""
     from .. import validation as V
     log = logger or print
-    if have_h5py is None:
+    if have_h5py is None:                       # can this host write Keras .h5 files (h5py, or libhdf5 through hdf5.py)?
+        from ..formats import _h5_backend
         try:
-            import h5py  # noqa: F401
+            _h5_backend()
             have_h5py = True
         except ImportError:
             have_h5py = False
@@ -295,7 +296,7 @@ def init_callback_objects(callbacks, project_dir, logger=None, have_h5py=None):
             if not os.path.isabs(path):
                 path = os.path.normpath(os.path.join(project_dir, path))
             if path.endswith((".h5", ".hdf5")) and not have_h5py:
-                path = os.path.splitext(path)[0] + ".npz"          # no h5py here: the .npz mirror (formats.py)
+                path = os.path.splitext(path)[0] + ".npz"          # neither h5py nor libhdf5 here: the .npz mirror (formats.py)
             obj = V.ModelCheckPointClean(path, monitor=kw.get("monitor", "val_dice"), mode=kw.get("mode", "max"),
                                          verbose=kw.get("verbose", 1), logger=log)
         elif name == "CSVLogger":

@@ -158,6 +158,13 @@ def run(args):
         if rank == 0:
             model.save_weights(last)
             log("Saved", last)
+            try:                                           # bin/train.py:303-317: [project]/model/model_weights.h5 (Keras layout),
+                from ..formats import _h5_backend          # where this host can write HDF5 (h5py, or libhdf5 through hdf5.py)
+                _h5_backend()
+                model.save_weights(os.path.splitext(last)[0] + ".h5")
+                log("Saved", os.path.splitext(last)[0] + ".h5")
+            except ImportError:
+                pass
     return model
 
 

@@ -1,8 +1,9 @@
 """
 On-disk formats of a reference mpunet project, as OPTIONAL adapters: the accelerated path
 itself only needs name-keyed arrays. NIfTI volumes are read and written natively (nifti.py: numpy + gzip, no nibabel);
-Keras .h5 weight files degrade to a clear ImportError when h5py is not installed (it is absent from the build image;
-the .npz mirror is what this build writes). Nothing on the hot path imports this module.
+Keras .h5 weight files go through h5py when it imports, else through the HDF5 C library itself (hdf5.py: libhdf5 via
+ctypes -- this image has /opt/conda/lib/libhdf5.so but no h5py for its interpreter), else a clear ImportError; the .npz
+mirror is what this build writes by default. Nothing on the hot path imports this module.
 
   Keras weights  .h5 ... model.save_weights / load_weights(by_name=True) of tf.keras 2.3
                          (mpunet/models/model_init.py:31,56, mpunet/callbacks/mcp_clean.py:57):
@@ -50,43 +51,118 @@ def h5_entries(weights, depth=4):
     return out
 
 
-def _h5py():
-    try:
-        import h5py
-        return h5py
-    except ImportError as e:
-        raise ImportError("Keras .h5 weight files need h5py (pip install h5py); without it use the name-keyed .npz "
-                          "files this build writes, or convert on a machine that has h5py with "
-                          "tools/convert_weights.py") from e
+def _h5_backend():
+    """"h5py" when it imports, else "libhdf5" (hdf5.py: the HDF5 C library through ctypes), else ImportError."""
+    force = os.environ.get("MPU_H5_BACKEND", "")                      # "h5py" | "libhdf5": no fall-through (tests)
+    if force not in ("", "h5py", "libhdf5"):
+        raise ValueError("MPU_H5_BACKEND must be h5py or libhdf5")
+    if force != "libhdf5":
+        try:
+            import h5py  # noqa: F401
+            return "h5py"
+        except ImportError:
+            if force == "h5py":
+                raise
+    from . import hdf5
+    if hdf5.available():
+        return "libhdf5"
+    raise ImportError("Keras .h5 weight files need h5py (pip install h5py) or the HDF5 C library (libhdf5.so on the "
+                      "loader path, or MPU_LIBHDF5=/path/to/libhdf5.so); without either use the name-keyed .npz "
+                      "files this build writes, or convert elsewhere with tools/convert_weights.py")
+
+
+KERAS_ATTR_LIMIT = 64512       # HDF5_OBJECT_HEADER_LIMIT of keras/saving/hdf5_format.py: longer name lists are split into <name>0, <name>1, ...
+
+
+def _name_chunks(name, values):
+    """save_attributes_to_hdf5_group: one attribute, or `name0`, `name1`, ... when the list exceeds the header limit."""
+    vals = [v.encode("utf8") for v in values]
+    width = max([len(v) for v in vals] + [1])
+    if width * len(vals) <= KERAS_ATTR_LIMIT:
+        return [(name, vals)]
+    per = max(1, KERAS_ATTR_LIMIT // width)
+    return [("%s%d" % (name, i), vals[k:k + per]) for i, k in enumerate(range(0, len(vals), per))]
 
 
 def save_keras_h5(path, weights, depth=4):
-    """Write {'<layer>/<var>': array} as a tf.keras `save_weights` HDF5 file."""
-    h5py = _h5py()
+    """Write {'<layer>/<var>': array} as a tf.keras `save_weights` HDF5 file (keras/saving/hdf5_format.py
+    save_weights_to_hdf5_group: root attrs layer_names / backend / keras_version, one group per layer with attr
+    weight_names and one dataset per weight at <layer>/<layer>/<var>:0)."""
+    backend = _h5_backend()
     entries = h5_entries(weights, depth)
-    with h5py.File(path, "w") as f:
-        f.attrs["layer_names"] = np.array([l.encode("utf8") for l, _ in entries])
-        f.attrs["backend"] = b"tensorflow"
-        f.attrs["keras_version"] = b"2.4.0"
+    if backend == "h5py":
+        import h5py
+        with h5py.File(path, "w") as f:
+            for n, vals in _name_chunks("layer_names", [l for l, _ in entries]):
+                f.attrs[n] = np.array(vals)
+            f.attrs["backend"] = b"tensorflow"
+            f.attrs["keras_version"] = b"2.4.0"
+            for layer, ws in entries:
+                g = f.create_group(layer)
+                for n, vals in _name_chunks("weight_names", [n for n, _ in ws]):
+                    g.attrs[n] = np.array(vals)
+                for n, arr in ws:
+                    g.create_dataset(n, data=np.asarray(arr, np.float32))
+        return
+    from . import hdf5 as H
+    with H.open_file(path, "w") as f:
+        for n, vals in _name_chunks("layer_names", [l for l, _ in entries]):
+            H.write_strings_attr(f, n, vals)
+        H.write_strings_attr(f, "backend", b"tensorflow", scalar=True)
+        H.write_strings_attr(f, "keras_version", b"2.4.0", scalar=True)
         for layer, ws in entries:
-            g = f.create_group(layer)
-            g.attrs["weight_names"] = np.array([n.encode("utf8") for n, _ in ws])
-            for n, arr in ws:
-                g.create_dataset(n, data=np.asarray(arr, np.float32))
+            with H.create_group(f, layer) as g:
+                for n, vals in _name_chunks("weight_names", [n for n, _ in ws]):
+                    H.write_strings_attr(g, n, vals)
+                made = set()
+                for n, arr in ws:                                     # "<layer>/<var>:0": the dataset sits in a nested group
+                    parts = n.split("/")
+                    for k in range(1, len(parts)):
+                        sub = "/".join(parts[:k])
+                        if sub not in made:
+                            with H.create_group(g, sub):
+                                pass
+                            made.add(sub)
+                    H.write_dataset(g, n, np.asarray(arr, np.float32))
+
+
+def _chunked_names(read, has, name):
+    """load_attributes_from_hdf5_group: `name`, or the concatenation of `name0`, `name1`, ..."""
+    if has(name):
+        return list(read(name))
+    out, i = [], 0
+    while has("%s%d" % (name, i)):
+        out += list(read("%s%d" % (name, i)))
+        i += 1
+    return out
 
 
 def load_keras_h5(path):
     """{'<layer>/<var>': array} from a tf.keras weight file (also the `model_weights` group of a full-model file)."""
-    h5py = _h5py()
+    backend = _h5_backend()
     out = {}
-    with h5py.File(path, "r") as f:
-        root = f["model_weights"] if "layer_names" not in f.attrs and "model_weights" in f else f
-        for layer in root.attrs["layer_names"]:
-            layer = layer.decode("utf8") if isinstance(layer, bytes) else str(layer)
-            g = root[layer]
-            for wn in g.attrs["weight_names"]:
-                wn = wn.decode("utf8") if isinstance(wn, bytes) else str(wn)
-                out[wn.rsplit(":", 1)[0]] = np.asarray(g[wn])
+    dec = lambda v: v.decode("utf8") if isinstance(v, bytes) else str(v)          # noqa: E731
+    if backend == "h5py":
+        import h5py
+        with h5py.File(path, "r") as f:
+            root = f["model_weights"] if "layer_names" not in f.attrs and "layer_names0" not in f.attrs and "model_weights" in f else f
+            for layer in _chunked_names(lambda n: root.attrs[n], lambda n: n in root.attrs, "layer_names"):
+                g = root[dec(layer)]
+                for wn in _chunked_names(lambda n: g.attrs[n], lambda n: n in g.attrs, "weight_names"):
+                    out[dec(wn).rsplit(":", 1)[0]] = np.asarray(g[dec(wn)])
+        return out
+    from . import hdf5 as H
+    with H.open_file(path, "r") as f:
+        def read_layers(root):
+            for layer in _chunked_names(lambda n: H.read_strings_attr(root, n), lambda n: H.has_attr(root, n), "layer_names"):
+                with H.open_group(root, layer) as g:
+                    for wn in _chunked_names(lambda n: H.read_strings_attr(g, n), lambda n: H.has_attr(g, n), "weight_names"):
+                        out[wn.rsplit(":", 1)[0]] = H.read_dataset(g, wn)
+        if not H.has_attr(f, "layer_names") and not H.has_attr(f, "layer_names0") and H.has_link(f, "model_weights"):
+            with H.open_group(f, "model_weights") as root:
+                read_layers(root)
+        else:
+            read_layers(f)
     return out
 
 

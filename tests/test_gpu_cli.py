@@ -21,6 +21,14 @@ def test_mp_train_then_predict_synthetic(tmp_path):
                    "--train_images_per_epoch", "160", "--val_images_per_epoch", "32"])
     assert (proj / "model" / "model_weights.npz").exists() and (proj / "views.npz").exists()
     assert any(f.startswith("@epoch") for f in os.listdir(proj / "model"))
+    from multiplanarunet_amd import hdf5, formats
+    if hdf5.available():            # checkpoints in the reference's own format (Keras .h5 through libhdf5), as the YAML default names them
+        assert all(f.endswith(".h5") for f in os.listdir(proj / "model") if f.startswith("@epoch"))
+        w5 = formats.load_keras_h5(str(proj / "model" / "model_weights.h5"))
+        with np.load(proj / "model" / "model_weights.npz") as z:
+            assert sorted(w5) == sorted(k.replace("__", "/") for k in z.files)
+            for k in z.files:
+                np.testing.assert_array_equal(w5[k.replace("__", "/")], z[k])
     log = (proj / "logs" / "training.csv").read_text().strip().splitlines()
     losses = [float(l.split(",")[1]) for l in log[1:]]
     assert len(losses) == 6 and losses[-1] < losses[0]
