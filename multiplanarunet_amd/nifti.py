@@ -163,9 +163,9 @@ def read_nifti(path, dtype=np.float32, scaled=True):
         slope, inter = float(h["scl_slope"]), float(h["scl_inter"])
         if np.isfinite(slope) and slope != 0.0 and not (slope == 1.0 and (inter == 0.0 or not np.isfinite(inter))):
             data = data.astype(np.float64) * slope + (inter if np.isfinite(inter) else 0.0)
-        data = np.asarray(data, dtype=dtype)
+        data = np.array(data, dtype=dtype, order="C", copy=True)      # (own, writable memory: the file buffer is read-only)
     else:
-        data = data.astype(dt.newbyteorder("="))
+        data = np.array(data, dtype=dt.newbyteorder("="), order="C", copy=True)
     return data, best_affine(h), h
 
 
