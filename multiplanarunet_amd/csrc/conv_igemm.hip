@@ -728,7 +728,7 @@ int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
             const int w = try_conv_ws(dtype, mode, a, st);
             if (w != 0) { note("ws"); return w < 0 ? w : MPU_OK; }
             const int x = try_conv_halo16(dtype, mode, a, st);
-            if (x != 0) { note("halo16"); return x < 0 ? x : MPU_OK; }
+            if (x != 0) { note(x == 5 ? "halo16p" : "halo16"); return x < 0 ? x : MPU_OK; }
             const int h = try_conv_halo(dtype, mode, a, st);
             if (h != 0) { note(h == 2 ? "halo8" : (h == 4 ? "halo-upq" : "halo")); return h < 0 ? h : MPU_OK; }
         }

@@ -135,7 +135,7 @@ int  flush_wgrad_reduces(ReduceQueue& q, hipStream_t st);
 // untouched until the flush: every conv owns its dz buffer (Plan::dz).
 struct TapsGroupJob { WgradArgs a; TapsPlan p; int mode, blk_begin; };
 struct GldsGroupJob { WgradArgs a; int mode, blk_begin; };
-constexpr int TAPS_GROUP_MAX = 16, GLDS_GROUP_MAX = 12;
+constexpr int TAPS_GROUP_MAX = 24, GLDS_GROUP_MAX = 12;   // (24: every non-first conv of a depth-4 network; the job table stays under 4 KB of kernel arguments)
 struct WgradGroup {
     int ntaps = 0, nglds = 0; double taps_flops = 0, glds_flops = 0;
     TapsGroupJob taps[TAPS_GROUP_MAX]; GldsGroupJob glds[GLDS_GROUP_MAX];

@@ -464,6 +464,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_kernel(WgradArgs a, TapsPla
 // Every deferred wgrad_taps job of a backward pass in ONE launch (kernels.h: WgradGroup): workgroup -> job by the table's
 // block ranges (each a multiple of 8), then exactly the single-job kernel.
 struct TapsGroupTable { int njobs, _pad; TapsGroupJob job[TAPS_GROUP_MAX]; };
+static_assert(sizeof(TapsGroupTable) <= 4096, "kernel-argument size");
+static_assert(sizeof(TapsGroupTable) <= 4096, "kernel-argument size");
 template <bool STAG>
 __global__ __launch_bounds__(512, 1) void wgrad_taps_group_kernel(TapsGroupTable t) {
     extern __shared__ __attribute__((aligned(128))) unsigned char smem_all[];

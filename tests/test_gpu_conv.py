@@ -148,8 +148,8 @@ def test_halo16_cases(case):
     """(meaningful under MPU_HALO16=1 MPU_HALO16_MIN=1: test_halo16_subprocess runs it that way and asserts the schedule)"""
     import os
     conv = _schedules_of(lambda: _run_case(case, torch.bfloat16))
-    if os.environ.get("MPU_HALO16") == "1":
-        assert conv and conv[0] == "halo16", conv
+    if os.environ.get("MPU_HALO16") == "1":         # forward: the persistent form (plain epilogue); the masked data gradient: the staged one
+        assert conv and conv[0] == ("halo16" if os.environ.get("MPU_HALO16P") == "0" else "halo16p"), conv
 
 
 def test_halo16_subprocess():
@@ -157,10 +157,14 @@ def test_halo16_subprocess():
     the grid bound lowered so that every eligible small shape takes it -- in a fresh interpreter."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_conv.py"), "-x", "-q", "-k",
-                        "halo16_cases or forward_dgrad_wgrad"], env=dict(os.environ, MPU_HALO16="1", MPU_HALO16_MIN="1"),
-                       capture_output=True, text=True, cwd=os.path.dirname(here))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    # three passes: the persistent form with one tile per workgroup (grid = tiles), with 3 workgroups walking many tiles each
+    # (tile boundaries: the look-ahead into the next tile, the store-aware waits), and the staged non-persistent kernel alone
+    for extra in ({}, {"MPU_HALO16P_WGS": "3"}, {"MPU_HALO16P": "0"}):
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_conv.py"), "-x", "-q", "-k",
+                            "halo16_cases or forward_dgrad_wgrad"],
+                           env=dict(os.environ, MPU_HALO16="1", MPU_HALO16_MIN="1", **extra),
+                           capture_output=True, text=True, cwd=os.path.dirname(here))
+        assert r.returncode == 0, str(extra) + r.stdout[-2000:] + r.stderr[-2000:]
 
 
 UPQ_CASES = [

@@ -463,3 +463,58 @@ def test_staggered_schedules_equal_the_lockstep_ones_bitwise(tmp_path):
     assert np.isfinite(g1).all() and np.abs(g1).max() > 0
     assert np.array_equal(p1, p0)
     assert np.array_equal(g1, g0)
+
+
+def test_persistent_halo16_inference_equals_default_schedules_subprocess(tmp_path):
+    """conv_halo16p (round 4; the default for large inference grids, MPU_HALO16P=0 turns it off): the persistent 16-row kernel
+    with its wave-private epilogue (accumulators started at the bias, ReLU, folded-BN affine with NEGATIVE gammas, fused
+    2x2 max pooling from the read-back registers) on every eligible layer of a bf16 predict -- fresh interpreters with
+    the grid bound lowered, once with 5 workgroups so that every workgroup walks many tiles (look-ahead into the next
+    tile, store-aware waits, ragged last rounds), once with the full grid -- against the round-3 schedules
+    (MPU_HALO16P=0) on the same weights and inputs: same products, other summation order (32- instead of 64-channel
+    chunks, bias first)."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = r'''
+import sys, ctypes as C, numpy as np, torch
+sys.path.insert(0, %r)
+from multiplanarunet_amd.unet import UNet
+from multiplanarunet_amd import _lib
+from oracle import unet_ref as U
+sys.path.insert(0, %r)
+from test_gpu_unet import rand_weights, quiet
+K, Cn, D, cf, H, W, B = 3, 1, 3, 1, 128, 160, 5
+w = rand_weights(U, K, Cn, D, cf, seed=11)
+x = np.random.RandomState(3).randn(B, H, W, Cn).astype(np.float32)
+m = UNet(n_classes=K, img_rows=H, img_cols=W, n_channels=Cn, depth=D, complexity_factor=cf, dtype="bf16", logger=quiet)
+m.set_weights_dict(w)
+lib = _lib.load()
+lib.mpu_schedule_log_enable(1)
+out = m._forward(m._as_input(x), training=False).cpu().numpy()
+n = lib.mpu_schedule_log_read(None, 0)
+buf = C.create_string_buffer(int(n) + 1)
+lib.mpu_schedule_log_read(buf, n + 1)
+sched = [l.split()[1] for l in buf.value.decode().splitlines() if l.startswith("conv ")]
+print("SCHED", " ".join(sched))
+np.save(sys.argv[1], out)
+''' % (os.path.dirname(here), here)
+    res, sched = {}, {}
+    for tag, env in (("default", {"MPU_HALO16P": "0"}), ("p", {"MPU_HALO16_MIN": "1", "MPU_HALO16P_WGS": "5"}),
+                     ("p_full_grid", {"MPU_HALO16_MIN": "1"})):
+        path = str(tmp_path / (tag + ".npy"))
+        r = subprocess.run([sys.executable, "-c", script, path], env=dict(os.environ, **env), capture_output=True, text=True,
+                           cwd=os.path.dirname(here))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res[tag] = np.load(path)
+        sched[tag] = [l for l in r.stdout.splitlines() if l.startswith("SCHED")][0].split()[1:]
+    assert "halo16p" not in sched["default"]
+    # levels 1 (128 ch, 64 x 80) and 2 (256 ch, 32 x 40): both encoder convs (the second with the fused pool), the
+    # concat conv and the last conv of the up blocks
+    assert sched["p"].count("halo16p") >= 6, sched["p"]
+    assert sched["p"] == sched["p_full_grid"]
+    for tag in ("p", "p_full_grid"):
+        assert np.isfinite(res[tag]).all()
+        d = np.abs(res[tag] - res["default"])
+        print(tag, "max |dp| %.3e mean %.3e" % (d.max(), d.mean()))
+        assert d.max() <= 2e-2 and d.mean() <= 5e-4, (tag, d.max(), d.mean())
+    assert np.array_equal(res["p"], res["p_full_grid"])             # the tile walk does not change a single bit
