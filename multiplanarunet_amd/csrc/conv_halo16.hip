@@ -789,6 +789,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo16p_kernel(ConvArgs a, int pt
             }
             flush(TN - 1, TM - 1);
         }
+        // The epilogue is a phase of its own: [h0 epilogue | h1 C(8)], [h0 L(0) | h1 epilogue], [h0 C(0) | h1 L(0)] costs
+        // 2 x 3.6 k + 1.45 k cycles at a tile boundary where [h0 epilogue + L(0) | h1 C(8)], [h0 C(0) | h1 epilogue + L(0)]
+        // cost 2 x 5.05 k (measured: tile period 92.8 k -> 90.9 k cycles on the 4-chunk layer; a second barrier in the middle of
+        // the epilogue -- [E1 | C(8)] [E2 | E1] [L(0) | E2] -- measured 90.1 k there and 50.9 k vs 49.7 k on the 2-chunk layer: not kept).
+        __builtin_amdgcn_s_barrier();
         if (STAMP && stamps && ti < 6) stamps[3 + 2 * ti] = __builtin_amdgcn_s_memtime();      // (wave 0: epilogue issued)
         tb = nb_; ty0 = ny0; tx0 = nx0;
     }
