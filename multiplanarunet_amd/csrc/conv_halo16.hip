@@ -1,3 +1,6 @@
+// Two kernels: conv_halo16_kernel (one tile per workgroup, every epilogue; opt-in) and, further down, conv_halo16p_kernel (its
+// PERSISTENT form with the inference epilogue; the default for large predict grids). The schedule is described once, here.
+//
 // conv_halo16_kernel (bf16, round 4): the LDS-resident-patch 3x3 convolution for LARGE grids (predict batches, the
 // configs[3] train step): one 8-wave workgroup per CU on a 16-row x 32-pixel x 128-channel tile, the two halves of the
 // workgroup ONE PHASE APART as in conv_halo8 -- but with a 64-channel x 128-pixel accumulator tile per wave.
