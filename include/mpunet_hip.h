@@ -403,6 +403,11 @@ int mpu_probe_clock(uint64_t* d_samples, int32_t n, int32_t naps, void* stream);
 int mpu_schedule_log_enable(int32_t on);
 int64_t mpu_schedule_log_read(char* buf, int64_t cap);
 
+/* Environment switches (csrc/env.h: the library's only getenv; schedule / fusion on-off pairs for A/B runs, dev aids). One line
+ * per switch, "NAME\tvalue in force\tdefault\twhat it does", NUL-terminated and truncated to cap; returns the full length.
+ * Values are read once per process, at the first query. */
+int64_t mpu_env_describe(char* buf, int64_t cap);
+
 /* Dev aid: with MPU_STAMPS=1 in the environment a few workgroups of the instrumented kernels (conv_halo8, wgrad_taps)
  * record s_memtime stamps at their phase boundaries (entry, prologue landed, main loop done, stores issued) into a
  * 64 x 8 table of uint64 (slot = a function of the workgroup index). Reads and clears it (synchronises the device). */

@@ -139,6 +139,7 @@ _SIGS = {
     "mpu_probe_clock": (C.c_int, [c_p, i32, i32, c_p]),
     "mpu_schedule_log_enable": (C.c_int, [i32]),
     "mpu_schedule_log_read": (i64, [C.c_char_p, i64]),
+    "mpu_env_describe": (i64, [C.c_char_p, i64]),
     "mpu_conv2d_wgrad": (C.c_int, [i32, i32, c_p, i32, c_p, i32, c_p, i32, i32, i32, i32, c_p, c_p, c_p]),
     "mpu_unet_set_launch_tap": (C.c_int, [c_p, c_p, c_p]),
     "mpu_unet_adam_pack": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, c_p, f64, f64, f64, f64, c_p, c_p]),

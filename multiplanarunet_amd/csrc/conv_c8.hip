@@ -153,8 +153,7 @@ int launch_c8(const ConvArgs& a_in, hipStream_t st) {
 
 // 1 = launched, 0 = shape not suited (the caller falls back to the tiled kernels), < 0 = error
 int try_conv_c8(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("MPU_CONV_C8"); on = (e && e[0] == '0') ? 0 : 1; }
+    const bool on = env(ENV_CONV_C8) != 0;
     if (!on || dtype != MPU_BF16 || mode != CONV3 || a.C1 != 0 || a.in1 || a.C0 != 8) return 0;
     if (a.Cout % 8 || a.Cout > 128 || a.mask || a.post_scale || a.ksplit > 1) return 0;
     int rc;

@@ -935,12 +935,8 @@ template <typename T, int MODE>
 static int try_pipe(const ConvArgs& a, hipStream_t st) {
     if constexpr (sizeof(T) != 2 || MODE == CONV1) return 0;
     else {
-        static int on = -1, dbg = 0;
+        const int on = (int)env(ENV_CONV_PIPE), dbg = (int)env(ENV_PIPE_DEBUG);
         constexpr int min_steps = 12, wgs = 256;                 // >= 12 K steps per workgroup; about one workgroup per CU
-        if (on < 0) {
-            const char* d = getenv("MPU_PIPE_DEBUG"); if (d) dbg = atoi(d);
-            const char* e = getenv("MPU_CONV_PIPE"); on = (e && e[0] == '0') ? 0 : 1;
-        }
         if (!on || a.Cout < 128) return 0;
         const long M = (long)a.B * a.Ho * a.Wo;
         const long tiles = (long)cdiv(M, PipeCfg::BM) * cdiv(a.Cout, PipeCfg::BN);

@@ -1165,8 +1165,7 @@ int launch_halo_upq(const ConvArgs& a_in, hipStream_t st) {
 // cycles in the counted vmcnt wait, the tap is bound by MFMA issue + fragment reads)
 template <int BN, int TH, int MODE>
 int launch_halo8_cfg(const ConvArgs& a, hipStream_t st) {
-    static int sched = -1;                                       // MPU_HALO8_SCHED: 0 = lockstep halves, 1 = one phase apart (default)
-    if (sched < 0) { const char* e = getenv("MPU_HALO8_SCHED"); sched = e ? atoi(e) : 1; }
+    const long sched = env(ENV_HALO8_SCHED);                     // 0 = lockstep halves, 1 = one phase apart (default)
     if (sched != 1) return launch_halo8_cfg_n<BN, TH, MODE, 3, 0>(a, st);
     static int dev = -1;                                         // stamps asked for (MPU_STAMPS=1): the instrumented build
     if (dev < 0) dev = stamp_buffer() != nullptr ? 1 : 0;
@@ -1182,8 +1181,7 @@ int try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
         // (configs[1] levels 1-2: the single-buffer kernel's patch bursts are exposed there). MPU_HALO8=0 disables.
         // Grids of 192..400 workgroups (sweeps R3ag / R3aa: below, half the CUs idle; above, two rounds of one
         // workgroup per CU lose to the 4-wave kernel's two workgroups per CU).
-        static int h8 = -1; constexpr long h8_max = 400, h8_min = 192;
-        if (h8 < 0) { const char* e = getenv("MPU_HALO8"); h8 = (e && e[0] == '0') ? 0 : 1; }
+        const bool h8 = env(ENV_HALO8) != 0; constexpr long h8_max = 400, h8_min = 192;
         if (h8 && dtype == MPU_BF16 && a.Ho % 8 == 0 && !a.head_w && (mode == CONV3 || !(a.Wo & 1))) {
             const long pt = (long)a.B * (a.Ho / 8) * cdiv(a.Wo, 32);
             const long g128 = pt * cdiv(a.Cout, 128), g64 = pt * cdiv(a.Cout, 64);
@@ -1206,12 +1204,10 @@ int try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
         return rc ? rc : 4;
     }
     if (mode == UPCONV2) {                       // low-resolution patch variant of the up-convolution
-        static int up_on = -1;
-        if (up_on < 0) { const char* e = getenv("MPU_HALO_UPCONV"); up_on = (e && e[0] == '0') ? 0 : 1; }
+        const bool up_on = env(ENV_HALO_UPCONV) != 0;
         if (!up_on || dtype != MPU_BF16 || (a.Ho & 3) || (a.Wo & 1)) return 0;
         // 8-row tiles on large grids (predict batches): twice the work per workgroup for the same patch / weight prologue
-        static long up8_min = -1;
-        if (up8_min < 0) { const char* e = getenv("MPU_HALO_UP8_MIN"); up8_min = e ? atol(e) : 2048; }
+        const long up8_min = env(ENV_HALO_UP8_MIN);
         const long t8 = (long)a.B * cdiv(a.Ho, 8) * cdiv(a.Wo, 32) * cdiv(a.Cout, a.Cout > 64 ? 128 : 64);
         if (!(a.Ho & 7) && t8 >= up8_min)
             rc = a.Cout > 64 ? launch_halo_cfg<bf16_t, 128, 8, 3, UPCONV2>(a, st) : launch_halo_cfg<bf16_t, 64, 8, 3, UPCONV2>(a, st);
@@ -1232,8 +1228,7 @@ int try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
     const bool narrow = a.Cout > 64 && tiles4 * cdiv(a.Cout, 128) < bn64_below;
     if (dtype == MPU_BF16) {
 #ifdef MPU_HALO_KNOCKOUT_BUILD
-        static int knock = -1;                                   // dev aid: knock-out instantiations of the predict kernel
-        if (knock < 0) { const char* e = getenv("MPU_HALO_KNOCKOUT"); knock = e ? atoi(e) : 0; }
+        const int knock = (int)env(ENV_HALO_KNOCKOUT);           // dev aid: knock-out instantiations of the predict kernel
         if (a.Cout > 64 && !narrow && tall128 && knock) {
             switch (knock) {
 #define MPU_KO(V) case V: rc = launch_halo_cfg<bf16_t, 128, 8, 2, CONV3, V>(a, st); break;

@@ -810,7 +810,7 @@ int launch_halo16(const ConvArgs& a_in, hipStream_t st) {
     auto kern = sbuf ? conv_halo16_kernel<true> : conv_halo16_kernel<false>;
     ConvArgs a = a_in;
     a.dbg_buf = sbuf;
-    { static int first = -1; if (first < 0) { const char* e = getenv("MPU_STAMPS_FIRST"); first = e ? atoi(e) : 0; } a.dbg = first; }
+    a.dbg = (int)env(ENV_STAMPS_FIRST);
     if (a.w_elems <= 0) a.w_elems = (Cfg::NT - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
     static unsigned long long attr_set = 0;
     if (first_use_on_device(attr_set)) {
@@ -862,8 +862,7 @@ int launch_halo16p(const ConvArgs& a_in, hipStream_t st) {
         return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
     const int tiles_n = cdiv(a.Cout, Cfg::BN);
     const long ptiles = (long)a.B * (a.Ho / Cfg::TH) * cdiv(a.Wo, Cfg::TW);
-    static long wgs = -1;                                        // MPU_HALO16P_WGS: fewer workgroups (tests: many tiles each on small shapes)
-    if (wgs < 0) { const char* e = getenv("MPU_HALO16P_WGS"); wgs = e ? atol(e) : 0; }
+    const long wgs = env(ENV_HALO16P_WGS);                       // fewer workgroups (tests: many tiles each on small shapes)
     long gp = (wgs > 0 ? wgs : ncu) / tiles_n; if (gp < 1) gp = 1; if (gp > ptiles) gp = ptiles;
     if (a.stats_rows) *a.stats_rows = 0;
     a.stats = nullptr;
@@ -887,12 +886,9 @@ int try_conv_halo16(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
     // (gpurun R4p). conv_halo16 (one tile per workgroup, every epilogue) stays opt-in (MPU_HALO16=1): it ties with the
     // 4-wave kernel (gpurun R4e/R4f: 128 -> 128 @ 138 x 128^2: 799 vs 770 us; 256 -> 256 @ 64^2: 587 vs 606; 256 -> 128:
     // 1164 vs 1150), prologue + epilogue (8 % + 11 % of a workgroup's life) exposed with one workgroup per CU. DESIGN section 5.
-    static int on = -1, pers = -1; static long min_tiles = 768, min_tiles_p = 512;      // (persistent: two tiles per CU and up)
-    if (on < 0) {
-        const char* e = getenv("MPU_HALO16"); on = (e && e[0] == '1') ? 1 : 0;
-        const char* q = getenv("MPU_HALO16P"); pers = (q && q[0] == '0') ? 0 : 1;
-        const char* m = getenv("MPU_HALO16_MIN"); if (m) min_tiles = min_tiles_p = atol(m);
-    }
+    const bool on = env(ENV_HALO16) != 0, pers = env(ENV_HALO16P) != 0;
+    const long mt = env(ENV_HALO16_MIN);
+    const long min_tiles = mt >= 0 ? mt : 768, min_tiles_p = mt >= 0 ? mt : 512;       // (persistent: two tiles per CU and up)
     if ((!on && !pers) || dtype != MPU_BF16 || mode != CONV3 || a.Cout <= 64 || a.Wo < 32 || (a.Ho & 15) || a.head_w) return 0;
     // 32-channel chunks, two per block: sources that are multiples of 32 channels, an even number of chunks in total
     if ((a.C0 & 31) || (a.C1 & 31) || (((a.C0 + a.C1) >> 5) & 1)) return 0;

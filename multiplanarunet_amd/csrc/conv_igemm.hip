@@ -654,11 +654,7 @@ int flush_wgrad_group(int dtype, WgradGroup& g, hipStream_t st) {
 // MPU_CONV_IMPL=regs selects the register-staged kernel of this file; default is the LDS-DMA
 // kernel of conv_glds.hip (same tiling, same results).
 static int conv_impl() {
-    static int impl = -1;
-    if (impl < 0) {
-        const char* e = getenv("MPU_CONV_IMPL");
-        impl = (e && strcmp(e, "regs") == 0) ? 0 : 1;
-    }
+    const int impl = (int)env(ENV_CONV_IMPL);
     return impl;
 }
 
@@ -708,9 +704,7 @@ static int launch_conv_mode(const ConvArgs& a, hipStream_t st) {
 }
 
 static int halo_on() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("MPU_CONV_HALO"); on = (e && e[0] == '0') ? 0 : 1; }
-    return on;
+    return (int)env(ENV_CONV_HALO);
 }
 
 int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {

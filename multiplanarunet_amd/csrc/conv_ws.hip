@@ -403,8 +403,7 @@ int launch_ws(const ConvArgs& a_in, hipStream_t st) {
 
 // 1 = launched, 0 = shape not suited (the caller falls back to the tiled kernels), < 0 = error
 int try_conv_ws(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("MPU_CONV_WS"); on = (e && e[0] == '0') ? 0 : 1; }
+    const bool on = env(ENV_CONV_WS) != 0;
     if (!on || dtype != MPU_BF16 || mode != CONV3 || a.C1 != 0 || a.in1 || a.C0 > 64 || a.Cout > 64) return 0;
     if (a.ksplit > 1) return 0;
     const long tiles4 = (long)a.B * cdiv(a.Ho, 4) * cdiv(a.Wo, 32);

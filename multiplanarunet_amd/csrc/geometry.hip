@@ -1023,8 +1023,7 @@ static int fast_path_host() { return g_fast_host; }
 static int sync_fast_switch() {           // MPU_GEOM_FAST=0: exact search for every sample (read once per process)
     static int done = 0;
     if (done) return MPU_OK;
-    const char* e = getenv("MPU_GEOM_FAST");
-    const int v = (e && e[0] == '0') ? 0 : 1;
+    const int v = (int)env(ENV_GEOM_FAST);
     if (hipMemcpyToSymbol(HIP_SYMBOL(mpu::g_fast_geometry_dev), &v, sizeof(int)) != hipSuccess)
         return mpu::fail(MPU_EHIP, "%s", "geometry: cannot set the fast-path switch");
     g_fast_host = v;
@@ -1303,8 +1302,7 @@ int mpu_map_fuse_views(const mpu_voxel_grid* grid, const mpu_view_pred* views, i
         }
         f.nblk8 = (unsigned)((nblk + 7) / 8);
         const dim3 g(f.nblk8 * 8u), b(256);
-        static int fx_on = -1;                                   // MPU_FUSE_FX=0: the fp64 index arithmetic of round 2 (A/B, equality test)
-        if (fx_on < 0) { const char* e = getenv("MPU_FUSE_FX"); fx_on = (e && e[0] == '0') ? 0 : 1; }
+        const bool fx_on = env(ENV_FUSE_FX) != 0;                // 0: the fp64 index arithmetic of round 2 (A/B, equality test)
         bool fx = fx_on && cfg == 2;
         for (int v = 0; fx && v < n_views; ++v) fx = fx_eligible(f.v[v]);
         if (fx)            { MPU_DISPATCH_K(n_classes, (map_fuse_fast_kernel<KK, 2, true><<<g, b, 0, st>>>(f))); }

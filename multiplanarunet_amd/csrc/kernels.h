@@ -1,6 +1,7 @@
 // Internal C++ launch API shared by the translation units of libmpunet_hip.so.
 #pragma once
 #include "common.h"
+#include "env.h"
 
 namespace mpu {
 

@@ -27,7 +27,7 @@ namespace {
 bool g_open = false, g_first = false;
 int g_markers = -1;
 bool markers() {
-    if (g_markers < 0) { const char* e = getenv("MPU_PROF_MARKERS"); g_markers = (e && e[0] == '1') ? 1 : 0; }
+    if (g_markers < 0) g_markers = (int)env(ENV_PROF_MARKERS);
     return g_markers == 1;
 }
 void drop_open_scope() {                        // a scope that never saw a kernel (error return between begin and launch)
@@ -67,8 +67,7 @@ void sched_note(const char* fmt, ...) {
 namespace { unsigned long long* g_stamps = nullptr; int g_stamps_state = -1; }
 unsigned long long* stamp_buffer() {
     if (g_stamps_state < 0) {
-        const char* e = getenv("MPU_STAMPS");
-        g_stamps_state = (e && e[0] == '1') ? 1 : 0;
+        g_stamps_state = (int)env(ENV_STAMPS);
         if (g_stamps_state) {
             if (hipMalloc((void**)&g_stamps, 64 * 8 * sizeof(unsigned long long)) != hipSuccess) { g_stamps = nullptr; g_stamps_state = 0; }
             else (void)hipMemset(g_stamps, 0, 64 * 8 * sizeof(unsigned long long));

@@ -220,27 +220,23 @@ int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* i
              const float* post_scale = nullptr, const float* post_shift = nullptr, int* stats_rows = nullptr,
              void* pooled = nullptr, int* pooled_done = nullptr, const HeadFuse* head = nullptr) {
     ConvArgs a;
-    static int fused_head = -1;              // inference: 1x1 head out of the last conv's epilogue (partial logits)
-    if (fused_head < 0) { const char* e = getenv("MPU_FUSED_HEAD"); fused_head = (e && e[0] == '0') ? 0 : 1; }
+    const bool fused_head = env(ENV_FUSED_HEAD) != 0;   // inference: 1x1 head out of the last conv's epilogue (partial logits)
     if (head && head->done) *head->done = 0;
     if (head && fused_head && head->done) {
         a.head_w = head->w; a.head_k = head->k; a.head_ldw = head->ldw; a.head_partial = head->partial; a.head_done = head->done;
     }
-    static int fused_pool = -1;              // inference: 2x2 max pooling as a second output of the conv epilogue
-    if (fused_pool < 0) { const char* e = getenv("MPU_FUSED_POOL"); fused_pool = (e && e[0] == '0') ? 0 : 1; }
+    const bool fused_pool = env(ENV_FUSED_POOL) != 0;   // inference: 2x2 max pooling as a second output of the conv epilogue
     if (pooled_done) *pooled_done = 0;
     a.pooled = (fused_pool && pooled_done) ? pooled : nullptr; a.pooled_done = a.pooled ? pooled_done : nullptr;
     // training: the conv in front of a BatchNormalization also produces the per-tile column sums of its output
-    static int fused_stats = -1;
-    if (fused_stats < 0) { const char* e = getenv("MPU_FUSED_BN_STATS"); fused_stats = (e && e[0] == '0') ? 0 : 1; }
+    const bool fused_stats = env(ENV_FUSED_BN_STATS) != 0;
     if (!fused_stats) stats_rows = nullptr;
     a.stats = stats_rows ? (float*)r.at(r.P.partial) : nullptr; a.stats_rows = stats_rows; a.stats_cap = r.P.partial_floats;
     a.bn_x = nullptr; a.bn_mean = nullptr; a.bn_invstd = nullptr;
     a.flops = conv_flops(r, c, lvl); a.w_elems = 0;
     a.partial = r.P.cpartial_floats ? (float*)r.at(r.P.cpartial) : nullptr; a.partial_cap = r.P.cpartial_floats; a.ksplit = 1;
     a.post_scale = post_scale; a.post_shift = post_shift;
-    static int upq = -1;                     // MPU_UPQ=1: inference up-convs in the tap-combined form (opt-in: no gain measured)
-    if (upq < 0) { const char* e = getenv("MPU_UPQ"); upq = (e && e[0] == '1') ? 1 : 0; }
+    const bool upq = env(ENV_UPQ) != 0;      // 1: inference up-convs in the tap-combined form (opt-in: no gain measured)
     if (upq && post_scale && c.wq >= 0) a.w_quad = r.packed + c.wq;
     a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1;
     a.w = r.wf(c); a.w_tap_stride = (long)c.Cin * c.Cout; a.w_row_stride = c.Cin;
@@ -263,8 +259,7 @@ int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* i
 int conv_dgrad(const Run& r, const Conv& c, const void* dz, const void* mask, void* out, int out_lvl,
                int n_off, int n_cnt, const BN* bn = nullptr, const void* bn_x = nullptr, int* bn_rows = nullptr) {
     ConvArgs a;
-    static int fused_bwd = -1;
-    if (fused_bwd < 0) { const char* e = getenv("MPU_FUSED_BN_BWD_CONV"); fused_bwd = (e && e[0] == '0') ? 0 : 1; }
+    const bool fused_bwd = env(ENV_FUSED_BN_BWD_CONV) != 0;
     if (bn_rows) *bn_rows = 0;
     const bool want = fused_bwd && bn && bn_x && bn_rows && !mask;
     a.stats = want ? (float*)r.at(r.P.partial) : nullptr; a.stats_rows = want ? bn_rows : nullptr;
@@ -302,8 +297,7 @@ int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* 
     wgrad_partial_elems(c.mode, c.Cin, c.Cout, M, &a.ksplit, &a.mchunk, r.group);
     a.db = r.grads + c.b; a.db_partial = nullptr; a.colsum_scratch = (float*)r.at(r.P.partial2); a.fuse_db = 0;
     a.c0_logical = (C1 == 0 && C0 == c.Cin) ? c.lCin : 0;
-    static int defer = -1;         // MPU_WGRAD_BATCHED_REDUCE=0: reduce right behind every weight-gradient kernel (A/B)
-    if (defer < 0) { const char* e = getenv("MPU_WGRAD_BATCHED_REDUCE"); defer = (e && e[0] == '0') ? 0 : 1; }
+    const bool defer = env(ENV_WGRAD_BATCHED_REDUCE) != 0;   // 0: reduce right behind every weight-gradient kernel (A/B)
     ReduceQueue* q = defer ? &r.rq : nullptr;
     if (r.m->tap) {
         mpu_launch_info li{};
@@ -538,9 +532,7 @@ int make_run(Run& r, const mpu_unet* m, int batch, const float* params, const vo
     r.m = m; r.B = batch; r.st = (hipStream_t)stream; r.ws = (unsigned char*)ws; r.P = make_plan(m, batch);
     r.params = params; r.packed = (const unsigned char*)packed; r.state = state; r.grads = grads;
     r.esz = m->cfg.dtype == MPU_BF16 ? 2 : 4;
-    static int group = -1;          // MPU_WGRAD_GROUP=0: every weight-gradient kernel as its own launch, in place (A/B)
-    if (group < 0) { const char* e = getenv("MPU_WGRAD_GROUP"); group = (e && e[0] == '0') ? 0 : 1; }
-    r.group = group != 0;
+    r.group = env(ENV_WGRAD_GROUP) != 0;      // 0: every weight-gradient kernel as its own launch, in place (A/B)
     return MPU_OK;
 }
 

@@ -758,8 +758,7 @@ int launch_maxpool_bwd_add(int dtype, const void* n, const void* dskip, const vo
 int launch_maxpool_bwd_add_stats(int dtype, const void* n, const void* dskip, const void* dp, int B, int H, int W, int C,
                                  void* dn, const void* x, const float* mean, const float* invstd, float* partial,
                                  long partial_cap, int* rows, hipStream_t st) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("MPU_FUSED_BN_BWD"); on = (e && e[0] == '0') ? 0 : 1; }
+    const bool on = env(ENV_FUSED_BN_BWD) != 0;
     const int N = dtype == MPU_BF16 ? 8 : 4, cpr = C / N;
     const long work = (long)B * (H / 2) * (W / 2) * cpr;
     long blocks = (work + 255) / 256; if (blocks > 1024) blocks = 1024;
@@ -976,8 +975,7 @@ int launch_head_forward(int dtype, const void* n, long M, int C, int K, const fl
     int G = 1; while (G < C / N && G < 64) G <<= 1;
     const long ppb = 256 / G;
     long blocks = (M + ppb - 1) / ppb; if (blocks > 4096) blocks = 4096;
-    static int rs_on = -1;
-    if (rs_on < 0) { const char* e = getenv("MPU_HEAD_RS"); rs_on = (e && e[0] == '0') ? 0 : 1; }
+    const bool rs_on = env(ENV_HEAD_RS) != 0;
     if (rs_on && C == 64 && K * (C / N) <= 64) {                 // reduce-scatter variant: every lane finishes a pixel
         long rb = (M + 255) / 256; if (rb > 4096) rb = 4096;
         if (dtype == MPU_BF16) {

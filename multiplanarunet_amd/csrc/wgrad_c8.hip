@@ -160,8 +160,7 @@ __global__ __launch_bounds__(256) void wgrad_c8_finalize_kernel(const float* __r
 // number of strips (= partial rows, one per workgroup) or 0 when the shape is not suited.
 static long c8_strips(int dtype, int mode, int B, int H, int W, int C0, int C1, int c0_logical, int Cout, int* R_out,
                       int* strips_out) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("MPU_WGRAD_C8"); on = (e && e[0] == '0') ? 0 : 1; }
+    const bool on = env(ENV_WGRAD_C8) != 0;
     if (!on || dtype != MPU_BF16 || mode != CONV3 || C1 != 0 || C0 != 8) return 0;
     if (c0_logical < 1 || c0_logical > 2) return 0;
     const int groups = Cout / 8;

@@ -485,8 +485,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_taps_group_kernel(TapsGroupTable
 // the number of fp32 partial copies (one per strip) small: their write + re-read is the kernel's HBM traffic.
 TapsPlan wgrad_taps_plan(int dtype, int mode, int B, int H, int W, int C0, int C1, int Cout, bool grouped) {
     TapsPlan p; p.use = 0; p.RH = 0; p.sx = 0; p.sy = 0; p.nstrips = 0; p.split = 0;
-    static int on = -1; constexpr int target = 512; constexpr long max_cico = TAPS_MAX_CICO;
-    if (on < 0) { const char* e = getenv("MPU_WGRAD_TAPS"); on = (e && e[0] == '0') ? 0 : 1; }
+    const bool on = env(ENV_WGRAD_TAPS) != 0; constexpr int target = 512; constexpr long max_cico = TAPS_MAX_CICO;
     const int Cin = C0 + C1;
     if (!on || dtype != MPU_BF16 || (mode != CONV3 && mode != UPCONV2) || W < 32 || H < 8) return p;
     if (mode == UPCONV2 && ((H | W) & 1)) return p;
@@ -530,9 +529,7 @@ int wgrad_taps_grid(int /*mode*/, const WgradArgs& a, const TapsPlan& p) {
 }
 
 static bool taps_stag() {                                        // MPU_WGRAD_TAPS_STAG=0: the lockstep groups
-    static int stag = -1;
-    if (stag < 0) { const char* e = getenv("MPU_WGRAD_TAPS_STAG"); stag = (e && e[0] == '0') ? 0 : 1; }
-    return stag != 0;
+    return env(ENV_WGRAD_TAPS_STAG) != 0;
 }
 
 static int taps_attrs() {

@@ -120,3 +120,34 @@ def test_load_weights_reports_missing_tensors_and_maps_auto_named_head(tmp_path)
     assert any("bottom_BN" in s and "not in the file" in s for s in msgs)
     with pytest.raises(KeyError):
         m2.load_weights(str(tmp_path / "w.npz"), by_name=False)
+
+
+def test_environment_switch_table_is_the_only_getenv_and_is_documented():
+    """csrc/env.h holds every environment switch of the library (name, kind, default, description): no other getenv in
+    csrc/, mpu_env_describe lists exactly the table with the defaults in force here, and DESIGN.md names every switch."""
+    import ctypes as C, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "multiplanarunet_amd", "csrc")
+    offenders = []
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")) and f != "env.hip":
+            src = open(os.path.join(csrc, f)).read()
+            if re.search(r"\bgetenv\s*\(", src):
+                offenders.append(f)
+    assert offenders == [], offenders
+    table = re.findall(r'X\((\w+), "(MPU_\w+)", (ENV_\w+), (-?\d+),', open(os.path.join(csrc, "env.h")).read())
+    assert len(table) >= 30 and len({n for _, n, _, _ in table}) == len(table)
+    from multiplanarunet_amd import _lib
+    lib = _lib.load()
+    n = lib.mpu_env_describe(None, 0)
+    buf = C.create_string_buffer(int(n) + 1)
+    lib.mpu_env_describe(buf, n + 1)
+    rows = [l.split("\t") for l in buf.value.decode().splitlines()]
+    assert [r[0] for r in rows] == [name for _, name, _, _ in table]
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    for (ident, name, kind, dflt), row in zip(table, rows):
+        assert len(row) == 4 and row[3].strip(), row
+        assert int(row[2]) == int(dflt), row
+        if name not in os.environ:
+            assert int(row[1]) == int(dflt), row                 # unset: the default is in force
+        assert name in design, "DESIGN.md does not mention " + name
