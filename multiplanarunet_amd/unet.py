@@ -363,11 +363,48 @@ class UNet:
         return 2 if self.dtype == torch.bfloat16 else 4
 
     def auto_batch(self, n, cap=160):
-        """Even chunks of n images, as large as the operand bound (and `cap`) allow: big batches fill the chip at the
-        deep levels (276 planes of 256x256 -> 3 x 92)."""
+        """Even chunks of n images, as large as the operand bound (and `cap`) allow: big batches fill the chip at the deep
+        levels. Among the smallest chunk count and the next two, the one whose chunk size fills the rounds of the persistent
+        predict kernel best (conv_halo16p: one workgroup per CU walks `tiles / workgroups` tiles -- 138 planes of 256x256
+        leave its 512-channel level at 4.3 rounds, 92 planes at 2.9: 276 planes -> 3 x 92, measured -1.5 % per volume)."""
         bmax = max(1, min(cap, self.max_batch()))
-        chunks = -(-n // bmax)
-        return -(-n // chunks)
+        cmin = -(-n // bmax)
+        if self.dtype != torch.bfloat16:
+            return -(-n // cmin)
+        best, best_score = cmin, -1.0
+        for c in range(cmin, cmin + 3):
+            if c > cmin and -(-n // c) < 64:           # small batches lose more at the deep levels than a full round wins
+                break                                   # (69 planes per launch: +6 % per volume, measured)
+            score = self._round_fill(-(-n // c)) - 0.002 * (c - cmin)
+            if score > best_score + 1e-9:
+                best, best_score = c, score
+        return -(-n // best)
+
+    def _round_fill(self, B):
+        """Mean over the levels with 128-channel tiles of (rounds of 16 x 32-pixel tiles per persistent workgroup) /
+        ceil(rounds) for a batch of B images; a level too small for that kernel (< 512 tiles, rows not a multiple of 16,
+        narrower than 32 pixels) counts 0.9 (two workgroups per CU of the 4-wave kernel, measured flat)."""
+        H, W = self.img_shape[:2]
+        ncu = 256
+        if self.device.type == "cuda":
+            ncu = torch.cuda.get_device_properties(self.device).multi_processor_count or 256
+        effs = []
+        for l in range(1, self.depth + 1):
+            f = self.filters[l]
+            h, w = H >> l, W >> l
+            if f <= 64 or f % 32:
+                continue
+            if h % 16 or w < 32:
+                effs.append(0.9)
+                continue
+            nt = -(-f // 128)
+            tiles = B * (h // 16) * (-(-w // 32))
+            if tiles * nt < 512:
+                effs.append(0.9)
+                continue
+            rounds = tiles / max(1, ncu // nt)
+            effs.append(rounds / float(-(-tiles // max(1, ncu // nt))))
+        return sum(effs) / len(effs) if effs else 1.0
 
     def predict(self, X, batch_size=8, verbose=0):
         """model.predict: inference-mode forward in chunks of batch_size (None: auto_batch); returns a device tensor."""

@@ -151,3 +151,21 @@ def test_environment_switch_table_is_the_only_getenv_and_is_documented():
         if name not in os.environ:
             assert int(row[1]) == int(dflt), row                 # unset: the default is in force
         assert name in design, "DESIGN.md does not mention " + name
+
+
+def test_auto_batch_fills_the_rounds_of_the_persistent_predict_kernel():
+    """UNet.auto_batch (predict with batch_size=None): even chunks under the 2-GiB operand bound; for bf16 the chunk count
+    among the smallest three whose chunk size leaves the fewest idle rounds to conv_halo16p (256 workgroups) at the levels
+    with 128-channel tiles -- never chunks under 64 images (measured: 276 planes of 256 x 256 as 3 x 92 beat 2 x 138 by
+    1.5 %, 4 x 69 lose 6 %)."""
+    from multiplanarunet_amd.unet import UNet
+    q = lambda *a, **k: None
+    m = UNet(n_classes=3, dim=256, depth=4, complexity_factor=1, dtype="bf16", device="cpu", logger=q)
+    assert m.max_batch() == 255
+    assert [m.auto_batch(n) for n in (276, 184, 92, 138, 69, 35, 8, 1)] == [92, 92, 92, 138, 69, 35, 8, 1]
+    # level 3 (512 channels, 32 x 32): 138 planes = 276 pixel tiles on 64 workgroups per n-tile = 4.3 rounds, 92 planes 2.9
+    assert m._round_fill(92) > m._round_fill(138) > m._round_fill(69)
+    m5 = UNet(n_classes=5, dim=512, n_channels=2, depth=4, complexity_factor=1, dtype="bf16", device="cpu", logger=q)
+    assert m5.max_batch() == 63 and m5.auto_batch(532) == 60            # the operand bound decides: 9 chunks
+    mf = UNet(n_classes=3, dim=256, depth=4, complexity_factor=1, dtype="f32", device="cpu", logger=q)
+    assert mf.auto_batch(276) == 92                                      # f32: 3 chunks by the operand bound alone
