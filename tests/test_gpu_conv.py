@@ -150,6 +150,19 @@ def test_halo16_cases(case):
     conv = _schedules_of(lambda: _run_case(case, torch.bfloat16))
     if os.environ.get("MPU_HALO16") == "1":         # forward: the persistent form (plain epilogue); the masked data gradient: the staged one
         assert conv and conv[0] == ("halo16" if os.environ.get("MPU_HALO16P") == "0" else "halo16p"), conv
+    # the same forward WITHOUT the ReLU (the clamp's lower bound is -inf then) and without a bias
+    from multiplanarunet_amd import ops
+    mode, B, H, W, C0, C1, Cout = case
+    g = torch.Generator().manual_seed(7)
+    x = rnd(torch.randn(B, H, W, C0 + C1, generator=g), torch.bfloat16)
+    w = rnd(torch.randn(3, 3, C0 + C1, Cout, generator=g) / np.sqrt(9 * (C0 + C1)), torch.bfloat16)
+    ref = ref_forward(mode, x, w, torch.zeros(Cout, dtype=torch.float64))
+    xd = x.to("cuda", torch.bfloat16)
+    wf, _ = ops.pack_weights(w.to("cuda", torch.float32), mode, torch.bfloat16)
+    y = ops.conv2d(mode, xd[..., :C0].contiguous(), wf, Cout, (H, W), x1=xd[..., C0:].contiguous() if C1 else None, relu=False)
+    rt, at = tol(torch.bfloat16, ref)
+    assert float(ref.min()) < -0.1                                   # (negative outputs exist and survive)
+    np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), rtol=rt, atol=at)
 
 
 def test_halo16_subprocess():
