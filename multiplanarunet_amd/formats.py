@@ -43,11 +43,22 @@ def layer_weight_names(layer):
 
 def h5_entries(weights, depth=4):
     """[(layer, [(keras weight name "<layer>/<var>:0", array), ...]), ...] for a {'<layer>/<var>': array} dict."""
-    out = []
+    out, seen = [], set()
     for layer in keras_layer_names(depth):
         ws = [(n + ":0", np.asarray(weights[n])) for n in layer_weight_names(layer) if n in weights]
+        seen.update(n for n in layer_weight_names(layer))
         if ws:
             out.append((layer, ws))
+    # layers outside the canonical list (an auto-named head `conv2d_<N>` of a converted reference checkpoint): kept, in name
+    # order, variables in Keras' order
+    extra = {}
+    for n in weights:
+        if n not in seen and "/" in n:
+            extra.setdefault(n.split("/", 1)[0], []).append(n)
+    order = {v: i for i, v in enumerate(KERAS_VAR_ORDER["conv"] + KERAS_VAR_ORDER["bn"])}
+    for layer in sorted(extra):
+        names = sorted(extra[layer], key=lambda n: order.get(n.split("/", 1)[1], 99))
+        out.append((layer, [(n + ":0", np.asarray(weights[n])) for n in names]))
     return out
 
 

@@ -198,3 +198,19 @@ def test_nifti_round_trip(tmp_path):
     img, a2 = F.load_nifti(p)
     np.testing.assert_array_equal(img[..., 0].astype(np.uint8), lab)
     np.testing.assert_allclose(a2, aff)
+
+
+@needs_libhdf5
+def test_convert_keeps_layers_outside_the_canonical_name_list(tmp_path, monkeypatch):
+    """A reference checkpoint whose 1x1 head is auto-named conv2d_7: .h5 -> dict -> .h5 keeps that layer (h5_entries
+    appends layers it does not know, variables in Keras' order)."""
+    monkeypatch.setenv("MPU_H5_BACKEND", "libhdf5")
+    w = F.load_keras_h5(os.path.join(GOLDEN, "keras_unet_d1.h5"))
+    p = str(tmp_path / "again.h5")
+    F.save_keras_h5(p, w, depth=1)
+    w2 = F.load_keras_h5(p)
+    assert sorted(w2) == sorted(w) and "conv2d_7/kernel" in w2
+    for k in w:
+        np.testing.assert_array_equal(w2[k], w[k])
+    ent = F.h5_entries(w, depth=1)
+    assert ent[-1][0] == "conv2d_7" and [n for n, _ in ent[-1][1]] == ["conv2d_7/kernel:0", "conv2d_7/bias:0"]
