@@ -1,5 +1,5 @@
 """Convert U-Net weights between the reference's Keras .h5 files and this build's name-keyed .npz files.
-usage: python tools/convert_weights.py IN.{h5,npz} OUT.{npz,h5} [--depth 4]      (the .h5 side needs h5py)"""
+usage: python tools/convert_weights.py IN.{h5,npz} OUT.{npz,h5} [--depth 4]      (the .h5 side goes through h5py, or without it the HDF5 C library -- multiplanarunet_amd/hdf5.py)"""
 import argparse
 import os
 import sys
