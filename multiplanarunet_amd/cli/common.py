@@ -326,3 +326,29 @@ def remove_validation_callbacks(callbacks, logger=None):
             continue
         keep.append(cb)
     return keep
+
+
+def per_gpu_launch_command(script, argv, num_gpus, port=None):
+    """`mp <script> --num_GPUs N` in the reference is ONE process driving N GPUs (tf.distribute.MirroredStrategy,
+    mpunet/bin/train.py:349, bin/predict.py:214); here it is one process per GPU over RCCL. The command that re-runs the same
+    script under torch.distributed.run on this node (rendezvous on 127.0.0.1: the host name of a container may not resolve)."""
+    import socket
+    import sys
+    if port is None:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(num_gpus)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), "-m", "multiplanarunet_amd.cli.mp", script] + list(argv)
+
+
+def relaunch_per_gpu(script, argv, num_gpus):
+    """Called by the scripts' entry points: --num_GPUs N > 1 outside a torchrun job re-launches the script as N ranks and exits
+    with their status; inside one (WORLD_SIZE set) or with N <= 1 it returns and the caller carries on."""
+    import subprocess
+    if int(num_gpus) <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(per_gpu_launch_command(script, argv, num_gpus), env=env))
+

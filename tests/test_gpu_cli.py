@@ -70,3 +70,16 @@ def test_mp_train_then_predict_synthetic(tmp_path):
     np.testing.assert_array_equal(pred, lab_npz)
     res3 = (proj / "predictions_nii" / "csv" / "results.csv").read_text().splitlines()
     assert res3[1].startswith("toy_5000,") and res3[1].split(",")[1] == res2[1].split(",")[1], (res3, res2)
+    # `--num_GPUs 2` outside a torchrun job: the script re-launches itself as two ranks (here both on GPU 0 over gloo, the
+    # testing aid of tests/test_gpu_bench_multi.py) and the plane-sharded predict writes the same kind of result
+    import subprocess, sys
+    env = dict(os.environ, MPU_SHARE_GPU="1", MPU_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, "-m", "multiplanarunet_amd.cli.mp", "predict", "--project_dir", str(proj), "--synthetic", "1",
+                        "--num_GPUs", "2", "--out_dir", "predictions_2gpu"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lab2 = np.load(proj / "predictions_2gpu" / "nii_files" / "toy_5000_PRED.npz")["labels"]
+    assert lab2.shape == (64, 64, 64) and (lab2 != lab_npz).mean() <= 1e-3
+    res4 = (proj / "predictions_2gpu" / "csv" / "results.csv").read_text().splitlines()
+    assert abs(float(res4[1].split(",")[1]) - float(res2[1].split(",")[1])) <= 2e-3, (res4, res2)
