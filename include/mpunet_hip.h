@@ -32,6 +32,9 @@ typedef enum { MPU_F32 = 0, MPU_BF16 = 1 } mpu_dtype;
 
 int         mpu_abi_version(void);
 const char* mpu_last_error(void);
+/* 16 hex digits: sha256 over every source, header and compiler flag this library was built from (compiled in by
+ * multiplanarunet_amd/build.py). The ctypes host layer refuses a library whose hash is not that of the sources beside it. */
+const char* mpu_build_hash(void);
 
 /* ------------------------------------------------------------------------ *
  * Predict-time geometry (HBM-bound kernels)
@@ -306,12 +309,7 @@ int mpu_adam_step_device_counter(float* d_params, const float* d_grads, float* d
  * NULL; sizes: fwd taps*Cin*Cout elements, dgrad 9*Cin*Cout elements.
  * mpu_conv2d_igemm computes out[m][n] = act(sum_k in[m@tap][k] w[tap][n][k] + bias[n])
  * (* (mask[m][n] > 0) when d_mask is given) over the channel-concatenation of
- * in0 and in1.
- * mode 4 (bf16, forward only): the up-convolution (mode 1) on TAP-COMBINED weights -- mpu_conv2d_pack_weights(mode 4) writes
- * 9*Cin*Cout elements [9][Cout][Cin] to d_w_fwd (d_w_dgrad ignored), mpu_conv2d_igemm(mode 4) takes them as d_w_packed
- * (w_tap_stride = Cin*Cout, one source, no mask, output at least 16 x 64) and evaluates UpSampling2D(2) + Conv2D(2x2, SAME)
- * (mpunet/models/unet.py:148-160) as four parity-class convolutions on the low-resolution grid: 9 instead of 16 MFMA
- * taps per output quad; the weights of taps that read the same low-resolution pixel are summed in fp32 and rounded once. */
+ * in0 and in1. */
 int mpu_conv2d_pack_weights(int32_t dtype, int32_t mode, const float* d_w, int32_t Cin, int32_t Cout,
                             void* d_w_fwd, void* d_w_dgrad, void* stream);
 int mpu_conv2d_igemm(int32_t dtype, int32_t mode, const void* d_in0, int32_t C0,

@@ -78,6 +78,7 @@ class MpuError(RuntimeError):
 
 _SIGS = {
     "mpu_abi_version": (C.c_int, []),
+    "mpu_build_hash": (C.c_char_p, []),
     "mpu_last_error": (C.c_char_p, []),
     "mpu_sample_view_planes": (C.c_int, [c_p, c_p, C.POINTER(i32), c_p, c_p, c_p,
                                          C.POINTER(ViewGeom), c_p, c_p, u8, c_p, c_p,
@@ -179,8 +180,27 @@ def load():
             fn = getattr(lib, name)         # AttributeError if a symbol is missing
             fn.restype = res
             fn.argtypes = args
+        _check_build_hash(lib)
         _lib = lib
     return _lib
+
+
+def build_hash():
+    """The source hash the loaded library was built from (`mpu_build_hash()`, compiled in by build.py)."""
+    return (load().mpu_build_hash() or b"").decode()
+
+
+def _check_build_hash(lib):
+    """A library that was not built from the sources beside it is refused (a stale .so used to run unnoticed: build() compared
+    mtimes). Skipped when the sources are absent (an installed copy) and for an explicit MPU_LIB_PATH (A/B of two builds)."""
+    from . import srchash
+    if os.environ.get("MPU_LIB_PATH") or not srchash.sources_present():
+        return
+    from .build import expected_hash
+    have, want = (lib.mpu_build_hash() or b"").decode(), expected_hash()
+    if have != want:
+        raise MpuError("libmpunet_hip.so at %s was built from other sources (library %s, tree %s): rebuild it with "
+                       "`python -m multiplanarunet_amd.build`" % (LIB_PATH, have, want))
 
 
 def check(status, what):

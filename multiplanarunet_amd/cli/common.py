@@ -34,9 +34,12 @@ def load_hparams(project_dir):
         raw = yaml.safe_load(f) or {}
     hp = {k: dict(v) for k, v in DEFAULT_HPARAMS.items()}
     for sec, vals in raw.items():
-        if sec.startswith("__") or not isinstance(vals, dict):
+        if sec.startswith("__"):                               # the YAML's anchor sections (__CB_*, ...)
             continue
-        hp.setdefault(sec, {}).update(vals)
+        if isinstance(vals, dict):
+            hp.setdefault(sec, {}).update(vals)
+        else:                                                  # top-level scalars / lists, e.g. `class_counts: [..]`
+            hp[sec] = vals                                     #   (read by set_bias_weights_on_all_outputs)
     return hp
 
 

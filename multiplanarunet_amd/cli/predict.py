@@ -106,9 +106,9 @@ def run(args):
         if os.path.exists(dst) and not args.overwrite:
             raise OSError("%s exists (use --overwrite or --continue)" % dst)
         if world > 1:
-            labels = D.multi_view_predict_sharded(model, v, views, build["dim"], fit["real_space_span"], fm,
-                                                  sum_fusion=args.sum_fusion, batch_size=None)
-            probs = None
+            res = D.multi_view_predict_sharded(model, v, views, build["dim"], fit["real_space_span"], fm,
+                                               sum_fusion=args.sum_fusion, batch_size=None, want_probs=args.no_argmax)
+            probs, labels = res if args.no_argmax else (None, res)
         else:
             probs, labels = multi_view_predict(model, v, views, build["dim"], fit["real_space_span"], fm,
                                                sum_fusion=args.sum_fusion, batch_size=None,

@@ -34,7 +34,18 @@ def get_argparser():
     p.add_argument("--cpu", action="store_true", help="alias of --num_GPUs=0 (rejected: there is no CPU path)")
     p.add_argument("--synthetic", type=int, default=0, help="train on N generated toy volumes (no files needed)")
     p.add_argument("--dtype", default="bf16", choices=("bf16", "f32"))
+    p.add_argument("--no_overlap", action="store_true", help="cut every batch on the training stream (no side-stream "
+                   "producer, eager step, A/B aid; the default overlaps the sampler with the graphed step)")
     return p
+
+
+RANK0_ONLY = ("ModelCheckPointClean", "CSVLogger")         # file writers: one process only
+
+
+def runs_on_this_rank(cb, rank):
+    """File-writing callbacks run on rank 0 only; a DelayedCallback is judged by the callback it wraps (the wrapper's
+    own class name let every rank write and remove the same checkpoint / CSV file)."""
+    return rank == 0 or type(getattr(cb, "callback", cb)).__name__ not in RANK0_ONLY
 
 
 def validate_args(args):
@@ -97,8 +108,16 @@ def run(args):
     bkw = {k: v for k, v in build.items() if k != "model_class_name"}
     model = UNet(logger=log, flatten_output=True, dtype=args.dtype, device=device, **bkw)
     last = os.path.join(model_dir, "model_weights.npz")
-    if args.continue_training and os.path.exists(last):
-        model.load_weights(last, by_name=True)
+    init_epoch = 0
+    if args.continue_training:
+        # model_init.py:23-47: newest @epoch_ checkpoint, init_epoch, the learning rate logged for that epoch, CSV cut back.
+        # Rank 0 decides (it rewrites logs/training.csv) and every rank applies the same decision.
+        from ..resume import resume_state, apply_resume
+        state = [resume_state(project_dir, log) if rank == 0 else None]
+        if world > 1:
+            torch.distributed.broadcast_object_list(state, src=0)
+        apply_resume(model, hp, state[0], log)
+        init_epoch = int(fit["init_epoch"])
     # Initialize the bias of the output layer from the class frequencies (bin/train.py:293-299; YAML default
     # build.biased_output_layer: True). Counted on the volumes of the FULL training set of this rank's process: every rank
     # loads the same volumes, so the replicas start from identical weights.
@@ -131,24 +150,25 @@ def run(args):
     if validation is None:
         descr = remove_validation_callbacks(descr, log)    # bin/train.py:259-262 (--no_val)
     callbacks, cb_by_name = init_callback_objects(descr, project_dir, log)
-    rank0_only = ("ModelCheckPointClean", "CSVLogger")     # file writers: one process only
+    # Producer / consumer overlap (trainer.py:246-257: fit(workers=5, max_queue_size=5)): batch i+1 is cut on a side
+    # stream while step i -- one HIP-graph replay at N = 1 -- runs; the loss is summed on the device and read once per
+    # epoch (pipeline.TrainPipeline). No host synchronisation per step.
+    from ..pipeline import TrainPipeline
+    pipe = TrainPipeline(model, tr, overlap=not args.no_overlap, graphed=None if not args.no_overlap else False)
     try:
-        for ep in range(epochs):
-            tot = 0.0
-            for _ in range(steps):
-                x, y, w = tr()
-                tot += float(model.train_step(x, y, w).mean().item())
+        for ep in range(init_epoch, epochs):
+            loss = pipe.run_epoch(steps)
             if world > 1:                                  # the logged loss is the mean over all replicas' slices
-                t = torch.tensor([tot], dtype=torch.float64, device=device)
+                t = torch.tensor([loss], dtype=torch.float64, device=device)
                 torch.distributed.all_reduce(t)
-                tot = float(t.item()) / world
-            logs = {"loss": tot / steps}
+                loss = float(t.item()) / world
+            logs = {"loss": loss}
             if validation is not None:
                 validation.on_epoch_end(model, ep, logs)
             log("Epoch %d/%d - " % (ep + 1, epochs) + " - ".join("%s: %.5f" % kv for kv in logs.items()))
             logs["lr"] = model.optimizer_kwargs["lr"]
             for cb in callbacks:                           # list order, as Keras runs them
-                if rank == 0 or cb.__class__.__name__ not in rank0_only:
+                if runs_on_this_rank(cb, rank):
                     cb.on_epoch_end(model, ep, logs)
             if model.stop_training:
                 break

@@ -51,13 +51,34 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
 
 // "done once" flags of per-kernel attributes (hipFuncSetAttribute is per DEVICE): one bit per device of this process, so a
-// process that drives several GPUs sets the attribute on each of them (round 3 kept one flag per process).
-inline bool first_use_on_device(unsigned long long& mask) {
+// process that drives several GPUs sets the attribute on each of them. Two steps: first_use_on_device() only TESTS the
+// bit, mark_used_on_device() sets it AFTER the attribute calls have succeeded -- a second host thread on the same device either
+// sees the bit (attributes in place) or repeats the idempotent calls itself; it can never launch ahead of them.
+inline unsigned long long device_bit() {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
-    const unsigned long long bit = 1ull << dev;
-    const unsigned long long seen = __atomic_fetch_or(&mask, bit, __ATOMIC_RELAXED);
-    return (seen & bit) == 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return 0;
+    return 1ull << dev;
+}
+inline bool first_use_on_device(unsigned long long& mask) {
+    const unsigned long long bit = device_bit();
+    return bit == 0 || (__atomic_load_n(&mask, __ATOMIC_ACQUIRE) & bit) == 0;
+}
+inline void mark_used_on_device(unsigned long long& mask) {
+    const unsigned long long bit = device_bit();
+    if (bit) __atomic_fetch_or(&mask, bit, __ATOMIC_RELEASE);
+}
+// compute units of the CURRENT device (cached per device, not per process)
+inline int device_cu_count() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return 256;
+    int n = __atomic_load_n(&cus[dev], __ATOMIC_RELAXED);
+    if (!n) {
+        hipDeviceProp_t prop;
+        n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        __atomic_store_n(&cus[dev], n, __ATOMIC_RELAXED);
+    }
+    return n;
 }
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -535,6 +535,7 @@ static int launch_glds_cfg(const ConvArgs& a_in, hipStream_t st) {
     static unsigned long long attr_set = 0;
     if (first_use_on_device(attr_set)) {
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        mark_used_on_device(attr_set);
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const long tiles = (long)cdiv(a.Cout, BN) * cdiv(M, BM);
@@ -917,6 +918,7 @@ static int launch_pipe(const ConvArgs& a_in, int ks, hipStream_t st) {
     static unsigned long long attr_set = 0;
     if (first_use_on_device(attr_set)) {
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PipeCfg::SMEM));
+        mark_used_on_device(attr_set);
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const int tiles_m = cdiv(M, PipeCfg::BM), tiles_n = cdiv(a.Cout, PipeCfg::BN);

@@ -51,20 +51,12 @@ template <> struct HMma<float> {
 
 // MODE: CONV3 (3x3 SAME: halo of one pixel) or UPCONV2 (nearest-upsample x2 + 2x2 SAME with TF's 0/1 padding: the
 // patch lives at the LOW resolution, output pixel (oy, ox) and tap (ky, kx) read low-res pixel ((oy+ky)>>1, (ox+kx)>>1))
-// MODE UPQ (round 4, inference): the same up-convolution with its taps COMBINED per output-pixel parity class. Output pixel
-// (2y + a, 2x + b) of nearest-upsample + 2x2 SAME (0/1 padding) reads low-resolution pixels (y + dy, x + dx), dy <= a, dx <= b,
-// with weights summed over the kernel taps that map to the same low-resolution pixel: class (0,0) one tap (W00+W01+W10+W11),
-// (0,1) two (W00+W10 | W01+W11), (1,0) two (W00+W01 | W10+W11), (1,1) the four original taps -- 9 MFMA taps per four output
-// pixels instead of 16. A launch handles ONE class CLS = 2a + b as a 1x1 / 1x2 / 2x1 / 2x2 convolution on the low-resolution
-// grid (tile = TH x 32 low-resolution pixels, patch (TH+1) x 33 with its origin AT the tile: the taps look forward) and
-// stores its pixels with stride two into the output; weights [9][Cout][Cin] from launch_pack_upq (the class's taps
-// contiguous: a.w points at its first one).
-template <typename T, int BN, int TH, int NWS_, int MODE = CONV3, int CLS = 0>
+template <typename T, int BN, int TH, int NWS_, int MODE = CONV3>
 struct HaloCfg {
-    static constexpr int NT = MODE == UPQ ? (CLS == 0 ? 1 : (CLS == 3 ? 4 : 2)) : (MODE == UPCONV2 ? 4 : 9);
-    static constexpr int KW = (MODE == UPCONV2 || MODE == UPQ) ? 2 : 3;
-    static constexpr int TW = 32, PW = MODE == UPCONV2 ? TW / 2 + 2 : (MODE == UPQ ? TW + 1 : TW + 2);
-    static constexpr int PH = MODE == UPCONV2 ? TH / 2 + 1 : (MODE == UPQ ? TH + 1 : TH + 2);
+    static constexpr int NT = MODE == UPCONV2 ? 4 : 9;
+    static constexpr int KW = MODE == UPCONV2 ? 2 : 3;
+    static constexpr int TW = 32, PW = MODE == UPCONV2 ? TW / 2 + 2 : TW + 2;
+    static constexpr int PH = MODE == UPCONV2 ? TH / 2 + 1 : TH + 2;
     static constexpr int PROWS = (PH * PW + 7) / 8 * 8;          // patch rows, padded to whole DMA pieces
     static constexpr int PATCH = PROWS * 128;
     static constexpr int WSTAGE = BN * 128, NWS = NWS_;
@@ -79,9 +71,9 @@ struct HaloCfg {
 // kernel's components, the mask a COMPILE-TIME constant (a run-time mask spilled 1.1 KB of registers and ran 30x slower:
 // gpurun R4a) -- bit 0: no global stores, 1: no MFMAs, 2: no weight requests after the prologue, 3: no fragment reads,
 // 4: no patch reloads, 5: no epilogue at all, 6: no per-tap barrier. Results are garbage by design.
-template <typename T, int BN, int TH, int NWS, int MODE = CONV3, int DBG = 0, int CLS = 0>
+template <typename T, int BN, int TH, int NWS, int MODE = CONV3, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
-    using Cfg = HaloCfg<T, BN, TH, NWS, MODE, CLS>;
+    using Cfg = HaloCfg<T, BN, TH, NWS, MODE>;
     constexpr int ko = DBG;
     constexpr int NT = Cfg::NT, KW = Cfg::KW;
     constexpr int EPC = 16 / sizeof(T), BKE = 128 / sizeof(T);
@@ -98,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WAVES_N, wm = wave / WAVES_N;
-    const int H = MODE == UPQ ? a.Ho / 2 : a.Ho, W = MODE == UPQ ? a.Wo / 2 : a.Wo;   // (UPQ: the tile grid is the LOW-resolution one)
+    const int H = a.Ho, W = a.Wo;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int tiles_n = (a.Cout + BN - 1) / BN;
     // n-tile fastest: the n-tiles of one pixel tile are neighbours in time (shared patch in L2)
@@ -134,8 +126,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
         const int piece = wave + 4 * k;
         const int pr = piece * 8 + lrow;                         // patch row
         const int py = pr / PW, px = pr % PW;
-        const int iy = MODE == UPCONV2 ? y0 / 2 + py : (MODE == UPQ ? y0 + py : y0 + py - 1);
-        const int ix = MODE == UPCONV2 ? x0 / 2 + px : (MODE == UPQ ? x0 + px : x0 + px - 1);
+        const int iy = MODE == UPCONV2 ? y0 / 2 + py : y0 + py - 1;
+        const int ix = MODE == UPCONV2 ? x0 / 2 + px : x0 + px - 1;
         const bool v = piece < NPP && pr < Cfg::PH * PW && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
         ppix[k] = v ? (b * Hi + iy) * Wi + ix : (int)npix;      // padding: the first pixel BEYOND the tensor (out of range for either source)
         pchunk[k] = slot ^ ((pr >> 1) & 7);
@@ -251,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
     // sits in front of an MFMA or a fragment read of an in-order wave): tap position, request target and the counted
     // waits are compile-time; the chunk's scalars and the weight stage stay in registers.
     constexpr int AHEAD = NWS - 1;                               // prefetch distance (taps)
-    static_assert(AHEAD >= 1 && AHEAD <= NT && (AHEAD < NT || MODE == UPQ), "request distance");
+    static_assert(AHEAD >= 1 && AHEAD < NT, "request distance");
     auto chunk_woff = [&](int c_) { const bool s1 = c_ >= nch0; return (unsigned)(((s1 ? a.C0 : 0) + (s1 ? c_ - nch0 : c_) * BKE) * (int)sizeof(T)); };
     auto chunk_room = [&](int c_) { const bool s1 = c_ >= nch0; return (s1 ? a.C1 : a.C0) - (s1 ? c_ - nch0 : c_) * BKE; };
     // rows beyond Cout carry a poison offset that stays out of range after the add (operands < 2 GiB - 8 KiB: checked
@@ -291,8 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
             if (DBG && (ko & 4)) {}
             else if (wt < NT) request_w(woffA + (unsigned)wt * w_tap_b, roomA, stn);
             else if (hasnext) request_w(woffB + (unsigned)(wt - NT) * w_tap_b, roomB, stn);
-            if constexpr (MODE == UPQ) compute(CLS == 3 ? tap >> 1 : (CLS == 2 ? tap : 0), CLS == 3 ? tap & 1 : (CLS == 1 ? tap : 0), st, kv);
-            else compute(tap / KW, tap % KW, st, kv);
+            compute(tap / KW, tap % KW, st, kv);
             if (tap == NT - 1 && hasnext) {
                 // every wave has finished reading the patch before it is overwritten
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -373,18 +364,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
         // piece is fixed and the pixel advances by RPI rows of the tile per iteration (all compile-time strides)
         constexpr int CPRO = BN * (int)sizeof(T) / 16, RPI = 256 / CPRO, XPI = TW / RPI > 0 ? TW / RPI : 1;
         static_assert(RPI <= TW && TW % RPI == 0, "a pass covers a fraction of one tile row");
-        // UPQ: this launch's pixels sit at stride two in the output image (class (ca, cb) of every 2 x 2 output quad)
-        constexpr int OS = MODE == UPQ ? 2 : 1, ca = MODE == UPQ ? (CLS >> 1) : 0, cb = MODE == UPQ ? (CLS & 1) : 0;
-        const int Wout = OS * W, Hout = OS * H;
-        const long npo = (long)a.B * Hout * Wout;
+        const long npo = (long)a.B * H * W;
         const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(npo * a.Cout * (long)sizeof(T)), 0x00020000);
         const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask ? a.mask : a.out), 0,
                                                                               (int)(npo * a.Cout * (long)sizeof(T)), 0x00020000);
         const int c = tid % CPRO, r0 = tid / CPRO;
         const int n = n0 + c * EPC;
         const int pixB = a.Cout * (int)sizeof(T);
-        const int obase = ((b * Hout + OS * y0 + ca) * Wout + OS * x0 + cb) * pixB;   // scalar part
-        const int lane_off = n * (int)sizeof(T) + OS * r0 * pixB;
+        const int obase = ((b * H + y0) * W + x0) * pixB;            // scalar part
+        const int lane_off = n * (int)sizeof(T) + r0 * pixB;
         const unsigned char* srow = smem + r0 * OROW + c * 16;
         const bool n_ok = n < a.Cout;
         float ssum[EPC], ssq[EPC];                                                // fused BN statistics (a.stats)
@@ -406,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
         for (int it = 0; it < NIT; ++it) {
             const int yy = it / XPI, xx = (it % XPI) * RPI;
             const bool in = n_ok && (y0 + yy < H) && (x0 + xx + r0 < W);
-            const unsigned o = (unsigned)(obase + lane_off + (OS * yy * Wout + OS * xx) * pixB);
+            const unsigned o = (unsigned)(obase + lane_off + (yy * W + xx) * pixB);
             mkv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsm, (a.mask && in) ? o : OOB, 0, 0);
             bxv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (a.bn_x && in) ? o : OOB, 0, 0);
         }
@@ -441,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
             }
             // (no scalar offset operand: it is added after the range check of the vector offset, which would wrap
             // the out-of-range marker of masked lanes back into the buffer)
-            const unsigned off = ok ? (unsigned)(obase + lane_off + (OS * yy * Wout + OS * xx) * pixB) : OOB;
+            const unsigned off = ok ? (unsigned)(obase + lane_off + (yy * W + xx) * pixB) : OOB;
             if (a.mask) {
                 const u32x4 mk = mkv[it];
                 if (sizeof(T) == 2) {
@@ -1088,6 +1076,7 @@ int launch_halo8_cfg_n(const ConvArgs& a_in, hipStream_t st) {
     static unsigned long long attr_set = 0;
     if (first_use_on_device(attr_set)) {
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        mark_used_on_device(attr_set);
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
@@ -1110,24 +1099,24 @@ int launch_halo8_cfg_n(const ConvArgs& a_in, hipStream_t st) {
     return launch_ok();
 }
 
-template <typename T, int BN, int TH, int NWS, int MODE = CONV3, int DBG = 0, int CLS = 0>
-int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st, bool timed = true) {
-    using Cfg = HaloCfg<T, BN, TH, NWS, MODE, CLS>;
-    auto kern = conv_halo_kernel<T, BN, TH, NWS, MODE, DBG, CLS>;
+template <typename T, int BN, int TH, int NWS, int MODE = CONV3, int DBG = 0>
+int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
+    using Cfg = HaloCfg<T, BN, TH, NWS, MODE>;
+    auto kern = conv_halo_kernel<T, BN, TH, NWS, MODE, DBG>;
     ConvArgs a = a_in;
     if (a.w_elems <= 0) a.w_elems = (Cfg::NT - 1) * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
     static unsigned long long attr_set = 0;
     if (first_use_on_device(attr_set)) {
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        mark_used_on_device(attr_set);
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
-    const long Min = (MODE == UPCONV2 || MODE == UPQ) ? M / 4 : M;   // input pixels (32-bit DMA / buffer-store offsets)
+    const long Min = MODE == UPCONV2 ? M / 4 : M;   // input pixels (32-bit DMA / buffer-store offsets)
     if (Min * cmax * (long)sizeof(T) >= (1L << 31) - 8192 || a.w_elems * (long)sizeof(T) >= (1L << 31) - 8192 ||
         M * a.Cout * (long)sizeof(T) >= (1L << 31) - 8192)
         return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");
-    const int Ht = MODE == UPQ ? a.Ho / 2 : a.Ho, Wt = MODE == UPQ ? a.Wo / 2 : a.Wo;      // tile grid (UPQ: low resolution)
-    const long tiles = (long)a.B * cdiv(Ht, TH) * cdiv(Wt, Cfg::TW) * cdiv(a.Cout, BN);
+    const long tiles = (long)a.B * cdiv(a.Ho, TH) * cdiv(a.Wo, Cfg::TW) * cdiv(a.Cout, BN);
     const long ptiles = tiles / cdiv(a.Cout, BN);
     if (a.stats && a.stats_rows) {
         if (ptiles * 2 * a.Cout <= a.stats_cap) *a.stats_rows = (int)ptiles;
@@ -1135,28 +1124,10 @@ int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st, bool timed = true) {
     } else a.stats = nullptr;
     if (a.pooled && a.pooled_done && MODE == CONV3 && !a.mask && !(a.Ho & 1) && !(a.Wo & 1) && TH % 2 == 0) *a.pooled_done = 1;
     else a.pooled = nullptr;
-    if (timed && prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);
+    if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);
     launch_k(kern, dim3((unsigned)tiles), dim3(256), Cfg::SMEM, st, a);
-    if (timed && prof_on()) prof_end(st);
-    return launch_ok();
-}
-
-// the four class launches of the tap-combined up-convolution (heaviest class first); a.w_quad = [9][Cout][Cin]
-template <int BN>
-int launch_halo_upq(const ConvArgs& a_in, hipStream_t st) {
-    ConvArgs a = a_in;
-    a.stats = nullptr; a.pooled = nullptr; a.mask = nullptr; a.w_elems = 0;
-    const unsigned char* wq = (const unsigned char*)a_in.w_quad;
-    const long tapb = a.w_tap_stride * 2L;
-    const long M = (long)a.B * a.Ho * a.Wo;
-    if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * 4 * (a.C0 + a.C1), st);   // the LAYER's algorithmic FLOPs (4 taps)
-    int rc;
-    a.w = wq + 5 * tapb; rc = launch_halo_cfg<bf16_t, BN, 8, 2, UPQ, 0, 3>(a, st, false); if (rc) return rc;
-    a.w = wq + 1 * tapb; rc = launch_halo_cfg<bf16_t, BN, 8, 2, UPQ, 0, 1>(a, st, false); if (rc) return rc;
-    a.w = wq + 3 * tapb; rc = launch_halo_cfg<bf16_t, BN, 8, 2, UPQ, 0, 2>(a, st, false); if (rc) return rc;
-    a.w = wq;            rc = launch_halo_cfg<bf16_t, BN, 8, 2, UPQ, 0, 0>(a, st, false); if (rc) return rc;
     if (prof_on()) prof_end(st);
-    return MPU_OK;
+    return launch_ok();
 }
 
 }  // namespace
@@ -1193,15 +1164,6 @@ int try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
                 return rc ? rc : 2;
             }
         }
-    }
-    if (mode == UPCONV2 && a.w_quad && dtype == MPU_BF16 && !a.mask && !a.stats && !(a.Ho & 1) && !(a.Wo & 1) && a.Wo >= 64 &&
-        a.Ho >= 16) {
-        // tap-combined form, four class convolutions on the low-resolution grid (9 instead of 16 MFMA taps per output
-        // quad). Whoever sets w_quad asked for it: the C-ABI's mode 4, or the model's inference forward under MPU_UPQ=1
-        // (opt-in: on the 256^3 predict it measured 169.9-170.2 vs 168.0-168.7 ms -- the four launches' prologues,
-        // epilogues and patch loads cost what the 44 % fewer MFMAs save; gpurun R4k).
-        rc = a.Cout > 64 ? launch_halo_upq<128>(a, st) : launch_halo_upq<64>(a, st);
-        return rc ? rc : 4;
     }
     if (mode == UPCONV2) {                       // low-resolution patch variant of the up-convolution
         const bool up_on = env(ENV_HALO_UPCONV) != 0;

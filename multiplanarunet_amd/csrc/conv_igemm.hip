@@ -670,6 +670,7 @@ static int launch_conv_cfg(const ConvArgs& a_in, hipStream_t st) {
     static unsigned long long attr_set = 0;
     if (first_use_on_device(attr_set)) {
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        mark_used_on_device(attr_set);
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const long tiles = (long)cdiv(a.Cout, BN) * cdiv(M, BM);
@@ -722,9 +723,9 @@ int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
             const int w = try_conv_ws(dtype, mode, a, st);
             if (w != 0) { note("ws"); return w < 0 ? w : MPU_OK; }
             const int x = try_conv_halo16(dtype, mode, a, st);
-            if (x != 0) { note(x == 5 ? "halo16p" : "halo16"); return x < 0 ? x : MPU_OK; }
+            if (x != 0) { note("halo16p"); return x < 0 ? x : MPU_OK; }
             const int h = try_conv_halo(dtype, mode, a, st);
-            if (h != 0) { note(h == 2 ? "halo8" : (h == 4 ? "halo-upq" : "halo")); return h < 0 ? h : MPU_OK; }
+            if (h != 0) { note(h == 2 ? "halo8" : "halo"); return h < 0 ? h : MPU_OK; }
         }
         const int rc = launch_conv_glds(dtype, mode, a, st);
         note(last_glds_schedule());

@@ -371,14 +371,12 @@ int launch_ws(const ConvArgs& a_in, hipStream_t st) {
     auto kern = conv_ws_kernel<TH, HEAD>;
     ConvArgs a = a_in;
     if (a.w_elems <= 0) a.w_elems = 8 * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
-    static int ncu = 0;
-    if (!ncu) {
+    static unsigned long long attr_set = 0;                      // (per instantiation: this function is a template)
+    if (first_use_on_device(attr_set)) {
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
-        int dev = 0; hipDeviceProp_t prop;
-        MPU_CHECK_HIP(hipGetDevice(&dev));
-        MPU_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        mark_used_on_device(attr_set);
     }
+    const int ncu = device_cu_count();
     const long M = (long)a.B * a.Ho * a.Wo;
     if (M * a.C0 * 2L >= (1L << 31) || M * a.Cout * 2L >= (1L << 31) || a.w_elems * 2L >= (1L << 31))
         return fail(MPU_EUNSUPPORTED, "%s", "conv: operand larger than 2 GiB (split the batch)");

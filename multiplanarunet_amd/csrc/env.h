@@ -27,11 +27,9 @@ enum EnvKind {
     X(HALO_UPCONV, "MPU_HALO_UPCONV", ENV_ON, 1, "0: up-convolutions not on the low-resolution-patch conv_halo variant")             \
     X(HALO_UP8_MIN, "MPU_HALO_UP8_MIN", ENV_NUM, 2048, "grid size from which up-convolutions take 8-row tiles")                      \
     X(HALO_KNOCKOUT, "MPU_HALO_KNOCKOUT", ENV_NUM, 0, "dev aid (-DMPU_HALO_KNOCKOUT_BUILD only): knock-out mask of the predict conv kernel") \
-    X(HALO16, "MPU_HALO16", ENV_OFF, 0, "1: conv_halo16 (16-row tiles, one tile per workgroup) on large grids, every epilogue")      \
     X(HALO16P, "MPU_HALO16P", ENV_ON, 1, "0: large inference grids not on the persistent conv_halo16p (round-3 schedules instead)")  \
-    X(HALO16_MIN, "MPU_HALO16_MIN", ENV_NUM, -1, "grid bound of conv_halo16 / conv_halo16p in tiles (default 768 / 512; tests: 1)")   \
+    X(HALO16_MIN, "MPU_HALO16_MIN", ENV_NUM, -1, "grid bound of conv_halo16p in tiles (default 512; tests: 1)")   \
     X(HALO16P_WGS, "MPU_HALO16P_WGS", ENV_NUM, 0, "cap on conv_halo16p's persistent workgroups (0 = one per CU; tests: few, many tiles each)") \
-    X(UPQ, "MPU_UPQ", ENV_OFF, 0, "1: inference up-convolutions in the tap-combined form (9 instead of 16 taps per output quad)")    \
     X(FUSED_HEAD, "MPU_FUSED_HEAD", ENV_ON, 1, "0: inference 1x1 head as its own kernel instead of the last conv's epilogue")        \
     X(FUSED_POOL, "MPU_FUSED_POOL", ENV_ON, 1, "0: inference 2x2 max pooling as its own kernel instead of a second epilogue output") \
     X(FUSED_BN_STATS, "MPU_FUSED_BN_STATS", ENV_ON, 1, "0: BatchNorm statistics by colreduce instead of the conv epilogue")          \
@@ -46,8 +44,7 @@ enum EnvKind {
     X(GEOM_FAST, "MPU_GEOM_FAST", ENV_ON, 1, "0: geometry kernels on the op-by-op fp64 path only (no screened fast path)")           \
     X(FUSE_FX, "MPU_FUSE_FX", ENV_ON, 1, "0: fused back-mapping with fp64 index arithmetic instead of the fixed-point screen")       \
     X(PROF_MARKERS, "MPU_PROF_MARKERS", ENV_OFF, 0, "1: roofline-leg events as hipEventRecord markers instead of dispatch-bound events") \
-    X(STAMPS, "MPU_STAMPS", ENV_OFF, 0, "dev aid: 1 = the s_memtime-instrumented kernel instantiations + stamp buffer")              \
-    X(STAMPS_FIRST, "MPU_STAMPS_FIRST", ENV_NUM, 0, "dev aid: first workgroup of conv_halo16's stamped window")
+    X(STAMPS, "MPU_STAMPS", ENV_OFF, 0, "dev aid: 1 = the s_memtime-instrumented kernel instantiations + stamp buffer")
 
 enum EnvId {
 #define MPU_ENV_ID(id, name, kind, dflt, doc) ENV_##id,

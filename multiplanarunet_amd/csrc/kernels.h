@@ -5,7 +5,7 @@
 
 namespace mpu {
 
-enum { CONV3 = 0, UPCONV2 = 1, CONV3S2 = 2, CONV1 = 3, UPQ = 4 };     // UPQ: the tap-combined up-conv (conv_halo.hip), inference only
+enum { CONV3 = 0, UPCONV2 = 1, CONV3S2 = 2, CONV1 = 3 };
 
 struct ConvArgs {
     const void* in0; const void* in1; int C0, C1;
@@ -38,9 +38,6 @@ struct ConvArgs {
     // *head_done = 1 when the schedule did so; launch_head_combine then adds the halves and the bias and applies the
     // softmax. Otherwise the caller runs launch_head_forward on the stored output.
     const float* head_w = nullptr; int head_k = 0, head_ldw = 0; float* head_partial = nullptr; int* head_done = nullptr;
-    // Optional (inference, bf16): the up-conv's weights in the tap-combined form [9][Cout][Cin] (launch_pack_upq): the
-    // dispatcher may then run the layer as four class convolutions on the low-resolution grid (conv_halo UPQ)
-    const void* w_quad = nullptr;
     int dbg = 0;                 // profiling switches of conv_pipe_kernel (MPU_PIPE_DEBUG: 1 no stores, 2 no MFMAs, 4 no DMA,
                                  //   8 no fragment reads, 16 no barrier, 32 s_memtime stamps into dbg_buf)
     unsigned long long* dbg_buf = nullptr;
@@ -103,7 +100,7 @@ const char* last_glds_schedule();               // "glds" or "pipe": what the la
 int  try_conv_c8(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // <= 8 input channels: first layer (conv_c8.hip)
 int  try_conv_ws(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // register-stationary weights, persistent (conv_ws.hip)
 int  try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st);     // LDS-resident patch variant (conv_halo.hip)
-int  try_conv_halo16(int dtype, int mode, const ConvArgs& a, hipStream_t st);   // ... 16-row tiles, staggered halves: large grids (conv_halo16.hip)
+int  try_conv_halo16(int dtype, int mode, const ConvArgs& a, hipStream_t st);   // ... 16-row tiles, persistent, staggered halves: large inference grids (conv_halo16.hip)
 // grouped: the job will run inside a grouped launch (WgradGroup): it need not fill the chip on its own, so it takes
 // about half the workgroups (K splits / pixel strips) of a stand-alone launch -- half the fp32 partial copies
 long wgrad_partial_elems(int mode, int Cin, int Cout, long M, int* ksplit_out, int* mchunk_out, bool grouped = false);
@@ -172,7 +169,6 @@ int launch_pack_all(int dtype, PackTable& tab, const float* params, void* packed
 int launch_adam_pack_all(int dtype, PackTable& jobs, float* params, const float* grads, float* am, float* av, long n_params,
                          void* packed, long long* step, long long t_host, double lr, double b1, double b2, float eps,
                          hipStream_t st);
-int launch_pack_upq(const float* W, int Cin, int Cout, void* w_quad, hipStream_t st);   // bf16 [9][Cout][Cin] from f32 [2][2][Cin][Cout]
 int launch_pack_weights(int dtype, int mode, const float* W, int Cin, int Cout,
                         void* w_fwd, void* w_dgrad, hipStream_t st);
 int launch_cast_pad(int dtype, const float* x, long M, int Cin, int Cpad, void* out, hipStream_t st);

@@ -25,7 +25,7 @@ struct Tensor {                 // one entry of the flat parameter / BN-state ta
     int lshape[4];              // logical Keras shape
 };
 
-struct Conv { int mode, Cin, Cout; long w, b; long wf, wd; int lCin, lCout; long wq = -1; };   // wq: BYTE offset of the tap-combined weights (up-convs, bf16)        // offsets
+struct Conv { int mode, Cin, Cout; long w, b; long wf, wd; int lCin, lCout; };        // offsets
 struct BN { int C; long g, b, mm, mv; long st; };                    // st: mean,invstd,scale,shift (4*C)
 
 }  // namespace
@@ -39,7 +39,6 @@ struct mpu_unet {
     std::vector<Tensor> tensors;
     long n_params = 0, n_state = 0, n_packed = 0, n_stats = 0, n_logical = 0;
     long infer_off = 0;                      // byte offset of the inference BN coefficients inside the packed buffer
-    long quad_bytes = 0;                     // tap-combined up-conv weights (bf16 inference, Conv::wq) behind them
     int head_C = 0; long head_w = 0, head_b = 0;
     int cmax = 0;
     mpu_launch_tap_fn tap = nullptr; void* tap_user = nullptr;      // test aid: mpu_unet_set_launch_tap
@@ -236,8 +235,6 @@ int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* i
     a.flops = conv_flops(r, c, lvl); a.w_elems = 0;
     a.partial = r.P.cpartial_floats ? (float*)r.at(r.P.cpartial) : nullptr; a.partial_cap = r.P.cpartial_floats; a.ksplit = 1;
     a.post_scale = post_scale; a.post_shift = post_shift;
-    const bool upq = env(ENV_UPQ) != 0;      // 1: inference up-convs in the tap-combined form (opt-in: no gain measured)
-    if (upq && post_scale && c.wq >= 0) a.w_quad = r.packed + c.wq;
     a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1;
     a.w = r.wf(c); a.w_tap_stride = (long)c.Cin * c.Cout; a.w_row_stride = c.Cin;
     a.bias = r.params + c.b; a.mask = nullptr; a.out = out;
@@ -587,12 +584,6 @@ mpu_unet* mpu_unet_create(const mpu_unet_config* cfg) {
     add_conv(m, "conv2d", CONV1, cin, cfg->n_classes, lcin, cfg->n_classes);
     m->head_C = cin; m->head_w = m->conv.back().w; m->head_b = m->conv.back().b;
     m->infer_off = (m->n_packed * (cfg->dtype == MPU_BF16 ? 2 : 4) + 255) / 256 * 256;
-    if (cfg->dtype == MPU_BF16) {            // inference: the up-convs' weights in the tap-combined form (conv_halo UPQ)
-        long off = (m->infer_off + m->n_stats * 4 + 255) / 256 * 256;
-        for (Conv& c : m->conv)
-            if (c.mode == UPCONV2) { c.wq = off; off += (9L * c.Cin * c.Cout * 2 + 255) / 256 * 256; }
-        m->quad_bytes = off - (m->infer_off + m->n_stats * 4);
-    }
     return m;
 }
 
@@ -611,7 +602,7 @@ int64_t mpu_unet_param_floats(const mpu_unet* m) { return m ? m->n_params : 0; }
 int64_t mpu_unet_bn_state_floats(const mpu_unet* m) { return m ? m->n_state : 0; }
 int64_t mpu_unet_packed_bytes(const mpu_unet* m) {
     if (!m) return 0;
-    return m->infer_off + m->n_stats * 4 + m->quad_bytes;   // MFMA operands, scale/shift of every BN for inference, tap-combined up-conv weights
+    return m->infer_off + m->n_stats * 4;   // MFMA operands, scale/shift of every BN for inference
 }
 int64_t mpu_unet_logical_param_count(const mpu_unet* m) { return m ? m->n_logical : 0; }
 int32_t mpu_unet_num_tensors(const mpu_unet* m) { return m ? (int32_t)m->tensors.size() : 0; }
@@ -672,8 +663,6 @@ int mpu_unet_prepare_inference(const mpu_unet* m, const float* d_params, const f
     for (const BN& b : m->bn)
         RC(launch_bn_infer_coeffs(d_params + b.g, d_params + b.b, d_bn_state + b.mm, d_bn_state + b.mv, b.C, BN_EPS,
                                   co + b.st + 2L * b.C, co + b.st + 3L * b.C, (hipStream_t)stream));
-    for (const Conv& c : m->conv)
-        if (c.wq >= 0) RC(launch_pack_upq(d_params + c.w, c.Cin, c.Cout, (unsigned char*)d_packed + c.wq, (hipStream_t)stream));
     return MPU_OK;
 }
 
@@ -753,10 +742,7 @@ int mpu_conv2d_pack_weights(int32_t dtype, int32_t mode, const float* d_w, int32
                             void* d_w_fwd, void* d_w_dgrad, void* stream) {
     MPU_REQUIRE(d_w && d_w_fwd, "mpu_conv2d_pack_weights: null argument");
     MPU_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "mpu_conv2d_pack_weights: channels must be multiples of 8");
-    if (mode == UPQ) {                           // tap-combined up-conv weights [9][Cout][Cin] (bf16; forward only)
-        MPU_REQUIRE(dtype == MPU_BF16, "mpu_conv2d_pack_weights: mode 4 (tap-combined up-conv) is bf16 only");
-        return launch_pack_upq(d_w, Cin, Cout, d_w_fwd, (hipStream_t)stream);
-    }
+    MPU_REQUIRE(mode >= CONV3 && mode <= CONV1, "mpu_conv2d_pack_weights: unknown mode");
     return launch_pack_weights(dtype, mode, d_w, Cin, Cout, d_w_fwd, d_w_dgrad, (hipStream_t)stream);
 }
 
@@ -767,13 +753,9 @@ static int conv2d_igemm_impl(int32_t dtype, int32_t mode, const void* d_in0, int
     MPU_REQUIRE(d_in0 && d_w_packed && d_out, "mpu_conv2d_igemm: null argument");
     MPU_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && Cout % 8 == 0 && C0 > 0, "mpu_conv2d_igemm: channels must be multiples of 8");
     MPU_REQUIRE((C1 == 0) == (d_in1 == nullptr), "mpu_conv2d_igemm: in1 / C1 mismatch");
-    MPU_REQUIRE((mode != UPCONV2 && mode != UPQ) || (Ho % 2 == 0 && Wo % 2 == 0), "mpu_conv2d_igemm: UPCONV2 needs even output size");
+    MPU_REQUIRE(mode >= CONV3 && mode <= CONV1, "mpu_conv2d_igemm: unknown mode");
+    MPU_REQUIRE(mode != UPCONV2 || (Ho % 2 == 0 && Wo % 2 == 0), "mpu_conv2d_igemm: UPCONV2 needs even output size");
     ConvArgs a;
-    if (mode == UPQ) {                           // the up-conv on tap-combined weights (mpu_conv2d_pack_weights mode 4)
-        MPU_REQUIRE(dtype == MPU_BF16 && !d_mask && !d_in1 && Wo >= 64 && Ho >= 16, "mpu_conv2d_igemm: mode 4 needs bf16, one source, "
-                    "no mask and an output of at least 16 x 64");
-        a.w_quad = d_w_packed; mode = UPCONV2;
-    }
     a.in0 = d_in0; a.in1 = d_in1; a.C0 = C0; a.C1 = C1; a.w = d_w_packed; a.w_tap_stride = w_tap_stride;
     a.w_row_stride = w_row_stride; a.bias = d_bias; a.mask = d_mask; a.out = d_out;
     a.B = B; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.relu = relu; a.flops = 0; a.w_elems = 0;

@@ -235,26 +235,6 @@ int launch_pack_all(int dtype, PackTable& tab, const float* params, void* packed
     return launch_ok();
 }
 
-// Tap-combined weights of the 2x2 up-convolution (conv_halo UPQ, inference): out[t][co][ci] (bf16, K-contiguous rows as the
-// forward packing) for the nine (class, low-resolution shift) taps, the class's taps contiguous:
-//   t0 class (0,0): W00+W01+W10+W11 | t1, t2 class (0,1): W00+W10, W01+W11 | t3, t4 class (1,0): W00+W01, W10+W11 |
-//   t5..t8 class (1,1): W00, W01, W10, W11            (Wkykx = W[ky][kx][ci][co], summed in fp32, rounded once)
-__global__ void pack_upq_kernel(const float* __restrict__ W, int Cin, int Cout, bf16_t* __restrict__ out) {
-    const long n = (long)Cin * Cout;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const int ci = (int)(e / Cout), co = (int)(e - (long)ci * Cout);         // (reads coalesced over co)
-        const float w00 = W[e], w01 = W[n + e], w10 = W[2 * n + e], w11 = W[3 * n + e];
-        const float t[9] = {(w00 + w01) + (w10 + w11), w00 + w10, w01 + w11, w00 + w01, w10 + w11, w00, w01, w10, w11};
-        bf16_t* o = out + (long)co * Cin + ci;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) o[k * n] = f32_to_bf16(t[k]);
-    }
-}
-int launch_pack_upq(const float* W, int Cin, int Cout, void* w_quad, hipStream_t st) {
-    pack_upq_kernel<<<ew_grid((long)Cin * Cout), 256, 0, st>>>(W, Cin, Cout, (bf16_t*)w_quad);
-    return launch_ok();
-}
-
 int launch_pack_weights(int dtype, int mode, const float* W, int Cin, int Cout, void* wf, void* wd, hipStream_t st) {
     const int ntaps = mode == UPCONV2 ? 4 : (mode == CONV1 ? 1 : 9);
     long tiles = (long)ntaps * cdiv(Cin, 32) * cdiv(Cout, 32);

@@ -541,6 +541,7 @@ static int taps_attrs() {
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_kernel<UPCONV2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_group_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
         MPU_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_taps_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TAPS_SMEM));
+        mark_used_on_device(attr_set);
     }
     return MPU_OK;
 }

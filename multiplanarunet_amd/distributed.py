@@ -272,10 +272,13 @@ def all_gather_slabs(slab, X):
 
 
 def multi_view_predict_sharded(model, volume, views, dim, real_space_span, fusion_model=None,
-                               sum_fusion=False, batch_size=None, n_planes="same+20", exchange=None, timings=None):
+                               sum_fusion=False, batch_size=None, n_planes="same+20", exchange=None, timings=None,
+                               want_probs=False):
     """
     multiplanarunet_amd.predict.multi_view_predict over all ranks. Every rank
-    holds the full input volume; returns the full uint8 label volume on every rank.
+    holds the full input volume; returns the full uint8 label volume on every rank -- with want_probs=True
+    (`mp predict --no_argmax`) the pair (fused [X,Y,Z,K] f32 volume, labels): the slabs of the fused volume are
+    all-gathered as well (K * 4 more bytes per voxel than the labels).
 
     exchange="reduce_scatter" (default; MPU_PREDICT_EXCHANGE overrides): plane-chunk work items, partial
     fusion sums, reduce-scatter + label all-gather (module docstring). exchange="all_gather": the literal
@@ -287,7 +290,7 @@ def multi_view_predict_sharded(model, volume, views, dim, real_space_span, fusio
     exchange = exchange or os.environ.get("MPU_PREDICT_EXCHANGE") or "reduce_scatter"
     if exchange == "all_gather":
         return _multi_view_predict_allgather(model, volume, views, dim, real_space_span, fusion_model,
-                                             sum_fusion, batch_size, n_planes, timings)
+                                             sum_fusion, batch_size, n_planes, timings, want_probs)
     if exchange != "reduce_scatter":
         raise ValueError("exchange must be 'reduce_scatter' or 'all_gather'")
     from .interpolation import ViewGeometry, sample_view, map_accumulate, fusion_finalize
@@ -329,17 +332,18 @@ def multi_view_predict_sharded(model, volume, views, dim, real_space_span, fusio
         timings["planes"] = sum(hi_ - lo_ for _, lo_, hi_ in items)
     zs, (lo, hi) = reduce_scatter_slabs(z)
     b = None if sum_fusion else fusion_model.b
-    _, labels = fusion_finalize(zs, b, sum_fusion=sum_fusion, want_probs=False)
+    probs_s, labels = fusion_finalize(zs, b, sum_fusion=sum_fusion, want_probs=want_probs)
     out = all_gather_slabs(labels, X)
+    probs = all_gather_slabs(probs_s, X) if want_probs else None
     if timings is not None:
         torch.cuda.synchronize() if z.is_cuda else None
         timings["exchange_s"] = time.perf_counter() - t1
         timings["exchange_bytes_per_rank"] = int(z.numel() * 4 * (world - 1) // max(world, 1) + out.numel() * (world - 1) // max(world, 1))
-    return out
+    return (probs, out) if want_probs else out
 
 
 def _multi_view_predict_allgather(model, volume, views, dim, real_space_span, fusion_model, sum_fusion,
-                                  batch_size, n_planes, timings=None):
+                                  batch_size, n_planes, timings=None, want_probs=False):
     from .interpolation import ViewGeometry, sample_view, map_real_space_pred, pred_to_class
     import time
     world = world_size()
@@ -389,4 +393,4 @@ def _multi_view_predict_allgather(model, volume, views, dim, real_space_span, fu
         timings["exchange_s"] = t_ex
         timings["compute_s"] = time.perf_counter() - t_begin - t_ex
         timings["exchange_bytes_per_rank"] = int(rounds * X * Y * Z * K * 4 * (world - 1))
-    return out
+    return (merged.reshape(X, Y, Z, K), out) if want_probs else out

@@ -55,10 +55,10 @@ def _load():
             L = C.CDLL(p)
             if L.H5open() < 0:
                 raise OSError("H5open failed")
-        except OSError as e:
+            _declare(L)                                               # AttributeError: a build without one of the calls below
+        except (OSError, AttributeError) as e:                        #   -> this library is unusable, try the next
             tried.append("%s (%s)" % (p, e))
             continue
-        _declare(L)
         L.path = p
         _lib = L
         return _lib
@@ -90,7 +90,7 @@ def _declare(L):
         "H5Dcreate2": (hid, [hid, C.c_char_p, hid, hid, hid, hid, hid]), "H5Dopen2": (hid, [hid, C.c_char_p, hid]),
         "H5Dget_space": (hid, [hid]), "H5Dget_type": (hid, [hid]),
         "H5Dread": (C.c_int, [hid, hid, hid, hid, hid, p]), "H5Dwrite": (C.c_int, [hid, hid, hid, hid, hid, p]),
-        "H5Dvlen_reclaim": (C.c_int, [hid, hid, hid, p]), "H5Dclose": (C.c_int, [hid]),
+        "H5Dclose": (C.c_int, [hid]),
         "H5Acreate2": (hid, [hid, C.c_char_p, hid, hid, hid, hid]), "H5Aopen": (hid, [hid, C.c_char_p, hid]),
         "H5Aexists": (C.c_int, [hid, C.c_char_p]), "H5Aget_type": (hid, [hid]), "H5Aget_space": (hid, [hid]),
         "H5Aread": (C.c_int, [hid, hid, p]), "H5Awrite": (C.c_int, [hid, hid, p]), "H5Aclose": (C.c_int, [hid]),
@@ -99,6 +99,16 @@ def _declare(L):
     for name, (res, args) in sig.items():
         f = getattr(L, name)
         f.restype, f.argtypes = res, args
+    # variable-length reclaim: H5Dvlen_reclaim is deprecated (absent from builds without deprecated symbols); 1.12+ has H5Treclaim
+    L.vlen_reclaim = None
+    for name in ("H5Dvlen_reclaim", "H5Treclaim"):
+        f = getattr(L, name, None)
+        if f is not None:
+            f.restype, f.argtypes = C.c_int, [hid, hid, hid, p]
+            L.vlen_reclaim = f
+            break
+    if L.vlen_reclaim is None:
+        raise AttributeError("neither H5Dvlen_reclaim nor H5Treclaim")
     L.H5Eset_auto2(0, None, None)                                     # errors come back as return codes, not on stderr
     L.T = lambda name: hid.in_dll(L, name + "_g").value               # predefined datatype ids (valid after H5open)
 
@@ -196,7 +206,7 @@ def read_strings_attr(loc, name):
                 ptrs = (C.c_char_p * n)()
                 _ok(L.H5Aread(a, t, ptrs), "read attribute %s" % name)
                 out = [(ptrs[i] or b"").decode("utf8") for i in range(n)]
-                L.H5Dvlen_reclaim(t, s, 0, ptrs)
+                L.vlen_reclaim(t, s, 0, ptrs)
                 return out
             width = int(L.H5Tget_size(t))
             buf = C.create_string_buffer(n * width)

@@ -7,7 +7,6 @@ import torch
 from . import _lib
 
 CONV3, UPCONV2, CONV3S2, CONV1 = 0, 1, 2, 3
-UPQ = 4            # the up-convolution on tap-combined weights (inference form; pack_weights_upq + conv2d(UPQ, ...))
 _NTAPS = {CONV3: 9, UPCONV2: 4, CONV3S2: 9, CONV1: 1}
 
 
@@ -24,16 +23,6 @@ def pack_weights(w_hwio, mode, dtype):
     _lib.call("mpu_conv2d_pack_weights", _dt(dtype), mode, _lib.ptr(w), ci, co,
               _lib.ptr(wf), _lib.ptr(wd), _lib.stream_ptr())
     return wf, wd
-
-
-def pack_weights_upq(w_hwio):
-    """fp32 Keras HWIO 2x2 up-conv kernel (device) -> bf16 tap-combined operand [9][Cout][Cin] (csrc/conv_halo.hip, UPQ)."""
-    kh, kw, ci, co = w_hwio.shape
-    assert (kh, kw) == (2, 2)
-    w = w_hwio.to(torch.float32).contiguous()
-    wq = torch.empty(9 * co * ci, dtype=torch.bfloat16, device=w.device)
-    _lib.call("mpu_conv2d_pack_weights", _lib.MPU_BF16, UPQ, _lib.ptr(w), ci, co, _lib.ptr(wq), None, _lib.stream_ptr())
-    return wq
 
 
 def conv2d(mode, x0, w_packed, cout, out_hw, bias=None, x1=None, mask=None, relu=False,

@@ -1,0 +1,99 @@
+"""
+The producer / consumer overlap of `mp train` (mpunet/train/trainer.py:238-257: `model.fit(train, workers=5,
+max_queue_size=5)` -- five host threads cut batches while the GPU trains).
+
+Here the producer is the GPU plane sampler itself (data.TrainSampler), so the overlap is between two HIP streams of one
+process instead of between threads: batch i+1 is cut on a high-priority side stream while train step i runs on the main
+stream. The sampler's per-candidate host read (8 bytes of accept / reject statistics) synchronises only the side stream, so the
+host never waits for the train step; the step itself is one HIP-graph replay (UNet.make_graphed_train_step on fixed input
+tensors -- the cut batch is copied into them, 1 MB) and the loss is accumulated on the device and read once per epoch.
+
+  main stream : [copy b_i -> graph inputs][step i .............][copy b_i+1][step i+1 ..........]
+  side stream :          [cut b_i+1: ~16 candidates, each sample + stats + 8-byte read]   [cut b_i+2 ...]
+  host        : replay(i) | sampler loop of b_i+1 (blocks on the side stream only) | replay(i+1) | ...
+
+With data parallelism (model._grad_hook set) the step stays eager (the RCCL all-reduce is not captured); the sampler overlap
+and the device-side loss are the same.
+"""
+import torch
+
+
+class TrainPipeline:
+    def __init__(self, model, sampler, graphed=None, overlap=True):
+        self.model, self.sampler = model, sampler
+        dev = model.device
+        if dev.type != "cuda":
+            raise RuntimeError("TrainPipeline drives the HIP path: it needs a GPU device")
+        B, d = sampler.batch_size, sampler.dim
+        C = int(sampler.volumes[0].n_channels)
+        self.gx = torch.zeros((B, d, d, C), dtype=torch.float32, device=dev)      # the graph's input tensors
+        self.gy = torch.zeros((B, d * d, 1), dtype=torch.uint8, device=dev)
+        self.gw = torch.ones(B, dtype=torch.float32, device=dev)
+        self.loss_sum = torch.zeros(1, dtype=torch.float64, device=dev)           # sum over steps of the step's mean loss
+        self.steps_in_sum = 0
+        self.graphed = (model._grad_hook is None) if graphed is None else bool(graphed)
+        if self.graphed and model._grad_hook is not None:
+            raise NotImplementedError("the graphed step is single-GPU (the gradient all-reduce stays eager)")
+        self.overlap = bool(overlap)
+        self.side = torch.cuda.Stream(device=dev, priority=-1) if self.overlap else None
+        self._replay, self._lr = None, None
+        self._pending = None
+
+    # ---- producer ---------------------------------------------------------------------------------------------------------
+    def _produce(self):
+        """Cut one batch (on the side stream when overlapping). Returns (x, y, w, ready event | None)."""
+        if not self.overlap:
+            return self.sampler() + (None,)
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.side):
+            x, y, w = self.sampler()
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        for t in (x, y, w):                       # allocated on the side stream, read by the copy on the main stream
+            t.record_stream(main)
+        return x, y, w, ev
+
+    # ---- consumer ---------------------------------------------------------------------------------------------------------
+    def _launch_step(self):
+        m = self.model
+        if not self.graphed:
+            loss = m.train_step(self.gx, self.gy, self.gw)
+            self.loss_sum += loss.mean().double()
+            if m.l2_reg:
+                self.loss_sum += m.reg_loss.double()
+            return
+        lr = float(m.optimizer_kwargs["lr"])
+        if self._replay is None or lr != self._lr:      # first step, or ReduceLROnPlateau moved the rate: (re)capture
+            self._replay = m.make_graphed_train_step(self.gx, self.gy, self.gw, loss_sum=self.loss_sum,
+                                                     warmup=self._replay is None)
+            self._lr = lr
+            if self._replay.warmup_ran:                  # the capture's warm-up WAS this step (a real one, loss included)
+                return
+        self._replay()
+
+    def step(self):
+        """One training step on the next batch; returns nothing (the loss stays on the device: epoch_loss())."""
+        if self._pending is None:
+            self._pending = self._produce()
+        x, y, w, ev = self._pending
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        self.gx.copy_(x, non_blocking=True)
+        self.gy.copy_(y.reshape(self.gy.shape), non_blocking=True)
+        self.gw.copy_(w, non_blocking=True)
+        self._launch_step()
+        self.steps_in_sum += 1
+        self._pending = self._produce()                 # overlaps with the step just enqueued
+
+    def epoch_loss(self):
+        """Mean over the steps since the last call of the step's mean weighted per-pixel loss: ONE device read."""
+        n = max(1, self.steps_in_sum)
+        tot = float(self.loss_sum.item())
+        self.loss_sum.zero_()
+        self.steps_in_sum = 0
+        return tot / n
+
+    def run_epoch(self, steps):
+        for _ in range(int(steps)):
+            self.step()
+        return self.epoch_loss()

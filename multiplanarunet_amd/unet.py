@@ -524,11 +524,14 @@ class UNet:
         self._repack()
 
     # ---- HIP-graph replay of the whole step (launch-bound regime) ---------------------------------
-    def make_graphed_train_step(self, x, y, sample_weight=None):
+    def make_graphed_train_step(self, x, y, sample_weight=None, loss_sum=None, warmup=True):
         """
-        Capture forward + backward + Adam + repack (~260 kernel launches) into one HIP graph that reads the
+        Capture forward + backward + Adam + repack (~130 kernel launches) into one HIP graph that reads the
         given DEVICE tensors x, y, sample_weight in place; returns replay() which runs one train step per
         call. Single-GPU only (the RCCL all-reduce stays eager). The Adam step count lives on the device.
+        loss_sum: optional f64 device scalar; every step adds its mean weighted per-pixel loss (+ the l2 term) to it ON THE
+        DEVICE (`mp train` reads it once per epoch, pipeline.TrainPipeline). warmup=False: capture only (a re-capture after
+        a learning-rate change -- the rate is a kernel argument of the captured launches); `replay.warmup_ran` tells.
         """
         if self._grad_hook is not None:
             raise NotImplementedError("graphed train step is single-GPU (gradient all-reduce is eager)")
@@ -540,8 +543,12 @@ class UNet:
         k = self.optimizer_kwargs
 
         def body():
-            self.forward_backward(x, y, sample_weight, want_loss=False)
-            self._add_l2()
+            _, loss = self.forward_backward(x, y, sample_weight, want_loss=loss_sum is not None)
+            self._add_l2(want_loss=loss_sum is not None)
+            if loss_sum is not None:
+                loss_sum.add_(loss.mean().double())
+                if self.l2_reg:
+                    loss_sum.add_(self.reg_loss.double())
             if os.environ.get("MPU_FUSED_ADAM") == "0":         # A/B: the two separate passes
                 _lib.call("mpu_adam_step_device_counter", _lib.ptr(self.params), _lib.ptr(self.grads),
                           _lib.ptr(self._adam_m), _lib.ptr(self._adam_v), self.params.numel(), _lib.ptr(step_dev),
@@ -553,22 +560,25 @@ class UNet:
                       float(k["beta_2"]), float(k["epsilon"]), _lib.ptr(self.packed), _lib.stream_ptr())
             self._infer_dirty = True
 
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                   # warm-up outside capture (lazy inits, allocations)
-            body()
-        torch.cuda.current_stream().wait_stream(side)
+        if warmup:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):               # warm-up outside capture (lazy inits, allocations): a REAL step
+                body()
+            torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             body()
-        self.iterations += 1                            # the warm-up step
+        if warmup:
+            self.iterations += 1                        # the warm-up step
 
         def replay():
             graph.replay()
             self.iterations += 1
             self._infer_dirty = True
         replay.graph = graph
+        replay.warmup_ran = bool(warmup)
         return replay
 
     def train_step(self, x, y, sample_weight=None, want_loss=True):

@@ -111,10 +111,10 @@ def test_halo8_double_buffered_patch_schedule(case):
     assert conv and conv[0] == "halo8", conv                    # the forward launch of the case took the new schedule
 
 
-# Large grids of 128-channel tiles: the 16-row staggered kernel (conv_halo16, round 4). The first case reaches the
-# dispatcher's grid bound (768 tiles) at its real size; the others run in a subprocess with MPU_HALO16_MIN=1 (read once
-# per process) so that small shapes exercise the schedule: chunk boundaries (single-buffered patch reload), concat sources,
-# channel tails (k-step guards), ragged W / N tiles, one-tile grids.
+# Large inference grids of 128-channel tiles: the persistent 16-row staggered kernel (conv_halo16p, round 4). The first case
+# reaches the dispatcher's grid bound (512 tiles) at its real size; the others run in a subprocess with MPU_HALO16_MIN=1 (read
+# once per process) so that small shapes exercise the schedule: chunk boundaries, concat sources, channel tails (k-step
+# guards), ragged W / N tiles, one-tile grids.
 HALO16_BIG = (CONV3, 12, 128, 128, 64, 0, 256)
 HALO16_CASES = [
     # mode,   B, H,  W,  C0,  C1,  Cout          (sources in multiples of 32 channels, an even number of 32-channel chunks)
@@ -145,11 +145,11 @@ def _schedules_of(fn):
 
 @pytest.mark.parametrize("case", HALO16_CASES + [HALO16_BIG])
 def test_halo16_cases(case):
-    """(meaningful under MPU_HALO16=1 MPU_HALO16_MIN=1: test_halo16_subprocess runs it that way and asserts the schedule)"""
+    """(meaningful under MPU_HALO16_MIN=1: test_halo16_subprocess runs it that way and asserts the schedule)"""
     import os
     conv = _schedules_of(lambda: _run_case(case, torch.bfloat16))
-    if os.environ.get("MPU_HALO16") == "1":         # forward: the persistent form (plain epilogue); the masked data gradient: the staged one
-        assert conv and conv[0] == ("halo16" if os.environ.get("MPU_HALO16P") == "0" else "halo16p"), conv
+    if os.environ.get("MPU_HALO16_MIN") == "1" or case == HALO16_BIG:     # forward: the persistent form; the masked data gradient: conv_halo
+        assert conv and conv[0] == "halo16p", conv
     # the same forward WITHOUT the ReLU (the clamp's lower bound is -inf then) and without a bias
     from multiplanarunet_amd import ops
     mode, B, H, W, C0, C1, Cout = case
@@ -166,56 +166,18 @@ def test_halo16_cases(case):
 
 
 def test_halo16_subprocess():
-    """conv_halo16 is an opt-in schedule (MPU_HALO16=1, read once per process): its cases -- and the whole layer suite, with
-    the grid bound lowered so that every eligible small shape takes it -- in a fresh interpreter."""
+    """conv_halo16p with the grid bound lowered (MPU_HALO16_MIN=1, read once per process) so that every eligible small shape of its
+    cases -- and of the whole layer suite -- takes it, in a fresh interpreter."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
-    # three passes: the persistent form with one tile per workgroup (grid = tiles), with 3 workgroups walking many tiles each
-    # (tile boundaries: the look-ahead into the next tile, the store-aware waits), and the staged non-persistent kernel alone
-    for extra in ({}, {"MPU_HALO16P_WGS": "3"}, {"MPU_HALO16P": "0"}):
+    # two passes: one tile per workgroup (grid = tiles), and 3 workgroups walking many tiles each (tile boundaries: the
+    # look-ahead into the next tile, the store-aware waits)
+    for extra in ({}, {"MPU_HALO16P_WGS": "3"}):
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_conv.py"), "-x", "-q", "-k",
                             "halo16_cases or forward_dgrad_wgrad"],
-                           env=dict(os.environ, MPU_HALO16="1", MPU_HALO16_MIN="1", **extra),
+                           env=dict(os.environ, MPU_HALO16_MIN="1", **extra),
                            capture_output=True, text=True, cwd=os.path.dirname(here))
         assert r.returncode == 0, str(extra) + r.stdout[-2000:] + r.stderr[-2000:]
-
-
-UPQ_CASES = [
-    # B, Ho, Wo,  Cin, Cout      (output size; the low-resolution input is Ho/2 x Wo/2)
-    (2, 16, 64, 64, 128),        # one low-resolution tile row, one chunk
-    (1, 32, 96, 72, 40),         # channel tail (64 + 8), 64-channel tile variant with ragged N, three tile columns
-    (3, 18, 66, 64, 64),         # 9 x 33 low-resolution pixels: ragged tiles both ways, far-edge zero padding inside a tile
-    (1, 64, 128, 256, 136),      # four chunks (patch reloads), two n-tiles
-    (2, 48, 64, 128, 128),       # three tile rows
-]
-
-
-@pytest.mark.parametrize("case", UPQ_CASES)
-def test_tap_combined_upconv_inference_form(case):
-    """conv_halo UPQ (round 4): UpSampling2D(2) + Conv2D(2x2, SAME) with the kernel taps combined per output-pixel parity
-    class (9 MFMA taps per output quad instead of 16; weights summed in fp32 and rounded ONCE, so the result differs from the
-    four-tap evaluation by one bf16 rounding of a weight) against the fp64 reference of the layer, through the C-ABI
-    (mpu_conv2d_pack_weights / mpu_conv2d_igemm mode 4)."""
-    from multiplanarunet_amd import ops
-    B, H, W, Cin, Cout = case
-    g = torch.Generator().manual_seed(hash(case) % 2**31)
-    x = rnd(torch.randn(B, H // 2, W // 2, Cin, generator=g), torch.bfloat16)
-    w = rnd(torch.randn(2, 2, Cin, Cout, generator=g) / np.sqrt(4 * Cin), torch.bfloat16)
-    b = torch.randn(Cout, generator=g).to(torch.float64) * 0.1
-    ref = torch.relu(ref_forward(UPCONV2, x, w, b))
-    wq = ops.pack_weights_upq(w.to("cuda", torch.float32))
-    conv = _schedules_of(lambda: None)
-    got = {}
-    def run():
-        got["y"] = ops.conv2d(ops.UPQ, x.to("cuda", torch.bfloat16), wq, Cout, (H, W), bias=b.to("cuda", torch.float32), relu=True)
-    conv = _schedules_of(run)
-    assert conv == ["halo-upq"], conv
-    rt, at = tol(torch.bfloat16, ref)
-    np.testing.assert_allclose(got["y"].cpu().double().numpy(), ref.numpy(), rtol=rt, atol=at)
-    # ... and it agrees with the four-tap kernel on the same operands to the same tolerance
-    wf, _ = ops.pack_weights(w.to("cuda", torch.float32), UPCONV2, torch.bfloat16)
-    y4 = ops.conv2d(UPCONV2, x.to("cuda", torch.bfloat16), wf, Cout, (H, W), bias=b.to("cuda", torch.float32), relu=True)
-    np.testing.assert_allclose(got["y"].cpu().double().numpy(), y4.cpu().double().numpy(), rtol=rt, atol=at)
 
 
 @pytest.mark.parametrize("case", DEEP_CASES)

@@ -80,6 +80,26 @@ def test_capi_library_exports_every_declared_symbol():
     assert ctypes.sizeof(_lib.VoxelGrid) == 72 + 24 + 16
 
 
+def test_library_carries_the_hash_of_its_sources_and_a_stale_one_is_refused(monkeypatch):
+    """build.py compiles sha256(sources, headers, flags) into the library; _lib.load() refuses a library built from other
+    sources (round 4: build() compared mtimes only and could ship a stale binary)."""
+    from multiplanarunet_amd import build as B
+    want = B.expected_hash()
+    assert len(want) == 16 and _lib.build_hash() == want
+
+    class Stale:
+        @staticmethod
+        def mpu_build_hash():
+            return b"0123456789abcdef"
+    monkeypatch.delenv("MPU_LIB_PATH", raising=False)
+    with pytest.raises(_lib.MpuError, match="built from other sources"):
+        _lib._check_build_hash(Stale)
+    # the hash moves with a flag and with a header byte
+    from multiplanarunet_amd import srchash
+    assert srchash.build_sha16(lambda s: B.flags_of(s) + ["-DX"]) != want
+    assert srchash.unit_sha16("env.hip", B.flags_of("env.hip"), b"other headers") != srchash.unit_sha16("env.hip", B.flags_of("env.hip"))
+
+
 def test_axis_closed_forms_reproduce_the_arrays_bitwise(golden):
     """make_axis only claims a closed form when it reproduces the reference's axis array exactly."""
     def rebuild(a):
