@@ -260,6 +260,16 @@ int mpu_fusion_train_step(const float* d_x, const uint8_t* d_y, int64_t n, int32
                           int32_t n_classes, float* d_W, float* d_b, float* d_adam_m, float* d_adam_v,
                           int64_t t, double lr, double beta1, double beta2, double eps,
                           float* d_workspace, float* d_grads_out, float* d_loss_out, void* stream);
+/* The same step in two halves for data-parallel fitting (the reference builds its models under
+ * tf.distribute.MirroredStrategy, mpunet/bin/train_fusion.py:336): every rank turns ITS share of the batch (n >= 0 points)
+ * into d_sums[V*K + K + 2] doubles -- the gradient SUMS of the data term, the summed per-point loss and, last, its point count
+ * -- the host SUM-all-reduces the doubles over the ranks, and mpu_fusion_apply_sums divides by the total count, adds the
+ * regularisers and applies the Adam step. With one rank the pair gives bit for bit what mpu_fusion_train_step gives. */
+int mpu_fusion_grad_sums(const float* d_x, const uint8_t* d_y, int64_t n, int32_t n_views, int32_t n_classes,
+                         const float* d_W, const float* d_b, float* d_workspace, double* d_sums, void* stream);
+int mpu_fusion_apply_sums(const double* d_sums, int32_t n_views, int32_t n_classes, float* d_W, float* d_b,
+                          float* d_adam_m, float* d_adam_v, int64_t t, double lr, double beta1, double beta2,
+                          double eps, float* d_grads_out, float* d_loss_out, void* stream);
 
 /* Data-parallel training: the backward pass finishes the flat gradient buffer from its END towards its start
  * (head, up blocks, bottom, encoder levels). mpu_unet_grad_ready_points returns the number of ready points and

@@ -113,6 +113,8 @@ _SIGS = {
     "mpu_fusion_train_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "mpu_fusion_train_step": (C.c_int, [c_p, c_p, i64, C.c_int32, C.c_int32, c_p, c_p, c_p, c_p, i64, f64, f64, f64, f64,
                                         c_p, c_p, c_p, c_p]),
+    "mpu_fusion_grad_sums": (C.c_int, [c_p, c_p, i64, C.c_int32, C.c_int32, c_p, c_p, c_p, c_p, c_p]),
+    "mpu_fusion_apply_sums": (C.c_int, [c_p, C.c_int32, C.c_int32, c_p, c_p, c_p, c_p, i64, f64, f64, f64, f64, c_p, c_p, c_p]),
     "mpu_unet_grad_ready_points": (C.c_int32, [c_p, c_p, C.c_int32]),
     "mpu_unet_backward_events": (C.c_int, [c_p, C.c_int32] + [c_p] * 8 + [c_p, C.c_int32, c_p]),
     "mpu_adam_step_device_counter": (C.c_int, [c_p, c_p, c_p, c_p, i64, c_p, f64, f64, f64, f64, c_p]),

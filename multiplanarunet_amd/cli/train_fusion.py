@@ -5,6 +5,12 @@
 shuffled, split 80/20, and the FusionLayer is fitted with the per-point generalized Dice loss and Adam(1e-3)
 (FusionModel.fit -> mpu_fusion_train_step), early-stopped on the validation Dice. Weights are written to
 <project>/model/fusion_weights/<model>_fusion_weights.npz, where `mp predict` looks for them.
+
+--num_GPUs N (one process per GPU under torch.distributed; the reference builds its models under MirroredStrategy,
+train_fusion.py:336): the IMAGES of a round are dealt over the ranks -- each rank predicts and maps all views of its images
+(the expensive part: V U-Net passes per image) and keeps their points -- and FusionModel.fit runs data parallel: per step one
+SUM all-reduce of V*K + K + 2 doubles, per epoch one of the 3K validation counts. Every rank holds the same FusionLayer
+weights at all times; rank 0 alone writes the weights file.
 """
 import os
 from argparse import ArgumentParser
@@ -50,6 +56,10 @@ def collect_points(model, sampler, volumes, views, n_classes, batch_size, log, e
     from ..interpolation import dice_all
     rng = rng or np.random
     xs, ys = [], []
+    if not volumes:                                        # a rank without an image in this round (fewer images than ranks)
+        dev = model.device
+        return (torch.empty((0, len(views), n_classes), dtype=torch.float32, device=dev),
+                torch.empty((0,), dtype=torch.uint8, device=dev))
     for vol in volumes:
         n = int(np.prod(vol.image.shape[:3]))
         pts = torch.empty((n, len(views), n_classes), dtype=torch.float32, device=vol.image.device)
@@ -72,9 +82,15 @@ def run(args):
     validate_project_dir(project_dir)
     if args.force_GPU:
         os.environ["HIP_VISIBLE_DEVICES"] = args.force_GPU
-    device = torch.device("cuda")
-    log = lambda *a, **k: print(*a, flush=True)
-    rng = np.random.RandomState(args.seed)
+    from .. import distributed as D
+    rank, world, device = D.init_from_env()
+    log = (lambda *a, **k: print(*a, flush=True)) if rank == 0 else (lambda *a, **k: None)
+    seed = args.seed
+    if world > 1:                                          # every rank draws the same image order, rounds and splits
+        box = [int(np.random.randint(0, 2 ** 31 - 1)) if seed is None else int(seed)]
+        torch.distributed.broadcast_object_list(box, src=0)
+        seed = box[0]
+    rng = np.random.RandomState(seed)
     hp = load_hparams(project_dir)
     fit, build = hp["fit"], hp["build"]
     views = np.load(os.path.join(project_dir, "views.npz"))["arr_0"]
@@ -115,21 +131,28 @@ def run(args):
     rng.shuffle(ids)
     rounds = np.array_split(ids, len(ids) // sub)
     history = []
-    os.makedirs(fdir, exist_ok=True)
+    if rank == 0:
+        os.makedirs(fdir, exist_ok=True)
     for r, ids_r in enumerate(rounds):
         log("Set %d/%d: %s" % (r + 1, len(rounds), [images[i].identifier for i in ids_r]))
-        X, y = collect_points(unet, sampler, [images[i] for i in ids_r], views, n_classes, int(fit["batch_size"]),
-                              log, args.eval_prob, rng)
-        perm = torch.from_numpy(rng.permutation(X.shape[0])).to(device)
+        mine = [images[i] for i in list(ids_r)[rank::world]]          # the round's images dealt over the ranks
+        eval_rng = np.random.RandomState(int(rng.randint(0, 2 ** 31 - 1)) + rank)   # (keeps `rng` in step on every rank)
+        X, y = collect_points(unet, sampler, mine, views, n_classes, int(fit["batch_size"]),
+                              log, args.eval_prob, eval_rng)
+        fit_seed = int(rng.randint(0, 2 ** 31 - 1))
+        perm = torch.from_numpy(np.random.RandomState(fit_seed + 7919 * rank).permutation(X.shape[0])).to(device)
         X, y = X[perm], y[perm]
-        nv = int(0.20 * X.shape[0])
+        nv = int(0.20 * X.shape[0])                                   # 80 / 20 split of the rank's own points
         h = fm.fit(X[nv:], y[nv:], batch_size=args.batch_size, epochs=args.epochs, validation_data=(X[:nv], y[:nv]),
-                   early_stopping=args.early_stopping, verbose=1, seed=int(rng.randint(0, 2 ** 31 - 1)))
+                   early_stopping=args.early_stopping, verbose=1, seed=fit_seed + rank)
         history.append(h)
-        fm.save_weights(fpath)
+        if rank == 0:                                                 # one writer (the weights are identical on every rank)
+            fm.save_weights(fpath)
         W, b = fm.get_weights()
         log("fusion weights W:\n%s\nb: %s" % (np.round(W, 4), np.round(b, 4)))
         del X, y
+    if world > 1:
+        torch.distributed.barrier()
     log("Saved fusion weights:", fpath)
     return history
 

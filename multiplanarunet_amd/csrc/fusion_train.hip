@@ -126,6 +126,60 @@ __global__ __launch_bounds__(256) void fusion_update_kernel(const float* __restr
     }
 }
 
+// ---- data-parallel form: the step in two halves with the replica SUM between them -----------
+// stage 2a: column sums of the block partials in fp64, fixed order -> sums[V*K + K + 1] (gradient SUMS of the data term and the
+// summed per-point loss over THIS rank's points) and sums[nacc] = the rank's point count. The host all-reduces the nacc + 1 doubles.
+__global__ __launch_bounds__(256) void fusion_sums_kernel(const float* __restrict__ partial, int nblk, int nacc, long n,
+                                                          double* __restrict__ sums) {
+    for (int a = threadIdx.x; a <= nacc; a += 256) {
+        if (a == nacc) { sums[a] = (double)n; continue; }
+        double s = 0.0;
+        for (int k = 0; k < nblk; ++k) s += (double)partial[(long)k * nacc + a];
+        sums[a] = s;
+    }
+}
+// stage 2b: exactly fusion_update_kernel's arithmetic on the (all-reduced) sums; n = sums[nacc] = the points of all ranks
+__global__ __launch_bounds__(256) void fusion_apply_kernel(const double* __restrict__ sums, int V, int K, float* W, float* b,
+                                                           float* m, float* v2, double alpha, float b1, float b2, float eps,
+                                                           int apply, float* grads_out, float* loss_out) {
+    const int np = V * K + K, nacc = np + 1;
+    const double n = sums[nacc];
+    for (int a = threadIdx.x; a < nacc; a += 256) {
+        const double s = sums[a];
+        if (a == np) {
+            double rw = 0.0, rb = 0.0;
+            for (int i = 0; i < V * K; ++i) rw += (double)W[i] * (double)W[i];
+            for (int i = 0; i < K; ++i) rb += (double)b[i] * (double)b[i];
+            if (loss_out) *loss_out = (float)(s / n + 1e-6 * rw / (V * K) + 1e-6 * rb / K);
+            continue;
+        }
+        float* p = a < V * K ? &W[a] : &b[a - V * K];
+        const double regd = a < V * K ? 2e-6 * (double)*p / (V * K) : 2e-6 * (double)*p / K;
+        const float g = (float)(s / n + regd);
+        if (grads_out) grads_out[a] = g;
+        if (apply) {
+            const float mm = m[a] + (g - m[a]) * (1.f - b1);
+            const float vv = v2[a] + (g * g - v2[a]) * (1.f - b2);
+            m[a] = mm; v2[a] = vv;
+            *p = *p - (mm * (float)alpha) / (sqrtf(vv) + eps);
+        }
+    }
+}
+
+int launch_fusion_grad(const float* d_x, const uint8_t* d_y, long n, int V, int K, const float* d_W, const float* d_b,
+                       float* d_workspace, long* blocks_out, hipStream_t st) {
+    long blocks = (n + 255) / 256; if (blocks > FT_MAX_BLOCKS) blocks = FT_MAX_BLOCKS;
+    *blocks_out = blocks;
+    if (blocks == 0) return MPU_OK;                              // a rank without points in this batch
+#define MPU_FT_CASE(KK) case KK: fusion_grad_kernel<KK><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d_x, d_y, n, V, d_W, d_b, d_workspace); break;
+    switch (K) {
+        MPU_FT_CASE(1) MPU_FT_CASE(2) MPU_FT_CASE(3) MPU_FT_CASE(4) MPU_FT_CASE(5) MPU_FT_CASE(6) MPU_FT_CASE(7) MPU_FT_CASE(8)
+        default: return fail(MPU_EINVAL, "%s", "mpu_fusion_train: bad class count");
+    }
+#undef MPU_FT_CASE
+    return launch_ok();
+}
+
 }  // namespace
 }  // namespace mpu
 
@@ -146,19 +200,39 @@ int mpu_fusion_train_step(const float* d_x, const uint8_t* d_y, int64_t n, int32
                 "mpu_fusion_train_step: need n >= 1, 1 <= views <= 16, 1 <= classes <= 8");
     MPU_REQUIRE(t == 0 || (d_adam_m && d_adam_v && t >= 1), "mpu_fusion_train_step: Adam state missing");
     hipStream_t st = (hipStream_t)stream;
-    long blocks = (n + 255) / 256; if (blocks > FT_MAX_BLOCKS) blocks = FT_MAX_BLOCKS;
-#define MPU_FT_CASE(KK) case KK: fusion_grad_kernel<KK><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d_x, d_y, (long)n, n_views, d_W, d_b, d_workspace); break;
-    switch (n_classes) {
-        MPU_FT_CASE(1) MPU_FT_CASE(2) MPU_FT_CASE(3) MPU_FT_CASE(4) MPU_FT_CASE(5) MPU_FT_CASE(6) MPU_FT_CASE(7) MPU_FT_CASE(8)
-        default: return fail(MPU_EINVAL, "%s", "mpu_fusion_train_step: bad class count");
-    }
-#undef MPU_FT_CASE
-    int rc = launch_ok();
+    long blocks = 0;
+    int rc = launch_fusion_grad(d_x, d_y, (long)n, n_views, n_classes, d_W, d_b, d_workspace, &blocks, st);
     if (rc) return rc;
     const double alpha = t >= 1 ? lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t)) : 0.0;
     fusion_update_kernel<<<1, 256, 0, st>>>(d_workspace, (int)blocks, n_views, n_classes, (long)n, d_W, d_b, d_adam_m,
                                             d_adam_v, alpha, (float)beta1, (float)beta2, (float)eps, t >= 1 ? 1 : 0,
                                             d_grads_out, d_loss_out);
+    return launch_ok();
+}
+
+int mpu_fusion_grad_sums(const float* d_x, const uint8_t* d_y, int64_t n, int32_t n_views, int32_t n_classes,
+                         const float* d_W, const float* d_b, float* d_workspace, double* d_sums, void* stream) {
+    MPU_REQUIRE(d_W && d_b && d_workspace && d_sums && (n == 0 || (d_x && d_y)), "mpu_fusion_grad_sums: null argument");
+    MPU_REQUIRE(n >= 0 && n_views >= 1 && n_views <= FT_MAXV && n_classes >= 1 && n_classes <= 8,
+                "mpu_fusion_grad_sums: need n >= 0, 1 <= views <= 16, 1 <= classes <= 8");
+    hipStream_t st = (hipStream_t)stream;
+    long blocks = 0;
+    int rc = launch_fusion_grad(d_x, d_y, (long)n, n_views, n_classes, d_W, d_b, d_workspace, &blocks, st);
+    if (rc) return rc;
+    fusion_sums_kernel<<<1, 256, 0, st>>>(d_workspace, (int)blocks, n_views * n_classes + n_classes + 1, (long)n, d_sums);
+    return launch_ok();
+}
+
+int mpu_fusion_apply_sums(const double* d_sums, int32_t n_views, int32_t n_classes, float* d_W, float* d_b,
+                          float* d_adam_m, float* d_adam_v, int64_t t, double lr, double beta1, double beta2, double eps,
+                          float* d_grads_out, float* d_loss_out, void* stream) {
+    MPU_REQUIRE(d_sums && d_W && d_b, "mpu_fusion_apply_sums: null argument");
+    MPU_REQUIRE(n_views >= 1 && n_views <= FT_MAXV && n_classes >= 1 && n_classes <= 8, "mpu_fusion_apply_sums: bad shape");
+    MPU_REQUIRE(t == 0 || (d_adam_m && d_adam_v && t >= 1), "mpu_fusion_apply_sums: Adam state missing");
+    const double alpha = t >= 1 ? lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t)) : 0.0;
+    fusion_apply_kernel<<<1, 256, 0, (hipStream_t)stream>>>(d_sums, n_views, n_classes, d_W, d_b, d_adam_m, d_adam_v, alpha,
+                                                            (float)beta1, (float)beta2, (float)eps, t >= 1 ? 1 : 0, d_grads_out,
+                                                            d_loss_out);
     return launch_ok();
 }
 

@@ -261,3 +261,110 @@ def test_gloo_world8_sharded_predict_and_bucketed_allreduce():
         assert all(v for k, v in ok.items() if not k.endswith("_items")), (rank, ok)
     items = sorted(ok["reduce_scatter_items"] for _, ok in res)
     assert items[0] >= 1 and sum(items) == 24            # 3 views x 8 chunks dealt over 8 ranks
+
+
+# --------------------------------------------------------------------------- #
+# SURVEY 8e row 3 (round 5): data-parallel FusionModel.fit. Two gloo ranks, each holding every second point of every
+# batch, must end with the weights / losses / val_dice of ONE rank fitting all points (shuffle off; fp32 sum order aside).
+# The three HIP-backed pieces (local gradient sums, apply, forward) are replaced by torch-CPU restatements built on
+# oracle/fusion_train_ref.py, so what runs here is the product's orchestration: batch shares, the two all-reduces,
+# ranks that run out of points, the shared early-stopping decision.
+# --------------------------------------------------------------------------- #
+def _fusion_points(n=1500, V=3, K=3, seed=3):
+    rng = np.random.RandomState(seed)
+    y = rng.randint(0, K, n).astype(np.uint8)
+    x = rng.rand(n, V, K).astype(np.float32)
+    x[np.arange(n), :, y] += 0.6 * rng.rand(n, V).astype(np.float32)       # views lean towards the target class
+    x /= x.sum(-1, keepdims=True)
+    return x, y
+
+
+def _install_fusion_standins(fm):
+    from oracle import fusion_train_ref as FR
+    from oracle.unet_ref import adam_update
+    V, K = fm.n_inputs, fm.n_classes
+
+    def local_sums(xd, yd):
+        out = torch.zeros(V * K + K + 2, dtype=torch.float64)
+        n = int(xd.shape[0])
+        out[-1] = n
+        if n:
+            W = fm.W.double().clone().requires_grad_(True)
+            b = fm.b.double().clone().requires_grad_(True)
+            ls = FR.sparse_generalized_dice_loss(yd.long(), FR.fusion_forward(W, b, xd.double()), fm.weight).sum()
+            ls.backward()
+            out[:V * K] = W.grad.reshape(-1); out[V * K:V * K + K] = b.grad.reshape(-1); out[V * K + K] = ls.detach()
+        return out
+
+    def apply_sums(sums, apply=True, want_grads=False):
+        n = float(sums[-1])
+        W, b = fm.W.double(), fm.b.double()
+        loss = sums[V * K + K] / n + FR.reg(W) + FR.reg(b)
+        gW = (sums[:V * K].reshape(V, K) / n + 2e-6 * W / (V * K)).float().numpy()
+        gb = (sums[V * K:V * K + K].reshape(1, K) / n + 2e-6 * b / K).float().numpy()
+        if apply:
+            fm.iterations += 1
+            k = fm.optimizer_kwargs
+            mW, mb = fm._adam_m[:V * K].reshape(V, K).numpy(), fm._adam_m[V * K:].reshape(1, K).numpy()
+            vW, vb = fm._adam_v[:V * K].reshape(V, K).numpy(), fm._adam_v[V * K:].reshape(1, K).numpy()
+            W2, mW2, vW2 = adam_update(fm.W.numpy(), gW, mW, vW, fm.iterations, k["lr"], k["beta_1"], k["beta_2"], k["epsilon"])
+            b2, mb2, vb2 = adam_update(fm.b.numpy(), gb, mb, vb, fm.iterations, k["lr"], k["beta_1"], k["beta_2"], k["epsilon"])
+            fm.W, fm.b = torch.tensor(np.asarray(W2, np.float32)), torch.tensor(np.asarray(b2, np.float32))
+            fm._adam_m = torch.tensor(np.concatenate([np.ravel(mW2), np.ravel(mb2)]).astype(np.float32))
+            fm._adam_v = torch.tensor(np.concatenate([np.ravel(vW2), np.ravel(vb2)]).astype(np.float32))
+        return loss.float().reshape(1), None
+
+    fm._local_sums = local_sums
+    fm._apply_sums = apply_sums
+    fm.predict = lambda x, batch_size=0, verbose=0: FR.fusion_forward(fm.W.double(), fm.b.double(), torch.as_tensor(x).double()).float()
+
+
+def _fit_fusion(x, y, xv, yv, batch_size, epochs, early):
+    from multiplanarunet_amd.fusion_model import FusionModel
+    fm = FusionModel(x.shape[1], x.shape[2], weight="Simple", verbose=False, device="cpu", logger=lambda *a: None)
+    fm.compile("Adam", optimizer_kwargs={"lr": 5e-2})
+    _install_fusion_standins(fm)
+    h = fm.fit(x, y, batch_size=batch_size, epochs=epochs, shuffle=False, validation_data=(xv, yv), early_stopping=early,
+               data_parallel=True)
+    return fm.get_weights(), h, fm.iterations
+
+
+def _worker_fusion(rank, world, port, q, scenario):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init_from_env("gloo")
+    x, y = _fusion_points()
+    xv, yv = _fusion_points(400, seed=11)
+    if scenario == "interleaved":          # rank r holds points r, r + world, ...: the union of the shares of step j is batch j
+        xs, ys, xvs, yvs = x[rank::world], y[rank::world], xv[rank::world], yv[rank::world]
+    else:                                  # "starved": rank 1 holds no points at all (fewer images than ranks)
+        xs, ys, xvs, yvs = (x, y, xv, yv) if rank == 0 else (x[:0], y[:0], xv[:0], yv[:0])
+    (W, b), h, it = _fit_fusion(xs, ys, xvs, yvs, 400, 6, 2)
+    q.put((rank, W, b, h, it))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["interleaved", "starved"])
+def test_gloo_world2_fusion_fit_equals_one_rank(scenario):
+    x, y = _fusion_points()
+    xv, yv = _fusion_points(400, seed=11)
+    # one rank, all points. "starved": rank 0 takes ceil(400 / 2) = 200 points per step, so the reference run uses batch 200
+    (W1, b1), h1, it1 = _fit_fusion(x, y, xv, yv, 400 if scenario == "interleaved" else 200, 6, 2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + (7 if scenario == "starved" else 0)
+    procs = [ctx.Process(target=_worker_fusion, args=(r, 2, port, q, scenario)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+    assert [r[0] for r in res] == [0, 1]
+    for rank, W, b, h, it in res:
+        assert it == it1 and len(h["loss"]) == len(h1["loss"])              # same number of steps and epochs on every rank
+        np.testing.assert_allclose(W, W1, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(b, b1, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(h["loss"], h1["loss"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(h["val_dice"], h1["val_dice"], rtol=0, atol=1e-7)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])   # identical on both ranks, bitwise
+    assert np.abs(W1 - 1.0).max() > 1e-2                                                   # (the fit moved the weights)

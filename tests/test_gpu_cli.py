@@ -83,3 +83,18 @@ def test_mp_train_then_predict_synthetic(tmp_path):
     assert lab2.shape == (64, 64, 64) and (lab2 != lab_npz).mean() <= 1e-3
     res4 = (proj / "predictions_2gpu" / "csv" / "results.csv").read_text().splitlines()
     assert abs(float(res4[1].split(",")[1]) - float(res2[1].split(",")[1])) <= 2e-3, (res4, res2)
+    # `mp train_fusion --num_GPUs 2` (round 5): two ranks (sharing GPU 0 over gloo here) deal the round's images,
+    # fit data parallel and write ONE weights file; the learned layer predicts as well as the one-rank fit's
+    before = set(os.listdir(fdir))
+    r = subprocess.run([sys.executable, "-m", "multiplanarunet_amd.cli.mp", "train_fusion", "--project_dir", str(proj), "--synthetic", "2",
+                        "--epochs", "4", "--images_per_round", "2", "--batch_size", "65536", "--seed", "0", "--overwrite",
+                        "--num_GPUs", "2"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert set(os.listdir(fdir)) == before and len(before) == 1            # one writer, the same single file
+    assert r.stdout.count("Saved fusion weights:") == 1                    # rank 0 alone reports
+    z2 = np.load(fdir / files[0])
+    assert z2["W"].shape == (3, 3) and not np.allclose(z2["W"], 1.0)
+    mp.entry_func(["predict", "--project_dir", str(proj), "--synthetic", "1", "--overwrite"])
+    res5 = (proj / "predictions" / "csv" / "results.csv").read_text().splitlines()
+    assert float(res5[1].split(",")[1]) > 0.5 and abs(float(res5[1].split(",")[1]) - float(res2[1].split(",")[1])) <= 2e-2, (res5, res2)
