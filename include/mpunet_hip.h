@@ -394,6 +394,10 @@ int mpu_probe_mfma_bf16(int32_t blocks, int32_t iters, float* d_sink, double* fl
 /* the same loop on pseudo-random bf16 operands: the matrix rate the part sustains under its POWER limit on real data */
 int mpu_probe_mfma_bf16_random(int32_t blocks, int32_t iters, float* d_sink, double* flops, void* stream);
 int mpu_probe_stream_triad(float* d_a, const float* d_b, const float* d_c, int64_t n, void* stream);
+/* dst = src over n floats (n % 4096 == 0), 16 bytes per lane, four float4s per thread in flight: 8 * n bytes of HBM traffic -- the
+ * "float4 copy" MI355X_MICROARCH.md quotes at 6.29 TB/s. variant 0: default cache policy; 1: non-temporal loads and stores;
+ * 2: default policy, grid-stride. */
+int mpu_probe_stream_copy(float* d_dst, const float* d_src, int64_t n, int32_t variant, void* stream);
 /* out[i] = x[3i] + x[3i+1] + x[3i+2]: 12 contiguous bytes per lane, 12 n bytes read exactly once -- the access width of
  * the fused back-mapping's K = 3 gathers; calibrates rocprofv3's FETCH_SIZE for that width (MI355X_MICROARCH.md: the
  * gfx950 x2 correction is established for 16-byte accesses only). */

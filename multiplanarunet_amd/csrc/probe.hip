@@ -85,6 +85,36 @@ __global__ __launch_bounds__(256) void probe_triad_kernel(float4* __restrict__ a
     }
 }
 
+// dst = src, 16 bytes per lane, UNROLL float4s per thread with all loads in flight before the first store: the "float4 copy"
+// the guide quotes at 6.29 TB/s (MI355X_MICROARCH.md, chip table). VARIANT 0: default cache policy, one shot (a workgroup per
+// 256 * UNROLL float4s); 1: non-temporal loads and stores (streamed once: do not keep the lines); 2: default policy, grid-stride
+// over 256 * 32 workgroups (the triad probe's shape). Settles whether this pool's boxes reach that rate.
+// (n4 is a multiple of 256 * UNROLL: no tail guards -- a guarded store drags its load under the branch and serialises the
+// four round trips, the "serialised loads" of DESIGN section 5.)
+template <int VARIANT, int UNROLL>
+__global__ __launch_bounds__(256) void probe_copy_kernel(float4* __restrict__ dst, const float4* __restrict__ src, long n4) {
+    const long stride = VARIANT == 2 ? (long)gridDim.x * blockDim.x * UNROLL : n4;
+    for (long base = ((long)blockIdx.x * UNROLL) * blockDim.x + threadIdx.x; base < n4; base += stride) {
+        float4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const float4* p = src + base + (long)u * blockDim.x;
+            if (VARIANT == 1) {
+                v[u].x = __builtin_nontemporal_load(&p->x); v[u].y = __builtin_nontemporal_load(&p->y);
+                v[u].z = __builtin_nontemporal_load(&p->z); v[u].w = __builtin_nontemporal_load(&p->w);
+            } else v[u] = *p;
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            float4* q = dst + base + (long)u * blockDim.x;
+            if (VARIANT == 1) {
+                __builtin_nontemporal_store(v[u].x, &q->x); __builtin_nontemporal_store(v[u].y, &q->y);
+                __builtin_nontemporal_store(v[u].z, &q->z); __builtin_nontemporal_store(v[u].w, &q->w);
+            } else *q = v[u];
+        }
+    }
+}
+
 // out[i] = x[3i] + x[3i+1] + x[3i+2]: every lane reads 12 contiguous bytes (the K = 3 gather width of the fused
 // back-mapping), the wave 768 contiguous bytes: 12 n bytes read exactly once. Calibrates FETCH_SIZE for 12-byte accesses.
 __global__ __launch_bounds__(256) void probe_gather12_kernel(const float* __restrict__ x, float* __restrict__ out, long n) {
@@ -144,6 +174,21 @@ int mpu_probe_mfma_bf16_random(int32_t blocks, int32_t iters, float* d_sink, dou
     MPU_REQUIRE(blocks > 0 && iters > 0 && d_sink, "mpu_probe_mfma_bf16_random: bad argument");
     probe_mfma_random_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(iters, d_sink);
     if (flops) *flops = (double)blocks * 4.0 * iters * 8.0 * 2.0 * 32 * 32 * 16;
+    return launch_ok();
+}
+
+// dst = src over n floats (n % 4096 == 0); HBM bytes moved = 8 * n. variant 0: default policy, one shot; 1: non-temporal; 2: default
+// policy, grid-stride.
+int mpu_probe_stream_copy(float* d_dst, const float* d_src, int64_t n, int32_t variant, void* stream) {
+    constexpr int U = 4;
+    MPU_REQUIRE(d_dst && d_src && n > 0 && n % (4 * 256 * U) == 0 && variant >= 0 && variant <= 2,
+                "mpu_probe_stream_copy: bad argument (n must be a multiple of 4096)");
+    const long n4 = n / 4;
+    const long blocks = n4 / (256L * U);
+    hipStream_t st = (hipStream_t)stream;
+    if (variant == 0) probe_copy_kernel<0, U><<<dim3((unsigned)blocks), dim3(256), 0, st>>>((float4*)d_dst, (const float4*)d_src, n4);
+    else if (variant == 1) probe_copy_kernel<1, U><<<dim3((unsigned)blocks), dim3(256), 0, st>>>((float4*)d_dst, (const float4*)d_src, n4);
+    else probe_copy_kernel<2, U><<<dim3((unsigned)(blocks < 256L * 32 ? blocks : 256L * 32)), dim3(256), 0, st>>>((float4*)d_dst, (const float4*)d_src, n4);
     return launch_ok();
 }
 

@@ -279,10 +279,18 @@ def _predict_properties(D, C_, K, dim_batch=None):
                            lo, hi, owns_oob=(lo == 0), z=z)
             del Xs, pred
     _, lab3 = fusion_finalize(z, fm.b, want_probs=False)
-    mism = float((lab3 != lab).float().mean().item())
-    print("predict %d^3 x %d K=%d: %s; fused vs accumulate path mismatching voxels %.2e; label histogram %s"
-          % (D, C_, K, {k: round(v, 1) for k, v in t.items()}, mism, hist.tolist()))
-    assert mism <= 1e-4
+    # Both paths take the SAME back-mapping decision for every voxel (integer work: exact); their f32 sums over the views
+    # differ in contraction only, so a label may differ solely where the two largest fused scores tie within float noise.
+    zb = z + torch.as_tensor(fm.b, device=z.device).reshape(1, 1, 1, K)
+    top2 = zb.topk(2, dim=-1).values
+    margin = top2[..., 0] - top2[..., 1]
+    diff = lab3 != lab
+    outside = diff & (margin > 8e-6 * top2[..., 0].abs().clamp_min(1.0))
+    n_diff, n_out = int(diff.sum().item()), int(outside.sum().item())
+    print("predict %d^3 x %d K=%d: %s; fused vs accumulate path: %d labels differ, %d outside the float tie band; label histogram %s"
+          % (D, C_, K, {k: round(v, 1) for k, v in t.items()}, n_diff, n_out, hist.tolist()))
+    assert n_out == 0 and n_diff <= 1e-5 * D ** 3
+    del zb, top2, margin, diff, outside
     return t
 
 

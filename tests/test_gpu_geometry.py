@@ -1,9 +1,11 @@
 """
 GPU parity: HIP resampling / back-mapping / fusion kernels (through the C ABI)
-against the reference goldens and the oracle. Tolerances: sampled image values
-atol 2e-6 (fp64 accumulate -> f32; expected bit-exact), labels / mapped
-vectors exact except fp64-tie voxels (<= 1e-3 of voxels), fusion probabilities
-atol 1e-6.
+against the reference goldens and the oracle. Integer / index work is held to EXACT equality (round 5; rounds 1-4
+allowed 1e-3 of the voxels to differ and observed 0): sampled image values bit for bit (fp64 accumulate -> f32 as the
+reference computes them), nearest labels and back-mapped vectors identical, ties as NumPy breaks them. Floating point:
+fusion probabilities atol 2e-6; a fused LABEL (argmax of f32 sums whose summation order differs between NumPy and the
+kernel) may differ only where the oracle's two largest values are closer than that float band -- those voxels are
+counted, everything outside the band must be identical.
 """
 import numpy as np
 import pytest
@@ -12,6 +14,18 @@ import torch
 pytestmark = pytest.mark.gpu
 
 AFFS = ("ident", "aniso", "rot")
+
+
+def assert_labels_equal_outside_float_ties(got, ref_labels, ref_scores, band=8e-6):
+    """argmax of float scores: identical wherever the reference's top-2 margin exceeds `band` (relative to the largest
+    score); returns the number of differing voxels inside the band."""
+    srt = np.sort(np.asarray(ref_scores, np.float64), axis=-1)
+    margin = srt[..., -1] - srt[..., -2]
+    scale = np.maximum(1.0, np.abs(srt[..., -1]))
+    diff = np.asarray(got) != np.asarray(ref_labels)
+    outside = diff & (margin > band * scale)
+    assert not outside.any(), "%d labels differ outside the float tie band (of %d differing)" % (outside.sum(), diff.sum())
+    return int(diff.sum())
 
 
 def _vol(golden, an):
@@ -33,9 +47,8 @@ def test_get_view_from_vs_reference_golden(golden, an, dim):
         assert tuple(Xs.shape) == golden["g3_X_" + key].shape
         X = Xs.cpu().numpy()
         y = ys.cpu().numpy()
-        np.testing.assert_allclose(X, golden["g3_X_" + key], rtol=0, atol=2e-6)
-        assert (X != golden["g3_X_" + key]).mean() <= 1e-4
-        assert (y != golden["g3_y_" + key]).mean() <= 1e-3
+        np.testing.assert_array_equal(X, golden["g3_X_" + key])            # bit for bit
+        np.testing.assert_array_equal(y, golden["g3_y_" + key])
         np.testing.assert_array_equal(ib, golden["g3_invb_" + key])
 
 
@@ -47,8 +60,8 @@ def test_two_channel_planes_vs_reference_golden(golden, an):
         g = ViewGeometry(golden["views"][int(v)], int(dim), span, "same")
         g.offsets = np.array([off]); g.n_planes = 1
         X, y = sample_view(vol, g)
-        np.testing.assert_allclose(X[0].cpu().numpy(), golden["g2_im_%s_%d" % (an, pi)], rtol=0, atol=2e-6)
-        assert (y[0].cpu().numpy() != golden["g2_lab_%s_%d" % (an, pi)]).mean() <= 1e-3
+        np.testing.assert_array_equal(X[0].cpu().numpy(), golden["g2_im_%s_%d" % (an, pi)])
+        np.testing.assert_array_equal(y[0].cpu().numpy(), golden["g2_lab_%s_%d" % (an, pi)])
 
 
 @pytest.mark.parametrize("an", AFFS)
@@ -62,8 +75,7 @@ def test_map_real_space_pred_vs_reference_golden(golden, an):
             pr = torch.tensor(golden["g5_pred_%s_%d_%d" % (an, v, K)], device="cuda")
             ref = golden["g5_map_%s_%d_%d" % (an, v, K)]
             mp = map_real_space_pred(pr, grid, golden["g3_invb_" + key], vol).cpu().numpy()
-            assert mp.shape == ref.shape
-            assert np.any(mp != ref, axis=-1).mean() <= 1e-3
+            np.testing.assert_array_equal(mp, ref)                          # every voxel carries the reference's vector
 
 
 @pytest.mark.parametrize("an", AFFS)
@@ -89,9 +101,9 @@ def test_fused_map_fuse_vs_oracle(golden, an, sum_fusion):
     probs, labels = map_and_fuse(vol, vps, W, b, sum_fusion=sum_fusion)
     torch.cuda.synchronize()
     p = probs.cpu().numpy()
-    bad = np.abs(p - merged_ref).max(-1) > 2e-6
-    assert bad.mean() <= 1e-3, bad.mean()
-    assert (labels.cpu().numpy() != map_ref).mean() <= 2e-3
+    assert np.abs(p - merged_ref).max() <= 2e-6                          # every voxel: no wrong back-mapping index anywhere
+    n_ties = assert_labels_equal_outside_float_ties(labels.cpu().numpy(), map_ref, merged_ref)
+    assert n_ties <= 4, n_ties
     # plane-sharded accumulate path (multi-GPU predict) == fused path
     z = torch.zeros_like(probs)
     for vi, (pr, grid, ib) in enumerate(vps):
@@ -102,7 +114,61 @@ def test_fused_map_fuse_vs_oracle(golden, an, sum_fusion):
             map_accumulate(vol, pr[lo:hi].contiguous(), grid, ib, Wv, lo, hi, lo == 0, z)
     p2, l2 = fusion_finalize(z, b, sum_fusion=sum_fusion)
     np.testing.assert_allclose(p2.cpu().numpy(), p, rtol=0, atol=2e-6)
-    assert (l2 != labels).float().mean().item() <= 1e-3
+    assert assert_labels_equal_outside_float_ties(l2.cpu().numpy(), labels.cpu().numpy(), p) <= 4
+
+
+@pytest.mark.parametrize("an", ("rot", "aniso"))
+def test_sample_map_fuse_at_128_cubed_equals_the_oracle_exactly(golden, an):
+    """the whole geometry chain at D = 128 against oracle/geometry.py (the NumPy restatement that is
+    bit-exact on the reference goldens): a 128^3 x 2-channel volume under the goldens' rotated / anisotropic affine, six
+    views, 148 planes of 128 x 128 each, K = 5. Sampled planes bit for bit, nearest labels identical, every back-mapped
+    vector identical, fused probabilities to 2e-6 and fused labels identical outside the f32 tie band."""
+    from multiplanarunet_amd.interpolation import Volume, ViewSampler, map_real_space_pred, map_and_fuse
+    from oracle import geometry as G
+    D, C_, K = 128, 2, 5
+    rng = np.random.RandomState(128)
+    g = np.indices((D, D, D)).astype(np.float32) / D
+    image = np.stack([60 * np.sin(5 * g[0]) * np.cos(3 * g[1]) + 40 * g[2] + 4 * rng.randn(D, D, D),
+                      50 * np.cos(4 * g[2] + g[0]) + 30 * g[1] * g[1] + 4 * rng.randn(D, D, D)], -1).astype(np.float32)
+    lab = ((g[0] > .3).astype(np.uint8) + (g[1] > .5) + (g[2] > .6) + ((g[0] - .5) ** 2 + (g[1] - .5) ** 2 < .04)).astype(np.uint8)
+    aff = golden["aff_" + an]
+    bg = [float(np.percentile(image[..., c], 1)) for c in range(C_)]
+    center, scale = Volume.fit_robust_scaler(image)
+    vol = Volume(image, lab, aff, bg_value=bg, scaler=(center, scale))
+    views = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [0.3, 0.5, 0.8], [0.7, -0.2, 0.6], [-0.4, 0.6, 0.55]], float)
+    views /= np.linalg.norm(views, axis=1, keepdims=True)
+    span = float(D) * 1.05
+    seq = ViewSampler(views, D, span, n_classes=K)
+    A = (rng.randn(C_, K) * 1.5).astype(np.float32)
+    vg = G.voxel_grid_real_space(image.shape[:3], aff)
+    W = rng.uniform(0.5, 1.5, (len(views), K)).astype(np.float32)
+    b = rng.uniform(-0.2, 0.2, (K,)).astype(np.float32)
+    combined, vps = [], []
+    n_oob = 0
+    for view in views:
+        Xr, yr, grid, ib = G.get_view_from(image, lab, aff, view, D, span, bg_value=bg, center=center, scale=scale)
+        Xs, ys, grid_h, ib_h = seq.get_view_from(vol, view, "same+20")
+        np.testing.assert_array_equal(Xs.cpu().numpy(), Xr)               # 2.4 M trilinear samples x 2 channels, bit for bit
+        np.testing.assert_array_equal(ys.cpu().numpy(), yr)
+        np.testing.assert_array_equal(ib_h, ib)
+        for a_h, a_r in zip(grid_h, grid):
+            np.testing.assert_array_equal(np.asarray(a_h), a_r)
+        z = Xr @ A + 0.02 * np.arange(K, dtype=np.float32)                # a per-pixel "prediction" both sides share
+        e = np.exp(z - z.max(-1, keepdims=True))
+        pred = (e / e.sum(-1, keepdims=True)).astype(np.float32)          # [d,d,P,K]
+        ref = G.map_real_space_pred(pred, grid, ib, vg)
+        got = map_real_space_pred(torch.tensor(pred, device="cuda"), grid, ib, vol).cpu().numpy()
+        np.testing.assert_array_equal(got, ref)                           # 2.1 M voxels x 5 floats: the same vector everywhere
+        n_oob += int((ref[..., 0] == 1.0).sum())
+        combined.append(ref)
+        vps.append((torch.tensor(np.moveaxis(pred, 2, 0).copy(), device="cuda"), grid, ib))
+    assert n_oob > 0                                                      # (the OOB fill rule was exercised)
+    merged_ref, map_ref = G.merge_multi_view_preds(np.stack(combined), W, b, False)
+    probs, labels = map_and_fuse(vol, vps, W, b, sum_fusion=False)
+    assert np.abs(probs.cpu().numpy() - merged_ref).max() <= 2e-6
+    n_ties = assert_labels_equal_outside_float_ties(labels.cpu().numpy(), map_ref, merged_ref)
+    assert n_ties <= 8, n_ties
+    assert np.bincount(map_ref.ravel(), minlength=K).min() > 0.01 * D ** 3   # (all five classes are present)
 
 
 def test_fusion_forward_vs_oracle():
@@ -122,7 +188,7 @@ def test_fusion_forward_vs_oracle():
         _lib.call("mpu_fusion_forward", _lib.ptr(xd), N, V, K, _lib.ptr(Wd), _lib.ptr(bd),
                   _lib.ptr(probs), _lib.ptr(lab), _lib.stream_ptr())
         np.testing.assert_allclose(probs.cpu().numpy(), ref, rtol=0, atol=1e-6)
-        assert (lab.cpu().numpy() != ref.argmax(-1)).mean() <= 1e-3
+        assert assert_labels_equal_outside_float_ties(lab.cpu().numpy(), ref.argmax(-1), ref, band=4e-6) <= 2
 
 
 def test_error_behaviour():
