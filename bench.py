@@ -467,10 +467,13 @@ def bench_train_e2e(model, device, B, dim, headline, steps=120, warmup=12):
     for _ in range(3):
         s0()
     torch.cuda.synchronize(); t0 = time.perf_counter()
+    rounds = 0
     for _ in range(30):
         s0()
+        rounds += getattr(s0, "rounds", 0)
     torch.cuda.synchronize()
     res["sampler_alone_slices_per_s"] = round(30 * B / (time.perf_counter() - t0), 1)
+    res["sampler_host_reads_per_batch"] = round(rounds / 30.0, 2)      # one per round of candidates (data.TrainSampler)
     # serial loop (round 4): cut, eager step, host read of the loss
     s1 = mk(6)
     for _ in range(3):

@@ -212,8 +212,9 @@ class TrainSampler:
             c = self._cache[vi] = _VolCache(self.volumes[vi], self.dim, self.span)
         return c
 
-    def _cut(self, vi, X, Y, slot, off_dev, stats):
-        """One candidate plane of volume vi into X[slot], Y[slot]; returns (class mask, not-all-bg flag)."""
+    def _issue_cut(self, vi, X, Y, slot, off_dev, stats):
+        """Enqueue one candidate plane of volume vi into X[slot], Y[slot] and its statistics into stats[slot] (class mask,
+        not-all-background flag): two launches, NO host synchronisation. off_dev: f64 [>= slot + 1] scratch, stats: i32 [., 2]."""
         import ctypes as C
         from . import _lib
         vol, vc = self.volumes[vi], self._vc(vi)
@@ -223,42 +224,71 @@ class TrainSampler:
         noise = self.rng.normal(scale=self.noise_sd, size=3) if self.noise_sd else None
         g = vc.geom
         g.basis[:] = plane_basis_fast(view, noise)
-        off_dev.fill_(off)                                    # scalar fill: no host->device copy of a tensor
+        od = off_dev[slot:slot + 1]
+        od.fill_(off)                                         # scalar fill: no host->device copy of a tensor
         st = _lib.stream_ptr()
         p = vc.ptrs
         xs, ys = X[slot], Y[slot]
-        _lib.call("mpu_sample_view_planes", p[0], p[1], vc.shape, p[2], p[3], p[4], C.byref(g), _lib.ptr(off_dev),
+        _lib.call("mpu_sample_view_planes", p[0], p[1], vc.shape, p[2], p[3], p[4], C.byref(g), _lib.ptr(od),
                   p[5], vol.bg_class, p[6], p[7], _lib.ptr(xs), _lib.ptr(ys), st)
         _lib.call("mpu_plane_stats", _lib.ptr(ys), _lib.ptr(xs), self.dim * self.dim, vol.n_channels,
-                  _lib.ptr(vc.bg_scaled), _lib.ptr(stats), st)
-        m, nb = stats.tolist()                                # the one synchronisation per candidate
+                  _lib.ptr(vc.bg_scaled), _lib.ptr(stats[slot]), st)
+
+    def _cut(self, vi, X, Y, slot, off_dev, stats):
+        """One candidate plane of volume vi into X[slot], Y[slot]; returns (class mask, not-all-bg flag) -- synchronises."""
+        if stats.ndim == 1:                                   # (the one-candidate form: off_dev [1], stats [2])
+            self._issue_cut(vi, X[slot:slot + 1], Y[slot:slot + 1], 0, off_dev, stats.reshape(1, 2))
+            m, nb = stats.tolist()
+        else:
+            self._issue_cut(vi, X, Y, slot, off_dev, stats)
+            m, nb = stats[slot].tolist()
         return m, bool(nb)
 
     def __call__(self):
+        """One batch. Round 5: the candidates of ALL undecided slots are cut before the host reads their statistics -- one
+        read (one stream synchronisation) per ROUND instead of one per candidate: a batch whose first candidates are all
+        accepted costs a single round trip, which is what lets the sampler run on a side stream beside a train step without
+        queueing behind its kernels 2 x B times (pipeline.TrainPipeline). The accept / reject rule and its sequential state
+        (foreground balance, classes seen) are the reference's, applied slot by slot in order; candidates are i.i.d. draws, so
+        deciding a slot on a candidate drawn before the earlier slots were settled changes nothing statistically. With no
+        rejection the random stream is consumed in the same order as the one-candidate-at-a-time form."""
         B, d = self.batch_size, self.dim
         vol0 = self.volumes[0]
         dev = vol0.device
         X = torch.empty((B, d, d, vol0.n_channels), dtype=torch.float32, device=dev)
         Y = torch.empty((B, d, d), dtype=torch.uint8, device=dev)
-        off_dev = torch.empty(1, dtype=torch.float64, device=dev)
-        stats = torch.empty(2, dtype=torch.int32, device=dev)
-        ws, bgs = [], []
+        off_dev = torch.empty(B, dtype=torch.float64, device=dev)
+        stats = torch.empty((B, 2), dtype=torch.int32, device=dev)
         has_fg, fg_vec = 0, 0                                 # fg_vec: bit mask of the fg classes seen so far
         nfg = len(self.fg_classes)
-        for slot in range(B):
-            vi = self.rng.randint(0, len(self.volumes))
-            for t in range(1, self.max_tries + 1):
-                m, nonbg = self._cut(vi, X, Y, slot, off_dev, stats)
+        vis = [None] * B
+        tries = [0] * B
+        fresh = [False] * B                                   # slot holds a candidate not yet judged
+        first = 0                                             # first undecided slot
+        self.rounds = 0                                       # (diagnostic: host reads of this batch)
+        while first < B:
+            for slot in range(first, B):                      # (re)cut what is missing: all enqueued, nothing read yet
+                if not fresh[slot]:
+                    if vis[slot] is None:
+                        vis[slot] = self.rng.randint(0, len(self.volumes))
+                    tries[slot] += 1
+                    self._issue_cut(vis[slot], X, Y, slot, off_dev, stats)
+                    fresh[slot] = True
+            st = stats.tolist()                               # the round's one synchronisation
+            self.rounds += 1
+            while first < B:                                  # judge in slot order until a candidate is rejected
+                slot = first
+                m, nonbg = st[slot][0], bool(st[slot][1])
+                fresh[slot] = False
                 present = m & self._fg_mask
-                last = t == self.max_tries
+                last = tries[slot] >= self.max_tries
+                fg_try = fg_vec
                 if self.force_all_fg and not last:
                     new = fg_vec | present
                     missing = nfg - bin(new).count("1")
                     if not (missing == 0 or missing < (B - slot)):
-                        continue
+                        break                                 # rejected: this slot gets a new candidate next round
                     fg_try = new
-                else:
-                    fg_try = fg_vec
                 if present:
                     ok, inc = True, 1
                 elif (self.n_fg_slices - has_fg) < (B - slot):
@@ -268,8 +298,11 @@ class TrainSampler:
                 if (ok or last) and (last or nonbg):
                     has_fg += inc
                     fg_vec = fg_try
+                    first += 1
+                else:
                     break
-            ws.append(self.sample_weights[vi]); bgs.append(list(self.volumes[vi].bg_value))
+        ws = [self.sample_weights[vi] for vi in vis]
+        bgs = [list(self.volumes[vi].bg_value) for vi in vis]
         x, y = X, Y
         w = torch.tensor(ws, dtype=torch.float32, device=dev)
         for aug in self.augmenters:

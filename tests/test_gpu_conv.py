@@ -180,6 +180,49 @@ def test_halo16_subprocess():
         assert r.returncode == 0, str(extra) + r.stdout[-2000:] + r.stderr[-2000:]
 
 
+# Whole-image halo-patch schedule of the deep levels (conv_deep, round 5): 3x3 layers on square 8 / 16-pixel maps whose
+# pixels make whole 256-pixel tiles, sources in multiples of 64 channels, filters in multiples of 128, fewer tiles than CUs.
+DEEPH_CASES = [
+    # mode,   B, H,  W,  C0,  C1,  Cout
+    (CONV3,   16, 16, 16, 512, 0, 512),     # encoder_L3_conv2: 64 tiles, K split 4 ways, two chunks per workgroup
+    (CONV3,   16, 8, 8, 512, 0, 1024),      # bottom_conv1: 32 tiles, 8 ways, ONE chunk per workgroup (no patch prefetch at all)
+    (CONV3,   4, 16, 16, 192, 0, 128),      # 4 tiles, three chunks split three ways
+    (CONV3,   4, 8, 8, 320, 0, 256),        # 2 tiles, five chunks split five ways (four 8x8 images per tile)
+    (CONV3,   8, 8, 8, 64, 128, 128),       # concat, three chunks over the two sources
+    (CONV3,   1, 16, 16, 448, 64, 384),     # one image; eight chunks, the last one from the second source; three n-tiles
+    (CONV3,   12, 8, 8, 448, 0, 128),       # 3 tiles, seven chunks split seven ways
+    (CONV3,   32, 16, 16, 128, 0, 128),     # 32 tiles, two chunks: K split two ways (the minimum)
+]
+
+
+def _conv_schedules_of(fn):
+    import ctypes as C
+    from multiplanarunet_amd import _lib
+    lib = _lib.load()
+    lib.mpu_schedule_log_enable(1)
+    try:
+        fn()
+        n = lib.mpu_schedule_log_read(None, 0)
+        buf = C.create_string_buffer(int(n) + 1)
+        lib.mpu_schedule_log_read(buf, n + 1)
+    finally:
+        lib.mpu_schedule_log_enable(0)
+    return [l.split()[1] for l in buf.value.decode().splitlines() if l.startswith("conv ")]
+
+
+@pytest.mark.parametrize("case", DEEPH_CASES + [c for c in DEEP_CASES[:3]])
+def test_whole_image_halo_patch_schedule_of_the_deep_levels(case):
+    """conv_deep (VERDICT r4 item 1): forward and data gradient of the case run on it (schedule log) and match the fp64 layer;
+    the result is bit-identical from launch to launch (fixed-order split-K finish)."""
+    import os
+    conv = _conv_schedules_of(lambda: _run_case(case, torch.bfloat16, workspace=True))
+    if os.environ.get("MPU_CONV_DEEP") != "0":
+        assert conv and conv[0] == "deep", conv                  # the forward launch (data gradients: when their own shape is eligible)
+        mode, B, H, W, C0, C1, Cout = case
+        if (C0 + C1) % 128 == 0 and Cout % 64 == 0:
+            assert conv.count("deep") >= 2, conv
+
+
 @pytest.mark.parametrize("case", DEEP_CASES)
 def test_deep_level_layers_split_k_schedule(case):
     """bf16, with the split-K workspace (the path mpu_unet_forward / backward take at the deep levels)."""

@@ -20,6 +20,9 @@ def assert_labels_equal_outside_float_ties(got, ref_labels, ref_scores, band=8e-
     """argmax of float scores: identical wherever the reference's top-2 margin exceeds `band` (relative to the largest
     score); returns the number of differing voxels inside the band."""
     srt = np.sort(np.asarray(ref_scores, np.float64), axis=-1)
+    if srt.shape[-1] < 2:                                            # one class: nothing to tie with
+        assert np.array_equal(np.asarray(got), np.asarray(ref_labels))
+        return 0
     margin = srt[..., -1] - srt[..., -2]
     scale = np.maximum(1.0, np.abs(srt[..., -1]))
     diff = np.asarray(got) != np.asarray(ref_labels)
