@@ -1046,7 +1046,9 @@ __device__ __forceinline__ int deep_pix_in_block(int l31) {
 constexpr int deep_rsize(int j, int np) { const int m = ((j % 9) + 9) % 9; return 2 + ((m == 4 || m == 8) ? np : 0); }
 constexpr int deep_allow(int k, int np) { return deep_rsize(k - 3, np) + deep_rsize(k - 2, np) + deep_rsize(k - 1, np); }
 
-template <int W_>
+// STAMP (dev aid, MPU_STAMPS=1): s_memtime stamps of thread 0 of every 8th workgroup at the phase boundaries (the row layout
+// of tools/stamps.py: entry, prologue done, main loop done, staged, stores issued, drained, intervals; 8..12: interval 4)
+template <int W_, bool STAMP>
 __global__ __launch_bounds__(512, 2) void conv_deep_kernel(ConvArgs a, int tiles_m, int tiles_n) {
     using Cfg = DeepCfg<W_>;
     constexpr int BN = Cfg::BN, BM = Cfg::BM, HW = Cfg::HW, PW = Cfg::PW, IMG = Cfg::IMG, NP = Cfg::NP, PBUF = Cfg::PBUF;
@@ -1071,6 +1073,10 @@ __global__ __launch_bounds__(512, 2) void conv_deep_kernel(ConvArgs a, int tiles
     const unsigned lds0 = (unsigned)(uintptr_t)smem;
     const unsigned ldsW = lds0 + 2 * PBUF;
     const unsigned w_tap_b = (unsigned)(a.w_tap_stride * 2L);
+    // (rows 0..15: wave 0 of workgroups 0, 8, .., 120; rows 16..31: wave 7 of the same workgroups)
+    unsigned long long* stamps = (STAMP && a.dbg_buf && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 16 && (tid == 0 || tid == 448))
+                                     ? a.dbg_buf + ((blockIdx.x >> 3) + (tid ? 16 : 0)) * 16 : nullptr;
+    if (STAMP && stamps) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[6] = (unsigned long long)(9 * (c_end - c_begin)); }
 
     // ---- per-lane DMA roles (a piece = 16 rows of 64 bytes: row = lane / 4, 16-byte slot = lane % 4) ----------------
     const int drow = lane >> 2, dslot = lane & 3;
@@ -1183,6 +1189,7 @@ __global__ __launch_bounds__(512, 2) void conv_deep_kernel(ConvArgs a, int tiles
     // One interval: steps 0..2 with the next step's reads under the MFMAs, then the barrier (this stage is consumed: its
     // reads have returned; the next interval's stage and patch halves have landed), then step 3 with the first reads of
     // the next interval and the slot's requests R_IV.
+    bool first_chunk = true;
     auto interval = [&](auto ivc) {
         constexpr int IV = decltype(ivc)::value;
         // (reads in the order the next step's MFMAs need them: fa[0], fb[0], fb[1], fa[1] -- each at least three MFMAs old)
@@ -1208,9 +1215,15 @@ __global__ __launch_bounds__(512, 2) void conv_deep_kernel(ConvArgs a, int tiles
             DEEP_MM(fa0, fb0, 1, 0); DEEP_SB(); DEEP_LD(fb1[1], po[tap_][1] ^ (unsigned)(ks_ << 5), half_ * PBUF); DEEP_SB();
             DEEP_MM(fa0, fb0, 1, 1); DEEP_SB(); DEEP_LD(fa1[1], wa_, it_ * WITEM + 2048); DEEP_SB(); }
         // every read of this interval's stage has returned; R_{IV-4} has landed (own pieces: vmcnt, all waves': barrier)
+        if (STAMP && stamps && IV == 4 && first_chunk) stamps[8] = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (STAMP && stamps && IV == 4 && first_chunk) stamps[9] = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(deep_allow(IV, NP)) : "memory");
+        if (STAMP && stamps && IV == 4 && first_chunk) stamps[10] = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();
+        if (STAMP && stamps && IV == 4 && first_chunk) stamps[11] = __builtin_amdgcn_s_memtime();
+        if (STAMP && stamps && IV == 5 && first_chunk) stamps[12] = __builtin_amdgcn_s_memtime();   // one interval later: the period
+        if (STAMP && stamps && IV == 3 && first_chunk) stamps[7] = __builtin_amdgcn_s_memtime();
         DEEP_SB();
         const unsigned freed = stb;                              // the stage this interval used: W(IV + 5) goes there
         stb += WSTAGE; if (stb == (unsigned)(NWS * WSTAGE)) stb = 0;
@@ -1234,6 +1247,7 @@ __global__ __launch_bounds__(512, 2) void conv_deep_kernel(ConvArgs a, int tiles
     // barrier of "interval -1": W(0) and P_A of the first chunk
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(deep_allow(-1, NP)) : "memory");
     __builtin_amdgcn_s_barrier();
+    if (STAMP && stamps) stamps[1] = __builtin_amdgcn_s_memtime();
     DEEP_LOAD_STEP(fa0, fb0, 0, 0, 0u);
     DEEP_WITEM(cur, 4, 0, 4 * WSTAGE); DEEP_WITEM(cur, 4, 1, 4 * WSTAGE);
     DEEP_PATCH(cur, 1);
@@ -1244,6 +1258,7 @@ __global__ __launch_bounds__(512, 2) void conv_deep_kernel(ConvArgs a, int tiles
         interval(std::integral_constant<int, 6>()); interval(std::integral_constant<int, 7>());
         interval(std::integral_constant<int, 8>());
         cur = nxt; nxt = chunk_of(c + 2);
+        first_chunk = false;
     }
 #undef DEEP_LD
 #undef DEEP_SB
@@ -1252,6 +1267,8 @@ __global__ __launch_bounds__(512, 2) void conv_deep_kernel(ConvArgs a, int tiles
 #undef DEEP_PATCH
 #undef DEEP_WITEM
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // the trailing (poisoned) requests still write zeros into LDS
+    if (STAMP && stamps) stamps[2] = __builtin_amdgcn_s_memtime();
+    if (a.dbg & 2) return;                                       // dev aid (MPU_PIPE_DEBUG): no epilogue at all
 
     // split-K: raw f32 partial sums [kz][M][Cout], staged through wave-private LDS rows (conv_pipe's epilogue; the pixel
     // rows un-permuted: MFMA column l31 of block j holds pixel deep_pix_in_block(l31))
@@ -1259,6 +1276,7 @@ __global__ __launch_bounds__(512, 2) void conv_deep_kernel(ConvArgs a, int tiles
         constexpr int SROW = PipeCfg::SROW;
         float* P = a.partial + (long)kz * M * a.Cout;
         __syncthreads();                                         // lagging waves still read the last stage
+        if (STAMP && stamps) stamps[13] = __builtin_amdgcn_s_memtime();
         unsigned char* sw = smem + wave * (64 * SROW);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -1269,14 +1287,21 @@ __global__ __launch_bounds__(512, 2) void conv_deep_kernel(ConvArgs a, int tiles
                     *(float4*)(sw + (j * 32 + pib) * SROW + (i * 32 + 8 * q + 4 * fh) * 4) =
                         make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (STAMP && stamps) stamps[14] = __builtin_amdgcn_s_memtime();
         const int nl = n0 + wn * 64 + (lane & 15) * 4;
         float4 v[16];
 #pragma unroll
         for (int it = 0; it < 16; ++it) v[it] = *(const float4*)(sw + (it * 4 + (lane >> 4)) * SROW + (lane & 15) * 16);
+        if (STAMP && stamps) stamps[3] = __builtin_amdgcn_s_memtime();
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int m = m0 + wm * 64 + it * 4 + (lane >> 4);
-            *(float4*)(P + (long)m * a.Cout + nl) = v[it];
+            if (!(a.dbg & 1)) *(float4*)(P + (long)m * a.Cout + nl) = v[it];     // (dev aid: 1 = no partial stores)
+        }
+        if (STAMP && stamps) {
+            stamps[4] = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamps[5] = __builtin_amdgcn_s_memtime();
         }
     }
 }
@@ -1284,12 +1309,16 @@ __global__ __launch_bounds__(512, 2) void conv_deep_kernel(ConvArgs a, int tiles
 template <int W_>
 static int launch_deep(const ConvArgs& a_in, int ks, hipStream_t st) {
     using Cfg = DeepCfg<W_>;
-    auto kern = conv_deep_kernel<W_>;
+    unsigned long long* sbuf = stamp_buffer();                  // MPU_STAMPS=1: the instrumented instantiation
+    auto kern = sbuf ? conv_deep_kernel<W_, true> : conv_deep_kernel<W_, false>;
     ConvArgs a = a_in;
+    a.dbg_buf = sbuf;
+    a.dbg = (int)env(ENV_PIPE_DEBUG);
     if (a.w_elems <= 0) a.w_elems = 8 * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
     static unsigned long long attr_set = 0;
     if (first_use_on_device(attr_set)) {
-        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<W_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<W_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
         mark_used_on_device(attr_set);
     }
     const long M = (long)a.B * a.Ho * a.Wo;

@@ -55,7 +55,7 @@ def run(W, B, C0, C1, Cout, ks, seed=0):
                                     if v:
                                         pix = m0 + img * HW + (py - 1) * W + (px - 1)
                                         ch = cb + half * 32 + logical * 8
-                                        patch[half, pr, dslot] = src[pix, ch - cb + cb:ch + 8] if False else src[pix, (ch):(ch + 8)]
+                                        patch[half, pr, dslot] = src[pix, ch:ch + 8]
                     for idx in range(18):                                 # items of the chunk
                         half, tap = (1, idx - 9) if idx >= 9 else (0, idx)
                         ky, kx = divmod(tap, 3)
@@ -71,28 +71,6 @@ def run(W, B, C0, C1, Cout, ks, seed=0):
                         for ksx in range(2):
                             for wave in range(8):
                                 wn, wm = wave & 1, wave >> 1
-                                for lane in range(64):
-                                    fh, l31 = lane >> 5, lane & 31
-                                    pib = pix_in_block(l31, W)
-                                    fa = []
-                                    for i in range(2):
-                                        row = wn * 64 + i * 32 + l31
-                                        byte = row * 64 + ((fh ^ ((l31 >> 2) & 3)) << 4)
-                                        byte ^= ksx << 5
-                                        fa.append(witem[byte // 64, (byte % 64) // 16])
-                                    fb = []
-                                    for j in range(2):
-                                        ml = wm * 64 + j * 32 + pib
-                                        img, rem = divmod(ml, HW); oy, ox = divmod(rem, W)
-                                        prow = img * IMG + (oy + ky) * PW + ox + kx
-                                        byte = prow * 64 + ((fh ^ ((prow >> 2) & 3)) << 4)
-                                        byte ^= ksx << 5
-                                        fb.append(patch[half, byte // 64, (byte % 64) // 16])
-                                    acc[wave, lane, :, :, 0] += 0       # (placeholders keep shapes obvious)
-                                    for i in range(2):
-                                        for j in range(2):
-                                            # this lane contributes A[row l31][k = 8 fh ..] and B[k][col l31]: collect per (wave, i, j)
-                                            pass
                                 # the MFMA itself: D[row][col] += sum_k A[row][k] B[k][col], k = 16 = (fh, 8)
                                 A = np.zeros((2, 32, 16)); Bm = np.zeros((2, 16, 32))
                                 for lane in range(64):
