@@ -506,8 +506,7 @@ static int launch_splitk_finish(const ConvArgs& a, int ks, long M, hipStream_t s
     // fused BN statistics: <= 256 blocks, every thread keeps its channel group (256 % cpr == 0, cpr <= 256)
     const bool st_ok = a.stats && a.stats_rows && cpr <= 256 && 256 % cpr == 0 && a.Cout % (16 / (int)sizeof(T)) == 0;
     if (st_ok) {
-        const long cap = env(ENV_SPLITK_STATS_ROWS);             // partial statistics rows = blocks of this pass
-        if (blocks > cap) blocks = cap;
+        if (blocks > 256) blocks = 256;                          // (512 / 1024 blocks measured slower: +0.4 % / +1.2 % on the step, gpurun R5c)
         if (blocks * 2 * a.Cout > a.stats_cap) blocks = a.stats_cap / (2 * a.Cout);
         *a.stats_rows = (int)blocks;
         if (a.bn_x)
@@ -988,379 +987,6 @@ static int try_pipe(const ConvArgs& a, hipStream_t st) {
     }
 }
 
-// ------------------------------------------------------------------------- //
-// conv_deep_kernel (bf16, CONV3, round 5): the split-K schedule of conv_pipe for WHOLE-IMAGE tiles of the deep levels'
-// 16 x 16 and 8 x 8 maps. What conv_pipe cannot do on these layers is keep enough bytes in flight: it
-// re-DMAs the tile's 256 pixels for every tap (32 of the 48 KB of a K step), its three 48-KB stages leave two steps =
-// 96 KB in flight per CU, and at the ~1.6 us an L2 / MALL / HBM -> LDS request takes under load that is ~60 GB/s per CU:
-// 1650 cycles per 16-MFMA step where the matrix pipe needs 1024 (s_waitcnt share 0.34-0.47, profiles/r03b_conv_pmc_*).
-// Here
-//   * the tile is whole images (one 16 x 16 image or four 8 x 8 images = 256 pixels) and the pixel operand is a HALO PATCH:
-//     (H + 2) x (W + 2) pixels per image, DMA'd once per 32-channel half chunk and read by all nine taps at shifted rows
-//     (conv_halo's idea; the W >= 32 restriction there was a tile-shape choice). Pixel-side fill per 64-channel chunk:
-//     2 x 24-32 KB instead of 9 x 32 KB;
-//   * the reduction runs over ITEMS (32-channel half chunk, tap), two per INTERVAL (16 MFMAs per wave), nine intervals per
-//     chunk: A taps (0,1) (2,3) (4,5) (6,7) | (A 8, B 0) | B taps (1,2) .. (7,8) -- conv_halo16's item stream. Two half-patch
-//     buffers: B of a chunk is requested when B of the previous chunk has been read (slot 8), A of the next chunk when A
-//     of this one has (slot 4): four intervals of lead each, no third buffer;
-//   * what the patch frees goes to the WEIGHT ring: five 16-KB stages, requests five intervals ahead (80 KB of weights
-//     in flight per CU instead of 32);
-//   * K is split over workgroups by whole chunks (chunk-major order; conv_pipe walks tap-major), partials and the finish
-//     pass (splitk_finish_kernel: bias, ReLU, masks, BatchNorm sums) are conv_pipe's, so every epilogue is covered.
-// LDS rows are 64 bytes (32 channels); slot p of row r holds 16-byte chunk p ^ ((r >> 2) & 3). A ds_read_b128 is served in
-// four NON-contiguous 16-lane groups, each of which must touch 16 distinct 16-byte slots of the 256-byte bank row: with
-// 64-byte rows that means each residue r & 3 four times with four different (r >> 2) & 3. Weight fragments (32 consecutive
-// rows) satisfy it as they are. Pixel fragments do not -- a 32-pixel MFMA block is 2 rows of a 16-pixel map or 4 rows of an
-// 8-pixel map, the patch rows jump at the image-row ends -- unless (a) the patch pitch is a multiple of 4 (20 / 12 columns
-// for 18 / 10 used) and (b) the lanes of a block take its pixels in a PERMUTED order (deep_pix_in_block: a lane group gets
-// 4-column runs 8 (4) columns apart, image rows PW / 4 = 5 (3) apart in r >> 2): checked exhaustively for every wave,
-// block and tap (the bank model is in the round's commit message), and by SQ_LDS_BANK_CONFLICT. The epilogue un-permutes.
-// In-order DMA queue of a wave, slot j = between the barriers of intervals j and j + 1: R_j = W(j + 5) [2 pieces] +
-// P_A(next chunk) [NP] if j % 9 == 4 + P_B(next chunk) [NP] if j % 9 == 8. The barrier of interval k needs W(k + 1) and the
-// patch halves first read in interval k + 1, all of them in R_{k-4}: allowed in flight = |R_{k-3}| + |R_{k-2}| + |R_{k-1}|,
-// a compile-time constant per interval (deep_allow). The prologue is slots -5 .. -1 of the same rule.
-// ------------------------------------------------------------------------- //
-template <int W_>
-struct DeepCfg {
-    static constexpr int W = W_, H = W_, HW = W * W, BN = 128, BM = 256, IPT = BM / HW;
-    static constexpr int PW = W == 16 ? 20 : 12, PH = H + 2, IMG = PH * PW;            // patch pitch = 0 (mod 4): the bank rule above
-    static constexpr int NP = W == 16 ? 3 : 4;                                           // DMA pieces per wave and half patch
-    static constexpr int PROWS = NP * 8 * 16;                                            // 384 / 512 rows of 64 bytes
-    static_assert(IPT * IMG <= PROWS, "patch rows");
-    static constexpr int PBUF = PROWS * 64;
-    static constexpr int WITEM = BN * 64, WSTAGE = 2 * WITEM, NWS = 5, AHEAD = 5;
-    static constexpr int MAIN = 2 * PBUF + NWS * WSTAGE;
-    static constexpr int SMEM = MAIN > PipeCfg::STG ? MAIN : PipeCfg::STG;
-};
-static_assert(DeepCfg<8>::SMEM <= 160 * 1024 && DeepCfg<16>::SMEM <= 160 * 1024, "LDS");
-
-// pixel (0..31, row-major in the block) that MFMA column `l31` of a 32-pixel block takes; see the bank rule above
-template <int W_>
-__device__ __forceinline__ int deep_pix_in_block(int l31) {
-    const int q = l31 >> 2, t = l31 & 3;
-    const int g = (0x96 >> q) & 1;                               // ds_read_b128 lane group of the lane: {0-3,12-15,20-27} = 0
-    const int k = (q >> 1) * 4 + t;                              // rank inside the group, 0..15
-    if (W_ == 16) return (k >> 3) * 16 + ((k >> 2) & 1) * 8 + (k & 3) + 4 * g;
-    return (k >> 2) * 8 + (k & 3) + 4 * g;
-}
-constexpr int deep_rsize(int j, int np) { const int m = ((j % 9) + 9) % 9; return 2 + ((m == 4 || m == 8) ? np : 0); }
-constexpr int deep_allow(int k, int np) { return deep_rsize(k - 3, np) + deep_rsize(k - 2, np) + deep_rsize(k - 1, np); }
-
-// STAMP (dev aid, MPU_STAMPS=1): s_memtime stamps of thread 0 of every 8th workgroup at the phase boundaries (the row layout
-// of tools/stamps.py: entry, prologue done, main loop done, staged, stores issued, drained, intervals; 8..12: interval 4)
-template <int W_, bool STAMP>
-__global__ __launch_bounds__(512, 2) void conv_deep_kernel(ConvArgs a, int tiles_m, int tiles_n) {
-    using Cfg = DeepCfg<W_>;
-    constexpr int BN = Cfg::BN, BM = Cfg::BM, HW = Cfg::HW, PW = Cfg::PW, IMG = Cfg::IMG, NP = Cfg::NP, PBUF = Cfg::PBUF;
-    constexpr int WITEM = Cfg::WITEM, WSTAGE = Cfg::WSTAGE, NWS = Cfg::NWS;
-    static_assert(Cfg::AHEAD == NWS, "a request reuses the stage freed at its barrier");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 1, wm = wave >> 1;                     // 2 x 4 waves of 64 channels x 64 pixels
-    const int logical = g_xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = logical % tiles_m, r1 = logical / tiles_m;
-    const int nt = r1 % tiles_n, kz = r1 / tiles_n;
-    const int n0 = nt * BN, m0 = mt * BM;
-    const int nch0 = a.C0 >> 6, nchunks = nch0 + (a.C1 >> 6);
-    const int ks = a.ksplit;
-    const int c_begin = (int)((long)kz * nchunks / ks), c_end = (int)((long)(kz + 1) * nchunks / ks);
-    const int M = a.B * HW;                                      // a multiple of BM (launcher)
-    const i32x4 rs0 = make_rsrc(a.in0, (long)M * a.C0 * 2L);
-    const i32x4 rs1 = make_rsrc(a.in1 ? a.in1 : a.in0, a.in1 ? (long)M * a.C1 * 2L : 0);
-    const i32x4 rsw = make_rsrc(a.w, a.w_elems * 2L);
-    const unsigned lds0 = (unsigned)(uintptr_t)smem;
-    const unsigned ldsW = lds0 + 2 * PBUF;
-    const unsigned w_tap_b = (unsigned)(a.w_tap_stride * 2L);
-    // (rows 0..15: wave 0 of workgroups 0, 8, .., 120; rows 16..31: wave 7 of the same workgroups)
-    unsigned long long* stamps = (STAMP && a.dbg_buf && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 16 && (tid == 0 || tid == 448))
-                                     ? a.dbg_buf + ((blockIdx.x >> 3) + (tid ? 16 : 0)) * 16 : nullptr;
-    if (STAMP && stamps) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[6] = (unsigned long long)(9 * (c_end - c_begin)); }
-
-    // ---- per-lane DMA roles (a piece = 16 rows of 64 bytes: row = lane / 4, 16-byte slot = lane % 4) ----------------
-    const int drow = lane >> 2, dslot = lane & 3;
-    unsigned wpo;                                                // weights: rows wave * 16 .. + 15 of an item
-    {
-        const int rl = wave * 16 + drow;
-        wpo = (unsigned)((n0 + rl) * a.w_row_stride * 2) + (unsigned)(((dslot ^ ((rl >> 2) & 3)) * 8) * 2);
-    }
-    int ppix[NP]; unsigned pch[NP];                              // patch: pieces wave, wave + 8, ...
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const int pr = (wave + 8 * k) * 16 + drow;
-        const int img = pr / IMG, rem = pr - img * IMG;
-        const int py = rem / PW, px = rem - py * PW;
-        const bool v = img < Cfg::IPT && py >= 1 && py <= Cfg::H && px >= 1 && px <= Cfg::W;
-        ppix[k] = v ? m0 + img * HW + (py - 1) * Cfg::W + (px - 1) : M;       // padding: the first pixel BEYOND the tensor
-        pch[k] = (unsigned)((dslot ^ ((pr >> 2) & 3)) * 16);
-    }
-    const unsigned sbase_p = lds0 + wave * 1024;
-    // scalars of a chunk: source, row pitch, channel base and weight column offset (bytes). A chunk past this workgroup's
-    // range carries the POISON in both byte offsets (SCALAR selects: a per-lane select on a uniform condition is compiled
-    // into a branch, and basic blocks inside the interval stream let the MFMAs sink away from their reads), so that its
-    // requests stay unconditional, fetch nothing and leave the counted vmcnt arithmetic intact
-    struct Chunk { i32x4 rs; int pitch2; unsigned cb2, wcol2; };
-    auto chunk_of = [&](int c) {
-        Chunk q;
-        const bool valid = c < c_end;
-        const bool s1 = c >= nch0;
-        const int cb = ((s1 ? c - nch0 : c) << 6);
-        q.rs.x = s1 ? rs1.x : rs0.x; q.rs.y = s1 ? rs1.y : rs0.y; q.rs.z = s1 ? rs1.z : rs0.z; q.rs.w = rs0.w;
-        q.pitch2 = (s1 ? a.C1 : a.C0) * 2;
-        q.cb2 = valid ? (unsigned)(cb * 2) : PIPE_POISON;
-        q.wcol2 = valid ? (unsigned)(((s1 ? a.C0 : 0) + cb) * 2) : PIPE_POISON;
-        return q;
-    };
-    // half patch `half` (0 = A: channels 0..31 of the chunk, buffer 0; 1 = B) of chunk q: NP pieces
-#define DEEP_PATCH(Q, HALF)                                                                                         \
-    do {                                                                                                            \
-        _Pragma("unroll") for (int k_ = 0; k_ < NP; ++k_) {                                                          \
-            const unsigned off_ = (unsigned)(ppix[k_] * (Q).pitch2) + (Q).cb2 + (unsigned)((HALF) * 64) + pch[k_];      \
-            if (k_ == 0) dma16_at<(HALF) * PBUF + 0 * 8192>((Q).rs, off_, sbase_p);                                  \
-            if (k_ == 1) dma16_at<(HALF) * PBUF + 1 * 8192>((Q).rs, off_, sbase_p);                                  \
-            if (k_ == 2) dma16_at<(HALF) * PBUF + 2 * 8192>((Q).rs, off_, sbase_p);                                  \
-            if (k_ == 3) dma16_at<(HALF) * PBUF + 3 * 8192>((Q).rs, off_, sbase_p);                                  \
-        }                                                                                                           \
-    } while (0)
-    // the two weight items of interval IV_ (0..8) of chunk Q into the stage at byte offset STB_ of the ring
-#define DEEP_WITEM(Q, IV_, IT_, STB_)                                                                               \
-    do {                                                                                                            \
-        constexpr int idx_ = 2 * (IV_) + (IT_), half_ = idx_ >= 9 ? 1 : 0, tap_ = idx_ - 9 * half_;                 \
-        const unsigned so_ = (unsigned)tap_ * w_tap_b + (Q).wcol2 + (unsigned)(half_ * 64);                          \
-        dma16_at<(IT_) * WITEM>(rsw, wpo + so_, ldsW + (STB_) + wave * 1024);                                        \
-    } while (0)
-
-    // ---- prologue = slots -5 .. -1 of the request rule: W(0) + P_A, W(1), W(2), W(3), W(4) + P_B (chunk c_begin) -------
-    Chunk cur = chunk_of(c_begin);
-    DEEP_WITEM(cur, 0, 0, 0 * WSTAGE); DEEP_WITEM(cur, 0, 1, 0 * WSTAGE);
-    DEEP_PATCH(cur, 0);
-    DEEP_WITEM(cur, 1, 0, 1 * WSTAGE); DEEP_WITEM(cur, 1, 1, 1 * WSTAGE);
-    DEEP_WITEM(cur, 2, 0, 2 * WSTAGE); DEEP_WITEM(cur, 2, 1, 2 * WSTAGE);
-    DEEP_WITEM(cur, 3, 0, 3 * WSTAGE); DEEP_WITEM(cur, 3, 1, 3 * WSTAGE);
-    // (R_{-1} = W(4) + P_B follows the first barrier below, as every R_k follows the barrier of interval k)
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // ---- fragment addresses ---------------------------------------------------------------------------------------
-    const int fh = lane >> 5, l31 = lane & 31;
-    const unsigned wlane = ldsW + (unsigned)((wn * 64 + l31) * 64) + (unsigned)((fh ^ ((l31 >> 2) & 3)) << 4);
-    const int pib = deep_pix_in_block<W_>(l31);
-    unsigned po[9][2];                                           // pixel fragment of (tap, block j), k-step 0, buffer A
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int ml = wm * 64 + j * 32 + pib;
-        const int img = ml / HW, rem = ml - img * HW;
-        const int oy = rem / Cfg::W, ox = rem - oy * Cfg::W;
-        const int brow = img * IMG + oy * PW + ox;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int prow = brow + (t / 3) * PW + (t % 3);
-            po[t][j] = lds0 + (unsigned)(prow * 64) + (unsigned)((fh ^ ((prow >> 2) & 3)) << 4);
-        }
-    }
-    typedef unsigned int deep_u32x4 __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) const deep_u32x4* lds_u4;
-#define DEEP_LD(DST, ADDR, IMM) DST = *(lds_u4)(uintptr_t)((ADDR) + (IMM))
-#define DEEP_SB() __builtin_amdgcn_sched_barrier(0)
-#define DEEP_MM(FA, FB, I, J)                                                                                      \
-    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, FA[I]), __builtin_bit_cast(s16x8, FB[J]), acc[I][J], 0, 0, 0)
-    deep_u32x4 fa0[2], fb0[2], fa1[2], fb1[2];                   // two fragment sets (k-steps alternate)
-
-    unsigned stb = 0;                                            // ring offset of the CURRENT interval's stage
-    Chunk nxt = chunk_of(c_begin + 1);
-    // fragment reads of step S_ (0..3: item S_ / 2, k-step S_ % 2) of interval IV_ whose stage sits at ring offset WST_
-#define DEEP_LOAD_STEP(FA, FB, IV_, S_, WST_)                                                                      \
-    do {                                                                                                            \
-        constexpr int it_ = (S_) >> 1, ks_ = (S_) & 1, idx_ = 2 * (IV_) + it_, half_ = idx_ >= 9 ? 1 : 0, tap_ = idx_ - 9 * half_; \
-        const unsigned wa_ = (wlane + (WST_)) ^ (unsigned)(ks_ << 5);                                               \
-        DEEP_LD(FA[0], wa_, it_ * WITEM);                                                                           \
-        DEEP_LD(FB[0], po[tap_][0] ^ (unsigned)(ks_ << 5), half_ * PBUF);                                           \
-        DEEP_LD(FB[1], po[tap_][1] ^ (unsigned)(ks_ << 5), half_ * PBUF);                                           \
-        DEEP_LD(FA[1], wa_, it_ * WITEM + 2048);                                                                    \
-    } while (0)
-
-    // One interval: steps 0..2 with the next step's reads under the MFMAs, then the barrier (this stage is consumed: its
-    // reads have returned; the next interval's stage and patch halves have landed), then step 3 with the first reads of
-    // the next interval and the slot's requests R_IV.
-    bool first_chunk = true;
-    auto interval = [&](auto ivc) {
-        constexpr int IV = decltype(ivc)::value;
-        // (reads in the order the next step's MFMAs need them: fa[0], fb[0], fb[1], fa[1] -- each at least three MFMAs old)
-        // step 0 (set 0) | reads of step 1 -> set 1
-        { constexpr int it_ = 0, ks_ = 1, idx_ = 2 * IV + it_, half_ = idx_ >= 9 ? 1 : 0, tap_ = idx_ - 9 * half_;
-            const unsigned wa_ = (wlane + stb) ^ (unsigned)(ks_ << 5);
-            DEEP_MM(fa0, fb0, 0, 0); DEEP_SB(); DEEP_LD(fa1[0], wa_, it_ * WITEM); DEEP_SB();
-            DEEP_MM(fa0, fb0, 0, 1); DEEP_SB(); DEEP_LD(fb1[0], po[tap_][0] ^ (unsigned)(ks_ << 5), half_ * PBUF); DEEP_SB();
-            DEEP_MM(fa0, fb0, 1, 0); DEEP_SB(); DEEP_LD(fb1[1], po[tap_][1] ^ (unsigned)(ks_ << 5), half_ * PBUF); DEEP_SB();
-            DEEP_MM(fa0, fb0, 1, 1); DEEP_SB(); DEEP_LD(fa1[1], wa_, it_ * WITEM + 2048); DEEP_SB(); }
-        // step 1 (set 1) | reads of step 2 -> set 0
-        { constexpr int it_ = 1, idx_ = 2 * IV + it_, half_ = idx_ >= 9 ? 1 : 0, tap_ = idx_ - 9 * half_;
-            const unsigned wa_ = (wlane + stb);
-            DEEP_MM(fa1, fb1, 0, 0); DEEP_SB(); DEEP_LD(fa0[0], wa_, it_ * WITEM); DEEP_SB();
-            DEEP_MM(fa1, fb1, 0, 1); DEEP_SB(); DEEP_LD(fb0[0], po[tap_][0], half_ * PBUF); DEEP_SB();
-            DEEP_MM(fa1, fb1, 1, 0); DEEP_SB(); DEEP_LD(fb0[1], po[tap_][1], half_ * PBUF); DEEP_SB();
-            DEEP_MM(fa1, fb1, 1, 1); DEEP_SB(); DEEP_LD(fa0[1], wa_, it_ * WITEM + 2048); DEEP_SB(); }
-        // step 2 (set 0) | reads of step 3 -> set 1
-        { constexpr int it_ = 1, ks_ = 1, idx_ = 2 * IV + it_, half_ = idx_ >= 9 ? 1 : 0, tap_ = idx_ - 9 * half_;
-            const unsigned wa_ = (wlane + stb) ^ (unsigned)(ks_ << 5);
-            DEEP_MM(fa0, fb0, 0, 0); DEEP_SB(); DEEP_LD(fa1[0], wa_, it_ * WITEM); DEEP_SB();
-            DEEP_MM(fa0, fb0, 0, 1); DEEP_SB(); DEEP_LD(fb1[0], po[tap_][0] ^ (unsigned)(ks_ << 5), half_ * PBUF); DEEP_SB();
-            DEEP_MM(fa0, fb0, 1, 0); DEEP_SB(); DEEP_LD(fb1[1], po[tap_][1] ^ (unsigned)(ks_ << 5), half_ * PBUF); DEEP_SB();
-            DEEP_MM(fa0, fb0, 1, 1); DEEP_SB(); DEEP_LD(fa1[1], wa_, it_ * WITEM + 2048); DEEP_SB(); }
-        // every read of this interval's stage has returned; R_{IV-4} has landed (own pieces: vmcnt, all waves': barrier)
-        if (STAMP && stamps && IV == 4 && first_chunk) stamps[8] = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (STAMP && stamps && IV == 4 && first_chunk) stamps[9] = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(deep_allow(IV, NP)) : "memory");
-        if (STAMP && stamps && IV == 4 && first_chunk) stamps[10] = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_barrier();
-        if (STAMP && stamps && IV == 4 && first_chunk) stamps[11] = __builtin_amdgcn_s_memtime();
-        if (STAMP && stamps && IV == 5 && first_chunk) stamps[12] = __builtin_amdgcn_s_memtime();   // one interval later: the period
-        if (STAMP && stamps && IV == 3 && first_chunk) stamps[7] = __builtin_amdgcn_s_memtime();
-        DEEP_SB();
-        const unsigned freed = stb;                              // the stage this interval used: W(IV + 5) goes there
-        stb += WSTAGE; if (stb == (unsigned)(NWS * WSTAGE)) stb = 0;
-        // step 3 (set 1) | first reads of the next interval -> set 0 | the slot's requests
-        {
-            constexpr int NIV = (IV + 1) % 9;                     // (IV = 8: interval 0 of the next chunk: half A, tap 0)
-            constexpr int nhalf = 2 * NIV >= 9 ? 1 : 0, ntap = 2 * NIV - 9 * nhalf;          // its item 0
-            constexpr int RIV = (IV + 5) % 9;
-            const Chunk& rq = IV + 5 < 9 ? cur : nxt;
-            const unsigned wa_ = wlane + stb;
-            DEEP_MM(fa1, fb1, 0, 0); DEEP_SB(); DEEP_LD(fa0[0], wa_, 0); DEEP_WITEM(rq, RIV, 0, freed); DEEP_SB();
-            DEEP_MM(fa1, fb1, 0, 1); DEEP_SB(); DEEP_LD(fb0[0], po[ntap][0], nhalf * PBUF); DEEP_WITEM(rq, RIV, 1, freed); DEEP_SB();
-            DEEP_MM(fa1, fb1, 1, 0); DEEP_SB(); DEEP_LD(fb0[1], po[ntap][1], nhalf * PBUF); DEEP_SB();
-            DEEP_MM(fa1, fb1, 1, 1); DEEP_SB(); DEEP_LD(fa0[1], wa_, 2048); DEEP_SB();
-            if (IV == 4) { DEEP_PATCH(nxt, 0); DEEP_SB(); }       // buffer A: last read in this interval's item 0
-            if (IV == 8) { DEEP_PATCH(nxt, 1); DEEP_SB(); }       // buffer B: (for IV = 8 `nxt` is still the chunk after `cur`)
-        }
-    };
-
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);               // (as conv_pipe: the younger half loses every arbitration otherwise)
-    // barrier of "interval -1": W(0) and P_A of the first chunk
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(deep_allow(-1, NP)) : "memory");
-    __builtin_amdgcn_s_barrier();
-    if (STAMP && stamps) stamps[1] = __builtin_amdgcn_s_memtime();
-    DEEP_LOAD_STEP(fa0, fb0, 0, 0, 0u);
-    DEEP_WITEM(cur, 4, 0, 4 * WSTAGE); DEEP_WITEM(cur, 4, 1, 4 * WSTAGE);
-    DEEP_PATCH(cur, 1);
-    for (int c = c_begin; c < c_end; ++c) {
-        interval(std::integral_constant<int, 0>()); interval(std::integral_constant<int, 1>());
-        interval(std::integral_constant<int, 2>()); interval(std::integral_constant<int, 3>());
-        interval(std::integral_constant<int, 4>()); interval(std::integral_constant<int, 5>());
-        interval(std::integral_constant<int, 6>()); interval(std::integral_constant<int, 7>());
-        interval(std::integral_constant<int, 8>());
-        cur = nxt; nxt = chunk_of(c + 2);
-        first_chunk = false;
-    }
-#undef DEEP_LD
-#undef DEEP_SB
-#undef DEEP_MM
-#undef DEEP_LOAD_STEP
-#undef DEEP_PATCH
-#undef DEEP_WITEM
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // the trailing (poisoned) requests still write zeros into LDS
-    if (STAMP && stamps) stamps[2] = __builtin_amdgcn_s_memtime();
-    if (a.dbg & 2) return;                                       // dev aid (MPU_PIPE_DEBUG): no epilogue at all
-
-    // split-K: raw f32 partial sums [kz][M][Cout], staged through wave-private LDS rows (conv_pipe's epilogue; the pixel
-    // rows un-permuted: MFMA column l31 of block j holds pixel deep_pix_in_block(l31))
-    {
-        constexpr int SROW = PipeCfg::SROW;
-        float* P = a.partial + (long)kz * M * a.Cout;
-        __syncthreads();                                         // lagging waves still read the last stage
-        if (STAMP && stamps) stamps[13] = __builtin_amdgcn_s_memtime();
-        unsigned char* sw = smem + wave * (64 * SROW);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *(float4*)(sw + (j * 32 + pib) * SROW + (i * 32 + 8 * q + 4 * fh) * 4) =
-                        make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (STAMP && stamps) stamps[14] = __builtin_amdgcn_s_memtime();
-        const int nl = n0 + wn * 64 + (lane & 15) * 4;
-        float4 v[16];
-#pragma unroll
-        for (int it = 0; it < 16; ++it) v[it] = *(const float4*)(sw + (it * 4 + (lane >> 4)) * SROW + (lane & 15) * 16);
-        if (STAMP && stamps) stamps[3] = __builtin_amdgcn_s_memtime();
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int m = m0 + wm * 64 + it * 4 + (lane >> 4);
-            if (!(a.dbg & 1)) *(float4*)(P + (long)m * a.Cout + nl) = v[it];     // (dev aid: 1 = no partial stores)
-        }
-        if (STAMP && stamps) {
-            stamps[4] = __builtin_amdgcn_s_memtime();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            stamps[5] = __builtin_amdgcn_s_memtime();
-        }
-    }
-}
-
-template <int W_>
-static int launch_deep(const ConvArgs& a_in, int ks, hipStream_t st) {
-    using Cfg = DeepCfg<W_>;
-    unsigned long long* sbuf = stamp_buffer();                  // MPU_STAMPS=1: the instrumented instantiation
-    auto kern = sbuf ? conv_deep_kernel<W_, true> : conv_deep_kernel<W_, false>;
-    ConvArgs a = a_in;
-    a.dbg_buf = sbuf;
-    a.dbg = (int)env(ENV_PIPE_DEBUG);
-    if (a.w_elems <= 0) a.w_elems = 8 * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
-    static unsigned long long attr_set = 0;
-    if (first_use_on_device(attr_set)) {
-        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<W_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
-        MPU_CHECK_HIP(hipFuncSetAttribute((const void*)conv_deep_kernel<W_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
-        mark_used_on_device(attr_set);
-    }
-    const long M = (long)a.B * a.Ho * a.Wo;
-    const int tiles_m = (int)(M / Cfg::BM), tiles_n = a.Cout / Cfg::BN;
-    if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * 9 * (a.C0 + a.C1), st);
-    a.ksplit = ks;
-    launch_k(kern, dim3((unsigned)((long)tiles_m * tiles_n * ks)), dim3(512), Cfg::SMEM, st, a, tiles_m, tiles_n);
-    int rc = launch_ok();
-    if (!rc) rc = launch_splitk_finish<bf16_t>(a, ks, M, st);
-    if (prof_on()) prof_end(st);
-    return rc;
-}
-
-// 1 = launched, 0 = shape not suited (conv_pipe / conv_glds take it), < 0 = error. bf16 3 x 3 layers on square 8- or
-// 16-pixel maps whose pixels make whole 256-pixel tiles, channels in multiples of 64 (sources) and 128 (filters), fewer
-// tiles than CUs (so that K is split: the finish pass applies the epilogue), the split-K workspace present.
-template <typename T, int MODE>
-static int try_deep(const ConvArgs& a, hipStream_t st) {
-    if constexpr (sizeof(T) != 2 || MODE != CONV3) return 0;
-    else {
-        if (!env(ENV_CONV_DEEP) || a.Ho != a.Wo || (a.Wo != 8 && a.Wo != 16) || !a.partial || a.head_w || a.pooled) return 0;
-        const long M = (long)a.B * a.Ho * a.Wo;
-        if (M % 256 || a.Cout % 128 || a.C0 % 64 || a.C1 % 64 || a.C0 <= 0) return 0;
-        const long tiles = (M / 256) * (a.Cout / 128);
-        const int nchunks = (a.C0 + a.C1) / 64;
-        constexpr long wgs = 256;
-        if (tiles >= wgs) return 0;
-        long ks = (wgs + tiles / 2) / tiles;                     // ~one workgroup per CU
-        if (ks > nchunks) ks = nchunks;
-        while (ks > 1 && ks * M * a.Cout > a.partial_cap) --ks;
-        if (ks < 2) return 0;
-        {   // 32-bit offsets with a poison margin (as conv_pipe)
-            const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
-            const long wel = a.w_elems > 0 ? a.w_elems : 8 * a.w_tap_stride + (long)a.Cout * a.w_row_stride;
-            const long lim = (1L << 31) - 8192;
-            if ((M + 1) * cmax * 2L >= lim || wel * 2L >= lim || M * a.Cout * 4L >= (1L << 40)) return 0;
-        }
-        const int rc = a.Wo == 16 ? launch_deep<16>(a, (int)ks, st) : launch_deep<8>(a, (int)ks, st);
-        return rc ? rc : 1;
-    }
-}
-
 static thread_local const char* g_glds_sched = "glds";       // which schedule the last launch_conv_glds took (schedule log)
 const char* last_glds_schedule() { return g_glds_sched; }
 
@@ -1370,8 +996,6 @@ static int launch_glds_mode(const ConvArgs& a_in, hipStream_t st) {
     a.ksplit = 1;
     g_glds_sched = "glds";
     {
-        const int d = try_deep<T, MODE>(a, st);
-        if (d != 0) { g_glds_sched = "deep"; return d < 0 ? d : MPU_OK; }
         const int p = try_pipe<T, MODE>(a, st);
         if (p != 0) { g_glds_sched = "pipe"; return p < 0 ? p : MPU_OK; }
     }

@@ -727,6 +727,10 @@ int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
             const int h = try_conv_halo(dtype, mode, a, st);
             if (h != 0) { note(h == 2 ? "halo8" : "halo"); return h < 0 ? h : MPU_OK; }
         }
+        if (halo_on()) {
+            const int k = try_conv_deepk(dtype, mode, a, st);
+            if (k != 0) { note("deepk"); return k < 0 ? k : MPU_OK; }
+        }
         const int rc = launch_conv_glds(dtype, mode, a, st);
         note(last_glds_schedule());
         return rc;

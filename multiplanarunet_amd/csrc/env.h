@@ -21,8 +21,7 @@ enum EnvKind {
     X(CONV_C8, "MPU_CONV_C8", ENV_ON, 1, "0: first layer (8 padded channels) not on conv_c8")                                        \
     X(CONV_WS, "MPU_CONV_WS", ENV_ON, 1, "0: 64-channel level-0 layers not on the weight-stationary conv_ws")                        \
     X(CONV_PIPE, "MPU_CONV_PIPE", ENV_ON, 1, "0: deep layers on conv_glds instead of the 8-wave split-K conv_pipe")                  \
-    X(SPLITK_STATS_ROWS, "MPU_SPLITK_STATS_ROWS", ENV_NUM, 256, "blocks (= partial BatchNorm-statistics rows) of a split-K finish pass with fused statistics (<= 1024)") \
-    X(CONV_DEEP, "MPU_CONV_DEEP", ENV_ON, 1, "0: 3x3 layers on 8 / 16-pixel maps on conv_pipe instead of the whole-image halo-patch conv_deep") \
+    X(CONV_DEEPK, "MPU_CONV_DEEPK", ENV_ON, 1, "0: no conv_deepk (3x3 on 16-pixel maps with K split over the waves of a workgroup, no split-K partials)") \
     X(PIPE_DEBUG, "MPU_PIPE_DEBUG", ENV_NUM, 0, "dev aid: 32 = s_memtime stamps in conv_pipe")                                       \
     X(HALO8, "MPU_HALO8", ENV_ON, 1, "0: 192-400-workgroup grids on the 4-wave conv_halo instead of the 8-wave conv_halo8")          \
     X(HALO8_SCHED, "MPU_HALO8_SCHED", ENV_NUM, 1, "0: conv_halo8 with lockstep halves (round-3 A/B); 1: halves one phase apart")      \

@@ -97,6 +97,7 @@ void sched_note(const char* fmt, ...);
 int  launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // dispatches on MPU_CONV_IMPL
 int  launch_conv_glds(int dtype, int mode, const ConvArgs& a, hipStream_t st);  // LDS-DMA variant (conv_glds.hip)
 const char* last_glds_schedule();               // "glds" or "pipe": what the last launch_conv_glds of this thread ran
+int  try_conv_deepk(int dtype, int mode, const ConvArgs& a, hipStream_t st);   // 3x3 on 16-pixel maps, K split over the waves of a workgroup (conv_deepk.hip)
 int  try_conv_c8(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // <= 8 input channels: first layer (conv_c8.hip)
 int  try_conv_ws(int dtype, int mode, const ConvArgs& a, hipStream_t st);       // register-stationary weights, persistent (conv_ws.hip)
 int  try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st);     // LDS-resident patch variant (conv_halo.hip)

@@ -13,7 +13,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HEADER = os.path.join(HERE, "..", "include", "mpunet_hip.h")
-CONV_SOURCES = ("common.h", "kernels.h", "env.h", "reduce.h", "conv_c8.hip", "conv_glds.hip", "conv_halo.hip", "conv_halo16.hip", "conv_igemm.hip",
+CONV_SOURCES = ("common.h", "kernels.h", "env.h", "reduce.h", "conv_c8.hip", "conv_deepk.hip", "conv_glds.hip", "conv_halo.hip", "conv_halo16.hip", "conv_igemm.hip",
                 "conv_ws.hip", "wgrad_c8.hip", "wgrad_taps.hip", "unet_model.hip", "unet_ops.hip")
 GEOMETRY_SOURCES = ("common.h", "geometry.hip")
 

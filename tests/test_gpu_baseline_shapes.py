@@ -116,7 +116,11 @@ def test_cfg1_bf16_train_step_per_tensor_and_dispatch():
     assert "regs" not in scheds(conv) and "regs" not in scheds(wg)      # no register-staged fallback on the bench path
     assert scheds(conv).get("c8") == 1 and scheds(wg).get("c8") == 1    # first layer kernels
     assert set(scheds(conv)) >= {"c8", "ws", "halo", "pipe"} and set(scheds(wg)) >= {"c8", "taps", "glds"}
-    assert scheds(conv).get("pipe", 0) >= 14, scheds(conv)              # the deep levels run on conv_pipe (16 of the 47 launches)
+    deep = scheds(conv).get("pipe", 0) + scheds(conv).get("deepk", 0) + scheds(conv).get("deep", 0)
+    assert deep >= 14, scheds(conv)                                     # the deep levels: conv_pipe, and since round 5 ...
+    import os
+    if os.environ.get("MPU_CONV_DEEPK") != "0":
+        assert scheds(conv).get("deepk", 0) >= 6, scheds(conv)          # ... conv_deepk for the 3x3 layers on the 16 x 16 maps
 
     # --- inference mode (well conditioned: BatchNorm with moving statistics): tight bound against the matched model
     m.flatten_output = False

@@ -180,8 +180,9 @@ def test_halo16_subprocess():
         assert r.returncode == 0, str(extra) + r.stdout[-2000:] + r.stderr[-2000:]
 
 
-# Whole-image halo-patch schedule of the deep levels (conv_deep, round 5): 3x3 layers on square 8 / 16-pixel maps whose
-# pixels make whole 256-pixel tiles, sources in multiples of 64 channels, filters in multiples of 128, fewer tiles than CUs.
+# More 3x3 layers on square 8 / 16-pixel maps (whole 256-pixel tiles, sources in multiples of 64 channels, filters in
+# multiples of 128, fewer tiles than CUs: the split-K schedules). Written for conv_deep, the whole-image halo-patch split-K
+# kernel of round 5 that lost to conv_pipe inside the step and was removed; kept as cases of conv_pipe.
 DEEPH_CASES = [
     # mode,   B, H,  W,  C0,  C1,  Cout
     (CONV3,   16, 16, 16, 512, 0, 512),     # encoder_L3_conv2: 64 tiles, K split 4 ways, two chunks per workgroup
@@ -210,17 +211,39 @@ def _conv_schedules_of(fn):
     return [l.split()[1] for l in buf.value.decode().splitlines() if l.startswith("conv ")]
 
 
-@pytest.mark.parametrize("case", DEEPH_CASES + [c for c in DEEP_CASES[:3]])
-def test_whole_image_halo_patch_schedule_of_the_deep_levels(case):
-    """conv_deep (VERDICT r4 item 1): forward and data gradient of the case run on it (schedule log) and match the fp64 layer;
-    the result is bit-identical from launch to launch (fixed-order split-K finish)."""
+@pytest.mark.parametrize("case", DEEPH_CASES)
+def test_more_deep_level_shapes_on_the_split_k_schedules(case):
+    """Forward, data gradients and weight gradient of the case against the fp64 layer (odd K splits, one chunk per workgroup,
+    concat chunks over two sources, three filter tiles)."""
+    conv = _conv_schedules_of(lambda: _run_case(case, torch.bfloat16, workspace=True))
+    assert conv and conv[0] in ("pipe", "glds", "deepk"), conv
+
+
+# 3x3 layers on 16-pixel maps with K split over the WAVES of a workgroup (conv_deepk, round 5): 128-pixel x 64-filter tiles,
+# no split-K partials, epilogue in the kernel. Eligible: 192..512 tiles, an even number of 64-channel chunks, plain epilogue.
+DEEPK_CASES = [
+    # mode,   B, H,  W,  C0,  C1,  Cout
+    (CONV3,   16, 16, 16, 256, 0, 512),     # encoder_L3_conv1: 256 tiles, two chunk pairs
+    (CONV3,   16, 16, 16, 512, 0, 512),     # encoder_L3_conv2 shape: the data gradient (ReLU mask) is eligible too
+    (CONV3,   16, 16, 16, 512, 512, 512),   # upsample concat: eight pairs over two sources; 512-tile data gradient
+    (CONV3,   12, 16, 16, 128, 0, 512),     # 192 tiles (the lower bound), ONE chunk pair
+    (CONV3,   8, 16, 16, 64, 64, 1024),     # one pair made of the two sources; 16 filter tiles
+    (CONV3,   5, 16, 16, 384, 0, 1280),     # 10 x 20 = 200 tiles: odd image count (a tile is half an image), three pairs
+]
+
+
+@pytest.mark.parametrize("case", DEEPK_CASES)
+def test_k_split_over_the_waves_schedule_of_the_16_pixel_maps(case):
+    """conv_deepk: the forward launch of every case takes it (schedule log) and matches the fp64 layer, as does every
+    eligible data gradient (ReLU mask in the kernel's epilogue)."""
     import os
     conv = _conv_schedules_of(lambda: _run_case(case, torch.bfloat16, workspace=True))
-    if os.environ.get("MPU_CONV_DEEP") != "0":
-        assert conv and conv[0] == "deep", conv                  # the forward launch (data gradients: when their own shape is eligible)
+    if os.environ.get("MPU_CONV_DEEPK") != "0":
+        assert conv and conv[0] == "deepk", conv
         mode, B, H, W, C0, C1, Cout = case
-        if (C0 + C1) % 128 == 0 and Cout % 64 == 0:
-            assert conv.count("deep") >= 2, conv
+        tiles_d = (B * 2) * ((C0 + C1) // 64)
+        if 192 <= tiles_d <= 512 and (Cout // 64) % 2 == 0:
+            assert conv.count("deepk") >= 2, conv
 
 
 @pytest.mark.parametrize("case", DEEP_CASES)
