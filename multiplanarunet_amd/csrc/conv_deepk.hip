@@ -440,6 +440,10 @@ int try_conv_deepk(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
     // 1024 -> 512 concat layer took 52.0 us here against 40.5 + 7.2 for conv_pipe + finish (gpurun R5j); up to 512 channels
     // this kernel is 3-7 us ahead per layer.
     if (a.C0 + a.C1 > 512) return 0;
+    // (8 x 8 maps -- tile = two images, 128 tiles at configs[1] sizes, K split two ways over workgroups with the finish pass of
+    // conv_pipe -- were built and parity-green in this round: 25.1 / 32.5 us against 29.6 / 34.1 for conv_pipe + finish back to
+    // back, but slower inside the step, where the 9-19 MB of bottom-level weights arrive cold and this kernel streams them for
+    // twice as many pixel tiles: step 2.598 ms with them against 2.584 without, gpurun R5m vs R5i; removed)
     {   // 32-bit offsets with a poison margin
         const long cmax = a.C0 > a.C1 ? a.C0 : a.C1;
         const long wel = a.w_elems > 0 ? a.w_elems : 8 * a.w_tap_stride + (long)a.Cout * a.w_row_stride;

@@ -599,9 +599,11 @@ __global__ __launch_bounds__(256) void map_fuse_fast_kernel(FuseFastArgs a) {
         for (int k = 0; k < K; ++k) z[u][k] = 0.f;
     }
     unsigned risky = 0;
-#ifdef MPU_FUSE_UNROLL
-#pragma unroll MPU_FUSE_UNROLL
-#endif
+    // two views per iteration (eight gathers in flight): 0.439 -> 0.433 ms at 256^3 x 6 views, same box (gpurun R5l). The same
+    // call measured NON-TEMPORAL gathers + label stores (the float4 nt copy probe reaches 6.4 TB/s on this part, VERDICT r4
+    // item 7a): 0.726 ms -- a view's 128-byte line serves ~10 neighbouring voxels of other lanes and bricks, nt throws that
+    // L2 reuse away; not kept.
+#pragma unroll 2
     for (int v = 0; v < a.V; ++v) {
         const AffView& w = a.v[v];
         const double hg = 0.5 * (double)(w.dim - 1), ho = 0.5 * (double)(w.P - 1);
@@ -669,12 +671,7 @@ __global__ __launch_bounds__(256) void map_fuse_fast_kernel(FuseFastArgs a) {
 #pragma unroll
         for (int u = 0; u < FZ; ++u) {
             float x[K];
-#ifdef MPU_FUSE_NT
-#pragma unroll
-            for (int k = 0; k < K; ++k) x[k] = __builtin_nontemporal_load(w.pred + off[u] + k);      // read once: do not keep the line
-#else
             __builtin_memcpy(x, w.pred + off[u], K * sizeof(float));
-#endif
             if (out[u]) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) x[k] = k == 0 ? 1.f : 0.f;
@@ -710,11 +707,7 @@ __global__ __launch_bounds__(256) void map_fuse_fast_kernel(FuseFastArgs a) {
             softmax_argmax_store<K>(z[u], !a.sum_fusion, t, a.probs, a.labels);
         }
     }
-#ifdef MPU_FUSE_NT
-    if (packed) __builtin_nontemporal_store(pack, (unsigned*)(a.labels + (((long)vx0 * a.Y + vy) * a.Z + vz0)));
-#else
     if (packed) *(unsigned*)(a.labels + (((long)vx0 * a.Y + vy) * a.Z + vz0)) = pack;
-#endif
 }
 
 // exact recomputation of the voxels on the work list (all voxels if the list overflowed). The list is short and the exact

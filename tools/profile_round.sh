@@ -2,7 +2,7 @@
 TAG=$1; R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-predict --no-cpu-baseline --no-graph --no-kernel-events --no-peaks"
+B="python $R/bench.py --no-predict --no-cpu-baseline --no-graph --no-kernel-events --no-peaks --no-e2e"
 rocprofv3 --kernel-trace --stats -d $O/stats -o s -- $B --steps 10 --warmup 3 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o f -- $B --steps 3 --warmup 2 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/write -o w -- $B --steps 3 --warmup 2 > /dev/null 2>&1
