@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--predict-dim", type=int, default=0, help="override the predict volume edge (tests)")
     ap.add_argument("--cf", type=float, default=1.0, help="complexity_factor of the train-leg network (2 = the default project YAML)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the train_e2e (sampler -> step pipeline) and f32_mode legs")
+    ap.add_argument("--e2e-only", action="store_true", help="only the train_e2e leg (dev aid: prints its JSON object)")
     args = ap.parse_args()
 
     from multiplanarunet_amd import distributed as D
@@ -163,6 +164,15 @@ def main():
     for _ in range(args.warmup):
         step()
     lib = _lib.load()
+    if args.e2e_only:
+        replay = model.make_graphed_train_step(x, y, sw)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            replay()
+        torch.cuda.synchronize()
+        head = B * args.steps / (time.perf_counter() - t0)
+        print(json.dumps({"headline_slices_per_s": round(head, 1), "train_e2e": bench_train_e2e(model, device, B, dim, headline=head)}), flush=True)
+        return
     loss_first = current_loss()
     events = not args.no_kernel_events
     # N=1: the whole step (fwd + bwd + Adam + repack, ~260 launches) is replayed from one HIP graph; the
@@ -494,7 +504,8 @@ def bench_train_e2e(model, device, B, dim, headline, steps=120, warmup=12):
     res["ms_per_step"] = round(dt / steps * 1e3, 4)
     res["epoch_loss"] = round(loss, 5)
     res["fraction_of_headline"] = round(res["value"] / headline, 4) if headline else None
-    res["launch"] = "sampler on a priority side stream one batch ahead; step = hip-graph replay; loss summed on the device"
+    res["producer_stream_latency_us"] = round(pipe.side_latency_us, 1) if pipe.side_latency_us is not None else None
+    res["launch"] = "sampler on a side stream (picked by measured latency beside a busy main stream) one batch ahead; step = hip-graph replay; loss summed on the device"
     return res
 
 

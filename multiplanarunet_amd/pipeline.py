@@ -3,8 +3,8 @@ The producer / consumer overlap of `mp train` (mpunet/train/trainer.py:238-257: 
 max_queue_size=5)` -- five host threads cut batches while the GPU trains).
 
 Here the producer is the GPU plane sampler itself (data.TrainSampler), so the overlap is between two HIP streams of one
-process instead of between threads: batch i+1 is cut on a high-priority side stream while train step i runs on the main
-stream. The sampler's per-candidate host read (8 bytes of accept / reject statistics) synchronises only the side stream, so the
+process instead of between threads: batch i+1 is cut on a side stream (chosen by measurement: pick_side_stream) while train
+step i runs on the main stream. The sampler's per-candidate host read (8 bytes of accept / reject statistics) synchronises only the side stream, so the
 host never waits for the train step; the step itself is one HIP-graph replay (UNet.make_graphed_train_step on fixed input
 tensors -- the cut batch is copied into them, 1 MB) and the loss is accumulated on the device and read once per epoch.
 
@@ -16,6 +16,43 @@ With data parallelism (model._grad_hook set) the step stays eager (the RCCL all-
 and the device-side loss are the same.
 """
 import torch
+
+
+def pick_side_stream(dev, candidates=6, busy_ms=3.0):
+    """A producer stream that really runs BESIDE the current stream. The HIP runtime multiplexes its streams onto a few hardware
+    queues; a side stream that lands on the queue of the training stream executes behind the whole graph replay, and every host read
+    of the sampler then costs a train step (measured, gpurun R5p / R5r: `train_e2e` 0.64 of the bench line when the streams created by
+    the legs before it had shifted the assignment, 0.97 otherwise). So the pipeline MEASURES: the current stream is kept busy for a
+    few milliseconds with large fills, each candidate stream (both priorities) gets one tiny kernel, and the candidate whose kernel
+    completes soonest -- it did not wait for the fills -- is taken. Returns (stream, its latency in microseconds)."""
+    import time
+    main = torch.cuda.current_stream(dev)
+    big = torch.empty(64 << 20, dtype=torch.float32, device=dev)           # 256 MB: ~0.1 ms per fill
+    tiny = torch.zeros(64, dtype=torch.float32, device=dev)
+    cands = [torch.cuda.Stream(device=dev, priority=-1 if k % 2 == 0 else 0) for k in range(candidates)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    big.fill_(1.0)
+    torch.cuda.synchronize(dev)
+    per_fill = max(time.perf_counter() - t0, 2e-5)
+    nfill = int(min(200, max(8, busy_ms * 1e-3 / per_fill)))
+    best = None
+    for st in cands:
+        torch.cuda.synchronize(dev)
+        for _ in range(nfill):
+            big.fill_(1.0)                                               # the "train step" of the probe
+        ev = torch.cuda.Event()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(st):
+            tiny.add_(1.0)
+            ev.record(st)
+        ev.synchronize()
+        lat = (time.perf_counter() - t0) * 1e6
+        if best is None or lat < best[1]:
+            best = (st, lat)
+    torch.cuda.synchronize(dev)
+    del big
+    return best
 
 
 class TrainPipeline:
@@ -35,7 +72,7 @@ class TrainPipeline:
         if self.graphed and model._grad_hook is not None:
             raise NotImplementedError("the graphed step is single-GPU (the gradient all-reduce stays eager)")
         self.overlap = bool(overlap)
-        self.side = torch.cuda.Stream(device=dev, priority=-1) if self.overlap else None
+        self.side, self.side_latency_us = (pick_side_stream(dev) if self.overlap else (None, None))
         self._replay, self._lr = None, None
         self._pending = None
 
