@@ -398,6 +398,10 @@ int mpu_probe_stream_triad(float* d_a, const float* d_b, const float* d_c, int64
  * "float4 copy" MI355X_MICROARCH.md quotes at 6.29 TB/s. variant 0: default cache policy; 1: non-temporal loads and stores;
  * 2: default policy, grid-stride. */
 int mpu_probe_stream_copy(float* d_dst, const float* d_src, int64_t n, int32_t variant, void* stream);
+/* Measurement aid: the n floats of d_src (n a power of two >= 8192) read once, in runs of run_bytes contiguous bytes (a power of
+ * two >= 16) visited in a scattered order; per-thread sums to d_out (n / 32 floats). What HBM delivers to a kernel whose requests
+ * are coalesced but whose DRAM pages are opened out of order (the gather kernels of fuse_and_predict.py:92-137). */
+int mpu_probe_permuted_read(const float* d_src, float* d_out, int64_t n, int32_t run_bytes, void* stream);
 /* out[i] = x[3i] + x[3i+1] + x[3i+2]: 12 contiguous bytes per lane, 12 n bytes read exactly once -- the access width of
  * the fused back-mapping's K = 3 gathers; calibrates rocprofv3's FETCH_SIZE for that width (MI355X_MICROARCH.md: the
  * gfx950 x2 correction is established for 16-byte accesses only). */

@@ -139,6 +139,7 @@ _SIGS = {
     "mpu_probe_mfma_bf16_random": (C.c_int, [i32, i32, c_p, C.POINTER(f64), c_p]),
     "mpu_probe_stream_triad": (C.c_int, [c_p, c_p, c_p, i64, c_p]),
     "mpu_probe_stream_copy": (C.c_int, [c_p, c_p, i64, i32, c_p]),
+    "mpu_probe_permuted_read": (C.c_int, [c_p, c_p, i64, i32, c_p]),
     "mpu_probe_gather12": (C.c_int, [c_p, c_p, i64, c_p]),
     "mpu_probe_clock": (C.c_int, [c_p, i32, i32, c_p]),
     "mpu_schedule_log_enable": (C.c_int, [i32]),

@@ -535,6 +535,9 @@ __global__ __launch_bounds__(256) void map_fuse_fast_kernel(FuseFastArgs a) {
     // CFG 2: a WAVE covers a 4x4x16 block, lane (tx, ty, tz) owns the 4 consecutive voxels z = 4 tz .. 4 tz + 3; the 4
     //        waves tile a 8x8x16 brick. Each of a view's 4 gather instructions then has a compact 4x4x(4 strided) footprint and
     //        the four together touch the lines of a 4x4x16 block once (fewest L2 requests per voxel for an arbitrary view).
+    // (Round 5, gpurun R5t: a lane owning z = tz, tz + 4, tz + 8, tz + 12 instead -- every gather instruction then covers a
+    //        COMPACT 4x4x4 cube, labels exchanged inside the quad by DPP -- measured 0.416 vs 0.424 ms: the number of distinct lines
+    //        per gather instruction is not what bounds this kernel; not kept.)
     constexpr int LY = CFG == 1 ? 8 : 4, BX = CFG ? 8 : 4, BY = CFG ? 8 : 4, BZ = CFG ? 16 : 64, OWN = CFG == 1 ? 0 : 2,
                   STRIDE = CFG == 1 ? 2 : (CFG == 2 ? 1 : 16);
     const int nz = (a.Z + BZ - 1) / BZ, ny = (a.Y + BY - 1) / BY, nx = (a.X + BX - 1) / BX;

@@ -115,6 +115,30 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(float4* __restrict__ ds
     }
 }
 
+// Read-once in PERMUTED runs (round 5): the n floats are cut into runs of RUN contiguous bytes (a power of two, 128 ... 4096) and
+// the runs are visited in a scattered order (run r of the walk = source run (r * odd constant) mod nruns, a bijection for a
+// power-of-two run count). Inside a run the lanes read contiguous 16-byte pieces, so every request is as coalesced as a copy's;
+// only the ORDER in which DRAM pages are opened differs from a stream. Calibrates what the gather kernels (fused back-mapping:
+// 128-byte lines of six prediction volumes in brick order) can expect from HBM: the stream figure is not their bound.
+// A thread sums 8 pieces and writes one float: 3 % write traffic.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void probe_permuted_read_kernel(const float4* __restrict__ src, float* __restrict__ out, long n4,
+                                                                  int run_shift4 /* log2(run bytes / 16) */, long run_mask) {
+    const long base = ((long)blockIdx.x * UNROLL) * 256 + threadIdx.x;
+    float4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const long e = base + (long)u * 256;
+        const long r = e >> run_shift4, w = e & ((1L << run_shift4) - 1);
+        const long rp = (r * 0x9E3779B1L) & run_mask;
+        v[u] = src[(rp << run_shift4) + w];
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+    out[(long)blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 // out[i] = x[3i] + x[3i+1] + x[3i+2]: every lane reads 12 contiguous bytes (the K = 3 gather width of the fused
 // back-mapping), the wave 768 contiguous bytes: 12 n bytes read exactly once. Calibrates FETCH_SIZE for 12-byte accesses.
 __global__ __launch_bounds__(256) void probe_gather12_kernel(const float* __restrict__ x, float* __restrict__ out, long n) {
@@ -189,6 +213,20 @@ int mpu_probe_stream_copy(float* d_dst, const float* d_src, int64_t n, int32_t v
     if (variant == 0) probe_copy_kernel<0, U><<<dim3((unsigned)blocks), dim3(256), 0, st>>>((float4*)d_dst, (const float4*)d_src, n4);
     else if (variant == 1) probe_copy_kernel<1, U><<<dim3((unsigned)blocks), dim3(256), 0, st>>>((float4*)d_dst, (const float4*)d_src, n4);
     else probe_copy_kernel<2, U><<<dim3((unsigned)(blocks < 256L * 32 ? blocks : 256L * 32)), dim3(256), 0, st>>>((float4*)d_dst, (const float4*)d_src, n4);
+    return launch_ok();
+}
+
+// Sum of n floats read once in permuted runs of run_bytes (128 ... 4096, a power of two; run_bytes >= 4 n: one run = a stream);
+// n a power of two >= 2^13; d_out holds n / 32 floats. HBM bytes read = 4 n.
+int mpu_probe_permuted_read(const float* d_src, float* d_out, int64_t n, int32_t run_bytes, void* stream) {
+    MPU_REQUIRE(d_src && d_out && n >= 8192 && (n & (n - 1)) == 0, "mpu_probe_permuted_read: n must be a power of two >= 8192");
+    MPU_REQUIRE(run_bytes >= 16 && (run_bytes & (run_bytes - 1)) == 0, "mpu_probe_permuted_read: run_bytes must be a power of two >= 16");
+    constexpr int U = 8;
+    const long n4 = n / 4;
+    int sh = 0; while ((16L << sh) < run_bytes && (1L << sh) < n4) ++sh;
+    const long nruns = n4 >> sh;
+    probe_permuted_read_kernel<U><<<dim3((unsigned)(n4 / (256L * U))), dim3(256), 0, (hipStream_t)stream>>>(
+        (const float4*)d_src, d_out, n4, sh, nruns - 1);
     return launch_ok();
 }
 

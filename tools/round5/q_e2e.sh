@@ -1,4 +1,5 @@
 # R5q: train_e2e under variants of the producer stream (priority), three repetitions each, same box
+# (historical: MPU_PIPE_PRIORITY was a switch of that experiment build only; pipeline.pick_side_stream replaced it)
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 for rep in 1 2 3; do
   for prio in -1 0; do

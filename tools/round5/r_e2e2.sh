@@ -1,4 +1,5 @@
 # R5r: why train_e2e drops to 0.6 of the headline when the predict leg ran before it (R5a, R5p) and not otherwise (R5b, R5q)
+# (historical: MPU_BENCH_KEEP_CACHE existed in that experiment build of bench.py only)
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 for keep in 1 0 1 0; do
   MPU_BENCH_KEEP_CACHE=$keep python bench.py --no-cpu-baseline --no-peaks --steps 30 2>/dev/null | python -c "
