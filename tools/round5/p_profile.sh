@@ -15,6 +15,9 @@ timeout 900 rocprofv3 --kernel-trace --stats -d $O/c4 -o c -- python $R/bench.py
 python $R/tools/rocpd_stats.py $(find $O/c4 -name "*.db" | head -1) 24 > $O/configs4_predict_kernel_stats.txt
 rm -rf $O/gf $O/gw $O/c3 $O/c4 $O/stats $O/fetch $O/write $O/predict
 cd $R
+# the bench lines below quote the HBM bytes of THIS build's counter passes (bench.py takes the newest profiles/*_pmc.json whose source
+# hash matches the tree)
+cp $O/hbm_traffic_pmc.json profiles/${TAG}_hbm_traffic_pmc.json; cp $O/geometry_pmc.json profiles/${TAG}_geometry_pmc.json
 timeout 600 python bench.py > $O/bench.log 2>&1; tail -1 $O/bench.log > $O/bench_line.json; cut -c1-300 $O/bench_line.json
 timeout 600 python bench.py --config 3 --no-predict --no-cpu-baseline > $O/bench3.log 2>&1; tail -1 $O/bench3.log > $O/bench_line_configs3.json; cut -c1-300 $O/bench_line_configs3.json
 timeout 900 python bench.py --config 4 > $O/bench4.log 2>&1; tail -1 $O/bench4.log > $O/bench_line_configs4.json; cut -c1-300 $O/bench_line_configs4.json
