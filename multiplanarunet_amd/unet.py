@@ -579,6 +579,11 @@ class UNet:
             self._infer_dirty = True
         replay.graph = graph
         replay.warmup_ran = bool(warmup)
+        # Everything the captured launches address must outlive the graph. The Adam step counter is created HERE: without this
+        # reference it was freed when this function returned, the caching allocator handed its block to the next small tensor
+        # on the stream, and the replayed Adam kernels then read that tensor's bytes as the step count -- a wrong bias correction
+        # (up to NaN) from the first allocation after the capture on (found by tests/test_gpu_pipeline.py, round 5).
+        replay.keep_alive = (step_dev, x, y, sample_weight, loss_sum)
         return replay
 
     def train_step(self, x, y, sample_weight=None, want_loss=True):
