@@ -196,6 +196,8 @@ def test_graphed_train_step_matches_eager():
         a.train_step(x, y, sw, want_loss=False)
     replay = b.make_graphed_train_step(x, y, sw)       # performs step 1 while warming up
     for _ in range(3):
+        junk = [torch.full((k + 1,), 7, dtype=torch.int64, device="cuda") for k in range(8)]   # small tensors between the replays: the
+        del junk                                       # graph's own buffers (Adam step counter) must not be theirs to reuse (round 5)
         replay()
     torch.cuda.synchronize()
     assert b.iterations == a.iterations == 4
