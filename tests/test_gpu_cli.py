@@ -98,3 +98,43 @@ def test_mp_train_then_predict_synthetic(tmp_path):
     mp.entry_func(["predict", "--project_dir", str(proj), "--synthetic", "1", "--overwrite"])
     res5 = (proj / "predictions" / "csv" / "results.csv").read_text().splitlines()
     assert float(res5[1].split(",")[1]) > 0.5 and abs(float(res5[1].split(",")[1]) - float(res2[1].split(",")[1])) <= 2e-2, (res5, res2)
+
+
+def test_mp_train_continue_training_resumes_where_the_reference_would(tmp_path):
+    """`mp train --continue_training` end to end (mpunet/models/model_init.py:23-47): the newest @epoch_ checkpoint is loaded, the
+    epoch loop restarts at its number + 1, logs/training.csv is cut back and appended to, the logged learning rate comes back."""
+    import re
+    from multiplanarunet_amd.cli import mp
+    proj = tmp_path / "proj"
+    proj.mkdir()
+    (proj / "train_hparams.yaml").write_text(
+        "build:\n  model_class_name: UNet\n  n_classes: 3\n  n_channels: 1\n  dim: 64\n  depth: 3\n"
+        "  complexity_factor: 0.0625\n  out_activation: softmax\n  seed: 0\n"
+        "fit:\n  views: 3\n  noise_sd: 0.1\n  real_space_span: 64.0\n  batch_size: 8\n  n_epochs: 2\n"
+        "  optimizer: Adam\n  optimizer_kwargs: {lr: 2.0e-3, decay: 0.0, beta_1: 0.9, beta_2: 0.999, epsilon: 1.0e-8}\n"
+        "  loss: SparseCategoricalCrossentropy\n  fg_batch_fraction: 0.5\n  bg_value: 1pct\n  scaler: RobustScaler\n")
+    common = ["train", "--project_dir", str(proj), "--synthetic", "4", "--train_images_per_epoch", "96", "--val_images_per_epoch", "32"]
+    mp.entry_func(common + ["--epochs", "4"])
+    csv = proj / "logs" / "training.csv"
+    rows0 = csv.read_text().strip().splitlines()
+    head = rows0[0].split(",")
+    ep0 = [int(r.split(",")[0]) for r in rows0[1:]]
+    assert ep0 == [0, 1, 2, 3]
+    loss0 = [float(r.split(",")[head.index("loss")]) for r in rows0[1:]]
+    ck = [int(re.findall(r"@epoch_(\d+)_", f)[0]) for f in os.listdir(proj / "model") if f.startswith("@epoch")]
+    assert ck, os.listdir(proj / "model")
+    N = max(ck)                                             # Keras' 1-based epoch number of the newest (= best kept) checkpoint
+    lr_logged = [float(r.split(",")[head.index("lr")]) for r in rows0[1:]]
+    with pytest.raises(OSError):                            # neither --overwrite nor --continue_training: refuses, as the reference
+        mp.entry_func(common + ["--epochs", "4"])
+    mp.entry_func(common + ["--epochs", "7", "--continue_training"])
+    rows1 = csv.read_text().strip().splitlines()
+    ep1 = [int(r.split(",")[0]) for r in rows1[1:]]
+    kept = [e for e in ep0 if e <= N]                       # rows [0, N] stay (utils.py:145-163) ...
+    assert ep1 == kept + list(range(N + 1, 7)), (N, ep1)    # ... and the loop continues at N + 1 (model_init.py:43-47)
+    assert rows1[1:1 + len(kept)] == rows0[1:1 + len(kept)]                  # the kept rows are the old ones, untouched
+    loss1 = [float(r.split(",")[head.index("loss")]) for r in rows1[1 + len(kept):]]
+    assert loss1 and loss1[0] < loss0[0] * 0.9, (loss0, loss1)               # trained weights came back, not a fresh network
+    lr1 = float(rows1[1 + len(kept)].split(",")[head.index("lr")])
+    want_lr = lr_logged[min(N, len(lr_logged) - 1)]         # the rate logged in row N of the CSV (the last row beyond it)
+    assert lr1 <= want_lr * (1 + 1e-12) and lr1 >= want_lr * 0.9 ** 3, (lr1, want_lr)     # (ReduceLROnPlateau may have stepped since)
