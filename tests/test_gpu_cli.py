@@ -138,3 +138,43 @@ def test_mp_train_continue_training_resumes_where_the_reference_would(tmp_path):
     lr1 = float(rows1[1 + len(kept)].split(",")[head.index("lr")])
     want_lr = lr_logged[min(N, len(lr_logged) - 1)]         # the rate logged in row N of the CSV (the last row beyond it)
     assert lr1 <= want_lr * (1 + 1e-12) and lr1 >= want_lr * 0.9 ** 3, (lr1, want_lr)     # (ReduceLROnPlateau may have stepped since)
+
+
+def test_mp_train_two_ranks_data_parallel_then_resume(tmp_path):
+    """`mp train --num_GPUs 2` end to end: the entry point re-launches itself as two ranks (sharing GPU 0 over gloo here, the testing
+    aid of tests/test_gpu_bench_multi.py), each rank cuts its own half of the batch on its producer stream, gradients are SUM
+    all-reduced, rank 0 alone writes checkpoints / CSV; `--continue_training` then resumes on both ranks from rank 0's decision."""
+    import subprocess, sys, re
+    proj = tmp_path / "proj"
+    proj.mkdir()
+    (proj / "train_hparams.yaml").write_text(
+        "build:\n  model_class_name: UNet\n  n_classes: 3\n  n_channels: 1\n  dim: 64\n  depth: 3\n"
+        "  complexity_factor: 0.0625\n  out_activation: softmax\n  seed: 0\n"
+        "fit:\n  views: 3\n  noise_sd: 0.1\n  real_space_span: 64.0\n  batch_size: 8\n  n_epochs: 2\n"
+        "  optimizer: Adam\n  optimizer_kwargs: {lr: 2.0e-3, decay: 0.0, beta_1: 0.9, beta_2: 0.999, epsilon: 1.0e-8}\n"
+        "  loss: SparseCategoricalCrossentropy\n  fg_batch_fraction: 0.5\n  bg_value: 1pct\n  scaler: RobustScaler\n")
+    env = dict(os.environ, MPU_SHARE_GPU="1", MPU_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, "-m", "multiplanarunet_amd.cli.mp", "train", "--project_dir", str(proj), "--synthetic", "4",
+            "--train_images_per_epoch", "96", "--val_images_per_epoch", "32", "--num_GPUs", "2"]
+    r = subprocess.run(base + ["--epochs", "3"], env=env, capture_output=True, text=True, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert r.stdout.count("Saved %s" % (proj / "model" / "model_weights.npz")) == 1      # rank 0 alone writes and reports
+    rows = (proj / "logs" / "training.csv").read_text().strip().splitlines()
+    head = rows[0].split(",")
+    assert [int(x.split(",")[0]) for x in rows[1:]] == [0, 1, 2]
+    loss = [float(x.split(",")[head.index("loss")]) for x in rows[1:]]
+    assert loss[-1] < loss[0], loss
+    ck = [int(re.findall(r"@epoch_(\d+)_", f)[0]) for f in os.listdir(proj / "model") if f.startswith("@epoch")]
+    assert ck
+    N = max(ck)
+    r = subprocess.run(base + ["--epochs", "6", "--continue_training"], env=env, capture_output=True, text=True, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert r.stdout.count("Training continues from") == 1
+    rows1 = (proj / "logs" / "training.csv").read_text().strip().splitlines()
+    ep1 = [int(x.split(",")[0]) for x in rows1[1:]]
+    assert ep1 == [e for e in (0, 1, 2) if e <= N] + list(range(N + 1, 6)), (N, ep1)
+    loss1 = float(rows1[-1].split(",")[head.index("loss")])
+    assert loss1 < loss[0], (loss, loss1)
