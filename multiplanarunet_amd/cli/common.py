@@ -331,6 +331,48 @@ def remove_validation_callbacks(callbacks, logger=None):
     return keep
 
 
+def await_pids(pids, check_every=120, logger=print, sleep=None):
+    """`--wait_for PID[,PID...]` (mpunet/utils/utils.py:337-375): return when none of the processes is running any more; the
+    process table is looked at every `check_every` seconds. A PID that is not an integer is a ValueError, as there."""
+    import time
+    if not pids:
+        return
+    for tok in str(pids).split(","):
+        tok = tok.strip()
+        if not tok:
+            continue
+        try:
+            pid = int(tok)
+        except ValueError as e:
+            raise ValueError("Cannot wait for PID '%s', must be an integer" % tok) from e
+        while _pid_running(pid):
+            logger("Process %i is still running... (sleeping %i seconds)" % (pid, check_every))
+            (sleep or time.sleep)(check_every)
+
+
+def _pid_running(pid):
+    try:
+        os.kill(pid, 0)                                    # signal 0: existence / permission check only
+    except ProcessLookupError:
+        return False
+    except PermissionError:
+        return True                                        # exists, owned by someone else
+    try:                                                   # a zombie is in the table but no longer running
+        with open("/proc/%d/stat" % pid) as f:
+            return f.read().rsplit(")", 1)[1].split()[0] != "Z"
+    except OSError:
+        return True
+
+
+def note_inert_flags(args, names, logger=print):
+    """Flags of the reference's parser that are accepted for command-line compatibility but steer subsystems outside this build
+    (image queues, TensorBoard images, the TF debugger, per-view evaluation): say so instead of ignoring them silently."""
+    for name, why in names:
+        val = getattr(args, name, None)
+        if val not in (None, False, "", 0) and not (name == "eval_prob" and float(val) == 1.0) and not (name == "num_access" and int(val) == 50):
+            logger("[OBS] --%s has no effect in this build (%s)" % (name, why))
+
+
 def per_gpu_launch_command(script, argv, num_gpus, port=None):
     """`mp <script> --num_GPUs N` in the reference is ONE process driving N GPUs (tf.distribute.MirroredStrategy,
     mpunet/bin/train.py:349, bin/predict.py:214); here it is one process per GPU over RCCL. The command that re-runs the same

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .common import (validate_project_dir, load_hparams, load_dataset, require_audited_hparams,
-                     fusion_weights_path)
+                     fusion_weights_path, note_inert_flags)
 
 
 def get_argparser():
@@ -64,6 +64,7 @@ def run(args):
     log = (lambda *a, **k: print(*a, flush=True)) if rank == 0 else (lambda *a, **k: None)
     hp = load_hparams(project_dir)
     fit, build = hp["fit"], hp["build"]
+    note_inert_flags(args, [("eval_prob", "per-view evaluation is not part of this build: the fused volume is always evaluated")], log)
     if args.f:
         img, lab, aff = load_volume_file(args.f)
         if args.l:
@@ -100,7 +101,10 @@ def run(args):
     for v in vols:
         src = str(getattr(v, "source_path", "") or "")
         as_nii = args.out_format == "nii" or (args.out_format == "auto" and src.endswith((".nii", ".nii.gz")))
-        dst = os.path.join(nii, "%s_PRED.%s" % (v.identifier, "nii.gz" if as_nii else "npz"))
+        # bin/predict.py:90-117: with --save_input_files the prediction goes into a sub-folder <identifier>/ of nii_files,
+        # next to <identifier>_IMAGE and <identifier>_LABELS
+        out_base = os.path.join(nii, v.identifier) if args.save_input_files else nii
+        dst = os.path.join(out_base, "%s_PRED.%s" % (v.identifier, "nii.gz" if as_nii else "npz"))
         if os.path.exists(dst) and args.continue_:
             continue
         if os.path.exists(dst) and not args.overwrite:
@@ -113,6 +117,20 @@ def run(args):
             probs, labels = multi_view_predict(model, v, views, build["dim"], fit["real_space_span"], fm,
                                                sum_fusion=args.sum_fusion, batch_size=None,
                                                want_probs=args.no_argmax)
+        if rank == 0 and args.save_input_files:
+            sub = out_base                                # the volume as it was read: unscaled image, label map
+            os.makedirs(sub, exist_ok=True)
+            raw = v.image.cpu().numpy()                   # (the volume as read: the scaler is applied by the sampling kernel)
+            raw = raw[..., 0] if raw.shape[-1] == 1 else raw
+            lab_h = None if v.labels is None else v.labels.cpu().numpy().astype(np.uint8)
+            if as_nii:
+                save_nifti(os.path.join(sub, "%s_IMAGE.nii.gz" % v.identifier), raw, v.affine)
+                if lab_h is not None:
+                    save_nifti(os.path.join(sub, "%s_LABELS.nii.gz" % v.identifier), lab_h, v.affine)
+            else:
+                np.savez_compressed(os.path.join(sub, "%s_IMAGE.npz" % v.identifier), image=raw, affine=v.affine)
+                if lab_h is not None:
+                    np.savez_compressed(os.path.join(sub, "%s_LABELS.npz" % v.identifier), labels=lab_h, affine=v.affine)
         if rank == 0:
             if as_nii:                                # the label map, or with --no_argmax the fused [X,Y,Z,K] probabilities
                 pred = probs.cpu().numpy() if (args.no_argmax and probs is not None) else labels.cpu().numpy().astype(np.uint8)
@@ -139,7 +157,9 @@ def entry_func(args=None):
     import sys
     argv = list(sys.argv[1:] if args is None else args)
     args = get_argparser().parse_args(argv)
-    from .common import relaunch_per_gpu
+    from .common import relaunch_per_gpu, await_pids
+    if args.wait_for and "RANK" not in os.environ:        # (once, in the launching process: utils.py:337-375)
+        await_pids(args.wait_for)
     relaunch_per_gpu("predict", argv, args.num_GPUs)     # --num_GPUs N > 1: one process per GPU (returns inside a torchrun job)
     run(args)
 

@@ -11,7 +11,7 @@ import torch
 
 from .common import (validate_project_dir, load_hparams, load_dataset, load_or_create_views,
                      fill_build_from_data, save_audited_hparams, set_bias_weights_on_all_outputs,
-                     init_callback_objects, remove_validation_callbacks, DEFAULT_CALLBACKS)
+                     init_callback_objects, remove_validation_callbacks, DEFAULT_CALLBACKS, note_inert_flags)
 
 
 def get_argparser():
@@ -81,6 +81,9 @@ def run(args):
         raise OSError("There seems to be existing files in the project 'model' folder. "
                       "Use --overwrite or --continue_training.")
     hp = load_hparams(project_dir)
+    note_inert_flags(args, [("no_images", "no sample images are written during training"), ("debug", "the TF debugger has no counterpart"),
+                            ("max_loaded_images", "volumes stay resident in HBM: there is no image queue"),
+                            ("num_access", "volumes stay resident in HBM: there is no image queue")], log)
     train = load_dataset(hp["train_data"], project_dir, hp, device, args.synthetic, seed=0)
     val = [] if args.no_val else load_dataset(hp["val_data"], project_dir, hp, device,
                                               max(1, args.synthetic // 4) if args.synthetic else 0, seed=1000)
@@ -193,7 +196,9 @@ def entry_func(args=None):
     argv = list(sys.argv[1:] if args is None else args)
     args = get_argparser().parse_args(argv)
     validate_args(args)
-    from .common import relaunch_per_gpu
+    from .common import relaunch_per_gpu, await_pids
+    if args.wait_for and "RANK" not in os.environ:        # (once, in the launching process: utils.py:337-375)
+        await_pids(args.wait_for)
     relaunch_per_gpu("train", argv, args.num_GPUs)       # --num_GPUs N > 1: one process per GPU (returns inside a torchrun job)
     run(args)
 

@@ -161,7 +161,9 @@ def entry_func(args=None):
     import sys
     argv = list(sys.argv[1:] if args is None else args)
     args = get_argparser().parse_args(argv)
-    from .common import relaunch_per_gpu
+    from .common import relaunch_per_gpu, await_pids
+    if args.wait_for and "RANK" not in os.environ:        # (once, in the launching process: utils.py:337-375)
+        await_pids(args.wait_for)
     relaunch_per_gpu("train_fusion", argv, args.num_GPUs)   # --num_GPUs N > 1: one process per GPU (returns inside a torchrun job)
     run(args)
 

@@ -296,3 +296,34 @@ def test_num_gpus_relaunches_one_process_per_gpu(monkeypatch):
     with pytest.raises(SystemExit):
         T.entry_func(["--project_dir", "nowhere", "--num_GPUs", "2"])
     assert len(calls) == 2 and calls[1][0][-4:] == ["--project_dir", "nowhere", "--num_GPUs", "2"]
+
+
+def test_wait_for_waits_until_the_processes_are_gone(tmp_path):
+    """`--wait_for PID[,PID]` (mpunet/utils/utils.py:337-375): returns only when none of the processes runs any more."""
+    import subprocess, sys, time
+    from multiplanarunet_amd.cli import common as C
+    C.await_pids("")                                                       # nothing to wait for
+    with pytest.raises(ValueError):
+        C.await_pids("12x")
+    p = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(0.6)"])
+    naps = []
+    t0 = time.time()
+    C.await_pids("%d" % p.pid, check_every=0.1, logger=lambda *a: None, sleep=lambda s: (naps.append(s), time.sleep(s)))
+    assert p.poll() is not None or not C._pid_running(p.pid)               # gone (or a zombie of ours: not running)
+    assert naps and time.time() - t0 >= 0.4
+    p.wait()
+    C.await_pids("%d, %d" % (p.pid, p.pid), check_every=0.05, logger=lambda *a: None)     # already gone: returns at once
+    assert C._pid_running(os.getpid())
+
+
+def test_inert_reference_flags_are_reported_not_silently_ignored():
+    from multiplanarunet_amd.cli import common as C, train as T, predict as P
+    said = []
+    a = T.get_argparser().parse_args(["--max_loaded_images", "10", "--no_images"])
+    C.note_inert_flags(a, [("no_images", "x"), ("debug", "y"), ("max_loaded_images", "z"), ("num_access", "w")], said.append)
+    assert len(said) == 2 and "--no_images" in said[0] and "--max_loaded_images" in said[1]
+    said.clear()
+    C.note_inert_flags(P.get_argparser().parse_args([]), [("eval_prob", "v")], said.append)
+    assert not said                                                        # the default (1.0) says nothing
+    C.note_inert_flags(P.get_argparser().parse_args(["--eval_prob", "0.5"]), [("eval_prob", "v")], said.append)
+    assert len(said) == 1

@@ -138,6 +138,20 @@ def test_mp_train_continue_training_resumes_where_the_reference_would(tmp_path):
     lr1 = float(rows1[1 + len(kept)].split(",")[head.index("lr")])
     want_lr = lr_logged[min(N, len(lr_logged) - 1)]         # the rate logged in row N of the CSV (the last row beyond it)
     assert lr1 <= want_lr * (1 + 1e-12) and lr1 >= want_lr * 0.9 ** 3, (lr1, want_lr)     # (ReduceLROnPlateau may have stepped since)
+    # `mp predict --save_input_files` (bin/predict.py:90-117): prediction, input image and labels in a sub-folder per volume
+    from multiplanarunet_amd.nifti import read_nifti
+    from multiplanarunet_amd.data import make_toy_volume
+    mp.entry_func(["predict", "--project_dir", str(proj), "--synthetic", "1", "--sum_fusion", "--save_input_files", "--out_format", "nii"])
+    sub = proj / "predictions" / "nii_files" / "toy_5000"
+    assert sorted(os.listdir(sub)) == ["toy_5000_IMAGE.nii.gz", "toy_5000_LABELS.nii.gz", "toy_5000_PRED.nii.gz"]
+    img, lab_true, aff = make_toy_volume(64, 5000)
+    im2, aff2, _ = read_nifti(str(sub / "toy_5000_IMAGE.nii.gz"))
+    np.testing.assert_array_equal(np.asarray(im2, np.float32), img[..., 0])
+    lb2, _, _ = read_nifti(str(sub / "toy_5000_LABELS.nii.gz"), scaled=False)
+    np.testing.assert_array_equal(lb2, lab_true)
+    np.testing.assert_array_equal(aff2, aff)
+    with pytest.raises(OSError):                            # the sub-folder's prediction exists: --overwrite or --continue
+        mp.entry_func(["predict", "--project_dir", str(proj), "--synthetic", "1", "--sum_fusion", "--save_input_files", "--out_format", "nii"])
 
 
 def test_mp_train_two_ranks_data_parallel_then_resume(tmp_path):
