@@ -583,7 +583,10 @@ class UNet:
         # reference it was freed when this function returned, the caching allocator handed its block to the next small tensor
         # on the stream, and the replayed Adam kernels then read that tensor's bytes as the step count -- a wrong bias correction
         # (up to NaN) from the first allocation after the capture on (found by tests/test_gpu_pipeline.py, round 5).
-        replay.keep_alive = (step_dev, x, y, sample_weight, loss_sum)
+        # (The model's own buffers too: a later, larger eager batch REPLACES self._ws -- the graph keeps running on the one it
+        # was captured with, which must therefore stay allocated.)
+        replay.keep_alive = (step_dev, x, y, sample_weight, loss_sum, self._ws, self._l2_ws, getattr(self, "reg_loss", None),
+                             self._adam_m, self._adam_v, self.params, self.grads, self.packed, self.bn_state)
         return replay
 
     def train_step(self, x, y, sample_weight=None, want_loss=True):

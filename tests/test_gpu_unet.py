@@ -205,6 +205,31 @@ def test_graphed_train_step_matches_eager():
     assert torch.equal(a.predict_on_batch(x), b.predict_on_batch(x))
 
 
+def test_graphed_train_step_survives_a_larger_eager_batch_in_between():
+    """An eager call on a LARGER batch replaces the model's workspace; the captured graph keeps running on the workspace it was
+    captured with, which therefore must stay allocated (round 5: the graph holds its buffers)."""
+    from multiplanarunet_amd.unet import UNet
+    rng = np.random.RandomState(5)
+    B, H = 4, 32
+    x = torch.tensor(rng.randn(B, H, H, 1).astype(np.float32), device="cuda")
+    y = torch.tensor(rng.randint(0, 3, (B, H * H, 1)).astype(np.uint8), device="cuda")
+    xb = torch.tensor(rng.randn(4 * B, H, H, 1).astype(np.float32), device="cuda")
+    sw = torch.ones(B, device="cuda")
+    a = UNet(n_classes=3, dim=H, depth=2, complexity_factor=0.25, dtype="bf16", logger=quiet, seed=0)
+    b = UNet(n_classes=3, dim=H, depth=2, complexity_factor=0.25, dtype="bf16", logger=quiet, seed=0)
+    replay = b.make_graphed_train_step(x, y, sw)
+    a.train_step(x, y, sw, want_loss=False)
+    for _ in range(2):
+        pa, pb = a.predict_on_batch(xb), b.predict_on_batch(xb)        # 4 x the batch: a new, larger workspace in both models
+        assert torch.equal(pa, pb)
+        junk = [torch.full((1 << 20,), 3, dtype=torch.int32, device="cuda") for _ in range(16)]    # whatever was freed gets reused
+        del junk
+        a.train_step(x, y, sw, want_loss=False)
+        replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a.params, b.params) and torch.equal(a.bn_state, b.bn_state)
+
+
 @pytest.mark.parametrize("dtype,cf,C", [("bf16", 1, 1), ("bf16", 2, 2), ("f32", 0.25, 1)])
 def test_fused_adam_pack_equals_adam_then_pack(dtype, cf, C):
     """mpu_unet_adam_pack (one launch: Adam + both packed operand copies) == mpu_adam_step + mpu_unet_pack_weights,
