@@ -14,18 +14,38 @@ def quiet(*a, **k):
     pass
 
 
-def _model_and_sampler(seed):
+def _model_and_sampler(seed, l2_reg=None, elastic=False, dtype="bf16"):
     from multiplanarunet_amd.unet import UNet
     from multiplanarunet_amd.data import make_toy_volume, as_volume, random_views, TrainSampler
+    from multiplanarunet_amd.augmentation import build_augmenters
     dev = torch.device("cuda")
     dim, B = 64, 8
-    m = UNet(n_classes=3, dim=dim, n_channels=1, depth=3, complexity_factor=0.25, flatten_output=True, dtype="bf16",
-             logger=quiet, seed=0, device=dev)
+    m = UNet(n_classes=3, dim=dim, n_channels=1, depth=3, complexity_factor=0.25, flatten_output=True, dtype=dtype,
+             l2_reg=l2_reg, logger=quiet, seed=0, device=dev)
     m.compile("Adam", "SparseCategoricalCrossentropy", optimizer_kwargs={"lr": 1e-3})
     img, lab, aff = make_toy_volume(64, 5)
     vol = as_volume(img, lab, aff, "1pct", "RobustScaler", dev, "toy64")
-    s = TrainSampler([vol], random_views(3, 60.0, 0), dim, float(dim), B, 3, noise_sd=0.1, fg_batch_fraction=0.5, seed=seed)
+    augs = build_augmenters([{"cls_name": "Elastic2D", "kwargs": {"alpha": [0, 100], "sigma": [6, 9], "apply_prob": 0.5}}],
+                            seed=4) if elastic else None
+    s = TrainSampler([vol], random_views(3, 60.0, 0), dim, float(dim), B, 3, noise_sd=0.1, fg_batch_fraction=0.5, seed=seed,
+                     augmenters=augs)
     return m, s
+
+
+@pytest.mark.parametrize("kw", [dict(l2_reg=1e-4), dict(elastic=True), dict(dtype="f32")], ids=["l2", "elastic", "f32"])
+def test_pipeline_variants_equal_the_serial_eager_loop_bitwise(kw):
+    """The same identity with the l2 term summed into the device-side loss, with the Elastic2D augmenter running on the producer
+    stream, and in the f32 mode."""
+    from multiplanarunet_amd.pipeline import TrainPipeline
+    m0, s0 = _model_and_sampler(21, **kw)
+    m1, s1 = _model_and_sampler(21, **kw)
+    p0 = TrainPipeline(m0, s0, graphed=False, overlap=False)
+    p1 = TrainPipeline(m1, s1)
+    for n in (4, 3):
+        a, b = p0.run_epoch(n), p1.run_epoch(n)
+        torch.cuda.synchronize()
+        assert np.isfinite(a) and a == b, (kw, a, b)
+        assert torch.equal(m0.params, m1.params) and torch.equal(m0.bn_state, m1.bn_state)
 
 
 def test_side_stream_runs_beside_a_busy_main_stream():
