@@ -293,7 +293,9 @@ def main():
             from multiplanarunet_amd.srchash import source_sha16, CONV_SOURCES
             with open(os.path.join(ROOT, "profiles", tfile)) as f:
                 tj = json.load(f)
-            if tj.get("source_sha16") == source_sha16(CONV_SOURCES):
+            if args.config != 1:     # the counter passes ran on configs[1]: their bytes per launch are not this workload's
+                out["config"]["traffic_source"] = None
+            elif tj.get("source_sha16") == source_sha16(CONV_SOURCES):
                 traffic = {k: v["hbm_bytes_per_launch"] for k, v in tj["classes"].items()}
                 out["config"]["traffic_source"] = "from_file:profiles/" + tfile      # a separate rocprofv3 --pmc pass, not this run
             else:   # the kernels changed after that counter pass: its bytes are not this build's
