@@ -189,6 +189,10 @@ int launch_bn_infer_coeffs(const float* gamma, const float* beta, const float* m
 // y = x*scale + shift (and optionally 2x2 max-pool of y)
 // 2x2/stride-2 max pooling (inference path; training pools inside bn_apply)
 int launch_maxpool(int dtype, const void* x, int B, int H, int W, int C, void* pooled, hipStream_t st);
+// finalize + apply (+ pool) in ONE launch for producers that left <= 64 column-major partial rows (1 = launched, 0 = not suited)
+int launch_bn_fold_fwd(int dtype, const void* x, int B, int H, int W, int C, const float* partial, int nblk,
+                       const float* gamma, const float* beta, float* mmean, float* mvar, float* mean, float* invstd,
+                       float* scale, float* shift, float eps, float momentum, void* y, void* pooled, hipStream_t st);
 int launch_bn_apply(int dtype, const void* x, int B, int H, int W, int C, const float* scale,
                     const float* shift, void* y, void* pooled, hipStream_t st);
 // BN backward: dgamma, dbeta and dz = (x>0) * d(x) where x is the post-ReLU BN input

@@ -322,6 +322,16 @@ int bn_fwd(const Run& r, const BN& b, const void* x, int lvl, int training, void
     const int H = r.m->cfg.H >> lvl, W = r.m->cfg.W >> lvl;
     const long M = (long)r.B * H * W;
     int rc;
+    if (training && stats_rows > 0) {   // few enough rows: finalize folded into the apply pass (one launch)
+        rc = launch_bn_fold_fwd(r.m->cfg.dtype, x, r.B, H, W, b.C, (const float*)r.at(r.P.partial), stats_rows, r.params + b.g,
+                                r.params + b.b, r.state + b.mm, r.state + b.mv, r.stat(b, 0), r.stat(b, 1), r.stat(b, 2), r.stat(b, 3),
+                                BN_EPS, BN_MOM, y, pooled, r.st);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            tap_aux(r, 3, (int)(&b - &r.m->bn[0]), lvl, b.C, b.C, x, nullptr, nullptr, pooled, y, b.g, b.b, r.stat(b, 0), r.stat(b, 1));
+            return MPU_OK;
+        }
+    }
     if (training)   // stats_rows > 0: the producing conv already wrote that many partial rows (sum, sum of squares)
         rc = launch_bn_stats(r.m->cfg.dtype, x, M, b.C, (float*)r.at(r.P.partial), r.params + b.g, r.params + b.b,
                              r.state + b.mm, r.state + b.mv, r.stat(b, 0), r.stat(b, 1), r.stat(b, 2), r.stat(b, 3),

@@ -399,6 +399,37 @@ static int launch_colreduce(int dtype, const void* a, const void* b, long M, int
 }
 
 
+// The arithmetic shared by the separate and the folded kernels lives in these helpers with EXPLICIT fused operations / contraction
+// off: left to -ffp-contract=fast the compiler fuses `a * b + c * d + e` differently in different kernels (measured: the folded
+// backward pass differed from the separate one in the last bit of most gradients until these were pinned).
+__device__ __forceinline__ float bn_affine(float v, float sc, float sh) { return fmaf(v, sc, sh); }
+__device__ __forceinline__ float bn_bwd_affine(float g, float v, float k1, float k2, float k3) { return fmaf(k1, g, fmaf(k2, v, k3)); }
+struct BnFwdCoef { float mean, invstd, scale, shift, mmean, mvar; };
+__device__ __forceinline__ BnFwdCoef bn_fwd_coeffs(double s, double ss, long M, float gamma, float beta, float mm, float mv,
+                                                   float eps, float mom) {
+#pragma clang fp contract(off)
+    BnFwdCoef r;
+    const double mu = s / (double)M;
+    double var = ss / (double)M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    r.invstd = (float)(1.0 / sqrt(var + (double)eps));
+    r.scale = gamma * r.invstd;
+    r.mean = (float)mu;
+    r.shift = beta - (float)mu * r.scale;
+    const double ub = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+    r.mmean = mm * mom + (float)mu * (1.f - mom);
+    r.mvar = mv * mom + (float)ub * (1.f - mom);
+    return r;
+}
+__device__ __forceinline__ void bn_bwd_coeffs(double s, double sx, long M, float gamma, float mean, float invstd,
+                                              float& k1, float& k2, float& k3) {
+#pragma clang fp contract(off)
+    const double sc = (double)gamma * (double)invstd;
+    const double mdn = s / (double)M, mdx = sx / (double)M;
+    const double k2d = -sc * mdx * (double)invstd;
+    k1 = (float)sc; k2 = (float)k2d; k3 = (float)(-sc * mdn - k2d * (double)mean);
+}
+
 // COLMAJOR: partial is [2][C][nblk] (written by the conv epilogues), else [nblk][2][C] (colreduce)
 template <bool COLMAJOR>
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
@@ -414,16 +445,9 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
         partial_sums<2>(partial, nblk, 2L * C, C, c, c < C, red, st);
         if (c >= C || threadIdx.x >= FIN_COLS) return;
     }
-    const double s = st[0], ss = st[1];
-    const double mu = s / (double)M;
-    double var = ss / (double)M - mu * mu;
-    if (var < 0.0) var = 0.0;
-    const float is = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[c] * is;
-    mean[c] = (float)mu; invstd[c] = is; scale[c] = sc; shift[c] = beta[c] - (float)mu * sc;
-    const double ub = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
-    mmean[c] = mmean[c] * mom + (float)mu * (1.f - mom);
-    mvar[c] = mvar[c] * mom + (float)ub * (1.f - mom);
+    const BnFwdCoef k = bn_fwd_coeffs(st[0], st[1], M, gamma[c], beta[c], mmean[c], mvar[c], eps, mom);
+    mean[c] = k.mean; invstd[c] = k.invstd; scale[c] = k.scale; shift[c] = k.shift;
+    mmean[c] = k.mmean; mvar[c] = k.mvar;
 }
 
 int launch_bn_stats(int dtype, const void* x, long M, int C, float* partial, const float* gamma, const float* beta,
@@ -456,6 +480,141 @@ int launch_bn_infer_coeffs(const float* gamma, const float* beta, const float* m
     return launch_ok();
 }
 
+// BatchNormalization finalize FOLDED into the apply pass (round 5) for producers that leave at most 64 partial rows per channel
+// (conv_deepk: 32; conv_halo8 on 64-filter tiles: 64): a workgroup owns a 64-channel slab x a pixel group, its first 128 threads
+// sum the rows of (channel, statistic) themselves -- strictly in row order, in double: for <= 64 rows that IS the order of
+// bn_stats_finalize_kernel (one row per k-lane, the k-lanes combined in order, the absent ones adding +0), so the coefficients
+// are the same bits -- and the pixel group 0 of a slab also writes mean / 1/std / scale / shift and the moving statistics, as
+// the finalize launch did. The pixels of the first pass are requested before the rows, gamma / beta at kernel entry. Rounds 3's
+// attempt at this lost 0.7 % with 256 rows (the serial reduction in front of every workgroup); with <= 64 rows it replaces a
+// 5.2-us launch by ~1 us inside the next one.
+constexpr int BN_FOLD_MAX_ROWS = 64;
+
+// rows of one (statistic, channel): partial[(st * C + c) * nblk + k], nblk % 4 == 0, nblk <= 64; sequential double sum
+__device__ __forceinline__ double bn_fold_rowsum(const float* __restrict__ p, int nblk) {
+    float4 v[BN_FOLD_MAX_ROWS / 4];
+#pragma unroll
+    for (int u = 0; u < BN_FOLD_MAX_ROWS / 4; ++u) {          // unconditional (clamped) loads: all in flight together
+        const float4 t = *(const float4*)(p + (4 * u < nblk ? 4 * u : 0));
+        const bool on = 4 * u < nblk;
+        v[u] = make_float4(on ? t.x : 0.f, on ? t.y : 0.f, on ? t.z : 0.f, on ? t.w : 0.f);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < BN_FOLD_MAX_ROWS / 4; ++u) { s += (double)v[u].x; s += (double)v[u].y; s += (double)v[u].z; s += (double)v[u].w; }
+    return s;
+}
+
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_fold_apply_kernel(const T* __restrict__ x, int B, int H, int W, int C,
+                                                            const float* __restrict__ partial, int nblk, long M,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* mmean, float* mvar, float* mean, float* invstd, float* scale,
+                                                            float* shift, float eps, float mom, T* __restrict__ y,
+                                                            T* __restrict__ pooled, int nslab, int ppw) {
+    constexpr int N = Vec<T>::N, TPP = 64 / N, PPP = 256 / TPP;  // threads per pixel (64 channels), pixels per pass
+    __shared__ double red[2][64];
+    __shared__ __attribute__((aligned(16))) float coef[2][64];
+    const int slab = (int)blockIdx.x % nslab, g = (int)blockIdx.x / nslab;
+    const int c0 = slab * 64, tc = (threadIdx.x % TPP) * N, tp = threadIdx.x / TPP;
+    const int Hp = H / 2, Wp = W / 2;
+    const long Q = POOL ? (long)B * Hp * Wp : (long)B * H * W;   // work items: pixels, or pooled pixels (2 x 2 source pixels each)
+    const long q0 = (long)g * ppw;
+    const int npass = ppw / PPP;
+    auto src_off = [&](long q, int d) -> long {                  // element offset of source pixel d (POOL: 0..3) of work item q
+        if (!POOL) return q * C + c0 + tc;
+        const int px = (int)(q % Wp); long t = q / Wp;
+        const int py = (int)(t % Hp); const int b = (int)(t / Hp);
+        return ((((long)b * H + 2 * py + (d >> 1)) * W + 2 * px + (d & 1)) * C) + c0 + tc;
+    };
+    constexpr int ND = POOL ? 4 : 1, NP = POOL ? 1 : 4;          // source pixels per item; passes per workgroup (all requested up front)
+    float xv[NP][ND][N];
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {                            // every pixel of the workgroup is requested BEFORE the rows
+        const long q = q0 + (long)it * PPP + tp;
+        const long qc = (it < npass && q < Q) ? q : (q0 < Q ? q0 : Q - 1);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) Vec<T>::load(x + src_off(qc, d), xv[it][d]);
+    }
+    float g_ = 0.f, b_ = 0.f, mm_ = 0.f, mv_ = 0.f;
+    if (threadIdx.x < 64) {
+        g_ = gamma[c0 + threadIdx.x]; b_ = beta[c0 + threadIdx.x];
+        mm_ = mmean[c0 + threadIdx.x]; mv_ = mvar[c0 + threadIdx.x];
+    }
+    if (threadIdx.x < 128) {
+        const int cl = threadIdx.x & 63, st = threadIdx.x >> 6;
+        red[st][cl] = bn_fold_rowsum(partial + ((long)st * C + c0 + cl) * nblk, nblk);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                                      // the arithmetic of bn_stats_finalize_kernel, expression for expression
+        const int c = c0 + threadIdx.x;
+        const BnFwdCoef k = bn_fwd_coeffs(red[0][threadIdx.x], red[1][threadIdx.x], M, g_, b_, mm_, mv_, eps, mom);
+        coef[0][threadIdx.x] = k.scale; coef[1][threadIdx.x] = k.shift;
+        if (g == 0) {
+            mean[c] = k.mean; invstd[c] = k.invstd; scale[c] = k.scale; shift[c] = k.shift;
+            mmean[c] = k.mmean; mvar[c] = k.mvar;
+        }
+    }
+    __syncthreads();
+    float sc[N], sh[N];
+#pragma unroll
+    for (int i = 0; i < N; i += 4) {
+        *reinterpret_cast<float4*>(sc + i) = *reinterpret_cast<const float4*>(&coef[0][tc + i]);
+        *reinterpret_cast<float4*>(sh + i) = *reinterpret_cast<const float4*>(&coef[1][tc + i]);
+    }
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        const long q = q0 + (long)it * PPP + tp;
+        if (it < npass && q < Q) {
+            float mx[N];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) xv[it][d][i] = bn_affine(xv[it][d][i], sc[i], sh[i]);
+                Vec<T>::store(y + src_off(q, d), xv[it][d]);
+                if (POOL) {                                      // the pooled value is the max of the STORED (rounded) values
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        const float r = to_f32<T>(from_f32<T>(xv[it][d][i]));
+                        mx[i] = d == 0 ? r : fmaxf(mx[i], r);
+                    }
+                }
+            }
+            if (POOL) Vec<T>::store(pooled + q * C + c0 + tc, mx);
+        }
+    }
+}
+
+// 1 = launched (finalize + apply in one pass), 0 = not suited (the caller runs the two launches)
+int launch_bn_fold_fwd(int dtype, const void* x, int B, int H, int W, int C, const float* partial, int nblk,
+                       const float* gamma, const float* beta, float* mmean, float* mvar, float* mean, float* invstd,
+                       float* scale, float* shift, float eps, float momentum, void* y, void* pooled, hipStream_t st) {
+    if (env(ENV_BN_FOLD) == 0 || nblk <= 0 || nblk > BN_FOLD_MAX_ROWS || (nblk & 3) || (C & 63)) return 0;
+    if (pooled && ((H | W) & 1)) return 0;
+    const long M = (long)B * H * W;
+    const long Q = pooled ? M / 4 : M;
+    const int nslab = C / 64;
+    const int ppp = dtype == MPU_BF16 ? 32 : 16;
+    const int maxp = pooled ? 1 : 4;                             // passes a workgroup keeps in registers (the kernel's NP)
+    long ppw = (Q * nslab + 255) / 256;                          // about one workgroup per CU, more when the pixels do not fit
+    ppw = (ppw + ppp - 1) / ppp * ppp;
+    if (ppw < ppp) ppw = ppp;
+    if (ppw > (long)maxp * ppp) ppw = (long)maxp * ppp;
+    const long groups = (Q + ppw - 1) / ppw;
+    if (groups * nslab > (1L << 20)) return 0;
+    const dim3 grid((unsigned)(groups * nslab)), blk(256);
+#define MPU_BNF(TT)                                                                                                       \
+    if (pooled) bn_fold_apply_kernel<TT, true><<<grid, blk, 0, st>>>((const TT*)x, B, H, W, C, partial, nblk, M, gamma, beta, mmean, mvar, \
+                                                                    mean, invstd, scale, shift, eps, momentum, (TT*)y, (TT*)pooled, nslab, (int)ppw); \
+    else bn_fold_apply_kernel<TT, false><<<grid, blk, 0, st>>>((const TT*)x, B, H, W, C, partial, nblk, M, gamma, beta, mmean, mvar, \
+                                                               mean, invstd, scale, shift, eps, momentum, (TT*)y, nullptr, nslab, (int)ppw);
+    if (dtype == MPU_BF16) { MPU_BNF(bf16_t) } else { MPU_BNF(float) }
+#undef MPU_BNF
+    if (sched_log_on()) sched_note("bn_fold fwd C=%d rows=%d pool=%d grid=%ld", C, nblk, pooled ? 1 : 0, groups * nslab);
+    const int rc = launch_ok();
+    return rc ? rc : 1;
+}
+
 // y = x*scale + shift ; POOL: also 2x2 max of y (taken after the affine: gamma may be negative)
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int B, int H, int W, int C,
@@ -479,7 +638,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
             coef_load<N>(lds, scale, c * N, sc);
             if (lds) coef_load<N>(lds, scale, C + c * N, sh); else coef_load<N>(nullptr, shift, c * N, sh);
 #pragma unroll
-            for (int i = 0; i < N; ++i) v[i] = v[i] * sc[i] + sh[i];
+            for (int i = 0; i < N; ++i) v[i] = bn_affine(v[i], sc[i], sh[i]);
             Vec<T>::store(y + e * N, v);
         };
         long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -508,7 +667,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
 #pragma unroll
-                for (int i = 0; i < N; ++i) v[d][i] = v[d][i] * sc[i] + sh[i];
+                for (int i = 0; i < N; ++i) v[d][i] = bn_affine(v[d][i], sc[i], sh[i]);
                 Vec<T>::store(y + o[d], v[d]);
                 // the pooled value is the max of the STORED (rounded) values
 #pragma unroll
@@ -579,12 +738,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     }
     const double s = st[0], sx = st[1];
     dgamma[c] = (float)sx; dbeta[c] = (float)s;
-    const double sc = (double)gamma[c] * (double)invstd[c];
-    const double mdn = s / (double)M, mdx = sx / (double)M;
-    const double k2 = -sc * mdx * (double)invstd[c];
-    coeffs[c] = (float)sc;
-    coeffs[C + c] = (float)k2;
-    coeffs[2 * C + c] = (float)(-sc * mdn - k2 * (double)mean[c]);
+    float k1, k2, k3;
+    bn_bwd_coeffs(s, sx, M, gamma[c], mean[c], invstd[c], k1, k2, k3);
+    coeffs[c] = k1; coeffs[C + c] = k2; coeffs[2 * C + c] = k3;
 }
 
 template <typename T>
@@ -601,7 +757,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         float k1[N], k2[N], k3[N], o[N];
         coef_load<N>(lds, k, c * N, k1); coef_load<N>(lds, k, C + c * N, k2); coef_load<N>(lds, k, 2 * C + c * N, k3);
 #pragma unroll
-        for (int i = 0; i < N; ++i) o[i] = v[i] > 0.f ? (k1[i] * g[i] + k2[i] * v[i] + k3[i]) : 0.f;
+        for (int i = 0; i < N; ++i) o[i] = v[i] > 0.f ? bn_bwd_affine(g[i], v[i], k1[i], k2[i], k3[i]) : 0.f;
         Vec<T>::store(dz + e * N, o);
     };
     long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -618,11 +774,91 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// BatchNorm backward with the finalize folded in (see bn_fold_apply_kernel): the producer of dn (a data-gradient epilogue) left
+// <= 64 column-major partial rows of (sum dn, sum dn * xhat) per channel
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_fold_kernel(const T* __restrict__ dn, const T* __restrict__ x, long M, int C,
+                                                          const float* __restrict__ partial, int nblk,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, float* dgamma, float* dbeta,
+                                                          float* coeffs, T* __restrict__ dz, int nslab, int ppw) {
+    constexpr int N = Vec<T>::N, TPP = 64 / N, PPP = 256 / TPP;
+    __shared__ double red[2][64];
+    __shared__ __attribute__((aligned(16))) float coef[3][64];
+    const int slab = (int)blockIdx.x % nslab, g = (int)blockIdx.x / nslab;
+    const int c0 = slab * 64, tc = (threadIdx.x % TPP) * N, tp = threadIdx.x / TPP;
+    const long q0 = (long)g * ppw;
+    const int npass = ppw / PPP;
+    constexpr int NP = 4;                                        // passes per workgroup, all requested up front
+    float gv[NP][N], xv[NP][N];
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        const long q = q0 + (long)it * PPP + tp;
+        const long qc = (it < npass && q < M) ? q : (q0 < M ? q0 : M - 1);
+        Vec<T>::load(dn + qc * C + c0 + tc, gv[it]); Vec<T>::load(x + qc * C + c0 + tc, xv[it]);
+    }
+    float g_ = 0.f, mu_ = 0.f, is_ = 0.f;
+    if (threadIdx.x < 64) { g_ = gamma[c0 + threadIdx.x]; mu_ = mean[c0 + threadIdx.x]; is_ = invstd[c0 + threadIdx.x]; }
+    if (threadIdx.x < 128) {
+        const int cl = threadIdx.x & 63, st = threadIdx.x >> 6;
+        red[st][cl] = bn_fold_rowsum(partial + ((long)st * C + c0 + cl) * nblk, nblk);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                                      // bn_bwd_finalize_kernel, expression for expression
+        const int c = c0 + threadIdx.x;
+        const double s = red[0][threadIdx.x], sx = red[1][threadIdx.x];
+        float k1f, k2f, k3f;
+        bn_bwd_coeffs(s, sx, M, g_, mu_, is_, k1f, k2f, k3f);
+        coef[0][threadIdx.x] = k1f; coef[1][threadIdx.x] = k2f; coef[2][threadIdx.x] = k3f;
+        if (g == 0) {
+            dgamma[c] = (float)sx; dbeta[c] = (float)s;
+            coeffs[c] = k1f; coeffs[C + c] = k2f; coeffs[2 * C + c] = k3f;
+        }
+    }
+    __syncthreads();
+    float k1[N], k2[N], k3[N];
+#pragma unroll
+    for (int i = 0; i < N; i += 4) {
+        *reinterpret_cast<float4*>(k1 + i) = *reinterpret_cast<const float4*>(&coef[0][tc + i]);
+        *reinterpret_cast<float4*>(k2 + i) = *reinterpret_cast<const float4*>(&coef[1][tc + i]);
+        *reinterpret_cast<float4*>(k3 + i) = *reinterpret_cast<const float4*>(&coef[2][tc + i]);
+    }
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        const long q = q0 + (long)it * PPP + tp;
+        if (it < npass && q < M) {
+            float o[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) o[i] = xv[it][i] > 0.f ? bn_bwd_affine(gv[it][i], xv[it][i], k1[i], k2[i], k3[i]) : 0.f;
+            Vec<T>::store(dz + q * C + c0 + tc, o);
+        }
+    }
+}
+
 int launch_bn_backward(int dtype, const void* dn, const void* x, long M, int C, float* partial, const float* gamma,
                        const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coeffs, void* dz,
                        int ready_rows, int ready_colmajor, hipStream_t st) {
     int nblk = ready_rows;                       // > 0: the producer of dn already wrote that many partial rows
     int rc = 0;
+    if (env(ENV_BN_FOLD) != 0 && ready_colmajor && nblk > 0 && nblk <= BN_FOLD_MAX_ROWS && !(nblk & 3) && !(C & 63)) {
+        const int nslab = C / 64, ppp = dtype == MPU_BF16 ? 32 : 16;       // finalize folded into the apply pass
+        long ppw = (M * nslab + 255) / 256;
+        ppw = (ppw + ppp - 1) / ppp * ppp;
+        if (ppw < ppp) ppw = ppp;
+        if (ppw > 4L * ppp) ppw = 4L * ppp;                     // (the kernel's NP passes)
+        const long groups = (M + ppw - 1) / ppw;
+        if (groups * nslab <= (1L << 20)) {
+            const dim3 grid((unsigned)(groups * nslab)), blk(256);
+            if (dtype == MPU_BF16)
+                bn_bwd_fold_kernel<bf16_t><<<grid, blk, 0, st>>>((const bf16_t*)dn, (const bf16_t*)x, M, C, partial, nblk, gamma, mean, invstd,
+                                                                 dgamma, dbeta, coeffs, (bf16_t*)dz, nslab, (int)ppw);
+            else
+                bn_bwd_fold_kernel<float><<<grid, blk, 0, st>>>((const float*)dn, (const float*)x, M, C, partial, nblk, gamma, mean, invstd,
+                                                                dgamma, dbeta, coeffs, (float*)dz, nslab, (int)ppw);
+            if (sched_log_on()) sched_note("bn_fold bwd C=%d rows=%d grid=%ld", C, nblk, groups * nslab);
+            return launch_ok();
+        }
+    }
     if (nblk <= 0) { ready_colmajor = 0; rc = launch_colreduce<1>(dtype, dn, x, M, C, mean, invstd, partial, &nblk, st); }
     if (rc) return rc;
     if (ready_colmajor)

@@ -492,6 +492,59 @@ def test_staggered_schedules_equal_the_lockstep_ones_bitwise(tmp_path):
     assert np.array_equal(g1, g0)
 
 
+_FOLD_SCRIPT = r"""
+import sys, numpy as np, torch, ctypes as C
+sys.path.insert(0, %r)
+from multiplanarunet_amd.unet import UNet
+from multiplanarunet_amd import _lib
+lib = _lib.load()
+quiet = lambda *a, **k: None
+B, K, D = 16, 3, 4
+m = UNet(n_classes=K, dim=128, n_channels=1, depth=D, complexity_factor=1, dtype="bf16", logger=quiet, flatten_output=True, seed=5)
+w = m.get_weights_dict()
+rng = np.random.RandomState(3)
+for k in w:                                        # gammas of both signs (the pooled value follows the affine), non-trivial betas
+    if k.endswith("/gamma"): w[k] = rng.uniform(-1.5, 1.5, w[k].shape).astype(np.float32)
+    if k.endswith("/beta"): w[k] = rng.uniform(-.3, .3, w[k].shape).astype(np.float32)
+m.set_weights_dict(w)
+rng = np.random.RandomState(7)
+x = torch.tensor(rng.randn(B, 128, 128, 1).astype(np.float32), device="cuda")
+y = torch.tensor(rng.randint(0, K, (B, 128 * 128, 1)).astype(np.uint8), device="cuda")
+sw = torch.ones(B, device="cuda")
+lib.mpu_schedule_log_enable(1)
+m.train_step(x, y, sw, want_loss=False)
+n = lib.mpu_schedule_log_read(None, 0); buf = C.create_string_buffer(int(n) + 1); lib.mpu_schedule_log_read(buf, n + 1)
+lib.mpu_schedule_log_enable(0)
+lines = buf.value.decode().splitlines()
+print("FOLD fwd=%%d bwd=%%d" %% (sum(1 for l in lines if l.startswith("bn_fold fwd")), sum(1 for l in lines if l.startswith("bn_fold bwd"))))
+m.train_step(x, y, sw, want_loss=False)
+torch.cuda.synchronize()
+np.save(sys.argv[1], np.concatenate([m.params.cpu().numpy(), m.bn_state.cpu().numpy(), m.grads.cpu().numpy()]))
+"""
+
+
+def test_bn_finalize_folded_into_apply_equals_the_two_launches_bitwise(tmp_path):
+    """Round 5: where a conv epilogue leaves <= 64 partial rows per channel, BatchNorm finalize + apply (+ pool), and the backward
+    finalize + apply, run as ONE launch each. The rows are summed in the finalize kernel's order and the coefficient arithmetic is
+    the same expressions, so parameters, moving statistics and gradients after two configs[1] train steps are the same bits with
+    MPU_BN_FOLD=0 (the separate launches). Switch read once per process: two subprocesses."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, env in (("fold", {}), ("separate", {"MPU_BN_FOLD": "0"})):
+        f = str(tmp_path / (tag + ".npy"))
+        r = subprocess.run([sys.executable, "-c", _FOLD_SCRIPT % root, f], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("FOLD ")][0]
+        nf, nb = (int(t.split("=")[1]) for t in line.split()[1:])
+        out[tag] = (np.load(f), nf, nb)
+    (a, nf, nb), (b, nf0, nb0) = out["fold"], out["separate"]
+    print("configs[1] step: %d forward and %d backward BatchNorms folded" % (nf, nb))
+    assert nf >= 3 and nb >= 2 and nf0 == 0 and nb0 == 0
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
 def test_persistent_halo16_inference_equals_default_schedules_subprocess(tmp_path):
     """conv_halo16p (round 4; the default for large inference grids, MPU_HALO16P=0 turns it off): the persistent 16-row kernel
     with its wave-private epilogue (accumulators started at the bias, ReLU, folded-BN affine with NEGATIVE gammas, fused
