@@ -2,6 +2,8 @@
 Pins the oracle (oracle/geometry.py, a NumPy restatement) against golden
 vectors produced by the reference's own unmodified NumPy code
 (oracle/gen_golden.py -> tests/golden/geometry_golden.npz).
+Every comparison is EXACT (round 6): the restatement reproduces the reference's
+arrays bit for bit, and tests/test_gpu_geometry.py leans on exactly that.
 CPU only.
 """
 import numpy as np
@@ -16,11 +18,9 @@ def test_g1_sample_plane_at(golden):
     for vi, v in enumerate(views):
         for ci, (dim, span, off) in enumerate(golden["g1_cfg"]):
             rg, g, ib = G.sample_plane_at(v, int(dim), span, off)
-            np.testing.assert_allclose(rg, golden["g1_grid_%d_%d" % (vi, ci)],
-                                       rtol=0, atol=1e-12)
+            np.testing.assert_array_equal(rg, golden["g1_grid_%d_%d" % (vi, ci)])
             np.testing.assert_array_equal(g, golden["g1_g_%d_%d" % (vi, ci)])
-            np.testing.assert_allclose(ib, golden["g1_invb_%d_%d" % (vi, ci)],
-                                       rtol=0, atol=1e-14)
+            np.testing.assert_array_equal(ib, golden["g1_invb_%d_%d" % (vi, ci)])
 
 
 @pytest.mark.parametrize("an", AFFS)
@@ -32,8 +32,8 @@ def test_g2_view_interpolator(golden, an):
         ref_im = golden["g2_im_%s_%d" % (an, pi)]
         ref_lb = golden["g2_lab_%s_%d" % (an, pi)]
         assert im.dtype == ref_im.dtype and lb.dtype == ref_lb.dtype
-        np.testing.assert_allclose(im, ref_im, rtol=0, atol=2e-6)
-        assert (lb != ref_lb).mean() <= 1e-3   # exact fp64 ties only
+        np.testing.assert_array_equal(im, ref_im)          # bit for bit (round 6: the allowances of rounds 1-5 were never needed)
+        np.testing.assert_array_equal(lb, ref_lb)
 
 
 @pytest.mark.parametrize("an", AFFS)
@@ -46,17 +46,17 @@ def test_g3_get_view_from(golden, an, dim):
             golden["g3_vol"], golden["g3_lab"], golden["aff_" + an],
             golden["views"][v], dim, span, bg_value=[12.5],
             center=golden["g3_center"], scale=golden["g3_scale"])
-        np.testing.assert_allclose(Xs, golden["g3_X_" + key], rtol=0, atol=2e-6)
-        assert (ys != golden["g3_y_" + key]).mean() <= 1e-3
+        np.testing.assert_array_equal(Xs, golden["g3_X_" + key])
+        np.testing.assert_array_equal(ys, golden["g3_y_" + key])
         np.testing.assert_array_equal(grid[0], golden["g3_g_" + key])
         np.testing.assert_array_equal(grid[2], golden["g3_off_" + key])
-        np.testing.assert_allclose(ib, golden["g3_invb_" + key], atol=1e-14)
+        np.testing.assert_array_equal(ib, golden["g3_invb_" + key])
 
 
 @pytest.mark.parametrize("an", AFFS)
 def test_g4_voxel_grid(golden, an):
     vg = G.voxel_grid_real_space(golden["g3_vol"].shape[:3], golden["aff_" + an])
-    np.testing.assert_allclose(vg, golden["g4_vgrid_" + an], rtol=0, atol=1e-11)
+    np.testing.assert_array_equal(vg, golden["g4_vgrid_" + an])
 
 
 @pytest.mark.parametrize("an", AFFS)
@@ -71,8 +71,7 @@ def test_g5_map_real_space_pred(golden, an):
             ref = golden["g5_map_%s_%d_%d" % (an, v, K)]
             mp = G.map_real_space_pred(pr, grid, golden["g3_invb_" + key], vg)
             assert mp.dtype == ref.dtype and mp.shape == ref.shape
-            bad = np.any(mp != ref, axis=-1).mean()
-            assert bad <= 1e-3, bad
+            np.testing.assert_array_equal(mp, ref)          # every voxel's vector is the reference's
 
 
 def test_g6_dice_and_class(golden):
@@ -99,7 +98,7 @@ def test_g7_round_trip(golden, an):
             mp = G.map_real_space_pred(onehot, grid, golden["g3_invb_" + key], vg)
             got = mp.argmax(-1).astype(np.uint8)
             ref = golden["g7_map_" + key]
-            assert (got != ref).mean() <= 1e-3
+            np.testing.assert_array_equal(got, ref)
             if dim == 32 and an == "ident" and v in (0, 1):
                 d = G.dice_all(lab, got, n_classes=3)
                 assert np.all(d > 0.9), d
