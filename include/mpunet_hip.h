@@ -302,6 +302,29 @@ int64_t mpu_unet_l2_workspace_doubles(void);
 int mpu_unet_adam_pack(const mpu_unet* m, float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t t,
                        int64_t* d_step, double lr, double beta1, double beta2, double eps, void* d_packed, void* stream);
 
+/* One Model.fit inner step's backward half AND its optimizer (mpunet/train/trainer.py:246: Keras runs the tape's
+ * gradients and optimizer.apply_gradients inside one fit step): mpu_unet_backward followed by mpu_unet_adam_pack, with the
+ * same results bit for bit, scheduled so that the HBM-bound optimizer runs BESIDE the MFMA-bound weight gradients
+ * instead of behind them (round 6). The deep levels' weight gradients (every layer that is not on the strip-resident
+ * wgrad_taps schedule: 86 % of the parameters of the configs[1] network) are finished first; their Adam update + operand
+ * refresh then run on a library-owned side stream, as a register- and LDS-lean kernel that shares the compute units with
+ * the grouped weight-gradient launch of the high-resolution levels; the remaining parameters follow that launch. Under
+ * stream capture the fork / join become parallel branches of the graph (run one eager call first: the side stream and
+ * its two events are created at the first use). MPU_TAIL_OVERLAP=0: the serial order. Single GPU, no l2 term (both need
+ * the gradients between the two halves: use the two calls). Arguments as mpu_unet_backward + mpu_unet_adam_pack;
+ * d_params / d_packed are read by the backward pass and updated by the optimizer. */
+int mpu_unet_backward_adam(const mpu_unet* m, int32_t batch, const uint8_t* d_y, const float* d_sample_weight,
+                           float* d_params, void* d_packed, float* d_bn_state, void* d_workspace, float* d_grads,
+                           float* d_loss, float* d_m, float* d_v, int64_t t, int64_t* d_step, double lr, double beta1,
+                           double beta2, double eps, void* stream);
+
+/* Dev aid: on != 0 arms eight timing events that mpu_unet_backward_adam records at the branch points of its tail (0 before the
+ * deep levels' weight gradients, 1 after their reductions = the fork, 2 / 3 side stream before / after its optimizer launch, 4 after
+ * the grouped wgrad_taps launch, 5 after its reductions, 6 after the remaining optimizer launch, 7 after the join); on == 0
+ * disarms, synchronises and writes the milliseconds of each since event 0 into ms_out[8] (-1: not recorded). Timestamps of BOTH
+ * streams without rocprofv3, whose per-dispatch signals change how the two queues interleave. */
+int mpu_debug_tail_events(int32_t on, float* ms_out);
+
 /* Keras Adam (TF ApplyAdam form), t = 1-based step; YAML defaults
  * lr 5e-5, beta_1 .9, beta_2 .999, epsilon 1e-8
  * (mpunet/bin/defaults/MultiPlanar/train_hparams.yaml:126). */

@@ -623,31 +623,46 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(ReduceTable t) {
     }
 }
 
-int flush_wgrad_reduces(ReduceQueue& q, hipStream_t st) {
+// which: WG_TAPS = the jobs whose partials come from wgrad_taps (ci-interleaved layout), WG_GLDS = all others; the jobs
+// not taken stay in the queue (renumbered), so two flushes with complementary masks run every job exactly once
+int flush_wgrad_reduces(ReduceQueue& q, hipStream_t st, int which) {
     if (q.njobs == 0) return MPU_OK;
-    ReduceTable t; t.njobs = q.njobs; t._pad = 0;
-    for (int k = 0; k < q.njobs; ++k) t.job[k] = q.job[k];
-    launch_k(wgrad_reduce_all_kernel, dim3((unsigned)q.nblocks), dim3(256), 0, st, t);
-    q.njobs = 0; q.nblocks = 0;
+    ReduceTable t; t.njobs = 0; t._pad = 0;
+    int nblocks = 0, kept = 0, kept_blocks = 0;
+    for (int k = 0; k < q.njobs; ++k) {
+        const bool is_taps = q.job[k].il4_cout > 0;
+        if (which & (is_taps ? WG_TAPS : WG_GLDS)) {
+            ReduceJob& j = t.job[t.njobs++];
+            j = q.job[k]; j.blk_begin = nblocks; nblocks += j.main_blocks + j.db_blocks;
+        } else {
+            ReduceJob j = q.job[k];
+            j.blk_begin = kept_blocks; kept_blocks += j.main_blocks + j.db_blocks;
+            q.job[kept++] = j;
+        }
+    }
+    q.njobs = kept; q.nblocks = kept_blocks;
+    if (t.njobs == 0 || nblocks == 0) return MPU_OK;
+    launch_k(wgrad_reduce_all_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, t);
     return launch_ok();
 }
 
 // every recorded weight-gradient kernel: the wgrad_taps jobs as one launch, the wgrad_glds jobs as another
-int flush_wgrad_group(int dtype, WgradGroup& g, hipStream_t st) {
+int flush_wgrad_group(int dtype, WgradGroup& g, hipStream_t st, int which) {
     int rc = MPU_OK;
-    if (g.ntaps) {
+    if (g.ntaps && (which & WG_TAPS)) {
         if (prof_on()) prof_begin(PROF_WGRAD, g.taps_flops, st);
         rc = launch_wgrad_taps_group(g.taps, g.ntaps, st);
         if (prof_on()) prof_end(st);
         if (sched_log_on()) sched_note("wgrad-group taps jobs=%d", g.ntaps);
+        g.ntaps = 0; g.taps_flops = 0;
     }
-    if (!rc && g.nglds) {
+    if (!rc && g.nglds && (which & WG_GLDS)) {
         if (prof_on()) prof_begin(PROF_WGRAD, g.glds_flops, st);
         rc = launch_wgrad_glds_group(dtype, g.glds, g.nglds, st);
         if (prof_on()) prof_end(st);
         if (sched_log_on()) sched_note("wgrad-group glds jobs=%d", g.nglds);
+        g.nglds = 0; g.glds_flops = 0;
     }
-    g.ntaps = g.nglds = 0; g.taps_flops = g.glds_flops = 0;
     return rc;
 }
 

@@ -43,6 +43,7 @@ enum EnvKind {
     X(WGRAD_TAPS_STAG, "MPU_WGRAD_TAPS_STAG", ENV_ON, 1, "0: wgrad_taps with lockstep wave groups (round-3 A/B)")                    \
     X(WGRAD_GROUP, "MPU_WGRAD_GROUP", ENV_ON, 1, "0: every weight-gradient kernel as its own launch instead of the grouped launches") \
     X(WGRAD_BATCHED_REDUCE, "MPU_WGRAD_BATCHED_REDUCE", ENV_ON, 1, "0: the K-split reduction right behind every weight-gradient kernel") \
+    X(TAIL_OVERLAP, "MPU_TAIL_OVERLAP", ENV_ON, 1, "0: mpu_unet_backward_adam runs the optimizer behind the weight gradients instead of beside them (round-6 A/B)") \
     X(GEOM_FAST, "MPU_GEOM_FAST", ENV_ON, 1, "0: geometry kernels on the op-by-op fp64 path only (no screened fast path)")           \
     X(FUSE_FX, "MPU_FUSE_FX", ENV_ON, 1, "0: fused back-mapping with fp64 index arithmetic instead of the fixed-point screen")       \
     X(PROF_MARKERS, "MPU_PROF_MARKERS", ENV_OFF, 0, "1: roofline-leg events as hipEventRecord markers instead of dispatch-bound events") \

@@ -124,7 +124,8 @@ struct ReduceJob {
 };
 constexpr int REDUCE_MAX_JOBS = 32;
 struct ReduceQueue { int njobs = 0, nblocks = 0; ReduceJob job[REDUCE_MAX_JOBS]; };
-int  flush_wgrad_reduces(ReduceQueue& q, hipStream_t st);
+enum { WG_TAPS = 1, WG_GLDS = 2, WG_ALL = 3 };  // which: jobs of the wgrad_taps schedule / all others
+int  flush_wgrad_reduces(ReduceQueue& q, hipStream_t st, int which = WG_ALL);
 // Deferred weight-gradient KERNELS (round 3): the weight gradients of a backward pass do not depend on each other, so
 // launch_wgrad(.., q, grp) only prepares them (schedule, split, scratch) and records them here; flush_wgrad_group() runs
 // all recorded wgrad_taps jobs as ONE launch and the wgrad_glds jobs as one launch per tile variant. A grid of many
@@ -139,7 +140,7 @@ struct WgradGroup {
     int ntaps = 0, nglds = 0; double taps_flops = 0, glds_flops = 0;
     TapsGroupJob taps[TAPS_GROUP_MAX]; GldsGroupJob glds[GLDS_GROUP_MAX];
 };
-int  flush_wgrad_group(int dtype, WgradGroup& g, hipStream_t st);
+int  flush_wgrad_group(int dtype, WgradGroup& g, hipStream_t st, int which = WG_ALL);
 int  launch_wgrad_taps_group(const TapsGroupJob* jobs, int n, hipStream_t st);          // wgrad_taps.hip
 int  launch_wgrad_glds_group(int dtype, const GldsGroupJob* jobs, int n, hipStream_t st);   // conv_glds.hip (bf16, 128 x 128 tiles)
 int  wgrad_taps_grid(int mode, const WgradArgs& a, const TapsPlan& p);                  // workgroups of one job
@@ -170,6 +171,11 @@ int launch_pack_all(int dtype, PackTable& tab, const float* params, void* packed
 int launch_adam_pack_all(int dtype, PackTable& jobs, float* params, const float* grads, float* am, float* av, long n_params,
                          void* packed, long long* step, long long t_host, double lr, double b1, double b2, float eps,
                          hipStream_t st);
+// ... of the parameters in nr (<= 2) ascending ranges [p_lo[k], p_hi[k]) only; lean: the register- and LDS-lean kernel that is
+// co-resident with wgrad_taps (bf16); a device step counter must already hold this step's number (see launch_head_backward)
+int launch_adam_pack_ranges(int dtype, PackTable& jobs, float* params, const float* grads, float* am, float* av, const long* p_lo,
+                            const long* p_hi, int nr, void* packed, long long* step, long long t_host, double lr, double b1,
+                            double b2, float eps, bool lean, hipStream_t st);
 int launch_pack_weights(int dtype, int mode, const float* W, int Cin, int Cout,
                         void* w_fwd, void* w_dgrad, hipStream_t st);
 int launch_cast_pad(int dtype, const float* x, long M, int Cin, int Cpad, void* out, hipStream_t st);
@@ -224,7 +230,7 @@ int launch_head_combine(const float* partial, long M, int K, const float* bh, in
 int launch_head_backward(int dtype, const void* n, const float* probs, const uint8_t* y,
                          const float* sample_w, long M, long pix_per_image, int C, int K,
                          const float* Wh, int ldw, float* partial, void* dn, float* dWh, float* dbh,
-                         float* loss, hipStream_t st);
+                         float* loss, hipStream_t st, long long* step_incr = nullptr /* device counter to advance by one */);
 
 // l2 kernel regulariser: grads += 2*l2*W over the listed tensors; reg_loss (optional) = l2 * sum W^2
 struct L2Table { int njobs, _pad; long off[PACK_MAX_JOBS]; long n[PACK_MAX_JOBS]; };

@@ -196,6 +196,7 @@ struct Run {
     void* const* ready_events = nullptr; int n_ready = 0;        // gradient-ready points (mpu_unet_backward_events)
     mutable ReduceQueue rq;                                      // deferred weight-gradient reductions (one launch per flush)
     mutable WgradGroup grp;                                      // deferred weight-gradient kernels (grouped launches at the end)
+    mutable std::vector<char> late;                              // per conv: its weight gradient sits in the wgrad_taps group (final only after that launch)
     bool group = false;
     int esz;
     void* at(long off) const { return ws + off; }
@@ -303,7 +304,10 @@ int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* 
         li.in0 = x0; li.in1 = x1; li.dz = dz; li.mask = nullptr; li.out = nullptr; li.w_off = c.w; li.b_off = c.b;
         r.m->tap(r.m->tap_user, &li);                  // (before the launch: x and dz are final, dW is read after the pass)
     }
-    return launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st, q, (r.group && q) ? &r.grp : nullptr);
+    const int ntaps_before = r.grp.ntaps;
+    const int rc = launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st, q, (r.group && q) ? &r.grp : nullptr);
+    if (!rc && r.grp.ntaps > ntaps_before) { if (r.late.size() != r.m->conv.size()) r.late.assign(r.m->conv.size(), 0); r.late[ci_] = 1; }
+    return rc;
 }
 
 // test aid: report a non-convolution launch to the tap (kinds 3-7 of mpu_launch_info)
@@ -458,7 +462,15 @@ int mark_ready(const Run& r, int k) {
     return MPU_OK;
 }
 
-int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_loss) {
+// The optimizer of mpu_unet_backward_adam (Keras Adam on the flat buffers + refresh of the packed operands)
+struct AdamOpt { float* params; void* packed; float* am; float* av; long long* step; long long t; double lr, b1, b2; float eps; };
+int finish_backward(const Run& r, const AdamOpt* opt);
+// the overlapped tail is decided BEFORE the pass (the device step counter then moves at its start): the switch, the dtype
+// and the grouped weight gradients it rides beside; whether a layer actually takes wgrad_taps is known only at the end --
+// finish_backward handles "none did" with the same pre-advanced counter
+bool tail_overlap_wanted(const Run& r) { return env(ENV_TAIL_OVERLAP) != 0 && r.m->cfg.dtype == MPU_BF16 && r.group; }
+
+int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_loss, const AdamOpt* opt = nullptr) {
     const mpu_unet* m = r.m; const int D = m->cfg.depth; const Plan& P = r.P;
     const int dt = m->cfg.dtype;
     const long M0 = (long)r.B * m->cfg.H * m->cfg.W;
@@ -466,7 +478,8 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
     const void* last = D > 0 ? r.at(P.n2[D - 1]) : r.at(P.nb);
     RC(launch_head_backward(dt, last, (const float*)r.at(P.probs), d_y, d_sw, M0, (long)m->cfg.H * m->cfg.W,
                             m->head_C, m->cfg.n_classes, r.params + m->head_w, m->cfg.n_classes,
-                            (float*)r.at(P.partial), gA, r.grads + m->head_w, r.grads + m->head_b, d_loss, r.st));
+                            (float*)r.at(P.partial), gA, r.grads + m->head_w, r.grads + m->head_b, d_loss, r.st,
+                            (opt && opt->step && tail_overlap_wanted(r)) ? opt->step : nullptr));
     tap_aux(r, 7, -1, 0, m->head_C, m->cfg.n_classes, last, r.at(P.probs), d_y, d_sw, gA, m->head_w, m->head_b);
     int point = 0;
     RC(mark_ready(r, point++));                                                            // head
@@ -528,8 +541,113 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
         RC(mark_ready(r, point++));                                                        // encoder level i
     }
     // the deferred weight-gradient kernels of the whole pass as grouped launches, then their reductions in one more
-    RC(flush_wgrad_group(r.m->cfg.dtype, r.grp, r.st));
-    return flush_wgrad_reduces(r.rq, r.st);
+    // (with an optimizer: the part of it whose gradients are final early runs BESIDE the last grouped launch)
+    return finish_backward(r, opt);
+}
+
+// per-device side stream + fork / join events of the tail overlap (created at the first use: run one eager step before
+// capturing a graph, as UNet.make_graphed_train_step does)
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+int side_stream(SideStream** out) {
+    static SideStream side[64];
+    int dev = 0;
+    MPU_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev > 63) return fail(MPU_EINVAL, "%s", "side_stream: device index out of range");
+    SideStream& d = side[dev];
+    if (!d.s) {
+        hipStream_t s; hipEvent_t f, j;
+        MPU_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        MPU_CHECK_HIP(hipEventCreateWithFlags(&f, hipEventDisableTiming));
+        MPU_CHECK_HIP(hipEventCreateWithFlags(&j, hipEventDisableTiming));
+        d.fork = f; d.join = j; d.s = s;
+    }
+    *out = &d;
+    return MPU_OK;
+}
+
+// dev aid (mpu_debug_tail_events): timing events at the branch points of the tail, recorded on BOTH streams -- the one way to
+// see the two branches' timeline without rocprofv3, whose per-dispatch signals change how the queues interleave
+constexpr int TAIL_EVENTS = 8;
+bool g_tail_events_on = false;
+hipEvent_t g_tail_ev[TAIL_EVENTS] = {nullptr};
+inline void tail_stamp(int k, hipStream_t st) { if (g_tail_events_on && g_tail_ev[k]) (void)hipEventRecord(g_tail_ev[k], st); }
+
+void pack_jobs_of(const mpu_unet* m, PackTable& tab) {
+    tab.njobs = 0; tab._pad = 0;
+    for (const Conv& c : m->conv) {
+        if (c.mode == CONV1 || tab.njobs >= PACK_MAX_JOBS) continue;
+        PackJob& j = tab.job[tab.njobs++];
+        j.mode = c.mode; j.Cin = c.Cin; j.Cout = c.Cout; j.unit_begin = j.fwd_units = j._pad = 0;
+        j.w = c.w; j.wf = c.wf; j.wd = c.wd;
+    }
+}
+
+// Round 6. The weight gradients of the high-resolution levels (wgrad_taps_group, ~13 % of a configs[1] step) are bound by
+// MFMA issue and LDS reads; the optimizer (adam_pack_all, ~7 %) by HBM. The gradients of the deep levels -- the layers that do
+// NOT take the wgrad_taps schedule: 86 % of the parameters at configs[1] -- are final once wgrad_glds_group and its
+// reductions have run, so: glds group -> its reductions -> fork: [side stream: Adam + pack of that contiguous parameter range
+// with the co-resident lean kernel] beside [main: wgrad_taps_group -> its reductions -> Adam + pack of the remaining
+// parameters] -> join -> step counter. Same kernels' arithmetic, disjoint parameter ranges: bit-identical to the serial
+// order (tests/test_gpu_unet.py); MPU_TAIL_OVERLAP=0 runs the serial order. Under stream capture the fork / join become
+// parallel branches of the graph.
+int finish_backward(const Run& r, const AdamOpt* opt) {
+    const mpu_unet* m = r.m; const int dt = m->cfg.dtype;
+    if (!opt) {
+        RC(flush_wgrad_group(dt, r.grp, r.st));
+        return flush_wgrad_reduces(r.rq, r.st);
+    }
+    PackTable jobs; pack_jobs_of(m, jobs);
+    if (!tail_overlap_wanted(r)) {                               // the serial order: the step counter moves behind the update
+        RC(flush_wgrad_group(dt, r.grp, r.st));
+        RC(flush_wgrad_reduces(r.rq, r.st));
+        return launch_adam_pack_all(dt, jobs, opt->params, r.grads, opt->am, opt->av, m->n_params, opt->packed, opt->step, opt->t,
+                                    opt->lr, opt->b1, opt->b2, opt->eps, r.st);
+    }
+    // (from here on a device step counter already holds this step's number: launch_head_backward advanced it)
+    long lo = 0, hi = 0;                                         // the early range: longest run of convs outside the taps group
+    if (r.grp.ntaps > 0 && r.late.size() == m->conv.size()) {
+        const int nc = (int)m->conv.size();
+        for (int i = 0; i < nc; ) {
+            if (r.late[i] || m->conv[i].mode == CONV1) { ++i; continue; }
+            int j = i;
+            while (j + 1 < nc && !r.late[j + 1] && m->conv[j + 1].mode != CONV1) ++j;
+            const long a = m->conv[i].w, b = j + 1 < nc ? m->conv[j + 1].w : m->n_params;
+            if (b - a > hi - lo) { lo = a; hi = b; }
+            i = j + 1;
+        }
+    }
+    const long all_lo[1] = {0}, all_hi[1] = {m->n_params};
+    if (hi - lo < (1L << 20)) {                                  // nothing worth a second stream
+        RC(flush_wgrad_group(dt, r.grp, r.st));
+        RC(flush_wgrad_reduces(r.rq, r.st));
+        return launch_adam_pack_ranges(dt, jobs, opt->params, r.grads, opt->am, opt->av, all_lo, all_hi, 1, opt->packed, opt->step,
+                                       opt->t, opt->lr, opt->b1, opt->b2, opt->eps, false, r.st);
+    }
+    SideStream* sd = nullptr;
+    RC(side_stream(&sd));
+    tail_stamp(0, r.st);
+    RC(flush_wgrad_group(dt, r.grp, r.st, WG_GLDS));
+    RC(flush_wgrad_reduces(r.rq, r.st, WG_GLDS));
+    tail_stamp(1, r.st);
+    MPU_CHECK_HIP(hipEventRecord(sd->fork, r.st));
+    MPU_CHECK_HIP(hipStreamWaitEvent(sd->s, sd->fork, 0));
+    tail_stamp(2, sd->s);
+    RC(launch_adam_pack_ranges(dt, jobs, opt->params, r.grads, opt->am, opt->av, &lo, &hi, 1, opt->packed, opt->step, opt->t, opt->lr,
+                               opt->b1, opt->b2, opt->eps, true, sd->s));
+    tail_stamp(3, sd->s);
+    MPU_CHECK_HIP(hipEventRecord(sd->join, sd->s));
+    if (sched_log_on()) sched_note("tail-overlap adam range=[%ld,%ld) of %ld", lo, hi, m->n_params);
+    RC(flush_wgrad_group(dt, r.grp, r.st, WG_TAPS));
+    tail_stamp(4, r.st);
+    RC(flush_wgrad_reduces(r.rq, r.st, WG_ALL));
+    tail_stamp(5, r.st);
+    const long rest_lo[2] = {0, hi}, rest_hi[2] = {lo, m->n_params};       // everything else in ONE launch
+    RC(launch_adam_pack_ranges(dt, jobs, opt->params, r.grads, opt->am, opt->av, rest_lo, rest_hi, 2, opt->packed, opt->step, opt->t,
+                               opt->lr, opt->b1, opt->b2, opt->eps, false, r.st));
+    tail_stamp(6, r.st);
+    MPU_CHECK_HIP(hipStreamWaitEvent(r.st, sd->join, 0));           // the side branch joins at the very end
+    tail_stamp(7, r.st);
+    return MPU_OK;
 }
 
 int make_run(Run& r, const mpu_unet* m, int batch, const float* params, const void* packed, float* state,
@@ -692,6 +810,37 @@ int mpu_unet_backward(const mpu_unet* m, int32_t batch, const uint8_t* d_y, cons
     Run r;
     RC(make_run(r, m, batch, d_params, d_packed, d_bn_state, d_grads, d_workspace, stream));
     return run_backward(r, d_y, d_sample_weight, d_loss);
+}
+
+int mpu_unet_backward_adam(const mpu_unet* m, int32_t batch, const uint8_t* d_y, const float* d_sample_weight,
+                           float* d_params, void* d_packed, float* d_bn_state, void* d_workspace, float* d_grads,
+                           float* d_loss, float* d_m, float* d_v, int64_t t, int64_t* d_step, double lr, double beta1,
+                           double beta2, double eps, void* stream) {
+    MPU_REQUIRE(d_y && d_sample_weight && d_grads && d_m && d_v, "mpu_unet_backward_adam: null argument");
+    MPU_REQUIRE(m && m->cfg.softmax, "mpu_unet_backward_adam: training needs out_activation='softmax'");
+    MPU_REQUIRE(d_step || t >= 1, "mpu_unet_backward_adam: need a device step counter or a 1-based step number");
+    Run r;
+    RC(make_run(r, m, batch, d_params, d_packed, d_bn_state, d_grads, d_workspace, stream));
+    AdamOpt o{d_params, d_packed, d_m, d_v, (long long*)d_step, (long long)t, lr, beta1, beta2, (float)eps};
+    return run_backward(r, d_y, d_sample_weight, d_loss, &o);
+}
+
+int mpu_debug_tail_events(int32_t on, float* ms_out) {
+    if (on) {
+        for (int k = 0; k < TAIL_EVENTS; ++k) if (!g_tail_ev[k]) MPU_CHECK_HIP(hipEventCreate(&g_tail_ev[k]));
+        g_tail_events_on = true;
+        return MPU_OK;
+    }
+    g_tail_events_on = false;
+    if (ms_out) {
+        MPU_CHECK_HIP(hipDeviceSynchronize());
+        for (int k = 0; k < TAIL_EVENTS; ++k) {
+            float t = -1.f;
+            if (g_tail_ev[0] && g_tail_ev[k] && hipEventElapsedTime(&t, g_tail_ev[0], g_tail_ev[k]) != hipSuccess) { t = -1.f; (void)hipGetLastError(); }
+            ms_out[k] = t;
+        }
+    }
+    return MPU_OK;
 }
 
 int32_t mpu_unet_grad_ready_points(const mpu_unet* m, int64_t* offsets, int32_t cap) {

@@ -1379,8 +1379,11 @@ __global__ __launch_bounds__(256, (K <= 3 ? 4 : 2)) void head_backward_kernel(co
 }
 
 __global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int K, int ldw,
-                                         float* dWh, float* dbh) {
+                                         float* dWh, float* dbh, long long* step_incr) {
     __shared__ double red[256];
+    // (mpu_unet_backward_adam: the optimizer's device step counter moves HERE, at the start of the backward pass -- nothing
+    // reads it before the optimizer kernels at the pass's end, and none of those then has to be the last reader)
+    if (step_incr && blockIdx.x == 0 && threadIdx.x == 0) *step_incr += 1;
     const int i = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
     const int tot = C * K + K;
     double s;
@@ -1391,7 +1394,7 @@ __global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __r
 
 int launch_head_backward(int dtype, const void* n, const float* probs, const uint8_t* y, const float* sw, long M,
                          long ppi, int C, int K, const float* Wh, int ldw, float* partial, void* dn, float* dWh,
-                         float* dbh, float* loss, hipStream_t st) {
+                         float* dbh, float* loss, hipStream_t st, long long* step_incr) {
     const int N = dtype == MPU_BF16 ? 8 : 4;
     const int cpr = C / N;
     if (C > HEAD_MAXC || cpr > 64 || C % N != 0)
@@ -1406,7 +1409,7 @@ int launch_head_backward(int dtype, const void* n, const float* probs, const uin
     }
     int rc = launch_ok();
     if (rc) return rc;
-    head_bwd_finalize_kernel<<<cdiv(C * K + K, FIN_COLS), 256, 0, st>>>(partial, (int)blocks, C, K, ldw, dWh, dbh);
+    head_bwd_finalize_kernel<<<cdiv(C * K + K, FIN_COLS), 256, 0, st>>>(partial, (int)blocks, C, K, ldw, dWh, dbh, step_incr);
     return launch_ok();
 }
 
@@ -1426,8 +1429,9 @@ __device__ __forceinline__ void adam_update(float gg, float& m, float& v, float&
     const float num = mm * alpha, den = sqrtf(vv) + eps;
     p = p - num / den;
 }
-__device__ __forceinline__ float adam_alpha_dev(const long long* step, double lr, double b1d, double b2d) {
-    const double t = (double)(*step + 1);
+// step_bias: 1 = the counter holds t - 1 (the caller increments it after the update), 0 = it already holds t
+__device__ __forceinline__ float adam_alpha_dev(const long long* step, double lr, double b1d, double b2d, int step_bias = 1) {
+    const double t = (double)(*step + step_bias);
     return (float)(lr * sqrt(1.0 - pow(b2d, t)) / (1.0 - pow(b1d, t)));
 }
 
@@ -1591,10 +1595,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void adam_pack_all_kernel(AdamPackTable tab, float* __restrict__ params,
                                                             const float* __restrict__ grads, float* __restrict__ am,
                                                             float* __restrict__ av, T* packed, const long long* __restrict__ step,
-                                                            double lr, double b1d, double b2d, float alpha_host, float eps) {
+                                                            double lr, double b1d, double b2d, float alpha_host, float eps, int step_bias) {
     __shared__ float tile_raw[4 * 32 * 33];                      // >= 64 x 65: both tile views live here
     float (*tile)[65] = reinterpret_cast<float (*)[65]>(tile_raw);
-    const float alpha = step ? adam_alpha_dev(step, lr, b1d, b2d) : alpha_host;
+    const float alpha = step ? adam_alpha_dev(step, lr, b1d, b2d, step_bias) : alpha_host;
     const float b1 = (float)b1d, b2 = (float)b2d;
     const int u0 = (int)blockIdx.x;
     if (u0 >= tab.plain_begin) {                                 // biases, BatchNorm parameters, 1x1 head
@@ -1662,10 +1666,257 @@ int launch_adam_pack_all(int dtype, PackTable& jobs, float* params, const float*
     float alpha_host = 0.f;
     if (!step) alpha_host = (float)(lr * std::sqrt(1.0 - std::pow(b2, (double)t_host)) / (1.0 - std::pow(b1, (double)t_host)));
     if (dtype == MPU_BF16)
-        adam_pack_all_kernel<bf16_t><<<units, 256, 0, st>>>(tab, params, grads, am, av, (bf16_t*)packed, step, lr, b1, b2, alpha_host, eps);
+        adam_pack_all_kernel<bf16_t><<<units, 256, 0, st>>>(tab, params, grads, am, av, (bf16_t*)packed, step, lr, b1, b2, alpha_host, eps, 1);
     else
-        adam_pack_all_kernel<float><<<units, 256, 0, st>>>(tab, params, grads, am, av, (float*)packed, step, lr, b1, b2, alpha_host, eps);
+        adam_pack_all_kernel<float><<<units, 256, 0, st>>>(tab, params, grads, am, av, (float*)packed, step, lr, b1, b2, alpha_host, eps, 1);
     if (step) incr_step_kernel<<<1, 1, 0, st>>>(step);
+    return launch_ok();
+}
+
+// ---- round 6: the optimizer beside the weight gradients -----------------------------------------------------------
+// adam_pack_lean_kernel (bf16 operands): the same update and the same two packed copies as adam_pack_all_kernel, but small
+// enough -- <= 64 registers, 8.5 KB of LDS -- to be CO-RESIDENT with a wgrad_taps workgroup (448 of a SIMD's 512 registers,
+// 148 of a CU's 160 KB): the grouped weight-gradient launch is bound by MFMA issue and LDS reads, this kernel by HBM, so the
+// optimizer of the parameters whose gradients are already final (the deep levels: 90 % of the bytes) runs on a second stream
+// UNDER the weight gradients of the high-resolution levels instead of behind them (run_backward_adam, unet_model.hip).
+//   CONV3 job  : unit = (tap, 64 ci, 64 co) tile as in adam_pack_all_kernel, loaded in two halves of 32 ci (8 instead of 16
+//                16-byte loads per thread in flight), the tile held in LDS as bf16 -- the values both copies store.
+//   UPCONV2 job: unit = (16 ci, 32 co) x the four taps, fp32 in LDS (the data-gradient copy sums taps in fp32 before rounding).
+//   plain units: as adam_pack_all_kernel.
+// Bit-identical to adam_pack_all_kernel (tests/test_gpu_unet.py).
+constexpr int LEAN_TP = 68;                      // bf16 tile pitch (elements): rows 8-byte aligned
+__global__ __launch_bounds__(256, 8) void adam_pack_lean_kernel(AdamPackTable tab, float* __restrict__ params,
+                                                                const float* __restrict__ grads, float* __restrict__ am,
+                                                                float* __restrict__ av, bf16_t* packed, const long long* __restrict__ step,
+                                                                double lr, double b1d, double b2d, float alpha_host, float eps, int step_bias) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[64 * LEAN_TP * 2];          // 8704 B >= 4 x 16 x 33 floats (8448)
+    const float alpha = step ? adam_alpha_dev(step, lr, b1d, b2d, step_bias) : alpha_host;
+    const float b1 = (float)b1d, b2 = (float)b2d;
+    const int u0 = (int)blockIdx.x;
+    if (u0 >= tab.plain_begin) {                                 // biases, BatchNorm parameters, 1x1 head
+        int ri = 0;
+        while (ri + 1 < tab.nranges && u0 >= tab.range[ri + 1].unit_begin) ++ri;
+        const AdamRange& r = tab.range[ri];
+        const long e = (long)(u0 - r.unit_begin) * 1024 + threadIdx.x * 4;
+        if (e >= r.n) return;
+        const long o = r.off + e;
+        if (e + 4 <= r.n && (o & 3) == 0) {
+            float4 g4 = *reinterpret_cast<const float4*>(grads + o), m4 = *reinterpret_cast<float4*>(am + o),
+                   v4 = *reinterpret_cast<float4*>(av + o), p4 = *reinterpret_cast<float4*>(params + o);
+            adam_update(g4.x, m4.x, v4.x, p4.x, alpha, b1, b2, eps); adam_update(g4.y, m4.y, v4.y, p4.y, alpha, b1, b2, eps);
+            adam_update(g4.z, m4.z, v4.z, p4.z, alpha, b1, b2, eps); adam_update(g4.w, m4.w, v4.w, p4.w, alpha, b1, b2, eps);
+            *reinterpret_cast<float4*>(am + o) = m4; *reinterpret_cast<float4*>(av + o) = v4; *reinterpret_cast<float4*>(params + o) = p4;
+        } else {
+            for (int i = 0; i < 4 && e + i < r.n; ++i) {
+                float mm = am[o + i], vv = av[o + i], pp = params[o + i];
+                adam_update(grads[o + i], mm, vv, pp, alpha, b1, b2, eps);
+                am[o + i] = mm; av[o + i] = vv; params[o + i] = pp;
+            }
+        }
+        return;
+    }
+    int ji = 0;
+    while (ji + 1 < tab.njobs && u0 >= tab.job[ji + 1].unit_begin) ++ji;
+    const PackJob& j = tab.job[ji];
+    const int t = u0 - j.unit_begin;
+    const int Cin = j.Cin, Cout = j.Cout;
+    if (j.mode != UPCONV2) {
+        bf16_t (*tile)[LEAN_TP] = reinterpret_cast<bf16_t (*)[LEAN_TP]>(lds_raw);
+        const int tci = (Cin + 63) / 64, tco = (Cout + 63) / 64;
+        const int tap = t / (tci * tco); const int r = t % (tci * tco);
+        const int ci0 = (r / tco) * 64, co0 = (r % tco) * 64;
+        const long base = j.w + (long)tap * Cin * Cout;
+        const int ty = threadIdx.x >> 4, tx4 = (threadIdx.x & 15) * 4;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            float4 g4[2], m4[2], v4[2], p4[2];
+            long off[2]; bool in[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int ci = ci0 + ty + 16 * (2 * half + k), co = co0 + tx4;
+                in[k] = ci < Cin && co < Cout;
+                off[k] = base + (long)(ci < Cin ? ci : Cin - 1) * Cout + (co < Cout ? co : Cout - 4);
+                g4[k] = *reinterpret_cast<const float4*>(grads + off[k]); m4[k] = *reinterpret_cast<const float4*>(am + off[k]);
+                v4[k] = *reinterpret_cast<const float4*>(av + off[k]); p4[k] = *reinterpret_cast<const float4*>(params + off[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                adam_update(g4[k].x, m4[k].x, v4[k].x, p4[k].x, alpha, b1, b2, eps);
+                adam_update(g4[k].y, m4[k].y, v4[k].y, p4[k].y, alpha, b1, b2, eps);
+                adam_update(g4[k].z, m4[k].z, v4[k].z, p4[k].z, alpha, b1, b2, eps);
+                adam_update(g4[k].w, m4[k].w, v4[k].w, p4[k].w, alpha, b1, b2, eps);
+                if (in[k]) {
+                    *reinterpret_cast<float4*>(am + off[k]) = m4[k]; *reinterpret_cast<float4*>(av + off[k]) = v4[k];
+                    *reinterpret_cast<float4*>(params + off[k]) = p4[k];
+                }
+                const int cil = ty + 16 * (2 * half + k);
+                const float4 q = in[k] ? p4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<uint2*>(&tile[cil][tx4]) = make_uint2(f32x2_to_bf16x2(q.x, q.y), f32x2_to_bf16x2(q.z, q.w));
+            }
+        }
+        __syncthreads();
+        bf16_t* dstf = packed + j.wf + (long)tap * Cin * Cout;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {                   // forward copy [co][ci]: columns of the tile
+            const int col = threadIdx.x / 8 + pass * 32, cil = (threadIdx.x % 8) * 8;
+            const int co = co0 + col, ci = ci0 + cil;
+            if (ci < Cin && co < Cout) {
+                uint32_t w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (uint32_t)tile[cil + 2 * e][col] | ((uint32_t)tile[cil + 2 * e + 1][col] << 16);
+                *reinterpret_cast<uint4*>(dstf + (long)co * Cin + ci) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        bf16_t* dstd = packed + j.wd + (long)(8 - tap) * Cin * Cout;      // data-gradient copy: rotated taps, rows of the tile
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int row = threadIdx.x / 8 + pass * 32, col = (threadIdx.x % 8) * 8;
+            const int ci = ci0 + row, co = co0 + col;
+            if (ci < Cin && co < Cout) {
+                const uint2 a = *reinterpret_cast<const uint2*>(&tile[row][col]), b = *reinterpret_cast<const uint2*>(&tile[row][col + 4]);
+                *reinterpret_cast<uint4*>(dstd + (long)ci * Cout + co) = make_uint4(a.x, a.y, b.x, b.y);
+            }
+        }
+        return;
+    }
+    // UPCONV2: unit = (16 ci, 32 co) x four taps
+    float (*tile)[16][33] = reinterpret_cast<float (*)[16][33]>(lds_raw);
+    const int tco = (Cout + 31) / 32;
+    const int ci0 = (t / tco) * 16, co0 = (t % tco) * 32;
+    const long per_tap = (long)Cin * Cout;
+    {
+        const int th = threadIdx.x >> 7, cil = (threadIdx.x & 127) >> 3, tx4 = (threadIdx.x & 7) * 4;
+        const int ci = ci0 + cil, co = co0 + tx4;
+        const bool in = ci < Cin && co < Cout;
+        const long o0 = j.w + (long)(ci < Cin ? ci : Cin - 1) * Cout + (co < Cout ? co : Cout - 4);
+        float4 g4[2], m4[2], v4[2], p4[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const long o = o0 + (2 * th + k) * per_tap;
+            g4[k] = *reinterpret_cast<const float4*>(grads + o); m4[k] = *reinterpret_cast<const float4*>(am + o);
+            v4[k] = *reinterpret_cast<const float4*>(av + o); p4[k] = *reinterpret_cast<const float4*>(params + o);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int tp = 2 * th + k;
+            adam_update(g4[k].x, m4[k].x, v4[k].x, p4[k].x, alpha, b1, b2, eps);
+            adam_update(g4[k].y, m4[k].y, v4[k].y, p4[k].y, alpha, b1, b2, eps);
+            adam_update(g4[k].z, m4[k].z, v4[k].z, p4[k].z, alpha, b1, b2, eps);
+            adam_update(g4[k].w, m4[k].w, v4[k].w, p4[k].w, alpha, b1, b2, eps);
+            const long o = o0 + tp * per_tap;
+            if (in) {
+                *reinterpret_cast<float4*>(am + o) = m4[k]; *reinterpret_cast<float4*>(av + o) = v4[k];
+                *reinterpret_cast<float4*>(params + o) = p4[k];
+            }
+            const float4 q = in ? p4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            tile[tp][cil][tx4] = q.x; tile[tp][cil][tx4 + 1] = q.y; tile[tp][cil][tx4 + 2] = q.z; tile[tp][cil][tx4 + 3] = q.w;
+        }
+    }
+    __syncthreads();
+    // forward copy [tap][co][ci]: 16 ci = two 16-byte groups per (tap, co)
+    {
+        const int tp = threadIdx.x >> 6, col = (threadIdx.x & 63) >> 1, cil = (threadIdx.x & 1) * 8;
+        const int co = co0 + col, ci = ci0 + cil;
+        if (ci < Cin && co < Cout) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[tp][cil + e][col];
+            Vec<bf16_t>::store(packed + j.wf + tp * per_tap + (long)co * Cin + ci, v);
+        }
+    }
+    // data-gradient copy [tap'][ci][co], tap' = (dy+1)*3 + (dx+1): S(-1) = {1}, S(0) = {0, 1}, S(1) = {0} per axis
+    // (same summation order as adam_pack_upconv_tile / pack_dgrad_chunk: ky outer, kx inner)
+    for (int idx = threadIdx.x; idx < 9 * 16 * 4; idx += 256) {
+        const int tp = idx / 64, rem = idx % 64;
+        const int row = rem / 4, col = (rem % 4) * 8;
+        const int ci = ci0 + row, co = co0 + col;
+        if (ci < Cin && co < Cout) {
+            const int dy = tp / 3 - 1, dx = tp % 3 - 1;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            for (int ky = 0; ky < 2; ++ky) {
+                if ((dy == -1 && ky != 1) || (dy == 1 && ky != 0)) continue;
+                for (int kx = 0; kx < 2; ++kx) {
+                    if ((dx == -1 && kx != 1) || (dx == 1 && kx != 0)) continue;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += tile[ky * 2 + kx][row][col + e];
+                }
+            }
+            Vec<bf16_t>::store(packed + j.wd + tp * per_tap + (long)ci * Cout + co, v);
+        }
+    }
+}
+
+// Adam + pack of the parameters in the nr (<= 2) ascending, disjoint ranges [p_lo[k], p_hi[k]) only (jobs: every packed kernel
+// of the model, ordered by offset; a job is taken when its kernel lies inside a range, which must not cut one). lean: the
+// co-resident kernel above (bf16 only). The device step counter (step != NULL) must already hold THIS step's number t
+// (step_bias 0): mpu_unet_backward_adam advances it at the start of the backward pass, so that no launch of the tail has to
+// wait for "every reader is done" before it moves.
+int launch_adam_pack_ranges(int dtype, PackTable& jobs, float* params, const float* grads, float* am, float* av, const long* p_lo,
+                            const long* p_hi, int nr, void* packed, long long* step, long long t_host, double lr, double b1,
+                            double b2, float eps, bool lean, hipStream_t st) {
+    AdamPackTable tab; tab.njobs = 0; tab.nranges = 0; tab._pad = 0;
+    const bool use_lean = lean && dtype == MPU_BF16;
+    int units = 0;
+    long prev_w = -1;
+    int job_range[PACK_MAX_JOBS];
+    for (int i = 0; i < jobs.njobs; ++i) {
+        PackJob j = jobs.job[i];
+        if (j.w < prev_w) return fail(MPU_EINVAL, "%s", "adam_pack: jobs must be ordered by parameter offset");
+        prev_w = j.w;
+        const long end = j.w + (long)(j.mode == UPCONV2 ? 4 : 9) * j.Cin * j.Cout;
+        int in = -1;
+        for (int k = 0; k < nr; ++k) {
+            if (end <= p_lo[k] || j.w >= p_hi[k]) continue;
+            if (j.w < p_lo[k] || end > p_hi[k]) return fail(MPU_EINVAL, "%s", "adam_pack: a parameter range cuts a kernel");
+            in = k;
+        }
+        if (in < 0) continue;
+        j.unit_begin = units;
+        j.fwd_units = j.mode == UPCONV2 ? cdiv(j.Cin, use_lean ? 16 : 32) * cdiv(j.Cout, 32) : 9 * cdiv(j.Cin, 64) * cdiv(j.Cout, 64);
+        units += j.fwd_units;
+        job_range[tab.njobs] = in;
+        tab.job[tab.njobs++] = j;
+    }
+    tab.plain_begin = units;
+    for (int k = 0; k < nr; ++k) {                               // the complement of the packed kernels inside each range
+        if (k > 0 && p_lo[k] < p_hi[k - 1]) return fail(MPU_EINVAL, "%s", "adam_pack: ranges must ascend and not overlap");
+        long cur = p_lo[k];
+        for (int i = 0; i <= tab.njobs; ++i) {
+            if (i < tab.njobs && job_range[i] != k) continue;
+            const long lo = i < tab.njobs ? tab.job[i].w : p_hi[k];
+            if (lo > cur) {
+                if (tab.nranges >= ADAM_MAX_RANGES) return fail(MPU_EINVAL, "%s", "adam_pack: too many parameter ranges");
+                AdamRange& r = tab.range[tab.nranges++];
+                r.off = cur; r.n = lo - cur; r.unit_begin = units; r._pad = 0;
+                units += (int)cdiv(r.n, 1024L);
+            }
+            if (i < tab.njobs) {
+                const PackJob& j = tab.job[i];
+                cur = j.w + (long)(j.mode == UPCONV2 ? 4 : 9) * j.Cin * j.Cout;
+            }
+        }
+    }
+    float alpha_host = 0.f;
+    if (!step) alpha_host = (float)(lr * std::sqrt(1.0 - std::pow(b2, (double)t_host)) / (1.0 - std::pow(b1, (double)t_host)));
+    if (units == 0) return MPU_OK;
+    if (use_lean) {
+        // ONE workgroup per compute unit, whatever arrives first: the launch claims 82 KB of LDS (8.5 KB used), so two of
+        // them never share a CU, and 82 + 74 KB (wgrad_taps) do. Without the cap the 7 k short workgroups of this kernel
+        // fill every CU eight deep and the weight-gradient workgroups (448 of 512 registers) wait for them to drain: the
+        // two launches then run one after the other (measured, gpurun R6c: 135 + 311 us instead of side by side).
+        constexpr int LEAN_CLAIM = 82 * 1024, LEAN_STATIC = 64 * LEAN_TP * 2;
+        static unsigned long long attr_set = 0;
+        if (first_use_on_device(attr_set)) {
+            MPU_CHECK_HIP(hipFuncSetAttribute((const void*)adam_pack_lean_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LEAN_CLAIM - LEAN_STATIC));
+            mark_used_on_device(attr_set);
+        }
+        adam_pack_lean_kernel<<<units, 256, LEAN_CLAIM - LEAN_STATIC, st>>>(tab, params, grads, am, av, (bf16_t*)packed, step, lr, b1, b2, alpha_host, eps, 0);
+    } else if (dtype == MPU_BF16)
+        adam_pack_all_kernel<bf16_t><<<units, 256, 0, st>>>(tab, params, grads, am, av, (bf16_t*)packed, step, lr, b1, b2, alpha_host, eps, 0);
+    else
+        adam_pack_all_kernel<float><<<units, 256, 0, st>>>(tab, params, grads, am, av, (float*)packed, step, lr, b1, b2, alpha_host, eps, 0);
     return launch_ok();
 }
 

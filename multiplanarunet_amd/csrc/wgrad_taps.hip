@@ -25,6 +25,7 @@
 // Output: fp32 partials [pair][tap][ci/4][co][4] (+ bias partials [pair][co]) reduced in fixed order
 // by wgrad_reduce*_kernel: deterministic, no atomics.
 #include <stdlib.h>
+#include <type_traits>
 #include "kernels.h"
 
 namespace mpu {
@@ -59,8 +60,58 @@ __device__ __forceinline__ s16x8 t_frag(const unsigned char* p_lo, const unsigne
 }
 
 constexpr int GROUP_LDS = NXR * XROWB + NZR * ZROWB;            // rings of one 4-wave group
-constexpr int XCH_A = 4 * 84 * 256, XCH_B = 4 * 64 * 256;       // accumulator exchange: taps 0-4 (+bias) / taps 5-8
-constexpr int TAPS_SMEM = XCH_A + XCH_B > 2 * GROUP_LDS ? XCH_A + XCH_B : 2 * GROUP_LDS;
+constexpr int TAPS_SMEM = 2 * GROUP_LDS;                        // 75776 B: the accumulator exchange at the end runs in rounds that fit the rings (round 6)
+
+// One round of the end-of-workgroup accumulator exchange between the two 4-wave groups: group 1 hands taps [A0, A1) (+ the
+// bias sums) to group 0, group 0 hands taps [B0, B1) to group 1, through [wave][floats][lane] arrays at the start of the LDS.
+template <int NT, int A0, int A1, bool BIAS, int B0, int B1>
+__device__ __forceinline__ void taps_xround(f32x4 (&acc)[NT][4], f32x4& accdb, unsigned char* smem_all, const int grp,
+                                            const int wave, const int lane) {
+    constexpr int NAF = (A1 - A0) * 16 + (BIAS ? 4 : 0), NBF = (B1 - B0) * 16;               // floats per lane, each way
+    static_assert(4 * (NAF + NBF) * 256 <= TAPS_SMEM, "exchange round larger than the rings");
+    float* xa = reinterpret_cast<float*>(smem_all) + (wave * NAF) * 64 + lane;               // [wave][NAF][lane]
+    float* xb = reinterpret_cast<float*>(smem_all + 4 * NAF * 256) + (wave * NBF) * 64 + lane;
+    if (grp == 1) {
+#pragma unroll
+        for (int tp = A0; tp < A1; ++tp)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xa[(((tp - A0) * 4 + cb) * 4 + r) * 64] = acc[tp][cb][r];
+        if constexpr (BIAS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xa[((A1 - A0) * 16 + r) * 64] = accdb[r];
+        }
+        asm volatile("; xround: group 1 wrote" ::: "memory");
+    } else {
+#pragma unroll
+        for (int tp = B0; tp < B1; ++tp)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xb[(((tp - B0) * 4 + cb) * 4 + r) * 64] = acc[tp][cb][r];
+        asm volatile("; xround: group 0 wrote" ::: "memory");
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int tp = A0; tp < A1; ++tp)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[tp][cb][r] += xa[(((tp - A0) * 4 + cb) * 4 + r) * 64];
+        if constexpr (BIAS) accdb[0] += xa[(A1 - A0) * 16 * 64];
+        asm volatile("; xround: group 0 added" ::: "memory");
+    } else {
+#pragma unroll
+        for (int tp = B0; tp < B1; ++tp)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[tp][cb][r] += xb[(((tp - B0) * 4 + cb) * 4 + r) * 64];
+        asm volatile("; xround: group 1 added" ::: "memory");
+    }
+}
 
 // MODE CONV3: nine taps, X rows y-1..y+1 at full resolution. MODE UPCONV2 (nearest-upsample x2 + 2x2 conv): four
 // taps; staged "X row r" is the low-resolution row (y0 + r) >> 1 (each low-res row is staged for both upsampled rows
@@ -371,44 +422,21 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
     }
     if (stamps) stamps[2] = __builtin_amdgcn_s_memtime();
     // ---- combine the two groups through LDS (the rings are free now): group 0 ends up with taps 0-4 and the
-    // bias sums, group 1 with taps 5-8; each stores its share of the pair's partial copy -----------------
+    // bias sums, group 1 with taps 5-8; each stores its share of the pair's partial copy.
+    // Round 6: in ROUNDS that fit the rings' own 74 KB (one pass needed 148 KB, which left a compute unit's LDS to this
+    // workgroup alone): the kernel now leaves 84 KB of LDS and 64 registers per lane free, exactly the room of one
+    // workgroup of the optimizer kernel that runs beside it (adam_pack_lean_kernel, unet_ops.hip).
     {
         constexpr int NA = (NT + 1) / 2;                                                     // taps kept by group 0
-        float* xa = reinterpret_cast<float*>(smem_all) + (wave * 84) * 64 + lane;            // [wave][<= 84][lane]
-        float* xb = reinterpret_cast<float*>(smem_all + XCH_A) + (wave * 64) * 64 + lane;    // [wave][64][lane]
-        if (grp == 1) {
-#pragma unroll
-            for (int tp = 0; tp < NA; ++tp)
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xa[((tp * 4 + cb) * 4 + r) * 64] = acc[tp][cb][r];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xa[(NA * 16 + r) * 64] = accdb[r];
+        if constexpr (NT == 9) {
+            taps_xround<NT, 0, 2, true, 5, 7>(acc, accdb, smem_all, grp, wave, lane);
+            __syncthreads();
+            taps_xround<NT, 2, 4, false, 7, 9>(acc, accdb, smem_all, grp, wave, lane);
+            __syncthreads();
+            taps_xround<NT, 4, 5, false, 9, 9>(acc, accdb, smem_all, grp, wave, lane);
         } else {
-#pragma unroll
-            for (int tp = NA; tp < NT; ++tp)
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xb[(((tp - NA) * 4 + cb) * 4 + r) * 64] = acc[tp][cb][r];
-        }
-        __syncthreads();
-        if (grp == 0) {
-#pragma unroll
-            for (int tp = 0; tp < NA; ++tp)
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[tp][cb][r] += xa[((tp * 4 + cb) * 4 + r) * 64];
-            accdb[0] += xa[NA * 16 * 64];
-        } else {
-#pragma unroll
-            for (int tp = NA; tp < NT; ++tp)
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[tp][cb][r] += xb[(((tp - NA) * 4 + cb) * 4 + r) * 64];
+            static_assert(NT == 4, "exchange rounds are written for nine or four taps");
+            taps_xround<NT, 0, NA, true, NA, NT>(acc, accdb, smem_all, grp, wave, lane);
         }
     }
     if (stamps) stamps[3] = __builtin_amdgcn_s_memtime();

@@ -461,10 +461,12 @@ class UNet:
         n = _lib.load().mpu_unet_grad_ready_points(self._h, buf, 32)
         return [int(buf[i]) for i in range(n)]
 
-    def forward_backward(self, x, y, sample_weight=None, want_loss=True, ready_events=None):
+    def forward_backward(self, x, y, sample_weight=None, want_loss=True, ready_events=None, adam=None):
         """Train-mode forward + backward; fills self.grads (sum-gradient). Returns (probs, loss[B,H*W] or None).
         ready_events: optional list (one entry per grad_ready_points(), None = skip) of torch.cuda.Event recorded
-        on the current stream when that part of the gradient buffer is final (data-parallel overlap)."""
+        on the current stream when that part of the gradient buffer is final (data-parallel overlap).
+        adam: (t, step_dev) -- ALSO apply the optimizer inside the same library call (mpu_unet_backward_adam: the
+        update of the deep levels' parameters runs beside the weight gradients of the high-resolution levels)."""
         X = self._as_input(x)
         B = X.shape[0]
         if not torch.is_tensor(y):
@@ -479,7 +481,17 @@ class UNet:
                                  else sample_weight).to(device=self.device, dtype=torch.float32).contiguous()
         probs = self._forward(X, training=True)
         loss = torch.empty((B, y.shape[1]), dtype=torch.float32, device=self.device) if want_loss else None
-        if ready_events is None:
+        if adam is not None:
+            if ready_events is not None:
+                raise ValueError("forward_backward: adam= and ready_events= exclude each other")
+            t, step_dev = adam
+            k = self.optimizer_kwargs
+            _lib.call("mpu_unet_backward_adam", self._h, B, _lib.ptr(y), _lib.ptr(sw), _lib.ptr(self.params),
+                      _lib.ptr(self.packed), _lib.ptr(self.bn_state), _lib.ptr(self._ws), _lib.ptr(self.grads),
+                      _lib.ptr(loss), _lib.ptr(self._adam_m), _lib.ptr(self._adam_v), int(t), _lib.ptr(step_dev),
+                      float(k["lr"]), float(k["beta_1"]), float(k["beta_2"]), float(k["epsilon"]), _lib.stream_ptr())
+            self._infer_dirty = True
+        elif ready_events is None:
             _lib.call("mpu_unet_backward", self._h, B, _lib.ptr(y), _lib.ptr(sw), _lib.ptr(self.params),
                       _lib.ptr(self.packed), _lib.ptr(self.bn_state), _lib.ptr(self._ws), _lib.ptr(self.grads),
                       _lib.ptr(loss), _lib.stream_ptr())
@@ -542,7 +554,14 @@ class UNet:
         step_dev = torch.tensor([self.iterations], dtype=torch.int64, device=self.device)
         k = self.optimizer_kwargs
 
+        fused_tail = not self.l2_reg and os.environ.get("MPU_FUSED_ADAM") != "0"
+
         def body():
+            if fused_tail:               # backward + optimizer in one call: the optimizer beside the weight gradients
+                _, loss = self.forward_backward(x, y, sample_weight, want_loss=loss_sum is not None, adam=(0, step_dev))
+                if loss_sum is not None:
+                    loss_sum.add_(loss.mean().double())
+                return
             _, loss = self.forward_backward(x, y, sample_weight, want_loss=loss_sum is not None)
             self._add_l2(want_loss=loss_sum is not None)
             if loss_sum is not None:
@@ -592,6 +611,11 @@ class UNet:
     def train_step(self, x, y, sample_weight=None, want_loss=True):
         """One Model.fit inner step. Returns the per-pixel loss [B,H*W] (device) or None."""
         hook = self._grad_hook
+        if hook is None and not self.l2_reg:     # single GPU, no l2 term: backward + optimizer as one library call
+            self._ensure_adam()
+            self.iterations += 1
+            _, loss = self.forward_backward(x, y, sample_weight, want_loss, adam=(self.iterations, None))
+            return loss
         events = getattr(hook, "ready_events", None)
         _, loss = self.forward_backward(x, y, sample_weight, want_loss, ready_events=events)
         if hook is not None:

@@ -253,6 +253,55 @@ def test_fused_adam_pack_equals_adam_then_pack(dtype, cf, C):
         assert torch.equal(a.packed.view(torch.uint8), b.packed.view(torch.uint8))
 
 
+@pytest.mark.parametrize("cfg", [(4, 1, 128, 16, "bf16"), (2, 2, 64, 3, "bf16"), (2, 1, 32, 2, "f32"), (3, 0.25, 64, 2, "bf16")])
+def test_backward_adam_one_call_equals_backward_then_adam_bitwise(cfg):
+    """mpu_unet_backward_adam (round 6: the optimizer of the deep levels' parameters on a side stream BESIDE the grouped
+    wgrad_taps launch, as the register-lean adam_pack_lean_kernel; the other parameters behind it) == mpu_unet_backward followed
+    by mpu_unet_adam_pack, bit for bit: parameters, both Adam moments, every byte of the packed operands, the gradients, the
+    loss -- over three steps, eager and replayed from a captured graph (fork / join as graph branches). The configs[1] network
+    takes the overlapped schedule (asserted from the schedule log); the small ones cover odd filter counts, the f32 dtype
+    and networks without a wgrad_taps layer (the serial fallback inside the same entry point)."""
+    import ctypes as C
+    from multiplanarunet_amd import _lib
+    from multiplanarunet_amd.unet import UNet
+    D, cf, H, B, dtype = cfg
+    rng = np.random.RandomState(12)
+    x = torch.tensor(rng.randn(B, H, H, 1).astype(np.float32), device="cuda")
+    y = torch.tensor(rng.randint(0, 3, (B, H * H, 1)).astype(np.uint8), device="cuda")
+    mk = lambda: UNet(n_classes=3, dim=H, n_channels=1, depth=D, complexity_factor=cf, dtype=dtype, logger=quiet, seed=3)
+    a, b, c = mk(), mk(), mk()
+    for m in (a, b, c):
+        m.compile("Adam", "SparseCategoricalCrossentropy", optimizer_kwargs=dict(lr=1e-3))
+    lib = _lib.load()
+    lib.mpu_schedule_log_enable(1)
+    la = a.train_step(x, y, None)                      # the one-call path (a single GPU, no l2 term)
+    buf = C.create_string_buffer(1 << 16)
+    lib.mpu_schedule_log_read(buf, len(buf))
+    lib.mpu_schedule_log_enable(0)
+    log = buf.value.decode()
+    if (D, cf, H, B) == (4, 1, 128, 16):
+        assert "tail-overlap adam range=" in log, log[-400:]
+        lo, hi = [int(v) for v in log.split("tail-overlap adam range=[")[1].split(")")[0].split(",")]
+        assert (hi - lo) > 0.8 * a.params.numel()          # the deep levels: 86 % of the parameters
+    _, lb = b.forward_backward(x, y, None)
+    b.apply_gradients()
+    same = lambda p, q: torch.equal(p.params, q.params) and torch.equal(p._adam_m, q._adam_m) and torch.equal(p._adam_v, q._adam_v) \
+        and torch.equal(p.packed.view(torch.uint8), q.packed.view(torch.uint8)) and torch.equal(p.grads, q.grads) \
+        and torch.equal(p.bn_state, q.bn_state)
+    assert torch.equal(la, lb) and same(a, b)
+    for _ in range(2):
+        a.train_step(x, y, None, want_loss=False)
+        b.forward_backward(x, y, None, want_loss=False)
+        b.apply_gradients()
+        assert same(a, b)
+    # ... and replayed from a graph (the warm-up step of make_graphed_train_step is a real step)
+    if dtype == "bf16":
+        rep = c.make_graphed_train_step(x, y)          # step 1 (eager warm-up)
+        rep(); rep()                                   # steps 2, 3
+        torch.cuda.synchronize()
+        assert same(a, c) and a.iterations == c.iterations == 3
+
+
 def test_backward_ready_events_same_gradients():
     """mpu_unet_backward_events == mpu_unet_backward; ready points are descending offsets ending at 0."""
     from multiplanarunet_amd.unet import UNet
