@@ -35,7 +35,9 @@ def get_argparser():
     p.add_argument("--synthetic", type=int, default=0, help="train on N generated toy volumes (no files needed)")
     p.add_argument("--dtype", default="bf16", choices=("bf16", "f32"))
     p.add_argument("--no_overlap", action="store_true", help="cut every batch on the training stream (no side-stream "
-                   "producer, eager step, A/B aid; the default overlaps the sampler with the graphed step)")
+                   "producer; A/B aid: the default overlaps the sampler with the train step)")
+    p.add_argument("--no_graph", action="store_true", help="launch the train step's kernels eagerly instead of replaying "
+                   "one HIP graph (A/B aid, independent of --no_overlap)")
     return p
 
 
@@ -157,7 +159,12 @@ def run(args):
     # stream while step i -- one HIP-graph replay at N = 1 -- runs; the loss is summed on the device and read once per
     # epoch (pipeline.TrainPipeline). No host synchronisation per step.
     from ..pipeline import TrainPipeline
-    pipe = TrainPipeline(model, tr, overlap=not args.no_overlap, graphed=None if not args.no_overlap else False)
+    pipe = TrainPipeline(model, tr, overlap=not args.no_overlap, graphed=False if args.no_graph else None)
+    if pipe.side_latency_us is not None:
+        log("Producer stream: probe latency %.0f us" % pipe.side_latency_us)
+        if pipe.side_latency_us >= 1500.0:               # (tests/test_gpu_pipeline.py: a stream BEHIND the training stream's queue)
+            log("[WARNING] no hardware queue beside the training stream was found: the batch producer will run behind every "
+                "train step (about 0.65 of the step rate). --no_overlap gives the serial loop.")
     try:
         for ep in range(init_epoch, epochs):
             loss = pipe.run_epoch(steps)

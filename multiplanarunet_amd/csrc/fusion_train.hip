@@ -103,13 +103,18 @@ __global__ __launch_bounds__(256) void fusion_update_kernel(const float* __restr
                                                             float b1, float b2, float eps, int apply, float* grads_out,
                                                             float* loss_out) {
     const int np = V * K + K, nacc = np + 1;
+    // (one block.) The regulariser of the reported loss is read BEFORE any thread updates W / b (it used to race
+    // with the updates of the same pass: a loss mixing pre- and post-update weights, ~1e-6, nondeterministic)
+    double rw = 0.0, rb = 0.0;
+    if (threadIdx.x == np % 256 && loss_out) {
+        for (int i = 0; i < V * K; ++i) rw += (double)W[i] * (double)W[i];
+        for (int i = 0; i < K; ++i) rb += (double)b[i] * (double)b[i];
+    }
+    __syncthreads();
     for (int a = threadIdx.x; a < nacc; a += 256) {
         double s = 0.0;
         for (int k = 0; k < nblk; ++k) s += (double)partial[(long)k * nacc + a];
         if (a == np) {                                          // loss: data term + regulariser
-            double rw = 0.0, rb = 0.0;
-            for (int i = 0; i < V * K; ++i) rw += (double)W[i] * (double)W[i];
-            for (int i = 0; i < K; ++i) rb += (double)b[i] * (double)b[i];
             if (loss_out) *loss_out = (float)(s / (double)n + 1e-6 * rw / (V * K) + 1e-6 * rb / K);
             continue;
         }
@@ -144,12 +149,17 @@ __global__ __launch_bounds__(256) void fusion_apply_kernel(const double* __restr
                                                            int apply, float* grads_out, float* loss_out) {
     const int np = V * K + K, nacc = np + 1;
     const double n = sums[nacc];
+    // the reported loss uses the weights BEFORE this step's update (thread `np` used to read W / b while the other
+    // threads of the same pass were updating them): every thread that will report reads first, then the block synchronises
+    double rw = 0.0, rb = 0.0;
+    if (threadIdx.x == np % 256 && loss_out) {
+        for (int i = 0; i < V * K; ++i) rw += (double)W[i] * (double)W[i];
+        for (int i = 0; i < K; ++i) rb += (double)b[i] * (double)b[i];
+    }
+    __syncthreads();
     for (int a = threadIdx.x; a < nacc; a += 256) {
         const double s = sums[a];
         if (a == np) {
-            double rw = 0.0, rb = 0.0;
-            for (int i = 0; i < V * K; ++i) rw += (double)W[i] * (double)W[i];
-            for (int i = 0; i < K; ++i) rb += (double)b[i] * (double)b[i];
             if (loss_out) *loss_out = (float)(s / n + 1e-6 * rw / (V * K) + 1e-6 * rb / K);
             continue;
         }

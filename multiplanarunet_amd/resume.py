@@ -121,7 +121,12 @@ def apply_resume(model, hparams, state, logger=print):
         model.load_weights(state["model_path"], by_name=True)
     hparams["fit"]["init_epoch"] = state["init_epoch"]
     if state["lr"]:
-        hparams["fit"].setdefault("optimizer_kwargs", {})[state["lr_name"]] = state["lr"]
+        kw = hparams["fit"].setdefault("optimizer_kwargs", {})
+        # one learning-rate key only: the CSV column is named "lr" in this build, a project YAML may spell it
+        # `learning_rate` (UNet.compile lets that alias win) -- the resumed rate replaces whichever spelling is there
+        for alias in ("lr", "learning_rate", "LR", "LearningRate"):
+            kw.pop(alias, None)
+        kw[state["lr_name"]] = state["lr"]
     logger("[NOTICE] Training continues from:\nModel: %s\nEpoch: %i\nLR:    %s"
            % (os.path.split(state["model_path"])[-1] if state["model_path"] else "<No model found>", state["epoch"], state["lr"]))
     return model

@@ -551,6 +551,10 @@ class UNet:
             if not torch.is_tensor(t) or t.device.type != "cuda":
                 raise ValueError("graphed train step needs device tensors")
         self._ensure_adam()
+        if not warmup and (self._ws is None or (self.l2_reg and self._l2_ws is None)):
+            #  a capture without a warm-up step is a RE-capture: the lazily created buffers must exist already, or
+            # their allocations would land in the graph's private pool
+            raise RuntimeError("make_graphed_train_step(warmup=False) needs a model that has already run a train step")
         step_dev = torch.tensor([self.iterations], dtype=torch.int64, device=self.device)
         k = self.optimizer_kwargs
 

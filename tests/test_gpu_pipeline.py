@@ -53,8 +53,49 @@ def test_side_stream_runs_beside_a_busy_main_stream():
     st, lat = pick_side_stream(torch.device("cuda"), busy_ms=3.0)
     assert isinstance(st, torch.cuda.Stream) and st != torch.cuda.current_stream()
     assert np.isfinite(lat) and lat > 0
-    if lat >= 1500.0:               # a stream queued BEHIND the probe's 3 ms of fills answers after >= 3000 us
-        pytest.skip("no hardware queue beside the main stream on this box (best candidate latency %.0f us)" % lat)
+    print("producer stream chosen: %r, probe latency %.0f us" % (st, lat))
+    # a stream queued BEHIND the probe's 3 ms of fills answers after >= 3000 us. Round 6: FAIL, do not skip --
+    # `mp train` on such a stream delivers 0.64 of the step rate (gpurun R5p), and a runtime update that changes the stream -> queue
+    # mapping must be seen here, not in a throughput regression nobody attributes
+    assert lat < 1500.0, "no hardware queue beside the main stream after 4 batches of candidates (best latency %.0f us)" % lat
+
+
+def test_mp_train_pipeline_delivers_at_least_090_of_the_step_rate():
+    """`train_e2e` as a guarded property: the producer / consumer loop of `mp train` (sampler of a 128^3 volume on
+    the measured side stream, one batch ahead of the graphed configs[1] step) must deliver >= 0.90 of the rate of the bare step
+    replayed on a fixed batch -- bench.py reports 0.97; 0.64 is what a producer stream on the training stream's queue gives."""
+    import time
+    from multiplanarunet_amd.unet import UNet
+    from multiplanarunet_amd.data import make_toy_volume, as_volume, random_views, TrainSampler
+    from multiplanarunet_amd.pipeline import TrainPipeline
+    dev = torch.device("cuda")
+    B, dim = 16, 128
+    m = UNet(n_classes=3, dim=dim, n_channels=1, depth=4, complexity_factor=1, flatten_output=True, dtype="bf16", logger=quiet,
+             seed=0, device=dev)
+    m.compile("Adam", "SparseCategoricalCrossentropy")
+    img, lab, aff = make_toy_volume(128, 77)
+    vol = as_volume(img, lab, aff, "1pct", "RobustScaler", dev, "toy128")
+    smp = TrainSampler([vol], random_views(6, 60.0, 0), dim, float(dim), B, 3, noise_sd=0.1, fg_batch_fraction=0.5, seed=7)
+    x, y, w = smp()
+    rep = m.make_graphed_train_step(x, y.reshape(B, dim * dim, 1), w)
+    for _ in range(10):
+        rep()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(60):
+        rep()
+    torch.cuda.synchronize()
+    bare = (time.perf_counter() - t0) / 60
+    pipe = TrainPipeline(m, smp)
+    pipe.run_epoch(12)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    loss = pipe.run_epoch(90)
+    torch.cuda.synchronize()
+    e2e = (time.perf_counter() - t0) / 90
+    frac = bare / e2e
+    print("bare step %.3f ms, mp-train loop %.3f ms per step, fraction %.3f, producer stream latency %.0f us, loss %.4f"
+          % (bare * 1e3, e2e * 1e3, frac, pipe.side_latency_us, loss))
+    assert np.isfinite(loss)
+    assert frac >= 0.90, "mp train's loop delivers %.2f of the step rate (producer stream latency %.0f us)" % (frac, pipe.side_latency_us)
 
 
 def test_overlapped_graphed_pipeline_equals_the_serial_eager_loop_bitwise():
