@@ -64,7 +64,6 @@ def run(args):
     log = (lambda *a, **k: print(*a, flush=True)) if rank == 0 else (lambda *a, **k: None)
     hp = load_hparams(project_dir)
     fit, build = hp["fit"], hp["build"]
-    note_inert_flags(args, [("eval_prob", "per-view evaluation is not part of this build: the fused volume is always evaluated")], log)
     if args.f:
         img, lab, aff = load_volume_file(args.f)
         if args.l:
@@ -97,7 +96,7 @@ def run(args):
     nii = os.path.join(out_dir, "nii_files")
     if rank == 0:
         os.makedirs(nii, exist_ok=True)
-    results = {}
+    results, per_view = {}, {}
     for v in vols:
         src = str(getattr(v, "source_path", "") or "")
         as_nii = args.out_format == "nii" or (args.out_format == "auto" and src.endswith((".nii", ".nii.gz")))
@@ -114,9 +113,14 @@ def run(args):
                                                sum_fusion=args.sum_fusion, batch_size=None, want_probs=args.no_argmax)
             probs, labels = res if args.no_argmax else (None, res)
         else:
+            pve = None
+            if v.labels is not None and not args.no_eval:     # bin/predict.py:334-346: per-view Dice inside the loop
+                rows = per_view.setdefault(v.identifier, {})
+                pve = dict(eval_prob=args.eval_prob, n_classes=build["n_classes"], log=log,
+                           report=lambda i, view, vd, md, mean, rows=rows: rows.__setitem__(i, (view, vd, md, float(mean))))
             probs, labels = multi_view_predict(model, v, views, build["dim"], fit["real_space_span"], fm,
                                                sum_fusion=args.sum_fusion, batch_size=None,
-                                               want_probs=args.no_argmax)
+                                               want_probs=args.no_argmax, per_view_eval=pve)
         if rank == 0 and args.save_input_files:
             sub = out_base                                # the volume as it was read: unscaled image, label map
             os.makedirs(sub, exist_ok=True)
@@ -150,6 +154,14 @@ def run(args):
             f.write("image,mean_dice," + ",".join("class_%d" % (c + 1) for c in range(build["n_classes"] - 1)) + "\n")
             for k, d in results.items():
                 f.write("%s,%.5f,%s\n" % (k, float(np.nanmean(d)), ",".join("%.5f" % x for x in d)))
+        if any(per_view.values()):                      # one row per (image, evaluated view): mean + per-class mapped Dice
+            with open(os.path.join(out_dir, "csv", "per_view.csv"), "w") as f:
+                f.write("image,view_index,view,mean_dice," + ",".join("class_%d" % c for c in range(build["n_classes"])) + "\n")
+                for k, rows in per_view.items():
+                    for i in sorted(rows):
+                        view, _, md, mean = rows[i]
+                        f.write("%s,%d,%s,%.5f,%s\n" % (k, i, " ".join("%.6g" % x for x in np.asarray(view).ravel()), mean,
+                                                        ",".join("%.5f" % x for x in md)))
     return results
 
 

@@ -7,14 +7,29 @@ the fp64 voxel grid of the reference are never materialised.
 import numpy as np
 import torch
 
-from .interpolation import ViewGeometry, sample_view, map_and_fuse
+from .interpolation import ViewGeometry, sample_view, map_and_fuse, map_real_space_pred
+
+
+def per_view_evaluation(pred, true, mapped_pred, mapped_true, n_classes):
+    """_per_view_evaluation's arithmetic (mpunet/bin/predict.py:248-275; `evaluate` :236-246: argmax, then dice_all with
+    ignore_zero=False) on the GPU: view_dices of the view-space prediction [P,dim,dim,K] against the sampled labels, mapped_dices of
+    the back-mapped prediction [X,Y,Z,K] against the volume's labels -- one pass each of mpu_validation_count (argmax + integer TP /
+    relevant / selected counts), Dice from the counts -- and mean_dice = mean of the non-NaN mapped dices without class 0."""
+    from .validation import count_cm_elements, dice_from_counts
+    view_dices = dice_from_counts(count_cm_elements(pred, true, n_classes))
+    mapped_dices = dice_from_counts(count_cm_elements(mapped_pred, mapped_true, n_classes))
+    mean_dice = mapped_dices[~np.isnan(mapped_dices)][1:].mean()
+    return view_dices, mapped_dices, mean_dice
 
 
 def multi_view_predict(model, volume, views, dim, real_space_span, fusion_model=None,
                        sum_fusion=False, batch_size=None, n_planes="same+20",
-                       want_probs=True, timings=None):
+                       want_probs=True, timings=None, per_view_eval=None):
     """
     Returns (merged f32 [X,Y,Z,K] or None, merged_map u8 [X,Y,Z]).
+    per_view_eval: None, or dict(eval_prob=float, n_classes=int, report=callable(view_index, view, view_dices, mapped_dices,
+    mean_dice) [, log=callable]): the reference's per-view evaluation inside the loop (predict.py:334-346) for volumes with
+    labels -- skipped for a view when np.random.rand() > eval_prob, as there.
     batch_size=None: even chunks of the view's planes as large as the kernels' operand bound allows
     (UNet.auto_batch; 276 planes of 256x256 -> 3 x 92) - the result does not depend on it.
     fusion_model: object with .W (V,K) and .b (1,K) device tensors (FusionModel) or None with sum_fusion.
@@ -28,7 +43,8 @@ def multi_view_predict(model, volume, views, dim, real_space_span, fusion_model=
         if timings is not None:
             e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             e0.record()
-        X, _ = sample_view(volume, geom, want_labels=False)
+        pve = per_view_eval if (per_view_eval is not None and volume.labels is not None) else None
+        X, y_view = sample_view(volume, geom, want_labels=pve is not None)
         if timings is not None:
             e1.record()
         pred = model.predict(X, batch_size=batch_size)
@@ -39,6 +55,19 @@ def multi_view_predict(model, volume, views, dim, real_space_span, fusion_model=
             ev.append((e0, e1, e2))
         view_preds.append((pred, (geom.real_axis, geom.real_axis, geom.offsets), geom.inv_basis,
                            geom.device_axes(volume.device)))
+        if pve is not None:
+            say = pve.get("log") or (lambda *a: None)
+            if np.random.rand() > pve["eval_prob"]:
+                say("Skipping evaluation for view %s... (eval_prob=%.3f)" % (view, pve["eval_prob"]))
+            else:
+                mapped = map_real_space_pred(pred.permute(1, 2, 0, 3), (geom.real_axis, geom.real_axis, geom.offsets),
+                                             geom.inv_basis, volume)
+                vd, md, mean = per_view_evaluation(pred, y_view, mapped, volume.labels, pve["n_classes"])
+                del mapped
+                say("View dice scores:   ", vd)
+                say("Mapped dice scores: ", md)
+                say("Mean dice (n=%i): " % (len(md) - 1), mean)
+                pve["report"](len(view_preds) - 1, view, vd, md, mean)
     if timings is not None:
         f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         f0.record()

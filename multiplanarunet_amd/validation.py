@@ -44,6 +44,19 @@ def count_cm_elements(pred, true, n_classes, counts=None):
     return counts
 
 
+def dice_from_counts(counts, smooth=1.0, ignore_zero=False):
+    """mpunet/evaluate/metrics.py:26-52 (dice_all, n_classes given, skip_if_no_y=False) from the integer counts of
+    count_cm_elements ([3, K]: TP, relevant = #(y == c), selected = #(p == c)): (smooth + 2 TP) / (smooth + relevant +
+    selected) in float64 stored as float32, NaN where the class is in neither array. Integer work: the counts are exact, so
+    the result IS the reference's."""
+    c = counts.cpu().numpy() if torch.is_tensor(counts) else np.asarray(counts)
+    tp, rel, sel = (c[i].astype(np.float64) for i in range(3))
+    out = np.full(tp.shape, np.nan, dtype=np.float32)
+    m = (rel > 0) | (sel > 0)
+    out[m] = ((smooth + 2 * tp[m]) / (smooth + rel[m] + sel[m])).astype(np.float32)
+    return out[1:] if ignore_zero else out
+
+
 def compute_dice(tp, rel, sel):
     """validation.py:59-89 (_compute_dice): zeros where a denominator is zero. numpy float32 out."""
     tp, rel, sel = (np.asarray(a, dtype=np.float64) for a in (tp, rel, sel))

@@ -40,6 +40,10 @@ def test_mp_train_then_predict_synthetic(tmp_path):
     res = (proj / "predictions" / "csv" / "results.csv").read_text().splitlines()
     mean_dice = float(res[1].split(",")[1])
     assert mean_dice > 0.5, res
+    # per-view evaluation inside the loop (bin/predict.py:334-346; round 6): one row per (image, view) with the mapped Dice
+    pv = (proj / "predictions" / "csv" / "per_view.csv").read_text().splitlines()
+    assert pv[0].startswith("image,view_index,view,mean_dice,class_0") and len(pv) == 1 + 3
+    assert all(0.2 < float(r.split(",")[3]) <= 1.0 for r in pv[1:]), pv
     # fusion-model training on the project, then predict with the learned FusionLayer
     hist = mp.entry_func(["train_fusion", "--project_dir", str(proj), "--synthetic", "2", "--epochs", "4",
                           "--images_per_round", "2", "--batch_size", "65536", "--seed", "0"])

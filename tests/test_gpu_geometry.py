@@ -348,3 +348,69 @@ def test_cell_division_is_ieee():
                    "mpu_geometry_check_cell_division")
         assert bad.value == 0, (i, m.kind, m.step, bad.value)
     assert kinds == {1, 2}
+
+
+@pytest.mark.parametrize("an", ("ident", "rot"))
+def test_per_view_evaluation_equals_the_oracle_exactly(golden, an):
+    """_per_view_evaluation (mpunet/bin/predict.py:248-275, inside the loop at :334-346). Per view the Dice of the
+    argmax of the view-space prediction against the SAMPLED labels and of the back-mapped prediction against the volume's labels
+    (dice_all, ignore_zero=False) and their mean without class 0 -- on the GPU through mpu_map_view_nearest + mpu_validation_count,
+    integer counts -> the oracle's float32 values exactly."""
+    from multiplanarunet_amd.interpolation import Volume, ViewSampler
+    from multiplanarunet_amd.predict import multi_view_predict
+    from oracle import geometry as G
+    D, K = 48, 4
+    rng = np.random.RandomState(48)
+    g = np.indices((D, D, D)).astype(np.float32) / D
+    image = (60 * np.sin(5 * g[0]) * np.cos(3 * g[1]) + 40 * g[2] + 4 * rng.randn(D, D, D)).astype(np.float32)[..., None]
+    lab = ((g[0] > .3).astype(np.uint8) + (g[1] > .5) + (g[2] > .6)).astype(np.uint8)
+    aff = golden["aff_" + an]
+    bg = [float(np.percentile(image[..., 0], 1))]
+    center, scale = Volume.fit_robust_scaler(image)
+    vol = Volume(image, lab, aff, bg_value=bg, scaler=(center, scale))
+    views = np.array([[1, 0, 0], [0.3, 0.5, 0.8], [-0.4, 0.6, 0.55]], float)
+    views /= np.linalg.norm(views, axis=1, keepdims=True)
+    span = float(D) * 1.05
+    A = (rng.randn(1, K) * 2.5).astype(np.float32)
+    vg = G.voxel_grid_real_space(image.shape[:3], aff)
+
+    def probs_of(X):                                                      # a per-pixel "U-Net" both sides share (f32 NumPy)
+        z = X @ A + 0.3 * np.arange(K, dtype=np.float32)
+        e = np.exp(z - z.max(-1, keepdims=True))
+        return (e / e.sum(-1, keepdims=True)).astype(np.float32)
+
+    class Net:                                                            # model.predict on [P,dim,dim,C] device planes
+        def predict(self, X, batch_size=None):
+            return torch.tensor(probs_of(X.cpu().numpy()), device=X.device)
+
+    want = []
+    for view in views:
+        Xr, yr, grid, ib = G.get_view_from(image, lab, aff, view, D, span, bg_value=bg, center=center, scale=scale)
+        pred = probs_of(Xr)                                               # [d,d,P,K]
+        mapped = G.map_real_space_pred(pred, grid, ib, vg)
+        vd = G.dice_all(yr, pred.argmax(-1), n_classes=K, ignore_zero=False)
+        md = G.dice_all(lab, mapped.argmax(-1), n_classes=K, ignore_zero=False)
+        want.append((vd, md, md[~np.isnan(md)][1:].mean()))
+    got = {}
+    np.random.seed(0)
+    multi_view_predict(Net(), vol, views, D, span, sum_fusion=True, want_probs=False,
+                       per_view_eval=dict(eval_prob=1.0, n_classes=K, report=lambda i, view, vd, md, mean: got.__setitem__(i, (vd, md, mean))))
+    assert sorted(got) == [0, 1, 2]
+    for i, (vd, md, mean) in enumerate(want):
+        np.testing.assert_array_equal(got[i][0], vd)
+        np.testing.assert_array_equal(got[i][1], md)
+        assert got[i][2] == mean and 0.0 < mean < 1.0
+    # eval_prob: the same draw as the reference (np.random.rand() > eval_prob skips the view)
+    np.random.seed(3)
+    draws = np.random.rand(3)
+    seen = []
+    np.random.seed(3)
+    multi_view_predict(Net(), vol, views, D, span, sum_fusion=True, want_probs=False,
+                       per_view_eval=dict(eval_prob=0.5, n_classes=K, report=lambda i, *a: seen.append(i)))
+    assert seen == [i for i in range(3) if not draws[i] > 0.5]
+    # no labels: nothing to evaluate, the prediction itself is unchanged
+    vol2 = Volume(image, None, aff, bg_value=bg, scaler=(center, scale))
+    l0 = multi_view_predict(Net(), vol, views, D, span, sum_fusion=True, want_probs=False)[1]
+    l1 = multi_view_predict(Net(), vol2, views, D, span, sum_fusion=True, want_probs=False,
+                            per_view_eval=dict(eval_prob=1.0, n_classes=K, report=lambda *a: seen.append("x")))[1]
+    assert torch.equal(l0, l1) and "x" not in seen

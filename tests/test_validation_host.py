@@ -85,3 +85,24 @@ def test_early_stopping_and_checkpoint_clean(tmp_path):
             break
     assert ep == 4 and es.stopped_epoch == 4                      # 3 epochs without beating 0.5 (equal is not better)
     assert os.listdir(tmp_path / "model") == ["@epoch_02_val_dice_0.50000.npz"]
+
+
+def test_dice_from_counts_is_the_references_dice_all():
+    """Per-view evaluation (mpunet/bin/predict.py:236-275) computes dice_all(ignore_zero=False) of two label arrays; the GPU path
+    counts TP / relevant / selected per class and forms the Dice from the integers: identical float32 values, NaN for a class in
+    neither array (oracle/geometry.dice_all is pinned on the reference's own outputs, golden G6)."""
+    from multiplanarunet_amd.validation import dice_from_counts
+    from oracle import geometry as G
+    rng = np.random.RandomState(4)
+    for K, holes in ((5, (3,)), (3, ()), (4, (0, 2))):
+        y = rng.randint(0, K, 5000).astype(np.uint8)
+        p = rng.randint(0, K, 5000).astype(np.uint8)
+        for h in holes:                                   # a class absent from both arrays -> NaN
+            y[y == h] = (h + 1) % K
+            p[p == h] = (h + 1) % K
+        counts = np.stack([np.bincount(y[y == p], minlength=K), np.bincount(y, minlength=K), np.bincount(p, minlength=K)]).astype(np.int64)
+        for ign in (False, True):
+            want = G.dice_all(y, p, n_classes=K, ignore_zero=ign)
+            got = dice_from_counts(counts, ignore_zero=ign)
+            assert got.dtype == np.float32
+            np.testing.assert_array_equal(got, want)
