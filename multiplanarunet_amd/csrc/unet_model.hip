@@ -555,6 +555,9 @@ int side_stream(SideStream** out) {
     if (dev < 0 || dev > 63) return fail(MPU_EINVAL, "%s", "side_stream: device index out of range");
     SideStream& d = side[dev];
     if (!d.s) {
+        // NORMAL priority. A high-priority side stream was measured (gpurun R6n): eager launches gain nothing (2.534 ms per step
+        // either way), and once the library has used a high-priority stream in a process, every REPLAY of a captured step takes
+        // 6.5 instead of 2.55 ms -- whichever stream the capture itself forked onto.
         hipStream_t s; hipEvent_t f, j;
         MPU_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         MPU_CHECK_HIP(hipEventCreateWithFlags(&f, hipEventDisableTiming));

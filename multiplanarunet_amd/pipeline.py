@@ -23,7 +23,7 @@ def pick_side_stream(dev, candidates=6, busy_ms=3.0, batches=4):
     queues; a side stream that lands on the queue of the training stream executes behind the whole graph replay, and every host read
     of the sampler then costs a train step (measured, gpurun R5p / R5r: `train_e2e` 0.64 of the bench line when the streams created by
     the legs before it had shifted the assignment, 0.97 otherwise). So the pipeline MEASURES: the current stream is kept busy for a
-    few milliseconds with large fills, each candidate stream (both priorities) gets one tiny kernel, and the candidate whose kernel
+    few milliseconds with large fills, each candidate stream (high priority: see below) gets one tiny kernel, and the candidate whose kernel
     completes soonest -- it did not wait for the fills -- is taken. If even the best candidate of a batch waited for a sizeable part
     of the fills (every one of them shares the busy queue), a further batch of streams is created (the runtime deals new streams
     round-robin over its queues), up to `batches` times. Returns (stream, its latency in microseconds)."""
@@ -38,7 +38,12 @@ def pick_side_stream(dev, candidates=6, busy_ms=3.0, batches=4):
     nfill = int(min(200, max(8, busy_ms * 1e-3 / per_fill)))
     best, kept = None, []
     for _ in range(max(1, int(batches))):
-        cands = [torch.cuda.Stream(device=dev, priority=-1 if k % 2 == 0 else 0) for k in range(candidates)]
+        # HIGH priority only (round 6, tools/round6/m_streams.py: twelve candidate streams under the real loop, three processes --
+        # every high-priority stream ran the loop at the step's rate, 2.68-2.71 ms, the normal-priority ones at 2.81-3.77 ms, and the
+        # fill probe below does not tell those apart: high-priority streams have hardware queues of their own, a normal-priority
+        # one can share its queue with the library's optimizer stream or a branch of the replayed graph and then waits behind a
+        # 0.4-ms kernel at every host read of the sampler)
+        cands = [torch.cuda.Stream(device=dev, priority=-1) for k in range(candidates)]
         kept.append(cands)                                               # (alive until the choice is made: a freed stream's queue slot is reused)
         for st in cands:
             torch.cuda.synchronize(dev)
