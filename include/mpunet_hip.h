@@ -17,6 +17,9 @@
  *   - activations are NHWC; `dtype` selects storage/arithmetic:
  *       MPU_F32  : f32 storage, exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
  *       MPU_BF16 : bf16 storage, v_mfma_f32_32x32x16_bf16, f32 accumulate.
+ *       MPU_F32X3: f32 storage, every product as three bf16 MFMAs on operands split hi + lo in registers (x ~ bf16(x) +
+ *                  bf16(x - bf16(x)): ~2^-16 relative per product) -- the tolerance-grade mode at bf16-class matrix rates
+ *                  (round 6; Python dtype "bf16x3"). Elementwise kernels, buffers and layouts are those of MPU_F32.
  */
 #ifndef MPUNET_HIP_H
 #define MPUNET_HIP_H
@@ -28,7 +31,7 @@ extern "C" {
 #endif
 
 typedef enum { MPU_OK = 0, MPU_EINVAL = -1, MPU_EHIP = -2, MPU_EUNSUPPORTED = -3 } mpu_status;
-typedef enum { MPU_F32 = 0, MPU_BF16 = 1 } mpu_dtype;
+typedef enum { MPU_F32 = 0, MPU_BF16 = 1, MPU_F32X3 = 2 } mpu_dtype;
 
 int         mpu_abi_version(void);
 const char* mpu_last_error(void);

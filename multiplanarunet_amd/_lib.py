@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MPU_LIB_PATH") or os.path.join(_HERE, "lib", "libmpun
 c_p = C.c_void_p
 i32, i64, f32, f64, u8 = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint8
 
-MPU_F32, MPU_BF16 = 0, 1
+MPU_F32, MPU_BF16, MPU_F32X3 = 0, 1, 2
 
 
 class Axis(C.Structure):                # mpu_axis

@@ -50,6 +50,35 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
 
+// ---- split-bf16 products (round 6, dtype "bf16x3": f32 storage, three bf16 MFMAs per product) ------------------------------
+// x = hi + lo + O(2^-17 |x|) with hi = bf16(x) (round to nearest even) and lo = bf16(x - hi) (x - hi is exact in fp32);
+// a * b ~ hi_a hi_b + hi_a lo_b + lo_a hi_b, the dropped lo_a lo_b <= 2^-18 |a b|: products good to ~2^-16 relative, accumulated
+// in fp32 by the matrix pipe at three bf16 MFMAs (3 x 32 cycles) per sixteen k-values instead of eight exact-f32 MFMAs
+// (8 x 64 cycles). The eight f32 of a lane are two 16-byte LDS chunks p, q; any k-order is fine as long as both operands
+// of a product use the same one.
+typedef short mpu_s16x8 __attribute__((ext_vector_type(8)));
+typedef float mpu_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void x3_split(const uint4& p, const uint4& q, mpu_s16x8& hi, mpu_s16x8& lo) {
+    const uint32_t x[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = __uint_as_float(x[2 * e]), x1 = __uint_as_float(x[2 * e + 1]);
+        h[e] = f32x2_to_bf16x2(x0, x1);
+        const float h0 = __uint_as_float(h[e] << 16), h1 = __uint_as_float(h[e] & 0xffff0000u);
+        l[e] = f32x2_to_bf16x2(x0 - h0, x1 - h1);
+    }
+    hi = __builtin_bit_cast(mpu_s16x8, make_uint4(h[0], h[1], h[2], h[3]));
+    lo = __builtin_bit_cast(mpu_s16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+// c += a * b from the split operands, smallest terms first
+__device__ __forceinline__ void x3_mma(const mpu_s16x8& ahi, const mpu_s16x8& alo, const mpu_s16x8& bhi, const mpu_s16x8& blo,
+                                       mpu_f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, c, 0, 0, 0);
+}
+
 // "done once" flags of per-kernel attributes (hipFuncSetAttribute is per DEVICE): one bit per device of this process, so a
 // process that drives several GPUs sets the attribute on each of them. Two steps: first_use_on_device() only TESTS the
 // bit, mark_used_on_device() sets it AFTER the attribute calls have succeeded -- a second host thread on the same device either

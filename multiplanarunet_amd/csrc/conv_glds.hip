@@ -230,12 +230,28 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
                 for (int j = 0; j < TM; ++j) bf[s][j] = *(const uint4*)(Pb + j * 32 * 128 + so);
             }
             __builtin_amdgcn_sched_barrier(0);                   // keep the reads ahead of the MFMAs (see conv_halo.hip)
+            if (sizeof(T) == 4 && a.x3) {                        // dtype "bf16x3": pairs of k-steps as split-bf16 products (common.h)
+#pragma unroll
+                for (int s = 0; s < SG; s += 2) {
+                    s16x8 ah[TN], al[TN];
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) x3_split(af[s][i], af[s + 1][i], ah[i], al[i]);
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) {               // (one pixel fragment split at a time: register budget)
+                        s16x8 bh, bl;
+                        x3_split(bf[s][j], bf[s + 1][j], bh, bl);
+#pragma unroll
+                        for (int i = 0; i < TN; ++i) x3_mma(ah[i], al[i], bh, bl, acc[i][j]);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int s = 0; s < SG; ++s)
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
                     for (int j = 0; j < TM; ++j) GMma<T>::run(af[s][i], bf[s][j], acc[i][j]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -1215,6 +1231,40 @@ __device__ __forceinline__ void wgrad_glds_body(const WgradArgs& a, const unsign
                     for (int j = 0; j < TJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        } else if (a.x3) {
+            // dtype "bf16x3": eight pixels (K) per lane and product -- lanes 0-31 rows k .. k+3 and k+8 .. k+11, lanes 32-63 the
+            // rows 4 further on; both operands in the same order (common.h x3_split)
+#pragma unroll 2
+            for (int k = 0; k < KP; k += 16) {
+                s16x8 ah[TI], al[TI], bh[TJ], bl[TJ];
+                const int r0 = k + 4 * (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const int byte = (wi * WCI + i * 32 + (lane & 31)) * 4;
+                    uint32_t v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int row = r0 + (e & 3) + 8 * (e >> 2);
+                        v[e] = *(const uint32_t*)(xb + row * RX + (((byte >> 4) ^ wg_swz16<RX>(row)) << 4) + (byte & 15));
+                    }
+                    x3_split(make_uint4(v[0], v[1], v[2], v[3]), make_uint4(v[4], v[5], v[6], v[7]), ah[i], al[i]);
+                }
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const int byte = (wj * WCO + j * 32 + (lane & 31)) * 4;
+                    uint32_t v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int row = r0 + (e & 3) + 8 * (e >> 2);
+                        v[e] = *(const uint32_t*)(zb + row * RZ + (((byte >> 4) ^ wg_swz16<RZ>(row)) << 4) + (byte & 15));
+                    }
+                    x3_split(make_uint4(v[0], v[1], v[2], v[3]), make_uint4(v[4], v[5], v[6], v[7]), bh[j], bl[j]);
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) x3_mma(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+            }
         } else {
 #pragma unroll 4
             for (int k = 0; k < KP; k += 2) {

@@ -75,6 +75,9 @@ template <typename T, int BN, int TH, int NWS, int MODE = CONV3, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
     using Cfg = HaloCfg<T, BN, TH, NWS, MODE>;
     constexpr int ko = DBG;
+    // bit 8 of the compile-time mask (no knock-out uses it): the split-bf16 instantiation of the f32 kernel (dtype "bf16x3",
+    // round 6). A run-time switch inside the unrolled tap loop cost the exact-f32 path 37 registers and 244 bytes of scratch.
+    constexpr bool X3 = (DBG & 256) != 0;
     constexpr int NT = Cfg::NT, KW = Cfg::KW;
     constexpr int EPC = 16 / sizeof(T), BKE = 128 / sizeof(T);
     constexpr int TW = Cfg::TW, PW = Cfg::PW, PROWS = Cfg::PROWS;
@@ -226,6 +229,20 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
                     for (int i = 0; i < TN; ++i)
 #pragma unroll
                         for (int j = 0; j < TM; ++j) acc[i][j][s] += __uint_as_float(af[s][i].x ^ bf[s][j].y);
+            } else if constexpr (sizeof(T) == 4 && X3) {         // dtype "bf16x3": pairs of k-steps as split-bf16 products (common.h)
+#pragma unroll
+                for (int s = 0; s < SG; s += 2) {
+                    s16x8 ah[TN], al[TN];
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) x3_split(af[s][i], af[s + 1][i], ah[i], al[i]);
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) {               // (one pixel fragment split at a time: register budget)
+                        s16x8 bh, bl;
+                        x3_split(bf[s][j], bf[s + 1][j], bh, bl);
+#pragma unroll
+                        for (int i = 0; i < TN; ++i) x3_mma(ah[i], al[i], bh, bl, acc[i][j]);
+                    }
+                }
             } else
 #pragma unroll
             for (int s = 0; s < SG; ++s) {
@@ -1205,7 +1222,8 @@ int try_conv_halo(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
                                                  : launch_halo_cfg<bf16_t, 128, 4, 3>(a, st);
         else rc = tall ? launch_halo_cfg<bf16_t, 64, 8, 3>(a, st) : launch_halo_cfg<bf16_t, 64, 4, 3>(a, st);
     } else if (dtype == MPU_F32) {
-        if (a.Cout > 64) rc = launch_halo_cfg<float, 128, 4, 3>(a, st);
+        if (a.x3) rc = a.Cout > 64 ? launch_halo_cfg<float, 128, 4, 3, CONV3, 256>(a, st) : launch_halo_cfg<float, 64, 4, 3, CONV3, 256>(a, st);
+        else if (a.Cout > 64) rc = launch_halo_cfg<float, 128, 4, 3>(a, st);
         else rc = launch_halo_cfg<float, 64, 4, 3>(a, st);
     } else return 0;
     return rc ? rc : 1;

@@ -38,6 +38,7 @@ struct ConvArgs {
     // *head_done = 1 when the schedule did so; launch_head_combine then adds the halves and the bias and applies the
     // softmax. Otherwise the caller runs launch_head_forward on the stored output.
     const float* head_w = nullptr; int head_k = 0, head_ldw = 0; float* head_partial = nullptr; int* head_done = nullptr;
+    int x3 = 0;                  // f32 storage only: split-bf16 products (three bf16 MFMAs, common.h x3_mma) instead of exact-f32 MFMAs
     int dbg = 0;                 // profiling switches of conv_pipe_kernel (MPU_PIPE_DEBUG: 1 no stores, 2 no MFMAs, 4 no DMA,
                                  //   8 no fragment reads, 16 no barrier, 32 s_memtime stamps into dbg_buf)
     unsigned long long* dbg_buf = nullptr;
@@ -45,6 +46,8 @@ struct ConvArgs {
 struct WgradArgs {
     const void* x0; const void* x1; int C0, C1;
     const void* dz; int Cout;
+    int x3 = 0;                  // f32 storage only: split-bf16 products instead of exact-f32 MFMAs (sits in the padding behind Cout:
+                                 //   the grouped launches carry 24 of these structs in 4 KB of kernel arguments)
     float* partial;              // [ksplit][ntaps*Cin*Cout]
     float* db_partial;           // [ksplit][Cout] (fused bias-gradient partials; set by the launcher)
     int B, Ho, Wo, ksplit, mchunk;
@@ -215,6 +218,8 @@ int launch_maxpool_bwd_add(int dtype, const void* n, const void* dskip, const vo
 int launch_maxpool_bwd_add_stats(int dtype, const void* n, const void* dskip, const void* dp, int B, int H, int W, int C,
                                  void* dn, const void* x, const float* mean, const float* invstd, float* partial,
                                  long partial_cap, int* rows, hipStream_t st);
+// f32 tensor -> three bf16 planes stacked along the batch axis (order 0: hi | lo | hi, 1: hi | hi | lo): dtype "bf16x3" weight gradients
+int launch_split3(const float* x, long n, void* out, int order, hipStream_t st);
 // db[c] = sum_m dz[m][c]
 int launch_colsum(int dtype, const void* dz, long M, int C, float* partial, float* out, hipStream_t st);
 // out[c] = sum_k partial[k*C + c], k < nblk (second stage only)

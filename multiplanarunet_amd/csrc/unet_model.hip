@@ -41,6 +41,7 @@ struct mpu_unet {
     long infer_off = 0;                      // byte offset of the inference BN coefficients inside the packed buffer
     int head_C = 0; long head_w = 0, head_b = 0;
     int cmax = 0;
+    int x3 = 0;                              // MPU_F32X3: cfg.dtype holds MPU_F32 (storage, every elementwise kernel), the MFMA kernels split
     mpu_launch_tap_fn tap = nullptr; void* tap_user = nullptr;      // test aid: mpu_unet_set_launch_tap
 
     // indices into conv / bn
@@ -107,6 +108,8 @@ struct Plan {
     std::vector<long> wscratch;                     // per conv: float offset of its weight-gradient scratch inside wpartial
     std::vector<long> dz;                           // per conv: its own dz (gradient at the conv's pre-activation output): the weight
                                                     // gradients of a whole backward pass run as grouped launches at its end
+    std::vector<long> x3x0, x3x1, x3dz;             // dtype "bf16x3": per conv the bf16 plane triples of its input source(s) and its dz
+                                                    // (launch_split3), read by the grouped bf16 weight-gradient launches at the pass's end
 };
 
 Plan make_plan(const mpu_unet* m, int B) {
@@ -167,8 +170,23 @@ Plan make_plan(const mpu_unet* m, int B) {
             const bool concat = c.mode == CONV3 && (int)i >= 2 * D + 2 && ((int)i - 2 * D - 2) % 3 == 1;
             const int C0 = concat ? c.Cin / 2 : c.Cin, C1 = concat ? c.Cin / 2 : 0;
             P.wscratch[i] = we;
-            we += wgrad_scratch_need(m->cfg.dtype, c.mode, B, m->cfg.H >> l, m->cfg.W >> l, C0, C1, c.Cout,
-                                     i == 0 ? c.lCin : 0);
+            // (dtype "bf16x3": the weight gradient runs on the bf16 kernels over three plane pairs = a batch of 3 B)
+            we += wgrad_scratch_need(m->x3 ? MPU_BF16 : m->cfg.dtype, c.mode, m->x3 ? 3 * B : B, m->cfg.H >> l, m->cfg.W >> l, C0, C1,
+                                     c.Cout, i == 0 ? c.lCin : 0);
+        }
+        if (m->x3) {
+            P.x3x0.assign(m->conv.size(), -1); P.x3x1.assign(m->conv.size(), -1); P.x3dz.assign(m->conv.size(), -1);
+            for (size_t i = 0; i < m->conv.size(); ++i) {
+                const Conv& c = m->conv[i];
+                if (c.mode == CONV1) continue;
+                const int l = level_of(i), li = c.mode == UPCONV2 ? l + 1 : l;      // (the up-conv reads the level below)
+                const bool concat = c.mode == CONV3 && (int)i >= 2 * D + 2 && ((int)i - 2 * D - 2) % 3 == 1;
+                const long pin = (long)B * (m->cfg.H >> li) * (m->cfg.W >> li), pout = (long)B * (m->cfg.H >> l) * (m->cfg.W >> l);
+                const int C0 = concat ? c.Cin / 2 : c.Cin;
+                P.x3x0[i] = take(3 * pin * C0 * 2);
+                if (concat) P.x3x1[i] = take(3 * pin * (c.Cin - C0) * 2);
+                P.x3dz[i] = take(3 * pout * c.Cout * 2);
+            }
         }
     }
     P.wpartial = take(we * 4);
@@ -205,6 +223,8 @@ struct Run {
     float* stat(const BN& b, int k) const { return (float*)(ws + P.stats) + b.st + (long)k * b.C; }
 };
 
+#define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
 // algorithmic FLOPs of one pass over conv `c` at its OUTPUT resolution level `lvl`
 // (2*M*N*K with the logical channel counts; the 2x2 up-conv counted at output resolution)
 double conv_flops(const Run& r, const Conv& c, int lvl, int n_cnt_logical = -1) {
@@ -240,6 +260,7 @@ int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* i
     a.w = r.wf(c); a.w_tap_stride = (long)c.Cin * c.Cout; a.w_row_stride = c.Cin;
     a.bias = r.params + c.b; a.mask = nullptr; a.out = out;
     a.B = r.B; a.Ho = r.m->cfg.H >> lvl; a.Wo = r.m->cfg.W >> lvl; a.Cout = c.Cout; a.relu = 1;
+    a.x3 = r.m->x3;
     const int rc = launch_conv(r.m->cfg.dtype, c.mode, a, r.st);
     if (!rc && r.m->tap && !post_scale) {
         mpu_launch_info li{};
@@ -272,6 +293,7 @@ int conv_dgrad(const Run& r, const Conv& c, const void* dz, const void* mask, vo
     a.B = r.B; a.Ho = r.m->cfg.H >> out_lvl; a.Wo = r.m->cfg.W >> out_lvl; a.Cout = n_cnt; a.relu = 0;
     // the data gradient costs the forward's FLOPs (at the conv's own output level), pro rata of the slice
     a.flops = conv_flops(r, c, c.mode == UPCONV2 ? out_lvl - 1 : out_lvl) * ((double)n_cnt / c.Cin);
+    a.x3 = r.m->x3;
     const int rc = launch_conv(r.m->cfg.dtype, c.mode == UPCONV2 ? CONV3S2 : CONV3, a, r.st);
     if (!rc && r.m->tap) {
         mpu_launch_info li{};
@@ -295,6 +317,7 @@ int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* 
     wgrad_partial_elems(c.mode, c.Cin, c.Cout, M, &a.ksplit, &a.mchunk, r.group);
     a.db = r.grads + c.b; a.db_partial = nullptr; a.colsum_scratch = (float*)r.at(r.P.partial2); a.fuse_db = 0;
     a.c0_logical = (C1 == 0 && C0 == c.Cin) ? c.lCin : 0;
+    a.x3 = r.m->x3;
     const bool defer = env(ENV_WGRAD_BATCHED_REDUCE) != 0;   // 0: reduce right behind every weight-gradient kernel (A/B)
     ReduceQueue* q = defer ? &r.rq : nullptr;
     if (r.m->tap) {
@@ -305,6 +328,20 @@ int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* 
         r.m->tap(r.m->tap_user, &li);                  // (before the launch: x and dz are final, dW is read after the pass)
     }
     const int ntaps_before = r.grp.ntaps;
+    if (r.m->x3) {
+        // dtype "bf16x3": split x and dz into bf16 plane triples (batch 3 B) and run the bf16 weight-gradient schedules on them
+        // (unet_ops.hip: launch_split3); the bias gradient, which is no product, is the plain column sum of the f32 dz
+        const int Hi = c.mode == UPCONV2 ? a.Ho / 2 : a.Ho, Wi = c.mode == UPCONV2 ? a.Wo / 2 : a.Wo;
+        const long pin = (long)r.B * Hi * Wi;
+        RC(launch_split3((const float*)x0, pin * C0, r.at(r.P.x3x0[ci_]), 0, r.st));
+        if (x1) RC(launch_split3((const float*)x1, pin * C1, r.at(r.P.x3x1[ci_]), 0, r.st));
+        RC(launch_split3((const float*)dz, M * c.Cout, r.at(r.P.x3dz[ci_]), 1, r.st));
+        RC(launch_colsum(MPU_F32, dz, M, c.Cout, a.colsum_scratch, a.db, r.st));
+        a.x0 = r.at(r.P.x3x0[ci_]); a.x1 = x1 ? r.at(r.P.x3x1[ci_]) : nullptr; a.dz = r.at(r.P.x3dz[ci_]);
+        a.B = 3 * r.B; a.db = nullptr; a.x3 = 0;
+        wgrad_partial_elems(c.mode, c.Cin, c.Cout, 3 * M, &a.ksplit, &a.mchunk, r.group);
+        return launch_wgrad(MPU_BF16, c.mode, a, r.grads + c.w, r.st, q, (r.group && q) ? &r.grp : nullptr);
+    }
     const int rc = launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st, q, (r.group && q) ? &r.grp : nullptr);
     if (!rc && r.grp.ntaps > ntaps_before) { if (r.late.size() != r.m->conv.size()) r.late.assign(r.m->conv.size(), 0); r.late[ci_] = 1; }
     return rc;
@@ -359,7 +396,6 @@ int bn_bwd(const Run& r, const BN& b, const void* dn, const void* x, int lvl, vo
     return rc;
 }
 
-#define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
 // inference: BatchNormalization (moving statistics) is a per-channel affine after the ReLU; it is applied in
 // the epilogue of the producing conv (coefficients from mpu_unet_prepare_inference), so no BN kernel runs.
@@ -454,7 +490,7 @@ int run_forward(const Run& r, const float* d_x, int training, float* d_out) {
 // above that offset of the flat gradient buffer has been enqueued; record the caller's event there
 int mark_ready(const Run& r, int k) {
     if (!r.ready_events || k >= r.n_ready || !r.ready_events[k]) return MPU_OK;
-    int rc = flush_wgrad_group(r.m->cfg.dtype, r.grp, r.st);     // the gradients above this point must be final before the event
+    int rc = flush_wgrad_group(r.m->x3 ? MPU_BF16 : r.m->cfg.dtype, r.grp, r.st);     // the gradients above this point must be final before the event
     if (rc) return rc;
     rc = flush_wgrad_reduces(r.rq, r.st);
     if (rc) return rc;
@@ -595,13 +631,14 @@ void pack_jobs_of(const mpu_unet* m, PackTable& tab) {
 // parallel branches of the graph.
 int finish_backward(const Run& r, const AdamOpt* opt) {
     const mpu_unet* m = r.m; const int dt = m->cfg.dtype;
+    const int wdt = m->x3 ? MPU_BF16 : dt;                       // (dtype "bf16x3": the grouped weight gradients are bf16 jobs)
     if (!opt) {
-        RC(flush_wgrad_group(dt, r.grp, r.st));
+        RC(flush_wgrad_group(wdt, r.grp, r.st));
         return flush_wgrad_reduces(r.rq, r.st);
     }
     PackTable jobs; pack_jobs_of(m, jobs);
     if (!tail_overlap_wanted(r)) {                               // the serial order: the step counter moves behind the update
-        RC(flush_wgrad_group(dt, r.grp, r.st));
+        RC(flush_wgrad_group(wdt, r.grp, r.st));
         RC(flush_wgrad_reduces(r.rq, r.st));
         return launch_adam_pack_all(dt, jobs, opt->params, r.grads, opt->am, opt->av, m->n_params, opt->packed, opt->step, opt->t,
                                     opt->lr, opt->b1, opt->b2, opt->eps, r.st);
@@ -672,13 +709,14 @@ mpu_unet* mpu_unet_create(const mpu_unet_config* cfg) {
     if (!cfg) { fail(MPU_EINVAL, "%s", "mpu_unet_create: null config"); return nullptr; }
     const int D = cfg->depth;
     if (cfg->n_classes < 1 || cfg->n_classes > 8 || cfg->n_channels < 1 || D < 1 || D > 6 || cfg->H < 1 || cfg->W < 1 ||
-        (cfg->H % (1 << D)) || (cfg->W % (1 << D)) || (cfg->dtype != MPU_F32 && cfg->dtype != MPU_BF16)) {
+        (cfg->H % (1 << D)) || (cfg->W % (1 << D)) || (cfg->dtype != MPU_F32 && cfg->dtype != MPU_BF16 && cfg->dtype != MPU_F32X3)) {
         fail(MPU_EINVAL, "%s", "mpu_unet_create: unsupported configuration (need 1<=n_classes<=8, 1<=depth<=6, "
-                               "H and W multiples of 2^depth, dtype f32|bf16)");
+                               "H and W multiples of 2^depth, dtype f32|bf16|f32x3)");
         return nullptr;
     }
     mpu_unet* m = new mpu_unet();
     m->cfg = *cfg;
+    if (cfg->dtype == MPU_F32X3) { m->cfg.dtype = MPU_F32; m->x3 = 1; }
     m->cin_pad = pad8(cfg->n_channels);
     for (int l = 0; l <= D; ++l) {
         const int fl = cfg->filters[l];
@@ -925,6 +963,7 @@ static int conv2d_igemm_impl(int32_t dtype, int32_t mode, const void* d_in0, int
     a.stats = nullptr; a.stats_rows = nullptr; a.stats_cap = 0;
     a.bn_x = nullptr; a.bn_mean = nullptr; a.bn_invstd = nullptr;
     a.post_scale = nullptr; a.post_shift = nullptr;
+    if (dtype == MPU_F32X3) { a.x3 = 1; dtype = MPU_F32; }
     return launch_conv(dtype, mode, a, (hipStream_t)stream);
 }
 
@@ -972,6 +1011,7 @@ int mpu_conv2d_wgrad(int32_t dtype, int32_t mode, const void* d_x0, int32_t C0, 
     a.c0_logical = 0;
     a.partial_cap = C1 == C0 ? mpu_conv2d_wgrad_workspace_floats(mode, C0 + C1, Cout, (long)B * Ho * Wo) : 0;   // (the query's contract)
     wgrad_partial_elems(mode, C0 + C1, Cout, (long)B * Ho * Wo, &a.ksplit, &a.mchunk);
+    if (dtype == MPU_F32X3) { a.x3 = 1; dtype = MPU_F32; }
     ReduceQueue q;                               // second stages recorded, then run as one launch (as the U-Net does)
     int rc = launch_wgrad(dtype, mode, a, d_dW, (hipStream_t)stream, &q);
     if (rc) return rc;

