@@ -71,6 +71,25 @@ __device__ __forceinline__ void x3_split(const uint4& p, const uint4& q, mpu_s16
     hi = __builtin_bit_cast(mpu_s16x8, make_uint4(h[0], h[1], h[2], h[3]));
     lo = __builtin_bit_cast(mpu_s16x8, make_uint4(l[0], l[1], l[2], l[3]));
 }
+// Weights are split ONCE, when the packed operand copies are refreshed (launch_x3_words): a packed 32-bit word then holds
+// bf16 hi in its low and bf16 lo in its high half, and a fragment of eight of them is regrouped with eight byte permutes
+// instead of the ~28 conversions of x3_split.
+__device__ __forceinline__ uint32_t x3_word(float x) {
+    const uint32_t h = f32x2_to_bf16x2(x, 0.f) & 0xffffu;
+    const uint32_t l = f32x2_to_bf16x2(x - __uint_as_float(h << 16), 0.f) & 0xffffu;
+    return h | (l << 16);
+}
+__device__ __forceinline__ void x3_unpack(const uint4& p, const uint4& q, mpu_s16x8& hi, mpu_s16x8& lo) {
+    const uint32_t w[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = __builtin_amdgcn_perm(w[2 * e + 1], w[2 * e], 0x05040100u);      // low halves: (w1.lo << 16) | w0.lo
+        l[e] = __builtin_amdgcn_perm(w[2 * e + 1], w[2 * e], 0x07060302u);      // high halves
+    }
+    hi = __builtin_bit_cast(mpu_s16x8, make_uint4(h[0], h[1], h[2], h[3]));
+    lo = __builtin_bit_cast(mpu_s16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
 // c += a * b from the split operands, smallest terms first
 __device__ __forceinline__ void x3_mma(const mpu_s16x8& ahi, const mpu_s16x8& alo, const mpu_s16x8& bhi, const mpu_s16x8& blo,
                                        mpu_f32x16& c) {

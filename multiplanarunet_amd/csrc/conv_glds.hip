@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
                 for (int s = 0; s < SG; s += 2) {
                     s16x8 ah[TN], al[TN];
 #pragma unroll
-                    for (int i = 0; i < TN; ++i) x3_split(af[s][i], af[s + 1][i], ah[i], al[i]);
+                    for (int i = 0; i < TN; ++i) x3_unpack(af[s][i], af[s + 1][i], ah[i], al[i]);   // weights: split when packed
 #pragma unroll
                     for (int j = 0; j < TM; ++j) {               // (one pixel fragment split at a time: register budget)
                         s16x8 bh, bl;

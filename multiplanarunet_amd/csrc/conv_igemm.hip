@@ -725,6 +725,8 @@ static int halo_on() {
 
 int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
     if (a.stats_rows) *a.stats_rows = 0;          // set by the schedules that produce the fused BN statistics
+    if (a.x3 && (conv_impl() != 1 || dtype != MPU_F32 || mode == CONV1))   // (packed hi | lo words: the LDS-DMA f32 kernels only)
+        return fail(MPU_EUNSUPPORTED, "%s", "conv: split-bf16 products (f32x3) need the LDS-DMA kernels, f32 tensors and a 3x3 / 2x2 layer");
     auto note = [&](const char* sched) {
         if (sched_log_on())
             sched_note("conv %s mode=%d B=%d H=%d W=%d Cin=%d Cout=%d dgrad=%d pool=%d head=%d", sched, mode, a.B, a.Ho, a.Wo,

@@ -181,6 +181,8 @@ int launch_adam_pack_ranges(int dtype, PackTable& jobs, float* params, const flo
                             double b2, float eps, bool lean, hipStream_t st);
 int launch_pack_weights(int dtype, int mode, const float* W, int Cin, int Cout,
                         void* w_fwd, void* w_dgrad, hipStream_t st);
+// dtype "bf16x3": n packed f32 words -> (bf16 hi | bf16 lo << 16) in place (after every refresh of the packed operand copies)
+int launch_x3_words(void* buf, long n, hipStream_t st);
 int launch_cast_pad(int dtype, const float* x, long M, int Cin, int Cpad, void* out, hipStream_t st);
 
 // BatchNormalization, training: batch statistics of x [M][C]

@@ -640,8 +640,9 @@ int finish_backward(const Run& r, const AdamOpt* opt) {
     if (!tail_overlap_wanted(r)) {                               // the serial order: the step counter moves behind the update
         RC(flush_wgrad_group(wdt, r.grp, r.st));
         RC(flush_wgrad_reduces(r.rq, r.st));
-        return launch_adam_pack_all(dt, jobs, opt->params, r.grads, opt->am, opt->av, m->n_params, opt->packed, opt->step, opt->t,
-                                    opt->lr, opt->b1, opt->b2, opt->eps, r.st);
+        RC(launch_adam_pack_all(dt, jobs, opt->params, r.grads, opt->am, opt->av, m->n_params, opt->packed, opt->step, opt->t,
+                                opt->lr, opt->b1, opt->b2, opt->eps, r.st));
+        return m->x3 ? launch_x3_words(opt->packed, m->n_packed, r.st) : MPU_OK;
     }
     // (from here on a device step counter already holds this step's number: launch_head_backward advanced it)
     long lo = 0, hi = 0;                                         // the early range: longest run of convs outside the taps group
@@ -716,7 +717,12 @@ mpu_unet* mpu_unet_create(const mpu_unet_config* cfg) {
     }
     mpu_unet* m = new mpu_unet();
     m->cfg = *cfg;
-    if (cfg->dtype == MPU_F32X3) { m->cfg.dtype = MPU_F32; m->x3 = 1; }
+    if (cfg->dtype == MPU_F32X3) {
+        if (env(ENV_CONV_IMPL) == 0) {      // (the packed operands of this mode are hi | lo words: only the LDS-DMA kernels read them)
+            delete m; fail(MPU_EUNSUPPORTED, "%s", "mpu_unet_create: dtype f32x3 is not available under MPU_CONV_IMPL=regs"); return nullptr;
+        }
+        m->cfg.dtype = MPU_F32; m->x3 = 1;
+    }
     m->cin_pad = pad8(cfg->n_channels);
     for (int l = 0; l <= D; ++l) {
         const int fl = cfg->filters[l];
@@ -806,7 +812,8 @@ int mpu_unet_pack_weights(const mpu_unet* m, const float* d_params, void* d_pack
         j.mode = c.mode; j.Cin = c.Cin; j.Cout = c.Cout; j.unit_begin = j.fwd_units = j._pad = 0;
         j.w = c.w; j.wf = c.wf; j.wd = c.wd;
     }
-    return launch_pack_all(m->cfg.dtype, tab, d_params, d_packed, (hipStream_t)stream);
+    RC(launch_pack_all(m->cfg.dtype, tab, d_params, d_packed, (hipStream_t)stream));
+    return m->x3 ? launch_x3_words(d_packed, m->n_packed, (hipStream_t)stream) : MPU_OK;
 }
 
 int mpu_unet_adam_pack(const mpu_unet* m, float* d_params, const float* d_grads, float* d_m, float* d_v, int64_t t,
@@ -821,8 +828,9 @@ int mpu_unet_adam_pack(const mpu_unet* m, float* d_params, const float* d_grads,
         j.mode = c.mode; j.Cin = c.Cin; j.Cout = c.Cout; j.unit_begin = j.fwd_units = j._pad = 0;
         j.w = c.w; j.wf = c.wf; j.wd = c.wd;
     }
-    return launch_adam_pack_all(m->cfg.dtype, tab, d_params, d_grads, d_m, d_v, m->n_params, d_packed, (long long*)d_step,
-                                (long long)t, lr, beta1, beta2, (float)eps, (hipStream_t)stream);
+    RC(launch_adam_pack_all(m->cfg.dtype, tab, d_params, d_grads, d_m, d_v, m->n_params, d_packed, (long long*)d_step,
+                            (long long)t, lr, beta1, beta2, (float)eps, (hipStream_t)stream));
+    return m->x3 ? launch_x3_words(d_packed, m->n_packed, (hipStream_t)stream) : MPU_OK;
 }
 
 int mpu_unet_prepare_inference(const mpu_unet* m, const float* d_params, const float* d_bn_state, void* d_packed,
@@ -943,6 +951,12 @@ int mpu_conv2d_pack_weights(int32_t dtype, int32_t mode, const float* d_w, int32
     MPU_REQUIRE(d_w && d_w_fwd, "mpu_conv2d_pack_weights: null argument");
     MPU_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "mpu_conv2d_pack_weights: channels must be multiples of 8");
     MPU_REQUIRE(mode >= CONV3 && mode <= CONV1, "mpu_conv2d_pack_weights: unknown mode");
+    if (dtype == MPU_F32X3) {                 // f32 operands, then the hi | lo words of the split-bf16 kernels
+        const long k = mode == UPCONV2 ? 4 : (mode == CONV1 ? 1 : 9);
+        RC(launch_pack_weights(MPU_F32, mode, d_w, Cin, Cout, d_w_fwd, d_w_dgrad, (hipStream_t)stream));
+        RC(launch_x3_words(d_w_fwd, k * Cin * Cout, (hipStream_t)stream));
+        return d_w_dgrad ? launch_x3_words(d_w_dgrad, (mode == CONV1 ? 1L : 9L) * Cin * Cout, (hipStream_t)stream) : MPU_OK;
+    }
     return launch_pack_weights(dtype, mode, d_w, Cin, Cout, d_w_fwd, d_w_dgrad, (hipStream_t)stream);
 }
 

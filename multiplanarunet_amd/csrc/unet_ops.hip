@@ -235,6 +235,25 @@ int launch_pack_all(int dtype, PackTable& tab, const float* params, void* packed
     return launch_ok();
 }
 
+// dtype "bf16x3": packed f32 operands -> (bf16 hi | bf16 lo << 16) words, in place, after every refresh of the packed copies
+// (common.h: x3_word / x3_unpack). n = 32-bit words.
+__global__ __launch_bounds__(256) void x3_words_kernel(uint32_t* __restrict__ buf, long n) {
+    const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 + 4 <= n) {
+        uint4 v = *reinterpret_cast<uint4*>(buf + i4);
+        v.x = x3_word(__uint_as_float(v.x)); v.y = x3_word(__uint_as_float(v.y));
+        v.z = x3_word(__uint_as_float(v.z)); v.w = x3_word(__uint_as_float(v.w));
+        *reinterpret_cast<uint4*>(buf + i4) = v;
+    } else {
+        for (long i = i4; i < n; ++i) buf[i] = x3_word(__uint_as_float(buf[i]));
+    }
+}
+int launch_x3_words(void* buf, long n, hipStream_t st) {
+    if (n <= 0) return MPU_OK;
+    x3_words_kernel<<<(unsigned)((n + 1023) / 1024), 256, 0, st>>>((uint32_t*)buf, n);
+    return launch_ok();
+}
+
 int launch_pack_weights(int dtype, int mode, const float* W, int Cin, int Cout, void* wf, void* wd, hipStream_t st) {
     const int ntaps = mode == UPCONV2 ? 4 : (mode == CONV1 ? 1 : 9);
     long tiles = (long)ntaps * cdiv(Cin, 32) * cdiv(Cout, 32);

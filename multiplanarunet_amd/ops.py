@@ -14,13 +14,14 @@ def _dt(dtype):
     return {torch.float32: _lib.MPU_F32, torch.bfloat16: _lib.MPU_BF16}[dtype]
 
 
-def pack_weights(w_hwio, mode, dtype):
-    """fp32 Keras HWIO kernel (device) -> (forward operand, data-gradient operand)."""
+def pack_weights(w_hwio, mode, dtype, x3=False):
+    """fp32 Keras HWIO kernel (device) -> (forward operand, data-gradient operand). x3: the split-bf16 form of the f32 operands
+    (mpu_dtype MPU_F32X3: each word holds bf16 hi | bf16 lo), for conv2d(x3=True)."""
     kh, kw, ci, co = w_hwio.shape
     w = w_hwio.to(torch.float32).contiguous()
     wf = torch.empty(kh * kw * co * ci, dtype=dtype, device=w.device)
     wd = torch.empty(9 * ci * co, dtype=dtype, device=w.device)
-    _lib.call("mpu_conv2d_pack_weights", _dt(dtype), mode, _lib.ptr(w), ci, co,
+    _lib.call("mpu_conv2d_pack_weights", _lib.MPU_F32X3 if x3 else _dt(dtype), mode, _lib.ptr(w), ci, co,
               _lib.ptr(wf), _lib.ptr(wd), _lib.stream_ptr())
     return wf, wd
 

@@ -1,7 +1,7 @@
 # R6q: where the bf16x3 (and f32) step spends its time
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r6q; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for dt in bf16x3 f32; do
+for dt in bf16x3; do
 cat > /tmp/x3step.py <<PY
 import sys, numpy as np, torch
 sys.path.insert(0, "$R")
@@ -17,6 +17,6 @@ torch.cuda.synchronize()
 PY
 rocprofv3 --kernel-trace --stats -d $O/$dt -o s -- python /tmp/x3step.py > /dev/null 2>&1
 S=$(find $O/$dt -name "*.db" | head -1)
-python $R/tools/rocpd_stats.py $S 16 > $O/stats_$dt.txt; echo "== $dt"; head -18 $O/stats_$dt.txt | cut -c1-150
+python $R/tools/rocpd_stats.py $S 28 > $O/stats_$dt.txt; echo "== $dt"; head -30 $O/stats_$dt.txt | cut -c1-150
 rm -rf $O/$dt
 done
