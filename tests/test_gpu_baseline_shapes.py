@@ -256,6 +256,83 @@ def test_bf16_six_view_pipeline_dice_delta_vs_f64_oracle():
     assert np.abs(d_hip - d_ref).max() <= 1e-3, (d_hip, d_ref)
 
 
+def test_real_network_bf16_six_view_dice_delta_vs_oracle():
+    """the north-star Dice tolerance on the REAL network -- depth 4, 64 base filters (31 M parameters), dim 128 --
+    not on a toy: 1300 Adam steps of 16 sampled planes on two 128^3 volumes (every class >= 2 % of the voxels), then the held-out
+    volume through the bf16 6-view predict + fuse on the GPU and through the oracle pipeline with the SAME weights (NumPy geometry
+    restatement, torch-CPU f32 U-Net, FusionLayer; mpunet/bin/predict.py:294-366, evaluate/metrics.py:26-52). Per-class Dice
+    against the ground truth differs by <= 1e-3."""
+    import time
+    from multiplanarunet_amd.unet import UNet
+    from multiplanarunet_amd.fusion_model import FusionModel
+    from multiplanarunet_amd.interpolation import dice_all
+    from multiplanarunet_amd.predict import multi_view_predict
+    from multiplanarunet_amd.data import as_volume, TrainSampler
+    from oracle import unet_ref as U
+    from oracle import geometry as G
+    K, D, depth, cf = 3, 128, 4, 1
+
+    def toy(seed):
+        rng = np.random.RandomState(seed)
+        g = np.mgrid[:D, :D, :D].astype(np.float32)
+        c1 = D * (0.30 + 0.08 * rng.rand(3)); r1 = D * (0.19 + 0.04 * rng.rand(3))
+        c2 = D * (0.66 + 0.06 * rng.rand(3)); h2 = D * (0.15 + 0.03 * rng.rand(3))
+        lab = np.zeros((D, D, D), np.uint8)
+        lab[(((g[0] - c1[0]) / r1[0]) ** 2 + ((g[1] - c1[1]) / r1[1]) ** 2 + ((g[2] - c1[2]) / r1[2]) ** 2) <= 1] = 1
+        lab[(abs(g[0] - c2[0]) < h2[0]) & (abs(g[1] - c2[1]) < h2[1]) & (abs(g[2] - c2[2]) < h2[2])] = 2
+        img = 0.3 * np.sin(g[0] / D * 3) + 0.2 * np.cos(g[1] / D * 5) + 0.05 * rng.randn(D, D, D)
+        img = (img + 0.8 * (lab == 1) + 1.5 * (lab == 2))[..., None].astype(np.float32)
+        assert np.bincount(lab.ravel(), minlength=K).min() >= 0.02 * D ** 3
+        return img, lab, np.eye(4)
+    vols = []
+    for s in range(3):
+        img, lab, aff = toy(140 + s)
+        vols.append((img, lab, as_volume(img, lab, aff, "1pct", "RobustScaler", "cuda", "toy%d" % s)))
+    m = UNet(n_classes=K, dim=D, depth=depth, complexity_factor=cf, flatten_output=True, dtype="bf16", logger=quiet, seed=0)
+    assert m.count_params() == 31046339
+    m.compile("Adam", "SparseCategoricalCrossentropy", optimizer_kwargs=dict(lr=5e-4))
+    tr = TrainSampler([v for _, _, v in vols[:2]], VIEWS6, D, float(D), 16, K, noise_sd=0.1, seed=1)
+    first = last = None
+    NSTEP = 700 + 600
+    for it in range(NSTEP):
+        if it == 700:            # the last 600 steps at a 25x smaller rate: the weights barely move, and BatchNorm's moving statistics
+            m.optimizer_kwargs["lr"] = 2e-5     # (momentum 0.99) catch up with them -- inference then sees what training saw
+        x, y, w = tr()
+        l = m.train_step(x, y, w)
+        if it == 0 or it == NSTEP - 1:
+            v = float(l.mean().item())
+            first = v if first is None else first
+            last = v
+    assert last < 0.3 * first, (first, last)
+    img, lab, vol = vols[2]                                     # held-out volume
+    rng = np.random.RandomState(0)
+    Wf = rng.uniform(.7, 1.3, (6, K)).astype(np.float32)
+    bf = rng.uniform(-.05, .05, (1, K)).astype(np.float32)
+    fm = FusionModel(6, K, verbose=False)
+    fm.set_weights([Wf, bf])
+    m.flatten_output = False
+    _, got = multi_view_predict(m, vol, VIEWS6, D, float(D), fm, batch_size=None, want_probs=False)
+    got = got.cpu().numpy()
+    wts = m.get_weights_dict()
+    c, s = vol.scaler
+    t0 = time.perf_counter()
+
+    def net(X):                                                  # torch-CPU f32, 37 planes at a time
+        return np.concatenate([U.predict(wts, X[i:i + 37], depth=depth, dtype=torch.float32) for i in range(0, X.shape[0], 37)])
+    _, ref_l, _ = G.multi_view_predict(img, np.eye(4), VIEWS6, D, float(D), net, Wf, bf, bg_value=vol.bg_value, center=c, scale=s)
+    t_ref = time.perf_counter() - t0
+    d_hip = dice_all(lab, got, n_classes=K, ignore_zero=False)
+    d_ref = dice_all(lab, ref_l, n_classes=K, ignore_zero=False)
+    d_x = dice_all(ref_l, got, n_classes=K, ignore_zero=False)
+    print("REAL network (depth 4, 64 filters, dim 128) bf16 6-view pipeline on a 128^3 volume: loss %.3f -> %.3f; dice vs truth hip %s "
+          "oracle %s | hip vs oracle %s | differing voxels %.2e | oracle pipeline %.0f s of CPU"
+          % (first, last, np.round(d_hip, 5), np.round(d_ref, 5), np.round(d_x, 5), (got != ref_l).mean(), t_ref))
+    for arr in (lab, got, ref_l):
+        assert set(np.unique(arr)) == set(range(K))
+    assert np.all(d_ref[1:] > 0.85), d_ref
+    assert np.abs(d_hip - d_ref).max() <= 1e-3, (d_hip, d_ref)
+
+
 def _predict_properties(D, C_, K, dim_batch=None):
     """6-view predict+fuse at full size: labels < K, deterministic, fused kernel == accumulate + finalize path
     (sum_fusion: bitwise-comparable pre-activations; FusionLayer: <= 1e-4 of voxels at fp32 ties)."""
