@@ -389,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void conv_deepk_kernel(ConvArgs a, int tile
             float t = 0.f;
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) t += sc[((ib * 4 + jb) * 2 + st2) * 32 + cl];
-            a.stats[((long)st2 * a.Cout + n0 + ch) * tiles_m + mt] = t;
+            stats_emit(a, st2, n0 + ch, tiles_m, mt, t);
         }
     }
     if (STAMP && stamps) {

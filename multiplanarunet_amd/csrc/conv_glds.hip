@@ -408,7 +408,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
                                                             const float* __restrict__ ph, T* __restrict__ out,
                                                             float* __restrict__ stats, const T* __restrict__ bn_x,
                                                             const float* __restrict__ bn_mean,
-                                                            const float* __restrict__ bn_invstd) {
+                                                            const float* __restrict__ bn_invstd, long long* stats_acc,
+                                                            float acc_scale0, float acc_scale1) {
     constexpr int EPC = 16 / sizeof(T);
     const long total = M * Cout / EPC, stride = M * Cout;
     float ssum[EPC], ssq[EPC], bmu[EPC], bis[EPC];
@@ -507,7 +508,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
             const int col = vv >> 1, st2 = vv & 1, cg2 = col / EPC, k = col % EPC;
             double acc = 0.0;
             for (int rl = 0; rl < nl; ++rl) acc += (double)red[(((rl * cpr) + cg2) * EPC + k) * 2 + st2];
-            stats[((long)st2 * Cout + col) * gridDim.x + blockIdx.x] = (float)acc;          // [2][Cout][blocks]
+            if (stats_acc) stats_acc_add(stats_acc, Cout, st2, col, (float)acc, st2 ? acc_scale1 : acc_scale0);
+            else stats[((long)st2 * Cout + col) * gridDim.x + blockIdx.x] = (float)acc;      // [2][Cout][blocks]
         }
         (void)cgi;
     }
@@ -528,15 +530,15 @@ static int launch_splitk_finish(const ConvArgs& a, int ks, long M, hipStream_t s
         if (a.bn_x)
             launch_k(splitk_finish_kernel<T, 2>, (unsigned)blocks, 256, 0, st, a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
                                                                          a.relu, a.post_scale, a.post_shift, (T*)a.out, a.stats,
-                                                                         (const T*)a.bn_x, a.bn_mean, a.bn_invstd);
+                                                                         (const T*)a.bn_x, a.bn_mean, a.bn_invstd, a.stats_acc, a.stats_scale[0], a.stats_scale[1]);
         else
             launch_k(splitk_finish_kernel<T, 1>, (unsigned)blocks, 256, 0, st, a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
                                                                          a.relu, a.post_scale, a.post_shift, (T*)a.out, a.stats,
-                                                                         nullptr, nullptr, nullptr);
+                                                                         nullptr, nullptr, nullptr, a.stats_acc, a.stats_scale[0], a.stats_scale[1]);
     } else {
         launch_k(splitk_finish_kernel<T, 0>, (unsigned)blocks, 256, 0, st, a.partial, ks, M, a.Cout, a.bias, (const T*)a.mask,
                                                                      a.relu, a.post_scale, a.post_shift, (T*)a.out, nullptr,
-                                                                     nullptr, nullptr, nullptr);
+                                                                     nullptr, nullptr, nullptr, nullptr, 0.f, 0.f);
     }
     return launch_ok();
 }

@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
                 double acc = 0.0;
                 for (int rl = 0; rl < RPI; ++rl) acc += (double)red[(rl * BN + col) * 2 + st2];
                 // layout [2][Cout][pixel tiles]: the finalize reads each column's partials as one contiguous run
-                if (n0 + col < a.Cout) a.stats[((long)st2 * a.Cout + n0 + col) * (gridDim.x / tiles_n) + ptile] = (float)acc;
+                if (n0 + col < a.Cout) stats_emit(a, st2, n0 + col, gridDim.x / tiles_n, ptile, (float)acc);
             }
         }
     }
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
                 const int col = v >> 1, st2 = v & 1;
                 double acc2 = 0.0;
                 for (int rl = 0; rl < RPI; ++rl) acc2 += (double)red[(rl * BN + col) * 2 + st2];
-                if (n0 + col < a.Cout) a.stats[((long)st2 * a.Cout + n0 + col) * (gridDim.x / tiles_n) + ptile] = (float)acc2;
+                if (n0 + col < a.Cout) stats_emit(a, st2, n0 + col, gridDim.x / tiles_n, ptile, (float)acc2);
             }
         }
     }

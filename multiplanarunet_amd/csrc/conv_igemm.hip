@@ -723,7 +723,7 @@ static int halo_on() {
     return (int)env(ENV_CONV_HALO);
 }
 
-int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
+static int launch_conv_impl(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
     if (a.stats_rows) *a.stats_rows = 0;          // set by the schedules that produce the fused BN statistics
     if (a.x3 && (conv_impl() != 1 || dtype != MPU_F32 || mode == CONV1))   // (packed hi | lo words: the LDS-DMA f32 kernels only)
         return fail(MPU_EUNSUPPORTED, "%s", "conv: split-bf16 products (f32x3) need the LDS-DMA kernels, f32 tensors and a 3x3 / 2x2 layer");
@@ -765,6 +765,14 @@ int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
     if (dtype == MPU_F32) { MPU_CONV_CASE(float) }
 #undef MPU_CONV_CASE
     return fail(MPU_EINVAL, "%s", "conv: bad dtype");
+}
+
+int launch_conv(int dtype, int mode, const ConvArgs& a, hipStream_t st) {
+    const int rc = launch_conv_impl(dtype, mode, a, st);
+    // accumulator mode of the fused statistics (ConvArgs.stats_acc): the schedule that produced them added them to the
+    // accumulator instead of writing its rows -- the caller sees "-1 rows"
+    if (!rc && a.stats_acc && a.stats_rows && *a.stats_rows > 0) *a.stats_rows = -1;
+    return rc;
 }
 
 // workspace (floats) the split-K partials of a wgrad call need

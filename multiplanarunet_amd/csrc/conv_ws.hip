@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
         if (wm == 0) {
             const float v = cb[wave * 64 + lane] + cb[(wave + 2) * 64 + lane];
             const int ch = wn * 32 + (lane >> 4) * 8 + ((lane & 15) >> 1), st2 = lane & 1;
-            if (ch < a.Cout) a.stats[((long)st2 * a.Cout + ch) * gridDim.x + blockIdx.x] = v;      // [2][Cout][workgroups]
+            if (ch < a.Cout) stats_emit(a, st2, ch, gridDim.x, blockIdx.x, v);      // [2][Cout][workgroups], or the accumulator
         }
     }
 }

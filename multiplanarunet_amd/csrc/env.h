@@ -35,6 +35,7 @@ enum EnvKind {
     X(FUSED_POOL, "MPU_FUSED_POOL", ENV_ON, 1, "0: inference 2x2 max pooling as its own kernel instead of a second epilogue output") \
     X(FUSED_BN_STATS, "MPU_FUSED_BN_STATS", ENV_ON, 1, "0: BatchNorm statistics by colreduce instead of the conv epilogue")          \
     X(BN_FOLD, "MPU_BN_FOLD", ENV_ON, 1, "0: BatchNorm finalize as its own launch also where the producer left <= 64 partial rows (round-5 A/B)") \
+    X(BN_ATOMIC, "MPU_BN_ATOMIC", ENV_ON, 1, "0: the fused BatchNorm sums as partial rows + finalize launches everywhere (round-5 form) instead of fixed-point accumulators") \
     X(FUSED_BN_BWD_CONV, "MPU_FUSED_BN_BWD_CONV", ENV_ON, 1, "0: BatchNorm-backward sums by colreduce instead of the data-gradient epilogue") \
     X(FUSED_BN_BWD, "MPU_FUSED_BN_BWD", ENV_ON, 1, "0: max-pool backward + skip add without the fused BatchNorm-backward sums")      \
     X(HEAD_RS, "MPU_HEAD_RS", ENV_ON, 1, "0: head forward without the reduce-scatter variant")                                       \

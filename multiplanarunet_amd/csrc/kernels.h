@@ -24,6 +24,11 @@ struct ConvArgs {
     // *stats_rows to the number of rows
     // (0: the schedule chosen for this shape does not produce them; the caller runs the column reduction instead).
     float* stats; int* stats_rows; long stats_cap;              // capacity of `stats` in floats
+    // Round 6: with stats_acc set the column sums are NOT written as partial rows but ADDED, as fixed-point integers, to
+    // stats_acc[8 XCDs][2][Cout] (int64, zeroed by the caller; stats_emit below) and the launcher reports *stats_rows = -1: the
+    // consumer then needs no finalize launch at all -- it sums eight integers per (statistic, channel). Integer sums are exact,
+    // so the result does not depend on the order in which workgroups arrive (deterministic, as the fixed-order rows were).
+    long long* stats_acc = nullptr; float stats_scale[2] = {0.f, 0.f};   // units per 1.0 of statistic 0 / 1 (powers of two)
     // With bn_x set the two sums are those of the BatchNorm BACKWARD pass of the layer that consumes this output as
     // its dn: sum out, sum out * (bn_x - mean) * invstd (bn_x: the BatchNorm's input, same shape as out). Schedules that
     // cannot produce them leave *stats_rows = 0.
@@ -43,6 +48,23 @@ struct ConvArgs {
                                  //   8 no fragment reads, 16 no barrier, 32 s_memtime stamps into dbg_buf)
     unsigned long long* dbg_buf = nullptr;
 };
+// One column sum of a producer's tile: a partial row (the fixed-order scheme), or -- stats_acc mode -- a fixed-point atomic add
+// into the row of THIS workgroup's XCD (hardware register XCC_ID, so the eight per-XCD L2 caches never share an address; inside an
+// XCD the L2 is the point of coherence of every compute unit, which is where a scope-less global atomic executes).
+__device__ __forceinline__ void stats_acc_add(long long* acc, int C, int st2, int ch, float v, float scale) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;       // HW_REG_XCC_ID[3:0]
+    double d = (double)v * (double)scale;
+    d = d > 9.0e18 ? 9.0e18 : (d < -9.0e18 ? -9.0e18 : d);       // (saturate: an overflowing sum must not wrap)
+    const long long q = __double2ll_rn(d);
+    __hip_atomic_fetch_add(acc + ((long)xcc * 2 + st2) * C + ch, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void stats_emit(const ConvArgs& a, int st2, int ch, long nrows, long row, float v) {
+    if (a.stats_acc) stats_acc_add(a.stats_acc, a.Cout, st2, ch, v, a.stats_scale[st2]);
+    else a.stats[((long)st2 * a.Cout + ch) * nrows + row] = v;
+}
+constexpr int BN_ACC_ROWS = 8;                   // XCDs
+inline long bn_acc_elems(int C) { return (long)BN_ACC_ROWS * 2 * C; }      // int64 elements of one accumulator
+
 struct WgradArgs {
     const void* x0; const void* x1; int C0, C1;
     const void* dz; int Cout;
@@ -203,23 +225,27 @@ int launch_maxpool(int dtype, const void* x, int B, int H, int W, int C, void* p
 // finalize + apply (+ pool) in ONE launch for producers that left <= 64 column-major partial rows (1 = launched, 0 = not suited)
 int launch_bn_fold_fwd(int dtype, const void* x, int B, int H, int W, int C, const float* partial, int nblk,
                        const float* gamma, const float* beta, float* mmean, float* mvar, float* mean, float* invstd,
-                       float* scale, float* shift, float eps, float momentum, void* y, void* pooled, hipStream_t st);
+                       float* scale, float* shift, float eps, float momentum, void* y, void* pooled, hipStream_t st,
+                       const long long* acc = nullptr, const float* acc_scale = nullptr);   // acc: the accumulator mode of ConvArgs.stats_acc
+bool bn_fold_shape_ok(int C, int H, int W, bool pooled);          // shapes the folded kernels take (accumulator mode is offered only there)
+int launch_zero_ll(long long* p, long n, hipStream_t st);
 int launch_bn_apply(int dtype, const void* x, int B, int H, int W, int C, const float* scale,
                     const float* shift, void* y, void* pooled, hipStream_t st);
 // BN backward: dgamma, dbeta and dz = (x>0) * d(x) where x is the post-ReLU BN input
 int launch_bn_backward(int dtype, const void* dn, const void* x, long M, int C, float* partial,
                        const float* gamma, const float* mean, const float* invstd,
                        float* dgamma, float* dbeta, float* coeffs /*[3][C]*/, void* dz,
-                       int ready_rows /* > 0: partial already holds that many partial rows */,
+                       int ready_rows /* > 0: partial already holds that many partial rows; -1: the producer used `acc` */,
                        int ready_colmajor /* their layout: 0 = [rows][2][C], 1 = [2][C][rows] (conv epilogues) */,
-                       hipStream_t st);
+                       hipStream_t st, long long* acc = nullptr /* zeroed accumulator of this BatchNorm (ConvArgs.stats_acc), or NULL */,
+                       const float* acc_scale = nullptr);
 // dn = dskip + unpool(dp) (gradient of MaxPooling2D routed to the first max of each window)
 int launch_maxpool_bwd_add(int dtype, const void* n, const void* dskip, const void* dp,
                            int B, int H, int W, int C, void* dn, hipStream_t st);
 // ... and the BN-backward partial sums (sum dn, sum dn * xhat) of the level's BatchNorm in the same pass
 int launch_maxpool_bwd_add_stats(int dtype, const void* n, const void* dskip, const void* dp, int B, int H, int W, int C,
                                  void* dn, const void* x, const float* mean, const float* invstd, float* partial,
-                                 long partial_cap, int* rows, hipStream_t st);
+                                 long partial_cap, int* rows, hipStream_t st, long long* acc = nullptr, const float* acc_scale = nullptr);
 // f32 tensor -> three bf16 planes stacked along the batch axis (order 0: hi | lo | hi, 1: hi | hi | lo): dtype "bf16x3" weight gradients
 int launch_split3(const float* x, long n, void* out, int order, hipStream_t st);
 // db[c] = sum_m dz[m][c]

@@ -13,6 +13,10 @@ using namespace mpu;
 namespace {
 
 constexpr float BN_EPS = 1e-3f, BN_MOM = 0.99f;      // Keras BatchNormalization defaults
+// fixed-point units of the accumulator mode (ConvArgs.stats_acc; powers of two): forward sum x in 2^-24, sum x^2 in 2^-16 (a
+// mean-square activation up to 6e4 per XCD share of a 128^2 x 16 batch before the int64 saturates; their errors, <= 2^-17 / 256
+// per pixel, are far below epsilon = 1e-3); the backward sums (gradients: small numbers) in 2^-40
+constexpr float BN_ACC_F[2] = {16777216.f, 65536.f}, BN_ACC_B[2] = {1099511627776.f, 1099511627776.f};
 
 inline int pad8(int c) { return (c + 7) / 8 * 8; }
 inline long align64(long e) { return (e + 63) / 64 * 64; }
@@ -108,6 +112,8 @@ struct Plan {
     std::vector<long> wscratch;                     // per conv: float offset of its weight-gradient scratch inside wpartial
     std::vector<long> dz;                           // per conv: its own dz (gradient at the conv's pre-activation output): the weight
                                                     // gradients of a whole backward pass run as grouped launches at its end
+    std::vector<long> bnacc_f, bnacc_b;             // per BatchNorm: its fixed-point accumulators of the forward statistics / backward sums
+    long bnacc, bnacc_elems;                        //   (ConvArgs.stats_acc: int64 [8 XCDs][2][C]); one region: forward half first
     std::vector<long> x3x0, x3x1, x3dz;             // dtype "bf16x3": per conv the bf16 plane triples of its input source(s) and its dz
                                                     // (launch_split3), read by the grouped bf16 weight-gradient launches at the pass's end
 };
@@ -202,6 +208,14 @@ Plan make_plan(const mpu_unet* m, int B) {
     }
     P.cpartial = take(ce * 4);
     P.cpartial_floats = ce;
+    {   // accumulators of the fused BatchNorm sums: forward ones first, then the backward ones (each half zeroed by ONE launch)
+        long e = 0;
+        P.bnacc_f.assign(m->bn.size(), 0); P.bnacc_b.assign(m->bn.size(), 0);
+        for (size_t i = 0; i < m->bn.size(); ++i) { P.bnacc_f[i] = e; e += bn_acc_elems(m->bn[i].C); }
+        for (size_t i = 0; i < m->bn.size(); ++i) { P.bnacc_b[i] = e; e += bn_acc_elems(m->bn[i].C); }
+        P.bnacc_elems = e;
+        P.bnacc = take(e * 8);
+    }
     P.coeffs = take(3L * m->cmax * 4);
     P.stats = take(m->n_stats * 4);
     P.total = off;
@@ -221,6 +235,9 @@ struct Run {
     const void* wf(const Conv& c) const { return packed + c.wf * esz; }
     const void* wd(const Conv& c) const { return packed + c.wd * esz; }
     float* stat(const BN& b, int k) const { return (float*)(ws + P.stats) + b.st + (long)k * b.C; }
+    long long* acc_f(const BN& b) const { return (long long*)(ws + P.bnacc) + P.bnacc_f[&b - &m->bn[0]]; }
+    long long* acc_b(const BN& b) const { return (long long*)(ws + P.bnacc) + P.bnacc_b[&b - &m->bn[0]]; }
+    bool acc_mode = false;                                       // fused BatchNorm sums into fixed-point accumulators (MPU_BN_ATOMIC)
 };
 
 #define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
@@ -238,7 +255,7 @@ struct HeadFuse { const float* w; int k, ldw; float* partial; int* done; };
 
 int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* in1, int C1, void* out, int lvl,
              const float* post_scale = nullptr, const float* post_shift = nullptr, int* stats_rows = nullptr,
-             void* pooled = nullptr, int* pooled_done = nullptr, const HeadFuse* head = nullptr) {
+             void* pooled = nullptr, int* pooled_done = nullptr, const HeadFuse* head = nullptr, long long* stats_acc = nullptr) {
     ConvArgs a;
     const bool fused_head = env(ENV_FUSED_HEAD) != 0;   // inference: 1x1 head out of the last conv's epilogue (partial logits)
     if (head && head->done) *head->done = 0;
@@ -252,6 +269,7 @@ int conv_fwd(const Run& r, const Conv& c, const void* in0, int C0, const void* i
     const bool fused_stats = env(ENV_FUSED_BN_STATS) != 0;
     if (!fused_stats) stats_rows = nullptr;
     a.stats = stats_rows ? (float*)r.at(r.P.partial) : nullptr; a.stats_rows = stats_rows; a.stats_cap = r.P.partial_floats;
+    if (stats_rows && stats_acc) { a.stats_acc = stats_acc; a.stats_scale[0] = BN_ACC_F[0]; a.stats_scale[1] = BN_ACC_F[1]; }
     a.bn_x = nullptr; a.bn_mean = nullptr; a.bn_invstd = nullptr;
     a.flops = conv_flops(r, c, lvl); a.w_elems = 0;
     a.partial = r.P.cpartial_floats ? (float*)r.at(r.P.cpartial) : nullptr; a.partial_cap = r.P.cpartial_floats; a.ksplit = 1;
@@ -284,6 +302,7 @@ int conv_dgrad(const Run& r, const Conv& c, const void* dz, const void* mask, vo
     a.stats = want ? (float*)r.at(r.P.partial) : nullptr; a.stats_rows = want ? bn_rows : nullptr;
     a.stats_cap = want ? r.P.partial_floats : 0;
     a.bn_x = want ? bn_x : nullptr; a.bn_mean = want ? r.stat(*bn, 0) : nullptr; a.bn_invstd = want ? r.stat(*bn, 1) : nullptr;
+    if (want && r.acc_mode && !(bn->C & 63)) { a.stats_acc = r.acc_b(*bn); a.stats_scale[0] = BN_ACC_B[0]; a.stats_scale[1] = BN_ACC_B[1]; }
     a.in0 = dz; a.in1 = nullptr; a.C0 = c.Cout; a.C1 = 0; a.w_elems = 0;
     a.partial = r.P.cpartial_floats ? (float*)r.at(r.P.cpartial) : nullptr; a.partial_cap = r.P.cpartial_floats; a.ksplit = 1;
     a.post_scale = nullptr; a.post_shift = nullptr;
@@ -363,6 +382,15 @@ int bn_fwd(const Run& r, const BN& b, const void* x, int lvl, int training, void
     const int H = r.m->cfg.H >> lvl, W = r.m->cfg.W >> lvl;
     const long M = (long)r.B * H * W;
     int rc;
+    if (training && stats_rows == -1) { // the producer added its sums to this BatchNorm's accumulator: no finalize at all
+        rc = launch_bn_fold_fwd(r.m->cfg.dtype, x, r.B, H, W, b.C, nullptr, -1, r.params + b.g, r.params + b.b, r.state + b.mm,
+                                r.state + b.mv, r.stat(b, 0), r.stat(b, 1), r.stat(b, 2), r.stat(b, 3), BN_EPS, BN_MOM, y, pooled, r.st,
+                                r.acc_f(b), BN_ACC_F);
+        if (rc < 0) return rc;
+        if (rc != 1) return fail(MPU_EINVAL, "%s", "bn_fwd: the folded kernel refused an accumulator-mode BatchNorm");
+        tap_aux(r, 3, (int)(&b - &r.m->bn[0]), lvl, b.C, b.C, x, nullptr, nullptr, pooled, y, b.g, b.b, r.stat(b, 0), r.stat(b, 1));
+        return MPU_OK;
+    }
     if (training && stats_rows > 0) {   // few enough rows: finalize folded into the apply pass (one launch)
         rc = launch_bn_fold_fwd(r.m->cfg.dtype, x, r.B, H, W, b.C, (const float*)r.at(r.P.partial), stats_rows, r.params + b.g,
                                 r.params + b.b, r.state + b.mm, r.state + b.mv, r.stat(b, 0), r.stat(b, 1), r.stat(b, 2), r.stat(b, 3),
@@ -391,7 +419,7 @@ int bn_bwd(const Run& r, const BN& b, const void* dn, const void* x, int lvl, vo
     const long M = (long)r.B * (r.m->cfg.H >> lvl) * (r.m->cfg.W >> lvl);
     const int rc = launch_bn_backward(r.m->cfg.dtype, dn, x, M, b.C, (float*)r.at(r.P.partial), r.params + b.g, r.stat(b, 0),
                                       r.stat(b, 1), r.grads + b.g, r.grads + b.b, (float*)r.at(r.P.coeffs), dz, ready_rows,
-                                      ready_colmajor, r.st);
+                                      ready_colmajor, r.st, (r.acc_mode && !(b.C & 63)) ? r.acc_b(b) : nullptr, BN_ACC_B);
     if (!rc) tap_aux(r, 4, (int)(&b - &r.m->bn[0]), lvl, b.C, b.C, dn, x, nullptr, nullptr, dz, b.g, b.b, r.stat(b, 0), r.stat(b, 1));
     return rc;
 }
@@ -451,29 +479,39 @@ int run_forward(const Run& r, const float* d_x, int training, float* d_out) {
     const mpu_unet* m = r.m; const int D = m->cfg.depth; const Plan& P = r.P;
     const long M0 = (long)r.B * m->cfg.H * m->cfg.W;
     RC(launch_cast_pad(m->cfg.dtype, d_x, M0, m->cfg.n_channels, m->cin_pad, r.at(P.xin), r.st));
+    // accumulator mode of the fused BatchNorm statistics: offered where the folded kernel takes the shape; all forward
+    // accumulators are zeroed by one launch
+    auto accf = [&](const BN& b, int lvl, bool pooled) -> long long* {
+        return (r.acc_mode && bn_fold_shape_ok(b.C, m->cfg.H >> lvl, m->cfg.W >> lvl, pooled)) ? r.acc_f(b) : nullptr;
+    };
+    if (r.acc_mode) RC(launch_zero_ll((long long*)r.at(P.bnacc), P.bnacc_elems / 2, r.st));
     const void* cur = r.at(P.xin); int Ccur = m->cin_pad;
     for (int i = 0; i < D; ++i) {
         RC(conv_fwd(r, m->conv[m->enc_c1(i)], cur, Ccur, nullptr, 0, r.at(P.c1[i]), i));
         int rows = 0;
-        RC(conv_fwd(r, m->conv[m->enc_c2(i)], r.at(P.c1[i]), m->F[i], nullptr, 0, r.at(P.c2[i]), i, nullptr, nullptr, &rows));
+        RC(conv_fwd(r, m->conv[m->enc_c2(i)], r.at(P.c1[i]), m->F[i], nullptr, 0, r.at(P.c2[i]), i, nullptr, nullptr, &rows,
+                    nullptr, nullptr, nullptr, accf(m->bn[m->enc_bn(i)], i, true)));
         RC(bn_fwd(r, m->bn[m->enc_bn(i)], r.at(P.c2[i]), i, training, r.at(P.n[i]), r.at(P.p[i]), rows));
         cur = r.at(P.p[i]); Ccur = m->F[i];
     }
     RC(conv_fwd(r, m->conv[m->bot_c1()], cur, Ccur, nullptr, 0, r.at(P.c1b), D));
     {
         int rows = 0;
-        RC(conv_fwd(r, m->conv[m->bot_c2()], r.at(P.c1b), m->F[D], nullptr, 0, r.at(P.c2b), D, nullptr, nullptr, &rows));
+        RC(conv_fwd(r, m->conv[m->bot_c2()], r.at(P.c1b), m->F[D], nullptr, 0, r.at(P.c2b), D, nullptr, nullptr, &rows,
+                    nullptr, nullptr, nullptr, accf(m->bn[m->bot_bn()], D, false)));
         RC(bn_fwd(r, m->bn[m->bot_bn()], r.at(P.c2b), D, training, r.at(P.nb), nullptr, rows));
     }
     const void* prev = r.at(P.nb); int Cprev = m->F[D];
     for (int j = 0; j < D; ++j) {
         const int lvl = D - 1 - j, f = m->F[lvl];
         int rows = 0;
-        RC(conv_fwd(r, m->conv[m->up_c(j, 0)], prev, Cprev, nullptr, 0, r.at(P.u1[j]), lvl, nullptr, nullptr, &rows));
+        RC(conv_fwd(r, m->conv[m->up_c(j, 0)], prev, Cprev, nullptr, 0, r.at(P.u1[j]), lvl, nullptr, nullptr, &rows,
+                    nullptr, nullptr, nullptr, accf(m->bn[m->up_bn(j, 0)], lvl, false)));
         RC(bn_fwd(r, m->bn[m->up_bn(j, 0)], r.at(P.u1[j]), lvl, training, r.at(P.n1[j]), nullptr, rows));
         RC(conv_fwd(r, m->conv[m->up_c(j, 1)], r.at(P.n[lvl]), f, r.at(P.n1[j]), f, r.at(P.c2u[j]), lvl));
         rows = 0;
-        RC(conv_fwd(r, m->conv[m->up_c(j, 2)], r.at(P.c2u[j]), f, nullptr, 0, r.at(P.c3u[j]), lvl, nullptr, nullptr, &rows));
+        RC(conv_fwd(r, m->conv[m->up_c(j, 2)], r.at(P.c2u[j]), f, nullptr, 0, r.at(P.c3u[j]), lvl, nullptr, nullptr, &rows,
+                    nullptr, nullptr, nullptr, accf(m->bn[m->up_bn(j, 1)], lvl, false)));
         RC(bn_fwd(r, m->bn[m->up_bn(j, 1)], r.at(P.c3u[j]), lvl, training, r.at(P.n2[j]), nullptr, rows));
         prev = r.at(P.n2[j]); Cprev = f;
     }
@@ -511,6 +549,8 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
     const int dt = m->cfg.dtype;
     const long M0 = (long)r.B * m->cfg.H * m->cfg.W;
     void* gA = r.at(P.gA); void* gB = r.at(P.gB);
+    if (r.acc_mode)                              // the backward halves of the BatchNorm accumulators (one launch)
+        RC(launch_zero_ll((long long*)r.at(P.bnacc) + P.bnacc_elems / 2, P.bnacc_elems / 2, r.st));
     const void* last = D > 0 ? r.at(P.n2[D - 1]) : r.at(P.nb);
     RC(launch_head_backward(dt, last, (const float*)r.at(P.probs), d_y, d_sw, M0, (long)m->cfg.H * m->cfg.W,
                             m->head_C, m->cfg.n_classes, r.params + m->head_w, m->cfg.n_classes,
@@ -565,7 +605,7 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
         int bwd_rows = 0;
         RC(launch_maxpool_bwd_add_stats(dt, r.at(P.n[i]), r.at(P.dskip[i]), gB, r.B, H, W, m->F[i], gA, r.at(P.c2[i]),
                                         r.stat(eb, 0), r.stat(eb, 1), (float*)r.at(P.partial), P.partial_floats, &bwd_rows,
-                                        r.st));
+                                        r.st, (r.acc_mode && !(eb.C & 63)) ? r.acc_b(eb) : nullptr, BN_ACC_B));
         tap_aux(r, 5, m->enc_bn(i), i, m->F[i], m->F[i], r.at(P.n[i]), r.at(P.dskip[i]), gB, nullptr, gA, 0, 0);
         RC(bn_bwd(r, eb, gA, r.at(P.c2[i]), i, DZ(i2), bwd_rows));
         RC(conv_wgrad(r, c2, r.at(P.c1[i]), m->F[i], nullptr, 0, DZ(i2), i));
@@ -699,6 +739,9 @@ int make_run(Run& r, const mpu_unet* m, int batch, const float* params, const vo
     r.params = params; r.packed = (const unsigned char*)packed; r.state = state; r.grads = grads;
     r.esz = m->cfg.dtype == MPU_BF16 ? 2 : 4;
     r.group = env(ENV_WGRAD_GROUP) != 0;      // 0: every weight-gradient kernel as its own launch, in place (A/B)
+    // bf16 storage only: a fixed-point unit of 2^-16 on a tile's sum of squares is far below the rounding of the stored bf16 values,
+    // but it is visible at the f32 parity mode's level (train-mode logits 1.3e-4 against 4e-5 with the rows: gpurun R6v)
+    r.acc_mode = env(ENV_BN_ATOMIC) != 0 && env(ENV_BN_FOLD) != 0 && env(ENV_FUSED_BN_STATS) != 0 && m->cfg.dtype == MPU_BF16;
     return MPU_OK;
 }
 

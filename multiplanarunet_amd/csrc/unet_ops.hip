@@ -312,7 +312,8 @@ constexpr int CR_THREADS = 512;      // column-reduction block size
 template <typename T, int OP>
 __global__ __launch_bounds__(CR_THREADS) void colreduce_kernel(const T* __restrict__ a, const T* __restrict__ b, long M, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                        int rows_per_blk, float* __restrict__ partial) {
+                                                        int rows_per_blk, float* __restrict__ partial, long long* acc_out,
+                                                        float acc_scale0, float acc_scale1) {
     constexpr int N = Vec<T>::N;
     constexpr int NS = OP == 2 ? 1 : 2;
     __shared__ float red[CR_THREADS * N * NS];
@@ -389,7 +390,10 @@ __global__ __launch_bounds__(CR_THREADS) void colreduce_kernel(const T* __restri
                 const float acc = (float)accd;
                 const int tx2 = v / (NS * N), s = (v / N) % NS, i = v % N;
                 const int c2 = cg + tx2;
-                if (c2 < cpr) partial[((long)blockIdx.x * NS + s) * C + c2 * N + i] = acc;
+                if (c2 < cpr) {
+                    if (acc_out) stats_acc_add(acc_out, C, s, c2 * N + i, acc, s ? acc_scale1 : acc_scale0);    // (accumulator mode, kernels.h)
+                    else partial[((long)blockIdx.x * NS + s) * C + c2 * N + i] = acc;
+                }
             }
         }
         __syncthreads();
@@ -407,13 +411,15 @@ static int red_blocks(long M, int C, int* rows_per_blk) {
 
 template <int OP>
 static int launch_colreduce(int dtype, const void* a, const void* b, long M, int C, const float* mean,
-                            const float* invstd, float* partial, int* nblk_out, hipStream_t st) {
+                            const float* invstd, float* partial, int* nblk_out, hipStream_t st, long long* acc = nullptr,
+                            const float* acc_scale = nullptr) {
     int rpb; const int nblk = red_blocks(M, C, &rpb);
     *nblk_out = nblk;
+    const float s0 = acc ? acc_scale[0] : 0.f, s1 = acc ? acc_scale[1] : 0.f;
     if (dtype == MPU_BF16)
-        colreduce_kernel<bf16_t, OP><<<nblk, CR_THREADS, 0, st>>>((const bf16_t*)a, (const bf16_t*)b, M, C, mean, invstd, rpb, partial);
+        colreduce_kernel<bf16_t, OP><<<nblk, CR_THREADS, 0, st>>>((const bf16_t*)a, (const bf16_t*)b, M, C, mean, invstd, rpb, partial, acc, s0, s1);
     else
-        colreduce_kernel<float, OP><<<nblk, CR_THREADS, 0, st>>>((const float*)a, (const float*)b, M, C, mean, invstd, rpb, partial);
+        colreduce_kernel<float, OP><<<nblk, CR_THREADS, 0, st>>>((const float*)a, (const float*)b, M, C, mean, invstd, rpb, partial, acc, s0, s1);
     return launch_ok();
 }
 
@@ -524,9 +530,21 @@ __device__ __forceinline__ double bn_fold_rowsum(const float* __restrict__ p, in
     return s;
 }
 
+// accumulator mode (round 6, ConvArgs.stats_acc): the eight per-XCD fixed-point sums of one (statistic, channel); exact
+__device__ __forceinline__ double bn_acc_sum(const long long* __restrict__ acc, int C, int st, int c, float inv_scale) {
+    long long v[BN_ACC_ROWS];
+#pragma unroll
+    for (int r = 0; r < BN_ACC_ROWS; ++r) v[r] = acc[((long)r * 2 + st) * C + c];          // all eight loads in flight
+    long long t = 0;
+#pragma unroll
+    for (int r = 0; r < BN_ACC_ROWS; ++r) t += v[r];
+    return (double)t * (double)inv_scale;
+}
+
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void bn_fold_apply_kernel(const T* __restrict__ x, int B, int H, int W, int C,
-                                                            const float* __restrict__ partial, int nblk, long M,
+                                                            const float* __restrict__ partial, int nblk,
+                                                            const long long* __restrict__ acc, float inv0, float inv1, long M,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* mmean, float* mvar, float* mean, float* invstd, float* scale,
                                                             float* shift, float eps, float mom, T* __restrict__ y,
@@ -562,7 +580,8 @@ __global__ __launch_bounds__(256) void bn_fold_apply_kernel(const T* __restrict_
     }
     if (threadIdx.x < 128) {
         const int cl = threadIdx.x & 63, st = threadIdx.x >> 6;
-        red[st][cl] = bn_fold_rowsum(partial + ((long)st * C + c0 + cl) * nblk, nblk);
+        red[st][cl] = acc ? bn_acc_sum(acc, C, st, c0 + cl, st ? inv1 : inv0)
+                          : bn_fold_rowsum(partial + ((long)st * C + c0 + cl) * nblk, nblk);
     }
     __syncthreads();
     if (threadIdx.x < 64) {                                      // the arithmetic of bn_stats_finalize_kernel, expression for expression
@@ -605,10 +624,25 @@ __global__ __launch_bounds__(256) void bn_fold_apply_kernel(const T* __restrict_
 }
 
 // 1 = launched (finalize + apply in one pass), 0 = not suited (the caller runs the two launches)
+__global__ __launch_bounds__(256) void zero_ll_kernel(long long* p, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = 0;
+}
+int launch_zero_ll(long long* p, long n, hipStream_t st) {
+    if (n <= 0) return MPU_OK;
+    long blocks = (n + 1023) / 1024; if (blocks > 512) blocks = 512;
+    zero_ll_kernel<<<(unsigned)blocks, 256, 0, st>>>(p, n);
+    return launch_ok();
+}
+
+// acc != NULL (nblk = -1): the producer added its sums to the fixed-point accumulator (scales acc_scale[2]) instead of writing rows
+bool bn_fold_shape_ok(int C, int H, int W, bool pooled) { return !(C & 63) && !(pooled && ((H | W) & 1)); }
 int launch_bn_fold_fwd(int dtype, const void* x, int B, int H, int W, int C, const float* partial, int nblk,
                        const float* gamma, const float* beta, float* mmean, float* mvar, float* mean, float* invstd,
-                       float* scale, float* shift, float eps, float momentum, void* y, void* pooled, hipStream_t st) {
-    if (env(ENV_BN_FOLD) == 0 || nblk <= 0 || nblk > BN_FOLD_MAX_ROWS || (nblk & 3) || (C & 63)) return 0;
+                       float* scale, float* shift, float eps, float momentum, void* y, void* pooled, hipStream_t st,
+                       const long long* acc, const float* acc_scale) {
+    if (acc) { if (C & 63) return fail(MPU_EINVAL, "%s", "bn_fold: accumulator mode needs a multiple of 64 channels"); }
+    else if (env(ENV_BN_FOLD) == 0 || nblk <= 0 || nblk > BN_FOLD_MAX_ROWS || (nblk & 3) || (C & 63)) return 0;
+    const float inv0 = acc ? 1.f / acc_scale[0] : 0.f, inv1 = acc ? 1.f / acc_scale[1] : 0.f;
     if (pooled && ((H | W) & 1)) return 0;
     const long M = (long)B * H * W;
     const long Q = pooled ? M / 4 : M;
@@ -623,9 +657,9 @@ int launch_bn_fold_fwd(int dtype, const void* x, int B, int H, int W, int C, con
     if (groups * nslab > (1L << 20)) return 0;
     const dim3 grid((unsigned)(groups * nslab)), blk(256);
 #define MPU_BNF(TT)                                                                                                       \
-    if (pooled) bn_fold_apply_kernel<TT, true><<<grid, blk, 0, st>>>((const TT*)x, B, H, W, C, partial, nblk, M, gamma, beta, mmean, mvar, \
+    if (pooled) bn_fold_apply_kernel<TT, true><<<grid, blk, 0, st>>>((const TT*)x, B, H, W, C, partial, nblk, acc, inv0, inv1, M, gamma, beta, mmean, mvar, \
                                                                     mean, invstd, scale, shift, eps, momentum, (TT*)y, (TT*)pooled, nslab, (int)ppw); \
-    else bn_fold_apply_kernel<TT, false><<<grid, blk, 0, st>>>((const TT*)x, B, H, W, C, partial, nblk, M, gamma, beta, mmean, mvar, \
+    else bn_fold_apply_kernel<TT, false><<<grid, blk, 0, st>>>((const TT*)x, B, H, W, C, partial, nblk, acc, inv0, inv1, M, gamma, beta, mmean, mvar, \
                                                                mean, invstd, scale, shift, eps, momentum, (TT*)y, nullptr, nslab, (int)ppw);
     if (dtype == MPU_BF16) { MPU_BNF(bf16_t) } else { MPU_BNF(float) }
 #undef MPU_BNF
@@ -738,6 +772,7 @@ int launch_bn_apply(int dtype, const void* x, int B, int H, int W, int C, const 
     return launch_ok();
 }
 
+#define RC_(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
 // BN backward finalize: dgamma, dbeta and the per-channel coefficients of
 // dx = k1*dn + k2*x + k3  (dx = scale*(dn - mean(dn) - xhat*mean(dn*xhat)))
 // COLMAJOR: partial is [2][C][nblk] (written by a conv epilogue), else [nblk][2][C] (colreduce, maxpool_bwd_add)
@@ -798,6 +833,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_fold_kernel(const T* __restrict__ dn, const T* __restrict__ x, long M, int C,
                                                           const float* __restrict__ partial, int nblk,
+                                                          const long long* __restrict__ acc, float inv0, float inv1,
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, float* dgamma, float* dbeta,
                                                           float* coeffs, T* __restrict__ dz, int nslab, int ppw) {
@@ -820,7 +856,8 @@ __global__ __launch_bounds__(256) void bn_bwd_fold_kernel(const T* __restrict__ 
     if (threadIdx.x < 64) { g_ = gamma[c0 + threadIdx.x]; mu_ = mean[c0 + threadIdx.x]; is_ = invstd[c0 + threadIdx.x]; }
     if (threadIdx.x < 128) {
         const int cl = threadIdx.x & 63, st = threadIdx.x >> 6;
-        red[st][cl] = bn_fold_rowsum(partial + ((long)st * C + c0 + cl) * nblk, nblk);
+        red[st][cl] = acc ? bn_acc_sum(acc, C, st, c0 + cl, st ? inv1 : inv0)
+                          : bn_fold_rowsum(partial + ((long)st * C + c0 + cl) * nblk, nblk);
     }
     __syncthreads();
     if (threadIdx.x < 64) {                                      // bn_bwd_finalize_kernel, expression for expression
@@ -856,25 +893,32 @@ __global__ __launch_bounds__(256) void bn_bwd_fold_kernel(const T* __restrict__ 
 
 int launch_bn_backward(int dtype, const void* dn, const void* x, long M, int C, float* partial, const float* gamma,
                        const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coeffs, void* dz,
-                       int ready_rows, int ready_colmajor, hipStream_t st) {
-    int nblk = ready_rows;                       // > 0: the producer of dn already wrote that many partial rows
-    int rc = 0;
-    if (env(ENV_BN_FOLD) != 0 && ready_colmajor && nblk > 0 && nblk <= BN_FOLD_MAX_ROWS && !(nblk & 3) && !(C & 63)) {
+                       int ready_rows, int ready_colmajor, hipStream_t st, long long* acc, const float* acc_scale) {
+    int nblk = ready_rows;                       // > 0: the producer of dn already wrote that many partial rows; -1: it added
+    int rc = 0;                                  //      its sums to the accumulator `acc` (which is offered, zeroed, whenever non-NULL)
+    const bool use_acc = acc && !(C & 63) && (nblk == -1 || nblk <= 0);
+    if (nblk == -1 && !use_acc) return fail(MPU_EINVAL, "%s", "bn_backward: accumulator-mode sums without an accumulator");
+    if (use_acc && nblk != -1)                   // no producer had the sums: the column reduction adds them to the accumulator itself
+        RC_(launch_colreduce<1>(dtype, dn, x, M, C, mean, invstd, partial, &nblk, st, acc, acc_scale));
+    if (use_acc || (env(ENV_BN_FOLD) != 0 && ready_colmajor && nblk > 0 && nblk <= BN_FOLD_MAX_ROWS && !(nblk & 3) && !(C & 63))) {
         const int nslab = C / 64, ppp = dtype == MPU_BF16 ? 32 : 16;       // finalize folded into the apply pass
         long ppw = (M * nslab + 255) / 256;
         ppw = (ppw + ppp - 1) / ppp * ppp;
         if (ppw < ppp) ppw = ppp;
         if (ppw > 4L * ppp) ppw = 4L * ppp;                     // (the kernel's NP passes)
         const long groups = (M + ppw - 1) / ppw;
-        if (groups * nslab <= (1L << 20)) {
+        if (groups * nslab <= (1L << 20) || use_acc) {
+            if (groups * nslab > (1L << 20)) return fail(MPU_EUNSUPPORTED, "%s", "bn_backward: tensor too large for the folded kernel");
             const dim3 grid((unsigned)(groups * nslab)), blk(256);
+            const long long* ac = use_acc ? acc : nullptr;
+            const float inv0 = use_acc ? 1.f / acc_scale[0] : 0.f, inv1 = use_acc ? 1.f / acc_scale[1] : 0.f;
             if (dtype == MPU_BF16)
-                bn_bwd_fold_kernel<bf16_t><<<grid, blk, 0, st>>>((const bf16_t*)dn, (const bf16_t*)x, M, C, partial, nblk, gamma, mean, invstd,
+                bn_bwd_fold_kernel<bf16_t><<<grid, blk, 0, st>>>((const bf16_t*)dn, (const bf16_t*)x, M, C, partial, nblk, ac, inv0, inv1, gamma, mean, invstd,
                                                                  dgamma, dbeta, coeffs, (bf16_t*)dz, nslab, (int)ppw);
             else
-                bn_bwd_fold_kernel<float><<<grid, blk, 0, st>>>((const float*)dn, (const float*)x, M, C, partial, nblk, gamma, mean, invstd,
+                bn_bwd_fold_kernel<float><<<grid, blk, 0, st>>>((const float*)dn, (const float*)x, M, C, partial, nblk, ac, inv0, inv1, gamma, mean, invstd,
                                                                 dgamma, dbeta, coeffs, (float*)dz, nslab, (int)ppw);
-            if (sched_log_on()) sched_note("bn_fold bwd C=%d rows=%d grid=%ld", C, nblk, groups * nslab);
+            if (sched_log_on()) sched_note("bn_fold bwd C=%d rows=%d grid=%ld", C, use_acc ? -1 : nblk, groups * nslab);
             return launch_ok();
         }
     }
@@ -902,7 +946,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const T* __restric
                                                               const T* __restrict__ dp, int B, int H, int W, int C,
                                                               T* __restrict__ dn, const T* __restrict__ x,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                              float* __restrict__ partial) {
+                                                              float* __restrict__ partial, long long* acc_out, float acc_scale0,
+                                                              float acc_scale1) {
     constexpr int N = Vec<T>::N;
     const int cpr = C / N, Hp = H / 2, Wp = W / 2;
     const long total = (long)B * Hp * Wp * cpr;
@@ -973,7 +1018,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const T* __restric
             const int st2 = v / C, col = v - st2 * C, cg = col / N, i = col - cg * N;
             double acc = 0.0;
             for (int rl = 0; rl < nl; ++rl) acc += (double)red[((rl * cpr + cg) * N + i) * 2 + st2];
-            partial[((long)blockIdx.x * 2 + st2) * C + col] = (float)acc;
+            if (acc_out) stats_acc_add(acc_out, C, st2, col, (float)acc, st2 ? acc_scale1 : acc_scale0);
+            else partial[((long)blockIdx.x * 2 + st2) * C + col] = (float)acc;
         }
     }
 }
@@ -982,9 +1028,9 @@ int launch_maxpool_bwd_add(int dtype, const void* n, const void* dskip, const vo
                            void* dn, hipStream_t st) {
     const long work = (long)B * (H / 2) * (W / 2) * C / 8;
     if (dtype == MPU_BF16)
-        maxpool_bwd_add_kernel<bf16_t, false><<<ew_grid(work), 256, 0, st>>>((const bf16_t*)n, (const bf16_t*)dskip, (const bf16_t*)dp, B, H, W, C, (bf16_t*)dn, nullptr, nullptr, nullptr, nullptr);
+        maxpool_bwd_add_kernel<bf16_t, false><<<ew_grid(work), 256, 0, st>>>((const bf16_t*)n, (const bf16_t*)dskip, (const bf16_t*)dp, B, H, W, C, (bf16_t*)dn, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f);
     else
-        maxpool_bwd_add_kernel<float, false><<<ew_grid(work), 256, 0, st>>>((const float*)n, (const float*)dskip, (const float*)dp, B, H, W, C, (float*)dn, nullptr, nullptr, nullptr, nullptr);
+        maxpool_bwd_add_kernel<float, false><<<ew_grid(work), 256, 0, st>>>((const float*)n, (const float*)dskip, (const float*)dp, B, H, W, C, (float*)dn, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f);
     return launch_ok();
 }
 
@@ -992,7 +1038,7 @@ int launch_maxpool_bwd_add(int dtype, const void* n, const void* dskip, const vo
 // ([rows][2][C]); 0 = shape not suited (plain kernel launched, the caller runs the column reduction).
 int launch_maxpool_bwd_add_stats(int dtype, const void* n, const void* dskip, const void* dp, int B, int H, int W, int C,
                                  void* dn, const void* x, const float* mean, const float* invstd, float* partial,
-                                 long partial_cap, int* rows, hipStream_t st) {
+                                 long partial_cap, int* rows, hipStream_t st, long long* acc, const float* acc_scale) {
     const bool on = env(ENV_FUSED_BN_BWD) != 0;
     const int N = dtype == MPU_BF16 ? 8 : 4, cpr = C / N;
     const long work = (long)B * (H / 2) * (W / 2) * cpr;
@@ -1001,10 +1047,10 @@ int launch_maxpool_bwd_add_stats(int dtype, const void* n, const void* dskip, co
     if (!on || C % N || cpr < 1 || cpr > 256 || 256 % cpr || blocks * 2 * C > partial_cap)
         return launch_maxpool_bwd_add(dtype, n, dskip, dp, B, H, W, C, dn, st);
     if (dtype == MPU_BF16)
-        maxpool_bwd_add_kernel<bf16_t, true><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)n, (const bf16_t*)dskip, (const bf16_t*)dp, B, H, W, C, (bf16_t*)dn, (const bf16_t*)x, mean, invstd, partial);
+        maxpool_bwd_add_kernel<bf16_t, true><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)n, (const bf16_t*)dskip, (const bf16_t*)dp, B, H, W, C, (bf16_t*)dn, (const bf16_t*)x, mean, invstd, partial, acc, acc ? acc_scale[0] : 0.f, acc ? acc_scale[1] : 0.f);
     else
-        maxpool_bwd_add_kernel<float, true><<<(unsigned)blocks, 256, 0, st>>>((const float*)n, (const float*)dskip, (const float*)dp, B, H, W, C, (float*)dn, (const float*)x, mean, invstd, partial);
-    *rows = (int)blocks;
+        maxpool_bwd_add_kernel<float, true><<<(unsigned)blocks, 256, 0, st>>>((const float*)n, (const float*)dskip, (const float*)dp, B, H, W, C, (float*)dn, (const float*)x, mean, invstd, partial, acc, acc ? acc_scale[0] : 0.f, acc ? acc_scale[1] : 0.f);
+    *rows = acc ? -1 : (int)blocks;
     return launch_ok();
 }
 
