@@ -241,6 +241,14 @@ int mpu_unet_backward(const mpu_unet* m, int32_t batch, const uint8_t* d_y,
 int mpu_plane_stats(const uint8_t* d_labels, const float* d_image, int64_t n_pixels, int32_t n_channels,
                     const float* d_bg, uint32_t* d_out2, void* stream);
 
+/* mpu_sample_view_planes for ONE plane followed by mpu_plane_stats of it: one candidate slice of the train-time sampler per call
+ * (arguments as the two; d_bg_scaled = the background value as the scaled plane shows it). */
+int mpu_sample_plane_stats(const float* d_vol, const uint8_t* d_labels, const int32_t vol_shape[4],
+                           const double* d_ax, const double* d_ay, const double* d_az,
+                           const mpu_view_geom* geom, const double* d_offset,
+                           const float* d_bg, uint8_t bg_class, const double* d_center, const double* d_scale,
+                           float* d_out, uint8_t* d_out_lab, const float* d_bg_scaled, uint32_t* d_stats2, void* stream);
+
 /* Elastic2D augmentation of one training slice (mpunet/augmentation/elastic_deformation.py:6-69, applied by
  * mpunet/augmentation/augmenters.py:87-107 after scaling): image [H][W][C] f32 bilinear with fill d_bg[c],
  * labels [H][W] u8 nearest with fill 0 (either pair may be NULL), displaced by alpha * gaussian_filter(2*noise-1)

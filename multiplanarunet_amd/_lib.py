@@ -150,6 +150,8 @@ _SIGS = {
     "mpu_unet_adam_pack": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, c_p, f64, f64, f64, f64, c_p, c_p]),
     "mpu_debug_stamps_read": (C.c_int, [c_p, i32]),
     "mpu_debug_tail_events": (C.c_int, [i32, c_p]),
+    "mpu_sample_plane_stats": (C.c_int, [c_p, c_p, C.POINTER(i32), c_p, c_p, c_p, C.POINTER(ViewGeom), c_p, c_p, u8, c_p, c_p,
+                                        c_p, c_p, c_p, c_p, c_p]),
     "mpu_unet_backward_adam": (C.c_int, [c_p, i32] + [c_p] * 10 + [i64, c_p, f64, f64, f64, f64, c_p]),
 }
 

@@ -127,6 +127,20 @@ int mpu_plane_stats(const uint8_t* d_labels, const float* d_image, int64_t n_pix
     return launch_ok();
 }
 
+/* One candidate slice of the train-time sampler in ONE call (round 6: the sampler's host loop had become what bounds `mp train`):
+ * mpu_sample_view_planes for a single plane followed by mpu_plane_stats of that plane. */
+int mpu_sample_plane_stats(const float* d_vol, const uint8_t* d_labels, const int32_t vol_shape[4],
+                           const double* d_ax, const double* d_ay, const double* d_az,
+                           const mpu_view_geom* geom, const double* d_offset,
+                           const float* d_bg, uint8_t bg_class, const double* d_center, const double* d_scale,
+                           float* d_out, uint8_t* d_out_lab, const float* d_bg_scaled, uint32_t* d_stats2, void* stream) {
+    MPU_REQUIRE(geom && geom->n_planes == 1 && d_stats2 && vol_shape, "mpu_sample_plane_stats: one plane and a statistics buffer");
+    const int rc = mpu_sample_view_planes(d_vol, d_labels, vol_shape, d_ax, d_ay, d_az, geom, d_offset, d_bg, bg_class, d_center,
+                                          d_scale, d_out, d_out_lab, stream);
+    if (rc) return rc;
+    return mpu_plane_stats(d_out_lab, d_out, (int64_t)geom->dim * geom->dim, vol_shape[3], d_bg_scaled, d_stats2, stream);
+}
+
 int64_t mpu_elastic_workspace_doubles(int32_t H, int32_t W) { return 4L * H * W; }
 
 int mpu_elastic_transform_2d(const float* d_image, const uint8_t* d_labels, int32_t H, int32_t W, int32_t C,

@@ -205,7 +205,8 @@ int launch_pack_weights(int dtype, int mode, const float* W, int Cin, int Cout,
                         void* w_fwd, void* w_dgrad, hipStream_t st);
 // dtype "bf16x3": n packed f32 words -> (bf16 hi | bf16 lo << 16) in place (after every refresh of the packed operand copies)
 int launch_x3_words(void* buf, long n, hipStream_t st);
-int launch_cast_pad(int dtype, const float* x, long M, int Cin, int Cpad, void* out, hipStream_t st);
+int launch_cast_pad(int dtype, const float* x, long M, int Cin, int Cpad, void* out, hipStream_t st, long long* zero_p = nullptr,
+                    long zero_n = 0);       // zero_p: int64 words zeroed by the same launch (the BatchNorm accumulators of a training step)
 
 // BatchNormalization, training: batch statistics of x [M][C]
 //   partial: [RED_MAX_BLOCKS][2][C] floats scratch
@@ -228,7 +229,6 @@ int launch_bn_fold_fwd(int dtype, const void* x, int B, int H, int W, int C, con
                        float* scale, float* shift, float eps, float momentum, void* y, void* pooled, hipStream_t st,
                        const long long* acc = nullptr, const float* acc_scale = nullptr);   // acc: the accumulator mode of ConvArgs.stats_acc
 bool bn_fold_shape_ok(int C, int H, int W, bool pooled);          // shapes the folded kernels take (accumulator mode is offered only there)
-int launch_zero_ll(long long* p, long n, hipStream_t st);
 int launch_bn_apply(int dtype, const void* x, int B, int H, int W, int C, const float* scale,
                     const float* shift, void* y, void* pooled, hipStream_t st);
 // BN backward: dgamma, dbeta and dz = (x>0) * d(x) where x is the post-ReLU BN input

@@ -478,13 +478,13 @@ int run_forward(const Run& r, const float* d_x, int training, float* d_out) {
     if (!training) return run_forward_infer(r, d_x, d_out);
     const mpu_unet* m = r.m; const int D = m->cfg.depth; const Plan& P = r.P;
     const long M0 = (long)r.B * m->cfg.H * m->cfg.W;
-    RC(launch_cast_pad(m->cfg.dtype, d_x, M0, m->cfg.n_channels, m->cin_pad, r.at(P.xin), r.st));
-    // accumulator mode of the fused BatchNorm statistics: offered where the folded kernel takes the shape; all forward
-    // accumulators are zeroed by one launch
+    // accumulator mode of the fused BatchNorm statistics: offered where the folded kernel takes the shape; the accumulators of BOTH
+    // passes are zeroed by the step's first launch (a backward pass belongs to exactly one training forward)
+    RC(launch_cast_pad(m->cfg.dtype, d_x, M0, m->cfg.n_channels, m->cin_pad, r.at(P.xin), r.st,
+                       r.acc_mode ? (long long*)r.at(P.bnacc) : nullptr, P.bnacc_elems));
     auto accf = [&](const BN& b, int lvl, bool pooled) -> long long* {
         return (r.acc_mode && bn_fold_shape_ok(b.C, m->cfg.H >> lvl, m->cfg.W >> lvl, pooled)) ? r.acc_f(b) : nullptr;
     };
-    if (r.acc_mode) RC(launch_zero_ll((long long*)r.at(P.bnacc), P.bnacc_elems / 2, r.st));
     const void* cur = r.at(P.xin); int Ccur = m->cin_pad;
     for (int i = 0; i < D; ++i) {
         RC(conv_fwd(r, m->conv[m->enc_c1(i)], cur, Ccur, nullptr, 0, r.at(P.c1[i]), i));
@@ -549,8 +549,6 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
     const int dt = m->cfg.dtype;
     const long M0 = (long)r.B * m->cfg.H * m->cfg.W;
     void* gA = r.at(P.gA); void* gB = r.at(P.gB);
-    if (r.acc_mode)                              // the backward halves of the BatchNorm accumulators (one launch)
-        RC(launch_zero_ll((long long*)r.at(P.bnacc) + P.bnacc_elems / 2, P.bnacc_elems / 2, r.st));
     const void* last = D > 0 ? r.at(P.n2[D - 1]) : r.at(P.nb);
     RC(launch_head_backward(dt, last, (const float*)r.at(P.probs), d_y, d_sw, M0, (long)m->cfg.H * m->cfg.W,
                             m->head_C, m->cfg.n_classes, r.params + m->head_w, m->cfg.n_classes,

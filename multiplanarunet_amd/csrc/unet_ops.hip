@@ -272,7 +272,10 @@ int launch_pack_weights(int dtype, int mode, const float* W, int Cin, int Cout, 
 // one thread = one group of 8 output channels of one pixel (Cpad % 8 == 0): clamped unconditional loads (a predicated
 // scalar load per element is waited for on the spot), 16-byte stores
 template <typename T>
-__global__ void cast_pad_kernel(const float* __restrict__ x, long M, int Cin, int Cpad, T* __restrict__ out) {
+__global__ void cast_pad_kernel(const float* __restrict__ x, long M, int Cin, int Cpad, T* __restrict__ out, long long* zero_p,
+                                long zero_n) {
+    // (training forward: the step's first launch also zeroes the BatchNorm accumulators of both passes -- ConvArgs.stats_acc)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += (long)gridDim.x * blockDim.x) zero_p[i] = 0;
     const int gpp = Cpad >> 3;
     const long n = M * gpp;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
@@ -294,10 +297,11 @@ __global__ void cast_pad_kernel(const float* __restrict__ x, long M, int Cin, in
         }
     }
 }
-int launch_cast_pad(int dtype, const float* x, long M, int Cin, int Cpad, void* out, hipStream_t st) {
+int launch_cast_pad(int dtype, const float* x, long M, int Cin, int Cpad, void* out, hipStream_t st, long long* zero_p, long zero_n) {
     if (Cpad % 8 || Cin < 1 || Cin > Cpad) return fail(MPU_EINVAL, "%s", "cast_pad: padded channel count must be a multiple of 8");
-    if (dtype == MPU_BF16) cast_pad_kernel<bf16_t><<<ew_grid(M * Cpad / 8), 256, 0, st>>>(x, M, Cin, Cpad, (bf16_t*)out);
-    else cast_pad_kernel<float><<<ew_grid(M * Cpad / 8), 256, 0, st>>>(x, M, Cin, Cpad, (float*)out);
+    if (!zero_p) zero_n = 0;
+    if (dtype == MPU_BF16) cast_pad_kernel<bf16_t><<<ew_grid(M * Cpad / 8), 256, 0, st>>>(x, M, Cin, Cpad, (bf16_t*)out, zero_p, zero_n);
+    else cast_pad_kernel<float><<<ew_grid(M * Cpad / 8), 256, 0, st>>>(x, M, Cin, Cpad, (float*)out, zero_p, zero_n);
     return launch_ok();
 }
 
@@ -624,16 +628,6 @@ __global__ __launch_bounds__(256) void bn_fold_apply_kernel(const T* __restrict_
 }
 
 // 1 = launched (finalize + apply in one pass), 0 = not suited (the caller runs the two launches)
-__global__ __launch_bounds__(256) void zero_ll_kernel(long long* p, long n) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = 0;
-}
-int launch_zero_ll(long long* p, long n, hipStream_t st) {
-    if (n <= 0) return MPU_OK;
-    long blocks = (n + 1023) / 1024; if (blocks > 512) blocks = 512;
-    zero_ll_kernel<<<(unsigned)blocks, 256, 0, st>>>(p, n);
-    return launch_ok();
-}
-
 // acc != NULL (nblk = -1): the producer added its sums to the fixed-point accumulator (scales acc_scale[2]) instead of writing rows
 bool bn_fold_shape_ok(int C, int H, int W, bool pooled) { return !(C & 63) && !(pooled && ((H | W) & 1)); }
 int launch_bn_fold_fwd(int dtype, const void* x, int B, int H, int W, int C, const float* partial, int nblk,
