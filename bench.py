@@ -485,7 +485,7 @@ def bench_predict_sharded(device, quiet, rank, world, exchange="both", D=256, V=
     return out
 
 
-def bench_train_e2e(model, device, B, dim, headline, steps=120, warmup=12):
+def bench_train_e2e(model, device, B, dim, headline, steps=120, warmup=50):
     """sampler -> step, end to end, as `mp train` runs it (pipeline.TrainPipeline): planes of a 128^3
     synthetic volume cut by the HIP sampler (6 views, noise, foreground balancing: one 8-byte host read per candidate) on a
     side stream while the previous batch's graphed train step runs. Reported next to the serial form (same sampler, eager
@@ -530,7 +530,8 @@ def bench_train_e2e(model, device, B, dim, headline, steps=120, warmup=12):
     res["epoch_loss"] = round(loss, 5)
     res["fraction_of_headline"] = round(res["value"] / headline, 4) if headline else None
     res["producer_stream_latency_us"] = round(pipe.side_latency_us, 1) if pipe.side_latency_us is not None else None
-    res["launch"] = "sampler on a side stream (picked by measured latency beside a busy main stream) one batch ahead; step = hip-graph replay; loss summed on the device"
+    res["producer_stream_candidates_ms_per_step"] = pipe.side_loop_ms     # the real-loop windows the stream was chosen by (warm-up steps)
+    res["launch"] = "sampler on a side stream (picked by measurement: fill probe, then the first candidates under the real loop) one batch ahead; step = hip-graph replay; loss summed on the device"
     return res
 
 

@@ -168,6 +168,9 @@ def run(args):
     try:
         for ep in range(init_epoch, epochs):
             loss = pipe.run_epoch(steps)
+            if ep == init_epoch and pipe.side_loop_ms:     # (the first CAL_STREAMS x CAL_WINDOW steps tried the candidates)
+                log("Producer stream: candidates under the training loop %s ms per step%s" % (
+                    pipe.side_loop_ms, "" if pipe._cal is None else " (choice continues next epoch)"))
             if world > 1:                                  # the logged loss is the mean over all replicas' slices
                 t = torch.tensor([loss], dtype=torch.float64, device=device)
                 torch.distributed.all_reduce(t)
