@@ -62,6 +62,10 @@ __device__ __forceinline__ void stats_emit(const ConvArgs& a, int st2, int ch, l
     if (a.stats_acc) stats_acc_add(a.stats_acc, a.Cout, st2, ch, v, a.stats_scale[st2]);
     else a.stats[((long)st2 * a.Cout + ch) * nrows + row] = v;
 }
+// bias gradients of dtype "bf16x3" out of accumulators of the same layout (unet_ops.hip: launch_split3_colsum / launch_db_from_acc)
+struct DbAccJob { const long long* acc; float* db; int C; };
+constexpr int DB_ACC_MAX_JOBS = 32;
+struct DbAccTable { DbAccJob job[DB_ACC_MAX_JOBS]; int n = 0; float inv_scale = 0.f; };
 constexpr int BN_ACC_ROWS = 8;                   // XCDs
 inline long bn_acc_elems(int C) { return (long)BN_ACC_ROWS * 2 * C; }      // int64 elements of one accumulator
 
@@ -248,6 +252,8 @@ int launch_maxpool_bwd_add_stats(int dtype, const void* n, const void* dskip, co
                                  long partial_cap, int* rows, hipStream_t st, long long* acc = nullptr, const float* acc_scale = nullptr);
 // f32 tensor -> three bf16 planes stacked along the batch axis (order 0: hi | lo | hi, 1: hi | hi | lo): dtype "bf16x3" weight gradients
 int launch_split3(const float* x, long n, void* out, int order, hipStream_t st);
+int launch_split3_colsum(const float* dz, long M, int C, void* planes, long long* acc, float scale, hipStream_t st);
+int launch_db_from_acc(const DbAccTable& t, hipStream_t st);
 // db[c] = sum_m dz[m][c]
 int launch_colsum(int dtype, const void* dz, long M, int C, float* partial, float* out, hipStream_t st);
 // out[c] = sum_k partial[k*C + c], k < nblk (second stage only)

@@ -115,6 +115,7 @@ struct Plan {
     std::vector<long> bnacc_f, bnacc_b;             // per BatchNorm: its fixed-point accumulators of the forward statistics / backward sums
     long bnacc, bnacc_elems;                        //   (ConvArgs.stats_acc: int64 [8 XCDs][2][C]); one region: forward half first
     std::vector<long> x3x0, x3x1, x3dz;             // dtype "bf16x3": per conv the bf16 plane triples of its input source(s) and its dz
+    std::vector<long> dbacc;                        //   and, in the accumulator region, the fixed-point sums of its bias gradient
                                                     // (launch_split3), read by the grouped bf16 weight-gradient launches at the pass's end
 };
 
@@ -213,6 +214,11 @@ Plan make_plan(const mpu_unet* m, int B) {
         P.bnacc_f.assign(m->bn.size(), 0); P.bnacc_b.assign(m->bn.size(), 0);
         for (size_t i = 0; i < m->bn.size(); ++i) { P.bnacc_f[i] = e; e += bn_acc_elems(m->bn[i].C); }
         for (size_t i = 0; i < m->bn.size(); ++i) { P.bnacc_b[i] = e; e += bn_acc_elems(m->bn[i].C); }
+        if (m->x3) {                                // (dtype "bf16x3": the bias-gradient sums of every conv, zeroed with the rest)
+            P.dbacc.assign(m->conv.size(), -1);
+            for (size_t i = 0; i < m->conv.size(); ++i)
+                if (m->conv[i].mode != CONV1) { P.dbacc[i] = e; e += bn_acc_elems(m->conv[i].Cout); }
+        }
         P.bnacc_elems = e;
         P.bnacc = take(e * 8);
     }
@@ -237,7 +243,9 @@ struct Run {
     float* stat(const BN& b, int k) const { return (float*)(ws + P.stats) + b.st + (long)k * b.C; }
     long long* acc_f(const BN& b) const { return (long long*)(ws + P.bnacc) + P.bnacc_f[&b - &m->bn[0]]; }
     long long* acc_b(const BN& b) const { return (long long*)(ws + P.bnacc) + P.bnacc_b[&b - &m->bn[0]]; }
+    long long* acc_db(size_t ci) const { return (long long*)(ws + P.bnacc) + P.dbacc[ci]; }
     bool acc_mode = false;                                       // fused BatchNorm sums into fixed-point accumulators (MPU_BN_ATOMIC)
+    mutable DbAccTable dbq;                                      // dtype "bf16x3": bias gradients waiting in their accumulators
 };
 
 #define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
@@ -324,6 +332,16 @@ int conv_dgrad(const Run& r, const Conv& c, const void* dz, const void* mask, vo
     return rc;
 }
 
+// dtype "bf16x3": the bias gradients queued by conv_wgrad, out of their accumulators (one launch for all of them)
+constexpr float DB_ACC_SCALE = 17592186044416.f;                 // 2^44: |sum dz| < 2^19, quantum 6e-14 per workgroup sum
+int flush_db(const Run& r) {
+    if (r.dbq.n == 0) return MPU_OK;
+    r.dbq.inv_scale = 1.f / DB_ACC_SCALE;
+    const int rc = launch_db_from_acc(r.dbq, r.st);
+    r.dbq.n = 0;
+    return rc;
+}
+
 int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* x1, int C1, const void* dz, int lvl) {
     WgradArgs a;
     a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.dz = dz; a.Cout = c.Cout;
@@ -354,8 +372,14 @@ int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* 
         const long pin = (long)r.B * Hi * Wi;
         RC(launch_split3((const float*)x0, pin * C0, r.at(r.P.x3x0[ci_]), 0, r.st));
         if (x1) RC(launch_split3((const float*)x1, pin * C1, r.at(r.P.x3x1[ci_]), 0, r.st));
-        RC(launch_split3((const float*)dz, M * c.Cout, r.at(r.P.x3dz[ci_]), 1, r.st));
-        RC(launch_colsum(MPU_F32, dz, M, c.Cout, a.colsum_scratch, a.db, r.st));
+        if (r.acc_mode) {                              // one pass over dz: its planes + its column sums (finalized by flush_db)
+            RC(launch_split3_colsum((const float*)dz, M, c.Cout, r.at(r.P.x3dz[ci_]), r.acc_db(ci_), DB_ACC_SCALE, r.st));
+            if (r.dbq.n == DB_ACC_MAX_JOBS) RC(flush_db(r));
+            r.dbq.job[r.dbq.n++] = DbAccJob{r.acc_db(ci_), r.grads + c.b, c.Cout};
+        } else {
+            RC(launch_split3((const float*)dz, M * c.Cout, r.at(r.P.x3dz[ci_]), 1, r.st));
+            RC(launch_colsum(MPU_F32, dz, M, c.Cout, a.colsum_scratch, a.db, r.st));
+        }
         a.x0 = r.at(r.P.x3x0[ci_]); a.x1 = x1 ? r.at(r.P.x3x1[ci_]) : nullptr; a.dz = r.at(r.P.x3dz[ci_]);
         a.B = 3 * r.B; a.db = nullptr; a.x3 = 0;
         wgrad_partial_elems(c.mode, c.Cin, c.Cout, 3 * M, &a.ksplit, &a.mchunk, r.group);
@@ -532,6 +556,8 @@ int mark_ready(const Run& r, int k) {
     if (rc) return rc;
     rc = flush_wgrad_reduces(r.rq, r.st);
     if (rc) return rc;
+    rc = flush_db(r);
+    if (rc) return rc;
     MPU_CHECK_HIP(hipEventRecord((hipEvent_t)r.ready_events[k], r.st));
     return MPU_OK;
 }
@@ -670,6 +696,7 @@ void pack_jobs_of(const mpu_unet* m, PackTable& tab) {
 int finish_backward(const Run& r, const AdamOpt* opt) {
     const mpu_unet* m = r.m; const int dt = m->cfg.dtype;
     const int wdt = m->x3 ? MPU_BF16 : dt;                       // (dtype "bf16x3": the grouped weight gradients are bf16 jobs)
+    RC(flush_db(r));
     if (!opt) {
         RC(flush_wgrad_group(wdt, r.grp, r.st));
         return flush_wgrad_reduces(r.rq, r.st);
@@ -678,9 +705,8 @@ int finish_backward(const Run& r, const AdamOpt* opt) {
     if (!tail_overlap_wanted(r)) {                               // the serial order: the step counter moves behind the update
         RC(flush_wgrad_group(wdt, r.grp, r.st));
         RC(flush_wgrad_reduces(r.rq, r.st));
-        RC(launch_adam_pack_all(dt, jobs, opt->params, r.grads, opt->am, opt->av, m->n_params, opt->packed, opt->step, opt->t,
-                                opt->lr, opt->b1, opt->b2, opt->eps, r.st));
-        return m->x3 ? launch_x3_words(opt->packed, m->n_packed, r.st) : MPU_OK;
+        return launch_adam_pack_all(m->x3 ? MPU_F32X3 : dt, jobs, opt->params, r.grads, opt->am, opt->av, m->n_params, opt->packed,
+                                    opt->step, opt->t, opt->lr, opt->b1, opt->b2, opt->eps, r.st);   // (x3: operand words written here)
     }
     // (from here on a device step counter already holds this step's number: launch_head_backward advanced it)
     long lo = 0, hi = 0;                                         // the early range: longest run of convs outside the taps group
@@ -739,7 +765,7 @@ int make_run(Run& r, const mpu_unet* m, int batch, const float* params, const vo
     r.group = env(ENV_WGRAD_GROUP) != 0;      // 0: every weight-gradient kernel as its own launch, in place (A/B)
     // bf16 storage only: a fixed-point unit of 2^-16 on a tile's sum of squares is far below the rounding of the stored bf16 values,
     // but it is visible at the f32 parity mode's level (train-mode logits 1.3e-4 against 4e-5 with the rows: gpurun R6v)
-    r.acc_mode = env(ENV_BN_ATOMIC) != 0 && env(ENV_BN_FOLD) != 0 && env(ENV_FUSED_BN_STATS) != 0 && m->cfg.dtype == MPU_BF16;
+    r.acc_mode = env(ENV_BN_ATOMIC) != 0 && env(ENV_BN_FOLD) != 0 && env(ENV_FUSED_BN_STATS) != 0 && (m->cfg.dtype == MPU_BF16 || m->x3);
     return MPU_OK;
 }
 
@@ -869,9 +895,8 @@ int mpu_unet_adam_pack(const mpu_unet* m, float* d_params, const float* d_grads,
         j.mode = c.mode; j.Cin = c.Cin; j.Cout = c.Cout; j.unit_begin = j.fwd_units = j._pad = 0;
         j.w = c.w; j.wf = c.wf; j.wd = c.wd;
     }
-    RC(launch_adam_pack_all(m->cfg.dtype, tab, d_params, d_grads, d_m, d_v, m->n_params, d_packed, (long long*)d_step,
-                            (long long)t, lr, beta1, beta2, (float)eps, (hipStream_t)stream));
-    return m->x3 ? launch_x3_words(d_packed, m->n_packed, (hipStream_t)stream) : MPU_OK;
+    return launch_adam_pack_all(m->x3 ? MPU_F32X3 : m->cfg.dtype, tab, d_params, d_grads, d_m, d_v, m->n_params, d_packed,
+                                (long long*)d_step, (long long)t, lr, beta1, beta2, (float)eps, (hipStream_t)stream);
 }
 
 int mpu_unet_prepare_inference(const mpu_unet* m, const float* d_params, const float* d_bn_state, void* d_packed,

@@ -313,11 +313,14 @@ int launch_cast_pad(int dtype, const float* x, long M, int Cin, int Cpad, void* 
 // partial layout [nblk][NS][C]
 // ------------------------------------------------------------------------- //
 constexpr int CR_THREADS = 512;      // column-reduction block size
-template <typename T, int OP>
+// SPLIT (dtype "bf16x3", OP 2 on the f32 dz of a conv): the pass that sums the bias gradient also writes the three bf16 planes
+// hi | hi | lo of its input for the weight-gradient kernels (see split3_kernel) -- dz is read once instead of twice
+template <typename T, int OP, bool SPLIT = false>
 __global__ __launch_bounds__(CR_THREADS) void colreduce_kernel(const T* __restrict__ a, const T* __restrict__ b, long M, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         int rows_per_blk, float* __restrict__ partial, long long* acc_out,
-                                                        float acc_scale0, float acc_scale1) {
+                                                        float acc_scale0, float acc_scale1, bf16_t* __restrict__ sp_out = nullptr) {
+    static_assert(!SPLIT || (OP == 2 && Vec<T>::N == 4), "SPLIT: the f32 bias-gradient pass");
     constexpr int N = Vec<T>::N;
     constexpr int NS = OP == 2 ? 1 : 2;
     __shared__ float red[CR_THREADS * N * NS];
@@ -339,6 +342,15 @@ __global__ __launch_bounds__(CR_THREADS) void colreduce_kernel(const T* __restri
 #pragma unroll
                 for (int i = 0; i < N; ++i) { mu[i] = mean[c * N + i]; is[i] = invstd[c * N + i]; }
             }
+            auto split_store = [&](const float* v, long e) {      // e: element index of v[0] in the [M][C] tensor
+                const long n = M * C;
+                const uint32_t h0 = f32x2_to_bf16x2(v[0], v[1]), h1 = f32x2_to_bf16x2(v[2], v[3]);
+                const uint32_t l0 = f32x2_to_bf16x2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
+                const uint32_t l1 = f32x2_to_bf16x2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+                *reinterpret_cast<uint2*>(sp_out + e) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(sp_out + n + e) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(sp_out + 2 * n + e) = make_uint2(l0, l1);
+            };
             auto accum = [&](const float* va, const float* vb) {
                 if (OP == 0) {
 #pragma unroll
@@ -360,13 +372,17 @@ __global__ __launch_bounds__(CR_THREADS) void colreduce_kernel(const T* __restri
                     if (OP == 1) Vec<T>::load(b + (r + (long)u * TY) * C + (long)c * N, vb[u]);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) accum(va[u], vb[u]);
+                for (int u = 0; u < 4; ++u) {
+                    accum(va[u], vb[u]);
+                    if (SPLIT) split_store(va[u], (r + (long)u * TY) * C + (long)c * N);
+                }
             }
             for (; r < r_end; r += TY) {
                 float va[N], vb[N];
                 Vec<T>::load(a + r * C + (long)c * N, va);
                 if (OP == 1) Vec<T>::load(b + r * C + (long)c * N, vb);
                 accum(va, vb);
+                if (SPLIT) split_store(va, r * C + (long)c * N);
             }
         }
         // reduce over ty through LDS
@@ -1077,6 +1093,30 @@ int launch_split3(const float* x, long n, void* out, int order, hipStream_t st) 
     return launch_ok();
 }
 
+// dtype "bf16x3" with the fixed-point accumulators on: ONE pass over the f32 dz of a conv writes its bf16 planes (hi | hi | lo) and adds
+// its column sums -- the bias gradient -- to an accumulator of the bn_acc layout (row 0 of each XCD's pair); launch_db_from_acc
+// turns the accumulators of all convs queued so far into the f32 bias gradients with one small launch
+int launch_split3_colsum(const float* dz, long M, int C, void* planes, long long* acc, float scale, hipStream_t st) {
+    if (C % 4 || !acc) return fail(MPU_EINVAL, "%s", "split3_colsum: channel count must be a multiple of 4, accumulator required");
+    if (M == 0) return MPU_OK;
+    int rpb; const int nblk = red_blocks(M, C, &rpb);
+    colreduce_kernel<float, 2, true><<<nblk, CR_THREADS, 0, st>>>(dz, nullptr, M, C, nullptr, nullptr, rpb, nullptr, acc, scale, 0.f,
+                                                                  (bf16_t*)planes);
+    return launch_ok();
+}
+__global__ __launch_bounds__(256) void db_from_acc_kernel(DbAccTable t) {
+    const DbAccJob j = t.job[blockIdx.y];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < j.C) j.db[c] = (float)bn_acc_sum(j.acc, j.C, 0, c, t.inv_scale);
+}
+int launch_db_from_acc(const DbAccTable& t, hipStream_t st) {
+    if (t.n <= 0) return MPU_OK;
+    int cmax = 0;
+    for (int i = 0; i < t.n; ++i) cmax = t.job[i].C > cmax ? t.job[i].C : cmax;
+    db_from_acc_kernel<<<dim3(cdiv(cmax, 256), t.n), 256, 0, st>>>(t);
+    return launch_ok();
+}
+
 int launch_colsum_finalize(const float* partial, int nblk, int C, float* out, hipStream_t st) {
     colsum_finalize_kernel<<<cdiv(C, FIN_COLS), 256, 0, st>>>(partial, nblk, C, out);
     return launch_ok();
@@ -1529,11 +1569,16 @@ __device__ __forceinline__ float adam_alpha_dev(const long long* step, double lr
 //                W_eff[dy][dx] = sum of the taps S(dy) x S(dx), which needs all four updated taps of an element).
 //   plain units: everything that is not a 3x3 / 2x2 kernel (biases, BatchNorm gamma / beta, the 1x1 head): Adam only,
 //                1024 floats per unit, ranges in the table.
+// dtype "bf16x3": the packed f32 operand words hold bf16 hi | bf16 lo << 16 (common.h: x3_word) -- written by the optimizer pass itself
+template <int N> __device__ __forceinline__ void x3_words_of(float (&v)[N]) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] = __uint_as_float(x3_word(v[e]));
+}
 struct AdamRange { long off, n; int unit_begin, _pad; };
 constexpr int ADAM_MAX_RANGES = 48;
 struct AdamPackTable { int njobs, nranges, plain_begin, _pad; PackJob job[PACK_MAX_JOBS]; AdamRange range[ADAM_MAX_RANGES]; };
 
-template <typename T>
+template <typename T, bool X3 = false>
 __device__ __forceinline__ void adam_pack_conv3_tile(const PackJob& j, int t, float* __restrict__ params,
                                                      const float* __restrict__ grads, float* __restrict__ am,
                                                      float* __restrict__ av, T* packed, float (*tile)[65], float alpha,
@@ -1582,6 +1627,7 @@ __device__ __forceinline__ void adam_pack_conv3_tile(const PackJob& j, int t, fl
             float v[N];
 #pragma unroll
             for (int e = 0; e < N; ++e) v[e] = tile[cil + e][col];
+            if (X3) x3_words_of<N>(v);
             Vec<T>::store(dstf + (long)co * Cin + ci, v);
         }
     }
@@ -1594,12 +1640,13 @@ __device__ __forceinline__ void adam_pack_conv3_tile(const PackJob& j, int t, fl
             float v[N];
 #pragma unroll
             for (int e = 0; e < N; ++e) v[e] = tile[row][col + e];
+            if (X3) x3_words_of<N>(v);
             Vec<T>::store(dstd + (long)ci * Cout + co, v);
         }
     }
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 __device__ __forceinline__ void adam_pack_upconv_tile(const PackJob& j, int t, float* __restrict__ params,
                                                       const float* __restrict__ grads, float* __restrict__ am,
                                                       float* __restrict__ av, T* packed, float (*tile64)[65], float alpha,
@@ -1648,6 +1695,7 @@ __device__ __forceinline__ void adam_pack_upconv_tile(const PackJob& j, int t, f
             float v[N];
 #pragma unroll
             for (int e = 0; e < N; ++e) v[e] = tile[tp][cil + e][col];
+            if (X3) x3_words_of<N>(v);
             Vec<T>::store(packed + j.wf + tp * per_tap + (long)co * Cin + ci, v);
         }
     }
@@ -1670,12 +1718,13 @@ __device__ __forceinline__ void adam_pack_upconv_tile(const PackJob& j, int t, f
                     for (int e = 0; e < N; ++e) v[e] += tile[ky * 2 + kx][row][col + e];
                 }
             }
+            if (X3) x3_words_of<N>(v);
             Vec<T>::store(packed + j.wd + tp * per_tap + (long)ci * Cout + co, v);
         }
     }
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256) void adam_pack_all_kernel(AdamPackTable tab, float* __restrict__ params,
                                                             const float* __restrict__ grads, float* __restrict__ am,
                                                             float* __restrict__ av, T* packed, const long long* __restrict__ step,
@@ -1711,8 +1760,8 @@ __global__ __launch_bounds__(256) void adam_pack_all_kernel(AdamPackTable tab, f
     while (ji + 1 < tab.njobs && u0 >= tab.job[ji + 1].unit_begin) ++ji;
     const PackJob& j = tab.job[ji];
     const int u = u0 - j.unit_begin;
-    if (j.mode == UPCONV2) adam_pack_upconv_tile<T>(j, u, params, grads, am, av, packed, tile, alpha, b1, b2, eps);
-    else adam_pack_conv3_tile<T>(j, u, params, grads, am, av, packed, tile, alpha, b1, b2, eps);
+    if (j.mode == UPCONV2) adam_pack_upconv_tile<T, X3>(j, u, params, grads, am, av, packed, tile, alpha, b1, b2, eps);
+    else adam_pack_conv3_tile<T, X3>(j, u, params, grads, am, av, packed, tile, alpha, b1, b2, eps);
 }
 
 __global__ void incr_step_kernel(long long* step);
@@ -1751,6 +1800,8 @@ int launch_adam_pack_all(int dtype, PackTable& jobs, float* params, const float*
     if (!step) alpha_host = (float)(lr * std::sqrt(1.0 - std::pow(b2, (double)t_host)) / (1.0 - std::pow(b1, (double)t_host)));
     if (dtype == MPU_BF16)
         adam_pack_all_kernel<bf16_t><<<units, 256, 0, st>>>(tab, params, grads, am, av, (bf16_t*)packed, step, lr, b1, b2, alpha_host, eps, 1);
+    else if (dtype == MPU_F32X3)                                 // (f32 storage, operand words = bf16 hi | lo: no x3_words pass afterwards)
+        adam_pack_all_kernel<float, true><<<units, 256, 0, st>>>(tab, params, grads, am, av, (float*)packed, step, lr, b1, b2, alpha_host, eps, 1);
     else
         adam_pack_all_kernel<float><<<units, 256, 0, st>>>(tab, params, grads, am, av, (float*)packed, step, lr, b1, b2, alpha_host, eps, 1);
     if (step) incr_step_kernel<<<1, 1, 0, st>>>(step);

@@ -276,11 +276,13 @@ def test_graphed_train_step_survives_a_larger_eager_batch_in_between():
     assert torch.equal(a.params, b.params) and torch.equal(a.bn_state, b.bn_state)
 
 
-@pytest.mark.parametrize("dtype,cf,C", [("bf16", 1, 1), ("bf16", 2, 2), ("f32", 0.25, 1)])
+@pytest.mark.parametrize("dtype,cf,C", [("bf16", 1, 1), ("bf16", 2, 2), ("f32", 0.25, 1), ("bf16x3", 0.5, 1), ("bf16x3", 2, 2)])
 def test_fused_adam_pack_equals_adam_then_pack(dtype, cf, C):
     """mpu_unet_adam_pack (one launch: Adam + both packed operand copies) == mpu_adam_step + mpu_unet_pack_weights,
     bit for bit: parameters, Adam moments and every byte of the packed buffer (3x3 rotated-tap and 2x2 combined-tap
-    data-gradient copies included), over three steps; odd filter counts (cf=2: 90/181/...) exercise the channel tails."""
+    data-gradient copies included), over three steps; odd filter counts (cf=2: 90/181/...) exercise the channel tails. dtype
+    "bf16x3": the fused pass writes the hi | lo operand words itself (adam_pack_all_kernel<float, true>), the two-pass form converts
+    the packed f32 operands afterwards (x3_words_kernel)."""
     from multiplanarunet_amd.unet import UNet
     rng = np.random.RandomState(8)
     B, H, D = 2, 32, 2
