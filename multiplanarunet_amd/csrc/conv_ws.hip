@@ -162,7 +162,10 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
     const bool n_ok = wn * 32 + (lane & 3) * 8 < a.Cout;
     const int out_l = ((wm * TM * W + (lane >> 2)) * a.Cout + wn * 32 + (lane & 3) * 8) * 2;
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(npix * a.Cout * 2L), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask ? a.mask : a.out), 0,
+    // second per-pixel input of the epilogue, same layout as the output: the ReLU mask of a data-gradient launch, or (round 6) the
+    // pre-BatchNorm activation x of a launch that also sums BatchNorm-backward terms (bn_x; the two never come together)
+    const bool bnx = a.stats && a.bn_x && !a.mask;
+    const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask ? a.mask : (bnx ? a.bn_x : a.out)), 0,
                                                                           (int)(npix * a.Cout * 2L), 0x00020000);
     float stat_acc = 0.f;     // fused BN statistics: lane L of a wave owns value L = (channel group, channel, sum | sum^2)
     int buf = 0;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
 #pragma unroll                                                       // up front, not one round trip per pass
             for (int it = 0; it < Cfg::WPX / 16; ++it) {
                 const int j = it >> 1;
-                const bool ok = a.mask && n_ok && ((it & 1) ? xok1 : xok0) && (y0 + wm * TM + j < H);
+                const bool ok = (a.mask || bnx) && n_ok && ((it & 1) ? xok1 : xok0) && (y0 + wm * TM + j < H);
                 mkv[it] = __builtin_amdgcn_raw_buffer_load_b128(
                     rsm, ok ? (unsigned)(obase + out_l + (j * W + (it & 1) * 16) * a.Cout * 2) : OOB, 0, 0);
             }
@@ -307,10 +310,15 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
                 __builtin_amdgcn_raw_buffer_store_b128(val, rso, off, 0, 0);
                 if (a.stats && ok) {
                     const uint32_t wv[4] = {val.x, val.y, val.z, val.w};
+                    const u32x4 xk = mkv[it];
+                    const uint32_t xv[4] = {xk.x, xk.y, xk.z, xk.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float lo = __uint_as_float(wv[e] << 16), hi = __uint_as_float(wv[e] & 0xffff0000u);
-                        tsum[2 * e] += lo; tsq[2 * e] += lo * lo; tsum[2 * e + 1] += hi; tsq[2 * e + 1] += hi * hi;
+                        // forward: (sum y, sum y^2); BatchNorm backward: (sum dn, sum dn * x) -- x still raw: sum dn * xhat =
+                        // invstd * (sum dn * x - mean * sum dn) is formed once per workgroup at the end
+                        const float lo2 = bnx ? __uint_as_float(xv[e] << 16) : lo, hi2 = bnx ? __uint_as_float(xv[e] & 0xffff0000u) : hi;
+                        tsum[2 * e] += lo; tsq[2 * e] += lo * lo2; tsum[2 * e + 1] += hi; tsq[2 * e + 1] += hi * hi2;
                     }
                 }
             }
@@ -358,8 +366,13 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
         cb[wave * 64 + lane] = stat_acc;
         __syncthreads();
         if (wm == 0) {
-            const float v = cb[wave * 64 + lane] + cb[(wave + 2) * 64 + lane];
+            float v = cb[wave * 64 + lane] + cb[(wave + 2) * 64 + lane];
             const int ch = wn * 32 + (lane >> 4) * 8 + ((lane & 15) >> 1), st2 = lane & 1;
+            if (bnx) {                                               // odd lanes: sum dn * x -> sum dn * xhat (even lane = sum dn)
+                const float sdn = __shfl_xor(v, 1, 64);
+                const int chc = ch < a.Cout ? ch : 0;
+                if (st2) v = a.bn_invstd[chc] * (v - a.bn_mean[chc] * sdn);
+            }
             if (ch < a.Cout) stats_emit(a, st2, ch, gridDim.x, blockIdx.x, v);      // [2][Cout][workgroups], or the accumulator
         }
     }
@@ -386,8 +399,9 @@ int launch_ws(const ConvArgs& a_in, hipStream_t st) {
     const long tx = cdiv(a.Wo, Cfg::TW), ty = cdiv(a.Ho, TH);
     if (tiles * (tx > ty ? tx : ty) >= (1L << 32)) return fail(MPU_EUNSUPPORTED, "%s", "conv: too many tiles");
     const unsigned mx = (unsigned)(((1UL << 32) + tx - 1) / tx), my = (unsigned)(((1UL << 32) + ty - 1) / ty);
-    if (a.stats && a.stats_rows && !a.bn_x && (long)grid * 2 * a.Cout <= a.stats_cap) *a.stats_rows = grid;
-    else a.stats = nullptr;                                      // (forward statistics only: bn_x -> the caller reduces)
+    if (a.stats && a.stats_rows && !(a.bn_x && (a.mask || HEAD || !a.bn_mean || !a.bn_invstd)) && (long)grid * 2 * a.Cout <= a.stats_cap)
+        *a.stats_rows = grid;                                    // (forward statistics, or the BatchNorm-backward sums of a data gradient)
+    else a.stats = nullptr;
     if (a.pooled && a.pooled_done && !a.mask && !(a.Ho & 1) && !(a.Wo & 1)) *a.pooled_done = 1;
     else a.pooled = nullptr;
     if (HEAD) *a.head_done = 1;
