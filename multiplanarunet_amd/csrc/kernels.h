@@ -73,7 +73,8 @@ struct WgradArgs {
     const void* x0; const void* x1; int C0, C1;
     const void* dz; int Cout;
     int x3 = 0;                  // f32 storage only: split-bf16 products instead of exact-f32 MFMAs (sits in the padding behind Cout:
-                                 //   the grouped launches carry 24 of these structs in 4 KB of kernel arguments)
+                                 //   the grouped launches carry 24 of these structs in 4 KB of kernel arguments). In a BF16 job of
+                                 //   wgrad_taps: -P = the batch is three plane pairs of P images over TWO stored planes (hi | lo)
     float* partial;              // [ksplit][ntaps*Cin*Cout]
     float* db_partial;           // [ksplit][Cout] (fused bias-gradient partials; set by the launcher)
     int B, Ho, Wo, ksplit, mchunk;
@@ -251,8 +252,12 @@ int launch_maxpool_bwd_add_stats(int dtype, const void* n, const void* dskip, co
                                  void* dn, const void* x, const float* mean, const float* invstd, float* partial,
                                  long partial_cap, int* rows, hipStream_t st, long long* acc = nullptr, const float* acc_scale = nullptr);
 // f32 tensor -> three bf16 planes stacked along the batch axis (order 0: hi | lo | hi, 1: hi | hi | lo): dtype "bf16x3" weight gradients
+struct Split3Job { const float* src; uint16_t* dst; long n; int blk_begin; int order; };   // order 0: hi | lo | hi, 1: hi | hi | lo, 2: hi | lo
+constexpr int SPLIT3_MAX_JOBS = 64;
+struct Split3Table { Split3Job job[SPLIT3_MAX_JOBS]; int n = 0; };
+int launch_split3_all(Split3Table& t, hipStream_t st);           // all jobs in one launch (blk_begin is filled in)
 int launch_split3(const float* x, long n, void* out, int order, hipStream_t st);
-int launch_split3_colsum(const float* dz, long M, int C, void* planes, long long* acc, float scale, hipStream_t st);
+int launch_split3_colsum(const float* dz, long M, int C, void* planes, long long* acc, float scale, hipStream_t st, int two_planes = 0);
 int launch_db_from_acc(const DbAccTable& t, hipStream_t st);
 // db[c] = sum_m dz[m][c]
 int launch_colsum(int dtype, const void* dz, long M, int C, float* partial, float* out, hipStream_t st);

@@ -246,6 +246,8 @@ struct Run {
     long long* acc_db(size_t ci) const { return (long long*)(ws + P.bnacc) + P.dbacc[ci]; }
     bool acc_mode = false;                                       // fused BatchNorm sums into fixed-point accumulators (MPU_BN_ATOMIC)
     mutable DbAccTable dbq;                                      // dtype "bf16x3": bias gradients waiting in their accumulators
+    mutable std::vector<char> x3_presplit;                       //   per conv: its input planes were written by the pass's first launch
+    mutable std::vector<char> x3_two;                            //   per conv: two stored planes (hi | lo): its weight gradient is a wgrad_taps job
 };
 
 #define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
@@ -332,6 +334,61 @@ int conv_dgrad(const Run& r, const Conv& c, const void* dz, const void* mask, vo
     return rc;
 }
 
+// The tensors the weight gradient of conv ci reads as its input (what run_backward passes to conv_wgrad; checked there)
+struct WgradIn { const void* x0; int C0; const void* x1; int C1; long pin; int lvl_out; };
+WgradIn wgrad_inputs(const Run& r, int ci) {
+    const mpu_unet* m = r.m; const int D = m->cfg.depth; const Plan& P = r.P;
+    WgradIn w{nullptr, 0, nullptr, 0, 0, 0};
+    int lvl_in;
+    if (ci < 2 * D) {
+        const int i = ci / 2; lvl_in = i;
+        if (ci % 2 == 0) { w.x0 = i > 0 ? r.at(P.p[i - 1]) : r.at(P.xin); w.C0 = i > 0 ? m->F[i - 1] : m->cin_pad; }
+        else { w.x0 = r.at(P.c1[i]); w.C0 = m->F[i]; }
+    } else if (ci == 2 * D) { w.x0 = D > 0 ? r.at(P.p[D - 1]) : r.at(P.xin); w.C0 = D > 0 ? m->F[D - 1] : m->cin_pad; lvl_in = D; }
+    else if (ci == 2 * D + 1) { w.x0 = r.at(P.c1b); w.C0 = m->F[D]; lvl_in = D; }
+    else {
+        const int j = (ci - 2 * D - 2) / 3, k = (ci - 2 * D - 2) % 3, lvl = D - 1 - j, f = m->F[lvl];
+        if (k == 0) { w.x0 = j > 0 ? r.at(P.n2[j - 1]) : r.at(P.nb); w.C0 = j > 0 ? m->F[lvl + 1] : m->F[D]; lvl_in = lvl + 1; }
+        else if (k == 1) { w.x0 = r.at(P.n[lvl]); w.C0 = f; w.x1 = r.at(P.n1[j]); w.C1 = f; lvl_in = lvl; }
+        else { w.x0 = r.at(P.c2u[j]); w.C0 = f; lvl_in = lvl; }
+    }
+    w.pin = (long)r.B * (m->cfg.H >> lvl_in) * (m->cfg.W >> lvl_in);
+    w.lvl_out = (ci >= 2 * D + 2 && (ci - 2 * D - 2) % 3 == 0) ? lvl_in - 1 : lvl_in;      // (the up-conv writes the level above its input)
+    return w;
+}
+// dtype "bf16x3": the bf16 planes of every conv's input in ONE launch at the start of the backward pass
+int x3_presplit_inputs(const Run& r) {
+    const mpu_unet* m = r.m;
+    Split3Table t;
+    r.x3_presplit.assign(m->conv.size(), 0);
+    // Which layers will be wgrad_taps jobs of the grouped launch (the only kernel that folds the batch onto two stored planes):
+    // launch_wgrad_mode's decision, from the shapes -- the first layer goes to wgrad_c8, a layer joins the taps group while it has
+    // room. conv_wgrad CHECKS the outcome and fails if a predicted job went elsewhere.
+    r.x3_two.assign(m->conv.size(), 0);
+    if (r.group && r.acc_mode && env(ENV_WGRAD_BATCHED_REDUCE) != 0) {     // (acc_mode: the dz pass that knows two planes)
+        int ntaps = 0, njobs = 0;
+        for (size_t ci = 1; ci < m->conv.size(); ++ci) {
+            const Conv& c = m->conv[ci];
+            if (c.mode == CONV1) continue;
+            const WgradIn w = wgrad_inputs(r, (int)ci);
+            const int Ho = m->cfg.H >> w.lvl_out, Wo = m->cfg.W >> w.lvl_out;
+            ++njobs;
+            if (wgrad_taps_plan(MPU_BF16, c.mode, 3 * r.B, Ho, Wo, w.C0, w.C1, c.Cout, true).use) { r.x3_two[ci] = 1; ++ntaps; }
+        }
+        if (ntaps > TAPS_GROUP_MAX || njobs + 1 >= REDUCE_MAX_JOBS) r.x3_two.assign(m->conv.size(), 0);
+    }
+    for (size_t ci = 0; ci < m->conv.size(); ++ci) {
+        if (m->conv[ci].mode == CONV1 || r.P.x3x0[ci] < 0) continue;
+        const WgradIn w = wgrad_inputs(r, (int)ci);
+        if (t.n + 2 > SPLIT3_MAX_JOBS) break;                    // (the rest is split layer by layer in conv_wgrad)
+        const int order = r.x3_two[ci] ? 2 : 0;
+        t.job[t.n++] = Split3Job{(const float*)w.x0, (uint16_t*)r.at(r.P.x3x0[ci]), w.pin * w.C0, 0, order};
+        if (w.x1) t.job[t.n++] = Split3Job{(const float*)w.x1, (uint16_t*)r.at(r.P.x3x1[ci]), w.pin * w.C1, 0, order};
+        r.x3_presplit[ci] = 1;
+    }
+    return launch_split3_all(t, r.st);
+}
+
 // dtype "bf16x3": the bias gradients queued by conv_wgrad, out of their accumulators (one launch for all of them)
 constexpr float DB_ACC_SCALE = 17592186044416.f;                 // 2^44: |sum dz| < 2^19, quantum 6e-14 per workgroup sum
 int flush_db(const Run& r) {
@@ -370,10 +427,17 @@ int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* 
         // (unet_ops.hip: launch_split3); the bias gradient, which is no product, is the plain column sum of the f32 dz
         const int Hi = c.mode == UPCONV2 ? a.Ho / 2 : a.Ho, Wi = c.mode == UPCONV2 ? a.Wo / 2 : a.Wo;
         const long pin = (long)r.B * Hi * Wi;
-        RC(launch_split3((const float*)x0, pin * C0, r.at(r.P.x3x0[ci_]), 0, r.st));
-        if (x1) RC(launch_split3((const float*)x1, pin * C1, r.at(r.P.x3x1[ci_]), 0, r.st));
+        if (ci_ < r.x3_presplit.size() && r.x3_presplit[ci_]) {  // (planes written by x3_presplit_inputs: same tensors?)
+            const WgradIn w = wgrad_inputs(r, (int)ci_);
+            if (w.x0 != x0 || w.x1 != x1 || w.C0 != C0 || w.C1 != C1 || w.pin != pin)
+                return fail(MPU_EINVAL, "%s", "conv_wgrad: the pre-split input planes belong to other tensors (wgrad_inputs out of date)");
+        } else {
+            RC(launch_split3((const float*)x0, pin * C0, r.at(r.P.x3x0[ci_]), 0, r.st));
+            if (x1) RC(launch_split3((const float*)x1, pin * C1, r.at(r.P.x3x1[ci_]), 0, r.st));
+        }
+        const bool two = r.acc_mode && ci_ < r.x3_presplit.size() && r.x3_presplit[ci_] && r.x3_two[ci_];   // (hi | lo planes: a wgrad_taps job)
         if (r.acc_mode) {                              // one pass over dz: its planes + its column sums (finalized by flush_db)
-            RC(launch_split3_colsum((const float*)dz, M, c.Cout, r.at(r.P.x3dz[ci_]), r.acc_db(ci_), DB_ACC_SCALE, r.st));
+            RC(launch_split3_colsum((const float*)dz, M, c.Cout, r.at(r.P.x3dz[ci_]), r.acc_db(ci_), DB_ACC_SCALE, r.st, two ? 1 : 0));
             if (r.dbq.n == DB_ACC_MAX_JOBS) RC(flush_db(r));
             r.dbq.job[r.dbq.n++] = DbAccJob{r.acc_db(ci_), r.grads + c.b, c.Cout};
         } else {
@@ -381,9 +445,12 @@ int conv_wgrad(const Run& r, const Conv& c, const void* x0, int C0, const void* 
             RC(launch_colsum(MPU_F32, dz, M, c.Cout, a.colsum_scratch, a.db, r.st));
         }
         a.x0 = r.at(r.P.x3x0[ci_]); a.x1 = x1 ? r.at(r.P.x3x1[ci_]) : nullptr; a.dz = r.at(r.P.x3dz[ci_]);
-        a.B = 3 * r.B; a.db = nullptr; a.x3 = 0;
+        a.B = 3 * r.B; a.db = nullptr; a.x3 = two ? -r.B : 0;
         wgrad_partial_elems(c.mode, c.Cin, c.Cout, 3 * M, &a.ksplit, &a.mchunk, r.group);
-        return launch_wgrad(MPU_BF16, c.mode, a, r.grads + c.w, r.st, q, (r.group && q) ? &r.grp : nullptr);
+        RC(launch_wgrad(MPU_BF16, c.mode, a, r.grads + c.w, r.st, q, (r.group && q) ? &r.grp : nullptr));
+        if (two && r.grp.ntaps != ntaps_before + 1)
+            return fail(MPU_EINVAL, "%s", "conv_wgrad (bf16x3): a layer split into two planes did not become a wgrad_taps job");
+        return MPU_OK;
     }
     const int rc = launch_wgrad(r.m->cfg.dtype, c.mode, a, r.grads + c.w, r.st, q, (r.group && q) ? &r.grp : nullptr);
     if (!rc && r.grp.ntaps > ntaps_before) { if (r.late.size() != r.m->conv.size()) r.late.assign(r.m->conv.size(), 0); r.late[ci_] = 1; }
@@ -581,6 +648,7 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
                             (float*)r.at(P.partial), gA, r.grads + m->head_w, r.grads + m->head_b, d_loss, r.st,
                             (opt && opt->step && tail_overlap_wanted(r)) ? opt->step : nullptr));
     tap_aux(r, 7, -1, 0, m->head_C, m->cfg.n_classes, last, r.at(P.probs), d_y, d_sw, gA, m->head_w, m->head_b);
+    if (m->x3) RC(x3_presplit_inputs(r));
     int point = 0;
     RC(mark_ready(r, point++));                                                            // head
     // (weight gradients on a side stream next to the data gradients were measured twice -- 3.08 vs 3.03 ms in round 2 --

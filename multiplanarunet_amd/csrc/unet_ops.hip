@@ -319,7 +319,8 @@ template <typename T, int OP, bool SPLIT = false>
 __global__ __launch_bounds__(CR_THREADS) void colreduce_kernel(const T* __restrict__ a, const T* __restrict__ b, long M, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         int rows_per_blk, float* __restrict__ partial, long long* acc_out,
-                                                        float acc_scale0, float acc_scale1, bf16_t* __restrict__ sp_out = nullptr) {
+                                                        float acc_scale0, float acc_scale1, bf16_t* __restrict__ sp_out = nullptr,
+                                                        int sp_two = 0 /* 1: two stored planes hi | lo */) {
     static_assert(!SPLIT || (OP == 2 && Vec<T>::N == 4), "SPLIT: the f32 bias-gradient pass");
     constexpr int N = Vec<T>::N;
     constexpr int NS = OP == 2 ? 1 : 2;
@@ -348,6 +349,7 @@ __global__ __launch_bounds__(CR_THREADS) void colreduce_kernel(const T* __restri
                 const uint32_t l0 = f32x2_to_bf16x2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
                 const uint32_t l1 = f32x2_to_bf16x2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
                 *reinterpret_cast<uint2*>(sp_out + e) = make_uint2(h0, h1);
+                if (sp_two) { *reinterpret_cast<uint2*>(sp_out + n + e) = make_uint2(l0, l1); return; }
                 *reinterpret_cast<uint2*>(sp_out + n + e) = make_uint2(h0, h1);
                 *reinterpret_cast<uint2*>(sp_out + 2 * n + e) = make_uint2(l0, l1);
             };
@@ -1086,6 +1088,45 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
     *reinterpret_cast<uint2*>(out + n + i4) = order == 0 ? lo : hi;
     *reinterpret_cast<uint2*>(out + 2 * n + i4) = order == 0 ? hi : lo;
 }
+// every input tensor of a backward pass in ONE launch (the activations are all final when the pass starts): 4096 elements per
+// block, four 16-byte loads in flight per thread; the thirteen deep-level tensors of configs[1] no longer cost a launch each
+__global__ __launch_bounds__(256) void split3_all_kernel(Split3Table t) {
+    int j = 0;
+    while (j + 1 < t.n && (int)blockIdx.x >= t.job[j + 1].blk_begin) ++j;
+    const float* __restrict__ x = t.job[j].src; bf16_t* __restrict__ out = t.job[j].dst;
+    const long n = t.job[j].n; const int order = t.job[j].order;
+    const long base = (long)((int)blockIdx.x - t.job[j].blk_begin) * 4096 + threadIdx.x * 4;
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                                // (clamped: n is a multiple of 8, so n - 4 is a valid, aligned index)
+        const long i4 = base + u * 1024;
+        v[u] = *reinterpret_cast<const float4*>(x + (i4 < n ? i4 : n - 4));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i4 = base + u * 1024;
+        if (i4 >= n) continue;
+        const uint32_t h0 = f32x2_to_bf16x2(v[u].x, v[u].y), h1 = f32x2_to_bf16x2(v[u].z, v[u].w);
+        const uint32_t l0 = f32x2_to_bf16x2(v[u].x - __uint_as_float(h0 << 16), v[u].y - __uint_as_float(h0 & 0xffff0000u));
+        const uint32_t l1 = f32x2_to_bf16x2(v[u].z - __uint_as_float(h1 << 16), v[u].w - __uint_as_float(h1 & 0xffff0000u));
+        const uint2 hi = make_uint2(h0, h1), lo = make_uint2(l0, l1);
+        *reinterpret_cast<uint2*>(out + i4) = hi;
+        if (order == 2) { *reinterpret_cast<uint2*>(out + n + i4) = lo; continue; }      // two stored planes (wgrad_taps folds the batch)
+        *reinterpret_cast<uint2*>(out + n + i4) = order == 0 ? lo : hi;
+        *reinterpret_cast<uint2*>(out + 2 * n + i4) = order == 0 ? hi : lo;
+    }
+}
+int launch_split3_all(Split3Table& t, hipStream_t st) {
+    int blocks = 0;
+    for (int i = 0; i < t.n; ++i) {
+        if (t.job[i].n % 8 || t.job[i].n <= 0) return fail(MPU_EINVAL, "%s", "split3_all: element counts must be positive multiples of 8");
+        t.job[i].blk_begin = blocks;
+        blocks += (int)((t.job[i].n + 4095) / 4096);
+    }
+    if (t.n == 0) return MPU_OK;
+    split3_all_kernel<<<blocks, 256, 0, st>>>(t);
+    return launch_ok();
+}
 int launch_split3(const float* x, long n, void* out, int order, hipStream_t st) {
     if (n % 4) return fail(MPU_EINVAL, "%s", "split3: element count must be a multiple of 4");
     if (n == 0) return MPU_OK;
@@ -1096,12 +1137,12 @@ int launch_split3(const float* x, long n, void* out, int order, hipStream_t st) 
 // dtype "bf16x3" with the fixed-point accumulators on: ONE pass over the f32 dz of a conv writes its bf16 planes (hi | hi | lo) and adds
 // its column sums -- the bias gradient -- to an accumulator of the bn_acc layout (row 0 of each XCD's pair); launch_db_from_acc
 // turns the accumulators of all convs queued so far into the f32 bias gradients with one small launch
-int launch_split3_colsum(const float* dz, long M, int C, void* planes, long long* acc, float scale, hipStream_t st) {
+int launch_split3_colsum(const float* dz, long M, int C, void* planes, long long* acc, float scale, hipStream_t st, int two_planes) {
     if (C % 4 || !acc) return fail(MPU_EINVAL, "%s", "split3_colsum: channel count must be a multiple of 4, accumulator required");
     if (M == 0) return MPU_OK;
     int rpb; const int nblk = red_blocks(M, C, &rpb);
     colreduce_kernel<float, 2, true><<<nblk, CR_THREADS, 0, st>>>(dz, nullptr, M, C, nullptr, nullptr, rpb, nullptr, acc, scale, 0.f,
-                                                                  (bf16_t*)planes);
+                                                                  (bf16_t*)planes, two_planes);
     return launch_ok();
 }
 __global__ __launch_bounds__(256) void db_from_acc_kernel(DbAccTable t) {

@@ -151,6 +151,11 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
     const int xs = strip % p.sx; int t_ = strip / p.sx;
     const int ys = t_ % p.sy; const int b = t_ / p.sy;
     const int x0 = xs * 32, y0 = ys * p.RH;
+    // dtype "bf16x3" (a.x3 = -images per plane): the batch is three plane pairs (x: hi | lo | hi, dz: hi | hi | lo) of TWO stored
+    // planes each (hi | lo) -- the image index of a strip is folded back onto the plane that holds its values
+    const int pl = a.x3 < 0 ? -a.x3 : 0;
+    const int bX = (pl && b >= 2 * pl) ? b - 2 * pl : b;
+    const int bZ = (pl && b >= pl) ? b - pl : b;
     const int nsteps = valid ? (y0 + p.RH < H ? y0 + p.RH : H) - y0 : 0;
     int nsteps_wg;                                               // both groups run the same number of barriers
     {
@@ -203,7 +208,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
         if (MODE == UPCONV2) { const int uy = y0 + r; rowok = uy < H; iy = uy >> 1; }
         else { iy = y0 - 1 + r; rowok = (unsigned)iy < (unsigned)H; }
         const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (r % NXRT) * XROWB);
-        const unsigned rowoff = (unsigned)(((b * Hi + iy) * Wi) * Cs * 2);
+        const unsigned rowoff = (unsigned)(((bX * Hi + iy) * Wi) * Cs * 2);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int q = wave + 4 * k;
@@ -216,7 +221,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
     auto issue_z = [&](int t) {                                  // dZ row of step t = image row y0 + t
         const int y = y0 + t;
         const unsigned base = __builtin_amdgcn_readfirstlane(ldsZ + (t % NZRT) * ZROWB);
-        const unsigned rowoff = (unsigned)(((b * H + y) * W) * a.Cout * 2);
+        const unsigned rowoff = (unsigned)(((bZ * H + y) * W) * a.Cout * 2);
         const unsigned off = (y < H && zlane != OOB) ? rowoff + zlane : OOB;
         t_dma16(rsz, off, base + wave * 1024);
     };
@@ -334,7 +339,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
             int iy; bool rowok;
             if (MODE == UPCONV2) { const int uy = y0 + rx; rowok = uy < H; iy = uy >> 1; }
             else { iy = iy_next; rowok = (unsigned)iy < (unsigned)H; }
-            const unsigned rowoff = (unsigned)((b * Hi + iy) * xrow_b);
+            const unsigned rowoff = (unsigned)((bX * Hi + iy) * xrow_b);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int q = wave + 4 * k;
@@ -349,7 +354,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradArgs& a, const TapsPl
         int rz = 0;
         auto req_z = [&]() {
             const int y = y0 + rz;
-            const unsigned rowoff = (unsigned)((b * H + y) * zrow_b);
+            const unsigned rowoff = (unsigned)((bZ * H + y) * zrow_b);
             const unsigned off = (y < H && zlane != OOB) ? rowoff + zlane : OOB;
             t_dma16(rsz, off, ldsZ + zslot + wave * 1024);
             ++rz;
