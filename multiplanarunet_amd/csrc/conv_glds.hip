@@ -356,14 +356,24 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
         T* out = (T*)a.out; const T* mask = (const T*)a.mask;
         constexpr int NIT = BM * CPRO / 256;
         static_assert(BM * CPRO % 256 == 0, "whole passes");
+        // Round 6, accumulator mode only (a.stats_acc, set by the launcher when K is not split): the fused BatchNorm sums of the
+        // stored values -- (sum y, sum y^2) of a forward launch, (sum dn, sum dn * xhat) of a data gradient whose output feeds a
+        // BatchNorm backward (bn_x: that BatchNorm's input, read where a ReLU mask would be; sum dn * x stays raw per thread and
+        // becomes invstd * (sum dn * x - mean * sum dn) once per workgroup). A thread keeps its channel chunk over all passes.
+        const bool st_on = a.stats_acc != nullptr;
+        const bool bnx = st_on && a.bn_x && !mask;
+        const T* aux = mask ? mask : (const T*)a.bn_x;
+        float ssum[EPC], ssq[EPC];
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) { ssum[k] = 0.f; ssq[k] = 0.f; }
         uint4 mkv[NIT];                         // ReLU masks of the data-gradient launches, requested up front (clamped
-        if (mask) {                             // addresses: a load inside the pass is one exposed round trip per pass)
+        if (mask || bnx) {                      // addresses: a load inside the pass is one exposed round trip per pass)
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int idx = tid + it * 256, row = idx / CPRO, c = idx % CPRO;
                 const long m = m0 + row;
                 const int n = n0 + c * EPC;
-                mkv[it] = *(const uint4*)(mask + ((m < M && n < a.Cout) ? m * a.Cout + n : 0));
+                mkv[it] = *(const uint4*)(aux + ((m < M && n < a.Cout) ? m * a.Cout + n : 0));
             }
         }
 #pragma unroll
@@ -375,6 +385,22 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
             if (m >= M || n >= a.Cout) continue;
             uint4 val = *(const uint4*)(smem + row * OROW + c * 16);
             const long o = m * a.Cout + n;
+            if (st_on) {
+                const uint4 xk = bnx ? mkv[it] : val;
+                const uint32_t vw[4] = {val.x, val.y, val.z, val.w}, xw[4] = {xk.x, xk.y, xk.z, xk.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (sizeof(T) == 2) {
+                        const float lo = __uint_as_float(vw[e] << 16), hi = __uint_as_float(vw[e] & 0xffff0000u);
+                        const float lo2 = __uint_as_float(xw[e] << 16), hi2 = __uint_as_float(xw[e] & 0xffff0000u);
+                        ssum[(2 * e) % EPC] += lo; ssq[(2 * e) % EPC] += lo * lo2;
+                        ssum[(2 * e + 1) % EPC] += hi; ssq[(2 * e + 1) % EPC] += hi * hi2;
+                    } else {
+                        const float v = __uint_as_float(vw[e]);
+                        ssum[e % EPC] += v; ssq[e % EPC] += v * __uint_as_float(xw[e]);
+                    }
+                }
+            }
             if (mask) {
                 const uint4 mk = mkv[it];
                 if (sizeof(T) == 2) {
@@ -393,6 +419,28 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(ConvArgs a) {
                 }
             }
             *(uint4*)(out + o) = val;
+        }
+        if (st_on) {                            // column sums over the 256 / CPRO row-lanes through the (now free) staging area
+            constexpr int R = 256 / CPRO;
+            __syncthreads();
+            float* red = (float*)smem;          // [R][BN][2]
+            const int rl = tid / CPRO, cc = tid % CPRO;
+#pragma unroll
+            for (int k = 0; k < EPC; ++k) {
+                red[((rl * BN) + cc * EPC + k) * 2] = ssum[k];
+                red[((rl * BN) + cc * EPC + k) * 2 + 1] = ssq[k];
+            }
+            __syncthreads();
+            for (int col = tid; col < BN; col += 256) {
+                float s0 = 0.f, s1 = 0.f;
+                for (int r2 = 0; r2 < R; ++r2) { s0 += red[(r2 * BN + col) * 2]; s1 += red[(r2 * BN + col) * 2 + 1]; }
+                const int ch = n0 + col;
+                if (ch < a.Cout) {
+                    if (bnx) s1 = a.bn_invstd[ch] * (s1 - a.bn_mean[ch] * s0);
+                    stats_acc_add(a.stats_acc, a.Cout, 0, ch, s0, a.stats_scale[0]);
+                    stats_acc_add(a.stats_acc, a.Cout, 1, ch, s1, a.stats_scale[1]);
+                }
+            }
         }
     }
 }
@@ -567,7 +615,13 @@ static int launch_glds_cfg(const ConvArgs& a_in, hipStream_t st) {
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * NT * (a.C0 + a.C1), st);
     const int ks = a.ksplit > 1 ? a.ksplit : 1;
     a.ksplit = ks;
-    launch_k(kern, dim3((unsigned)tiles, ks), dim3(256), Cfg::SMEM, st, a);
+    ConvArgs ak = a;                             // (the kernel's copy: its epilogue sums the BatchNorm terms only when K is not split
+    if (ks == 1) {                               //  and only into an accumulator; the split-K finish pass has its own)
+        const bool ok = a.stats_acc && a.stats && a.stats_rows && !(a.bn_x && (a.mask || !a.bn_mean || !a.bn_invstd)) &&
+                        Cfg::SMEM >= (256 / (BN * (int)sizeof(T) / 16)) * BN * 2 * 4;
+        if (ok) *a.stats_rows = 1; else ak.stats_acc = nullptr;
+    } else ak.stats_acc = nullptr;
+    launch_k(kern, dim3((unsigned)tiles, ks), dim3(256), Cfg::SMEM, st, ak);
     int rc = launch_ok();
     if (!rc && ks > 1) rc = launch_splitk_finish<T>(a, ks, M, st);
     if (prof_on()) prof_end(st);
