@@ -27,7 +27,7 @@ Added objects:
   train_e2e    : N=1 -- what `mp train` delivers: the GPU plane sampler cutting batches from a 128^3 synthetic volume on a
                  side stream one batch ahead of the graphed train step (multiplanarunet_amd/pipeline.py), slices/s over
                  >= 100 steps next to the serial loop of round 4 (sampler, eager step, host read of the loss every step).
-  bf16x3_mode  : N=1 -- the same for dtype "bf16x3" (f32 storage, split-bf16 products: tolerance-grade at ~2x the f32 mode's speed)
+  bf16x3_mode  : N=1 -- the same for dtype "bf16x3" (f32 storage, split-bf16 products: tolerance-grade at ~2.6x the f32 mode's speed)
   f32_mode     : N=1 -- ms per step of the SAME workload in dtype f32 (exact-f32 MFMA): the mode that meets the north star's
                  logits tolerance (atol 1e-4); the headline line is the bf16 storage mode (Dice delta <= 1e-3).
 

@@ -13,7 +13,13 @@ python $R/tools/rocpd_sequence.py $S > $O/train_step_sequence.txt 2>&1
 python $R/tools/round6/tail_trace.py $S > $O/train_step_tail_timeline.txt 2>&1
 python $R/tools/rocpd_stats.py $P 30 > $O/predict_kernel_stats.txt
 python $R/tools/rocpd_traffic.py $F $W $O/hbm_traffic_pmc.json > /dev/null
-rm -rf $O/stats $O/fetch $O/write $O/predict
+CHECK=0 REPS=2 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/gf -o f -- python $R/tools/bench_geometry.py > /dev/null 2>&1
+CHECK=0 REPS=2 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/gw -o w -- python $R/tools/bench_geometry.py > /dev/null 2>&1
+python $R/tools/geometry_pmc.py $(find $O/gf -name "*.db" | head -1) $(find $O/gw -name "*.db" | head -1) $O/geometry_pmc.json | head -6
+rm -rf $O/stats $O/fetch $O/write $O/predict $O/gf $O/gw
+# the bench lines below quote the HBM bytes of THIS build's counter passes (bench.py takes the newest profiles/*_pmc.json whose source
+# hash matches the tree)
+cp $O/hbm_traffic_pmc.json $R/profiles/${TAG}_hbm_traffic_pmc.json; cp $O/geometry_pmc.json $R/profiles/${TAG}_geometry_pmc.json
 head -14 $O/train_step_kernel_stats.txt | cut -c1-160; tail -2 $O/train_step_sequence.txt; tail -14 $O/train_step_tail_timeline.txt
 cd $R
 timeout 900 python bench.py > $O/bench.log 2>&1; tail -1 $O/bench.log > $O/bench_line.json; cut -c1-400 $O/bench_line.json
