@@ -39,6 +39,11 @@ def pick_side_streams(dev, candidates=6, busy_ms=3.0, batches=4):
     import time
     big = torch.empty(64 << 20, dtype=torch.float32, device=dev)           # 256 MB: ~0.1 ms per fill
     tiny = torch.zeros(64, dtype=torch.float32, device=dev)
+    # one-off costs out of the way first (a fresh process: the first fill, the first kernel of a high-priority stream -- bench.py's
+    # e2e leg reported a 6-ms "latency" for the stream its loop then ran fastest on)
+    big.fill_(0.0)
+    with torch.cuda.stream(torch.cuda.Stream(device=dev, priority=-1)):
+        tiny.add_(1.0)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     big.fill_(1.0)
