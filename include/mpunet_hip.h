@@ -220,6 +220,11 @@ int mpu_unet_prepare_inference(const mpu_unet* m, const float* d_params, const f
 /* d_out may be NULL in training mode: the probabilities then stay in the workspace only, at byte offset
  * mpu_unet_workspace_probs_offset(m, batch) (f32 [B,H,W,n_classes]; valid until the next forward on that workspace). */
 int64_t mpu_unet_workspace_probs_offset(const mpu_unet* m, int32_t batch);
+/* Byte offset (inside the workspace of `batch`) of ONE float: the mean over the B*H*W pixels of the weighted per-pixel loss of the
+ * last backward pass (= mean of the d_loss tensor mpu_unet_backward fills; written by the pass whether d_loss is NULL or not).
+ * It is what a training loop accumulates per step without a reduction of its own (reference: the `loss` Keras logs per batch,
+ * mpunet/train/trainer.py:246-257). Valid until the next backward pass on that workspace. */
+int64_t mpu_unet_workspace_loss_mean_offset(const mpu_unet* m, int32_t batch);
 int mpu_unet_forward(const mpu_unet* m, int32_t batch, const float* d_x, const float* d_params,
                      const void* d_packed, float* d_bn_state, void* d_workspace,
                      int32_t training, float* d_out, void* stream);

@@ -101,6 +101,7 @@ _SIGS = {
     "mpu_unet_tensor_info": (C.c_int, [c_p, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i64),
                                        C.POINTER(i32), C.POINTER(i32)]),
     "mpu_unet_workspace_probs_offset": (i64, [c_p, i32]),
+    "mpu_unet_workspace_loss_mean_offset": (i64, [c_p, i32]),
     "mpu_unet_pack_weights": (C.c_int, [c_p, c_p, c_p, c_p]),
     "mpu_unet_prepare_inference": (C.c_int, [c_p, c_p, c_p, c_p, c_p]),
     "mpu_unet_forward": (C.c_int, [c_p, i32, c_p, c_p, c_p, c_p, c_p, i32, c_p, c_p]),

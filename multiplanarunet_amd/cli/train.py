@@ -33,7 +33,9 @@ def get_argparser():
     p.add_argument("--num_access", type=int, default=50)
     p.add_argument("--cpu", action="store_true", help="alias of --num_GPUs=0 (rejected: there is no CPU path)")
     p.add_argument("--synthetic", type=int, default=0, help="train on N generated toy volumes (no files needed)")
-    p.add_argument("--dtype", default="bf16", choices=("bf16", "f32"))
+    p.add_argument("--dtype", default="bf16", choices=("bf16", "f32", "bf16x3"),
+                   help="bf16 (default, the benchmarked mode), f32 (exact-f32 MFMAs: the parity mode), bf16x3 (f32 storage, three bf16 "
+                        "MFMAs per product: f32-grade results at 2.6x the f32 speed)")
     p.add_argument("--no_overlap", action="store_true", help="cut every batch on the training stream (no side-stream "
                    "producer; A/B aid: the default overlaps the sampler with the train step)")
     p.add_argument("--no_graph", action="store_true", help="launch the train step's kernels eagerly instead of replaying "

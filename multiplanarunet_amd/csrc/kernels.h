@@ -274,7 +274,8 @@ int launch_head_combine(const float* partial, long M, int K, const float* bh, in
 int launch_head_backward(int dtype, const void* n, const float* probs, const uint8_t* y,
                          const float* sample_w, long M, long pix_per_image, int C, int K,
                          const float* Wh, int ldw, float* partial, void* dn, float* dWh, float* dbh,
-                         float* loss, hipStream_t st, long long* step_incr = nullptr /* device counter to advance by one */);
+                         float* loss, hipStream_t st, long long* step_incr = nullptr /* device counter to advance by one */,
+                         float* loss_mean = nullptr /* device scalar: mean of the weighted per-pixel loss */);
 
 // l2 kernel regulariser: grads += 2*l2*W over the listed tensors; reg_loss (optional) = l2 * sum W^2
 struct L2Table { int njobs, _pad; long off[PACK_MAX_JOBS]; long n[PACK_MAX_JOBS]; };

@@ -108,7 +108,7 @@ struct Plan {
     std::vector<long> c1, c2, n, p, dskip;          // encoder levels
     long c1b, c2b, nb;
     std::vector<long> u1, n1, c2u, c3u, n2;         // up levels
-    long probs, gA, gB, partial, partial_floats, partial2, wpartial, wpartial_floats, cpartial, cpartial_floats, coeffs, stats, total;
+    long probs, loss_mean, gA, gB, partial, partial_floats, partial2, wpartial, wpartial_floats, cpartial, cpartial_floats, coeffs, stats, total;
     std::vector<long> wscratch;                     // per conv: float offset of its weight-gradient scratch inside wpartial
     std::vector<long> dz;                           // per conv: its own dz (gradient at the conv's pre-activation output): the weight
                                                     // gradients of a whole backward pass run as grouped launches at its end
@@ -138,6 +138,7 @@ Plan make_plan(const mpu_unet* m, int B) {
     }
     const long M0 = (long)B * m->cfg.H * m->cfg.W;
     P.probs = take(M0 * m->cfg.n_classes * 4);
+    P.loss_mean = take(16);                          // the last backward pass's mean weighted per-pixel loss (one float)
     long gmax = 0;
     for (int l = 0; l <= D; ++l) {
         const long e = (long)B * (m->cfg.H >> l) * (m->cfg.W >> l) * m->F[l];
@@ -152,7 +153,7 @@ Plan make_plan(const mpu_unet* m, int B) {
         P.dz[i] = act(l, m->conv[i].Cout);
     }
     long pe = (long)RED_MAX_BLOCKS * 2 * m->cmax;
-    const long he = (long)HEAD_BWD_MAX_BLOCKS * (m->head_C * m->cfg.n_classes + m->cfg.n_classes);
+    const long he = (long)HEAD_BWD_MAX_BLOCKS * (m->head_C * m->cfg.n_classes + m->cfg.n_classes + 1);
     if (he > pe) pe = he;
     if (pe < (4L << 20)) pe = 4L << 20;         // room for the per-tile BN statistics rows of the fused conv epilogues
     P.partial = take(pe * 4);
@@ -646,7 +647,7 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
     RC(launch_head_backward(dt, last, (const float*)r.at(P.probs), d_y, d_sw, M0, (long)m->cfg.H * m->cfg.W,
                             m->head_C, m->cfg.n_classes, r.params + m->head_w, m->cfg.n_classes,
                             (float*)r.at(P.partial), gA, r.grads + m->head_w, r.grads + m->head_b, d_loss, r.st,
-                            (opt && opt->step && tail_overlap_wanted(r)) ? opt->step : nullptr));
+                            (opt && opt->step && tail_overlap_wanted(r)) ? opt->step : nullptr, (float*)r.at(P.loss_mean)));
     tap_aux(r, 7, -1, 0, m->head_C, m->cfg.n_classes, last, r.at(P.probs), d_y, d_sw, gA, m->head_w, m->head_b);
     if (m->x3) RC(x3_presplit_inputs(r));
     int point = 0;
@@ -935,6 +936,10 @@ int64_t mpu_unet_workspace_bytes(const mpu_unet* m, int32_t batch) {
 int64_t mpu_unet_workspace_probs_offset(const mpu_unet* m, int32_t batch) {
     if (!m || batch < 1) return -1;
     return make_plan(m, batch).probs;
+}
+int64_t mpu_unet_workspace_loss_mean_offset(const mpu_unet* m, int32_t batch) {
+    if (!m || batch < 1) return -1;
+    return make_plan(m, batch).loss_mean;
 }
 
 int mpu_unet_pack_weights(const mpu_unet* m, const float* d_params, void* d_packed, void* stream) {

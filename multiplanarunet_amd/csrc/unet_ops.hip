@@ -1411,7 +1411,10 @@ int launch_head_combine(const float* partial, long M, int K, const float* bh, in
 //   q = clip(p, eps, 1-eps); S = sum q; L = (-log q_y + log S) * w
 //   g_k = 1[eps <= p_k <= 1-eps] * (-[k==y]/q_y + 1/S) * w ;  dz_j = p_j (g_j - sum_k g_k p_k)
 // then dn = dz @ Wh^T, dWh += n^T dz, dbh += dz.
-// partial layout: [nblk][C*K + K]
+// partial layout: [nblk][C*K + K + 1]: head weight gradient, head bias gradient, and (round 6) the block's sum of the weighted
+// per-pixel loss -- head_bwd_finalize_kernel turns the last column into the step's MEAN loss (a device scalar in the workspace:
+// what `mp train` accumulates per step; a torch reduction of the 1-MB loss tensor inside the captured graph went stale for
+// stretches of replays in the bf16x3 graph -- its cross-block semaphore logic, gpurun R6al -- and costs three more launches)
 template <typename T, int K>
 __global__ __launch_bounds__(256, (K <= 3 ? 4 : 2)) void head_backward_kernel(const T* __restrict__ n, const float* __restrict__ probs,
                                                             const uint8_t* __restrict__ y, const float* __restrict__ sw,
@@ -1421,9 +1424,9 @@ __global__ __launch_bounds__(256, (K <= 3 ? 4 : 2)) void head_backward_kernel(co
     constexpr int N = Vec<T>::N;
     constexpr float EPS = 1e-7f;
     __shared__ float w[HEAD_MAXC * K];
-    __shared__ float red[HEAD_MAXC * K + K];
+    __shared__ float red[HEAD_MAXC * K + K + 1];
     for (int i = threadIdx.x; i < C * K; i += 256) w[i] = Wh[(i / K) * ldw + (i % K)];
-    for (int i = threadIdx.x; i < C * K + K; i += 256) red[i] = 0.f;
+    for (int i = threadIdx.x; i < C * K + K + 1; i += 256) red[i] = 0.f;
     __syncthreads();
     const int cpr = C / N;           // host guarantees cpr <= 64
     int G = 1; while (G < cpr) G <<= 1;
@@ -1448,6 +1451,7 @@ __global__ __launch_bounds__(256, (K <= 3 ? 4 : 2)) void head_backward_kernel(co
         for (int k = 0; k < K; ++k) aw[i][k] = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) ab[k] = 0.f;
+    float lsum = 0.f;                                            // this lane's sum of the weighted per-pixel loss
     for (long m0 = ((long)blockIdx.x * ppb + threadIdx.x / G) * G; m0 < M; m0 += (long)gridDim.x * ppb * G) {
         const long mm = m0 + sub;
         float dzv[K];
@@ -1474,7 +1478,9 @@ __global__ __launch_bounds__(256, (K <= 3 ? 4 : 2)) void head_backward_kernel(co
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) { dzv[k] = p[k] * (g[k] - dot); ab[k] += dzv[k]; }
-            if (loss) loss[mm] = (-logf(qy) + logf(S)) * wt;
+            const float lv = (-logf(qy) + logf(S)) * wt;
+            lsum += lv;
+            if (loss) loss[mm] = lv;
         }
         const long left = M - m0;
         const int nv = left < G ? (int)left : G;                 // pixels of this pass (uniform over the group)
@@ -1525,6 +1531,7 @@ __global__ __launch_bounds__(256, (K <= 3 ? 4 : 2)) void head_backward_kernel(co
     for (int o = 1; o < 64; o <<= 1) {
 #pragma unroll
         for (int k = 0; k < K; ++k) ab[k] += __shfl_xor(ab[k], o, 64);
+        lsum += __shfl_xor(lsum, o, 64);
     }
     for (int wv = 0; wv < 4; ++wv) {                             // G <= 64: lanes 0..G-1 of each wave hold its totals
         const bool mine = (int)(threadIdx.x >> 6) == wv;
@@ -1537,29 +1544,32 @@ __global__ __launch_bounds__(256, (K <= 3 ? 4 : 2)) void head_backward_kernel(co
         if (mine && lane == 0) {
 #pragma unroll
             for (int k = 0; k < K; ++k) red[C * K + k] += ab[k];
+            red[C * K + K] += lsum;
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < C * K + K; i += 256) partial[(long)blockIdx.x * (C * K + K) + i] = red[i];
+    for (int i = threadIdx.x; i < C * K + K + 1; i += 256) partial[(long)blockIdx.x * (C * K + K + 1) + i] = red[i];
 }
 
 __global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int K, int ldw,
-                                         float* dWh, float* dbh, long long* step_incr) {
+                                         float* dWh, float* dbh, long long* step_incr, float* loss_mean, double inv_m) {
     __shared__ double red[256];
     // (mpu_unet_backward_adam: the optimizer's device step counter moves HERE, at the start of the backward pass -- nothing
     // reads it before the optimizer kernels at the pass's end, and none of those then has to be the last reader)
     if (step_incr && blockIdx.x == 0 && threadIdx.x == 0) *step_incr += 1;
     const int i = blockIdx.x * FIN_COLS + (threadIdx.x % FIN_COLS);
-    const int tot = C * K + K;
+    const int tot = C * K + K + 1;
     double s;
     partial_sums<1>(partial, nblk, tot, 0, i, i < tot, red, &s);
     if (i >= tot || threadIdx.x >= FIN_COLS) return;
-    if (i < C * K) dWh[(i / K) * ldw + (i % K)] = (float)s; else dbh[i - C * K] = (float)s;
+    if (i < C * K) dWh[(i / K) * ldw + (i % K)] = (float)s;
+    else if (i < C * K + K) dbh[i - C * K] = (float)s;
+    else if (loss_mean) *loss_mean = (float)(s * inv_m);         // mean over the B*H*W pixels of the weighted per-pixel loss
 }
 
 int launch_head_backward(int dtype, const void* n, const float* probs, const uint8_t* y, const float* sw, long M,
                          long ppi, int C, int K, const float* Wh, int ldw, float* partial, void* dn, float* dWh,
-                         float* dbh, float* loss, hipStream_t st, long long* step_incr) {
+                         float* dbh, float* loss, hipStream_t st, long long* step_incr, float* loss_mean) {
     const int N = dtype == MPU_BF16 ? 8 : 4;
     const int cpr = C / N;
     if (C > HEAD_MAXC || cpr > 64 || C % N != 0)
@@ -1574,7 +1584,8 @@ int launch_head_backward(int dtype, const void* n, const float* probs, const uin
     }
     int rc = launch_ok();
     if (rc) return rc;
-    head_bwd_finalize_kernel<<<cdiv(C * K + K, FIN_COLS), 256, 0, st>>>(partial, (int)blocks, C, K, ldw, dWh, dbh, step_incr);
+    head_bwd_finalize_kernel<<<cdiv(C * K + K + 1, FIN_COLS), 256, 0, st>>>(partial, (int)blocks, C, K, ldw, dWh, dbh, step_incr, loss_mean,
+                                                                            1.0 / (double)M);
     return launch_ok();
 }
 

@@ -132,8 +132,8 @@ class TrainPipeline:
     def _launch_step(self):
         m = self.model
         if not self.graphed:
-            loss = m.train_step(self.gx, self.gy, self.gw)
-            self.loss_sum += loss.mean().double()
+            m.train_step(self.gx, self.gy, self.gw, want_loss=bool(m.l2_reg))      # (want_loss also switches the l2 term's value on)
+            self.loss_sum += m.loss_mean().double()         # (the backward pass's own mean: the value the graphed step adds)
             if m.l2_reg:
                 self.loss_sum += m.reg_loss.double()
             return

@@ -508,7 +508,16 @@ class UNet:
                       _lib.ptr(self.packed), _lib.ptr(self.bn_state), _lib.ptr(self._ws), _lib.ptr(self.grads),
                       _lib.ptr(loss), arr, len(ready_events), _lib.stream_ptr())
         self._ready_events_fresh = ready_events is not None      # the DP hook falls back to a full stream wait otherwise
+        self._last_batch = B
         return probs, loss
+
+    def loss_mean(self):
+        """Device scalar (a [1] f32 VIEW into the workspace, valid until the next backward pass): the mean over all pixels of the
+        weighted per-pixel loss of the last forward_backward / train_step -- what Keras logs per batch. Produced by the backward
+        pass itself (mpu_unet_workspace_loss_mean_offset), so a training loop needs no reduction of the 1-MB loss tensor; inside a
+        captured HIP graph that torch reduction (several blocks per output, semaphores) went stale for stretches of replays."""
+        off = int(_lib.load().mpu_unet_workspace_loss_mean_offset(self._h, self._last_batch))
+        return self._ws[off:off + 4].view(torch.float32)
 
     def _add_l2(self, want_loss=False):
         """kernel_regularizer=l2(self.l2_reg) (unet.py:189): grads += 2*l2*W on the 3x3 / 2x2 conv kernels; the
@@ -568,14 +577,14 @@ class UNet:
 
         def body():
             if fused_tail:               # backward + optimizer in one call: the optimizer beside the weight gradients
-                _, loss = self.forward_backward(x, y, sample_weight, want_loss=loss_sum is not None, adam=(0, step_dev))
+                self.forward_backward(x, y, sample_weight, want_loss=False, adam=(0, step_dev))
                 if loss_sum is not None:
-                    loss_sum.add_(loss.mean().double())
+                    loss_sum.add_(self.loss_mean().double())     # (the pass's own mean: no torch reduction inside the graph)
                 return
-            _, loss = self.forward_backward(x, y, sample_weight, want_loss=loss_sum is not None)
+            self.forward_backward(x, y, sample_weight, want_loss=False)
             self._add_l2(want_loss=loss_sum is not None)
             if loss_sum is not None:
-                loss_sum.add_(loss.mean().double())
+                loss_sum.add_(self.loss_mean().double())
                 if self.l2_reg:
                     loss_sum.add_(self.reg_loss.double())
             if os.environ.get("MPU_FUSED_ADAM") == "0":         # A/B: the two separate passes

@@ -123,6 +123,44 @@ def test_overlapped_graphed_pipeline_equals_the_serial_eager_loop_bitwise():
     assert p0.run_epoch(3) == p1.run_epoch(3)
 
 
+def test_epoch_loss_of_the_graphed_pipeline_on_the_real_network_split_bf16():
+    """Round 6 (found by tools/round6/af_soak.py): in the graphed bf16x3 step the epoch loss went STALE for stretches of replays -- the
+    parameters stayed bit-identical to the serial loop's, the per-pixel loss the library wrote was fresh, but torch's captured
+    `loss.mean()` (a multi-block reduction with semaphores) repeated an old value for up to 50 consecutive replays. The step's mean
+    loss now comes out of the backward pass itself (UNet.loss_mean: head_bwd_finalize_kernel), so no torch reduction is captured.
+    configs[1] network, 240 steps: epoch losses and every parameter equal the serial eager loop's, and loss_mean() agrees with the
+    mean of the per-pixel loss tensor."""
+    from multiplanarunet_amd.unet import UNet
+    from multiplanarunet_amd.data import make_toy_volume, as_volume, random_views, TrainSampler
+    from multiplanarunet_amd.pipeline import TrainPipeline
+    dev = torch.device("cuda")
+    B, dim = 16, 128
+    img, lab, aff = make_toy_volume(128, 77)
+    vol = as_volume(img, lab, aff, "1pct", "RobustScaler", dev, "toy128")
+    views = random_views(6, 60.0, 0)
+
+    def mk():
+        m = UNet(n_classes=3, dim=dim, n_channels=1, depth=4, complexity_factor=1, flatten_output=True, dtype="bf16x3", logger=quiet,
+                 seed=0, device=dev)
+        m.compile("Adam", "SparseCategoricalCrossentropy", optimizer_kwargs={"lr": 1e-4})
+        return m, TrainSampler([vol], views, dim, float(dim), B, 3, noise_sd=0.1, fg_batch_fraction=0.5, seed=3)
+    m0, s0 = mk()
+    m1, s1 = mk()
+    x, y, w = s0.__class__([vol], views, dim, float(dim), B, 3, noise_sd=0.1, fg_batch_fraction=0.5, seed=9)()
+    _, loss = m0.forward_backward(x, y, w)
+    lm, ref = float(m0.loss_mean().item()), float(loss.double().mean().item())
+    assert abs(lm - ref) <= 2e-6 * abs(ref), (lm, ref)
+    m0.grads.zero_()
+    m0.bn_state.copy_(m1.bn_state)                               # (the probe above moved the moving statistics)
+    p0 = TrainPipeline(m0, s0, graphed=False, overlap=False)
+    p1 = TrainPipeline(m1, s1)
+    for ep in range(4):
+        a, b = p0.run_epoch(60), p1.run_epoch(60)
+        torch.cuda.synchronize()
+        assert np.isfinite(a) and a == b, (ep, a, b)
+        assert torch.equal(m0.params, m1.params) and torch.equal(m0.bn_state, m1.bn_state), ep
+
+
 def test_a_learning_rate_change_recaptures_the_graph():
     from multiplanarunet_amd.pipeline import TrainPipeline
     m0, s0 = _model_and_sampler(3)

@@ -350,14 +350,16 @@ def test_backward_adam_one_call_equals_backward_then_adam_bitwise(cfg):
         assert same(a, c) and a.iterations == c.iterations == 3
 
 
-def test_backward_ready_events_same_gradients():
-    """mpu_unet_backward_events == mpu_unet_backward; ready points are descending offsets ending at 0."""
+@pytest.mark.parametrize("dtype,B,H,cf", [("bf16", 2, 32, 0.25), ("bf16x3", 2, 32, 0.25), ("bf16x3", 4, 64, 1)])
+def test_backward_ready_events_same_gradients(dtype, B, H, cf):
+    """mpu_unet_backward_events == mpu_unet_backward; ready points are descending offsets ending at 0. dtype "bf16x3": the
+    gradient-ready points also flush the bias gradients waiting in their accumulators (flush_db), and the larger case has layers on
+    two stored planes (wgrad_taps jobs) whose grouped launch is flushed at every point."""
     from multiplanarunet_amd.unet import UNet
     rng = np.random.RandomState(5)
-    B, H = 2, 32
     x = torch.tensor(rng.randn(B, H, H, 1).astype(np.float32), device="cuda")
     y = torch.tensor(rng.randint(0, 3, (B, H * H, 1)).astype(np.uint8), device="cuda")
-    m = UNet(n_classes=3, dim=H, depth=2, complexity_factor=0.25, dtype="bf16", logger=quiet, seed=0)
+    m = UNet(n_classes=3, dim=H, depth=2, complexity_factor=cf, dtype=dtype, logger=quiet, seed=0)
     pts = m.grad_ready_points()
     assert len(pts) == 2 * 2 + 2 and pts[-1] == 0 and all(a > b for a, b in zip(pts, pts[1:]))
     assert pts[0] < m.grads.numel()
