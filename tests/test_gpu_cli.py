@@ -196,3 +196,25 @@ def test_mp_train_two_ranks_data_parallel_then_resume(tmp_path):
     assert ep1 == [e for e in (0, 1, 2) if e <= N] + list(range(N + 1, 6)), (N, ep1)
     loss1 = float(rows1[-1].split(",")[head.index("loss")])
     assert loss1 < loss[0], (loss, loss1)
+
+
+def test_mp_train_then_predict_split_bf16(tmp_path):
+    """`--dtype bf16x3` through the CLIs (round 6): the graphed pipeline with the split-bf16 step, checkpoints, then a predict in the
+    same dtype on the saved weights."""
+    from multiplanarunet_amd.cli import mp
+    proj = tmp_path / "proj"
+    proj.mkdir()
+    (proj / "train_hparams.yaml").write_text(
+        "build:\n  model_class_name: UNet\n  n_classes: 3\n  n_channels: 1\n  dim: 64\n  depth: 3\n"
+        "  complexity_factor: 0.0625\n  out_activation: softmax\n  seed: 0\n"
+        "fit:\n  views: 3\n  noise_sd: 0.1\n  real_space_span: 64.0\n  batch_size: 8\n  n_epochs: 2\n"
+        "  optimizer: Adam\n  optimizer_kwargs: {lr: 1.0e-3, decay: 0.0, beta_1: 0.9, beta_2: 0.999, epsilon: 1.0e-8}\n"
+        "  loss: SparseCategoricalCrossentropy\n  fg_batch_fraction: 0.5\n  bg_value: 1pct\n  scaler: RobustScaler\n")
+    mp.entry_func(["train", "--project_dir", str(proj), "--synthetic", "4", "--epochs", "6", "--dtype", "bf16x3",
+                   "--train_images_per_epoch", "160", "--no_val"])
+    log = (proj / "logs" / "training.csv").read_text().strip().splitlines()
+    losses = [float(l.split(",")[1]) for l in log[1:]]
+    assert len(losses) == 6 and all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    mp.entry_func(["predict", "--project_dir", str(proj), "--synthetic", "1", "--sum_fusion", "--overwrite", "--dtype", "bf16x3"])
+    res = (proj / "predictions" / "csv" / "results.csv").read_text().splitlines()
+    assert float(res[1].split(",")[1]) > 0.5, res
