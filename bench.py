@@ -531,6 +531,9 @@ def bench_train_e2e(model, device, B, dim, headline, steps=120, warmup=50):
     res["fraction_of_headline"] = round(res["value"] / headline, 4) if headline else None
     res["producer_stream_latency_us"] = round(pipe.side_latency_us, 1) if pipe.side_latency_us is not None else None
     res["producer_stream_candidates_ms_per_step"] = pipe.side_loop_ms     # the real-loop windows the stream was chosen by (warm-up steps)
+    res["producer_stream_note"] = ("the stream is the fastest of the candidates' real-loop windows; producer_stream_latency_us is the fill "
+                                   "probe's figure for it, a ranking hint only (in this process, after the other legs' streams, it reads "
+                                   "several ms for every candidate although the loop runs at the step's rate)")
     res["launch"] = "sampler on a side stream (picked by measurement: fill probe, then the first candidates under the real loop) one batch ahead; step = hip-graph replay; loss summed on the device"
     return res
 
