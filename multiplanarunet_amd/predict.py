@@ -31,7 +31,9 @@ def multi_view_predict(model, volume, views, dim, real_space_span, fusion_model=
     mean_dice) [, log=callable]): the reference's per-view evaluation inside the loop (predict.py:334-346) for volumes with
     labels -- skipped for a view when np.random.rand() > eval_prob, as there.
     batch_size=None: even chunks of the view's planes as large as the kernels' operand bound allows
-    (UNet.auto_batch; 276 planes of 256x256 -> 3 x 92) - the result does not depend on it.
+    (UNet.auto_batch; 276 planes of 256x256 -> 3 x 92). The same batch size gives the same bits run after run; ANOTHER batch size
+    selects other kernel schedules for some layers, i.e. another bf16 rounding pattern (measured on an untrained configs[1] network,
+    128^3: fused probabilities within 1.7e-3, 0.013 % of the labels -- voxels whose two best classes are within 3e-4 -- differ).
     fusion_model: object with .W (V,K) and .b (1,K) device tensors (FusionModel) or None with sum_fusion.
     """
     if fusion_model is None and not sum_fusion:

@@ -39,4 +39,6 @@ for ep in range(10):
     if ep % 2 == 1:
         for m in (m0, m1):
             m.optimizer_kwargs["lr"] *= 0.9
-print("SOAK", dtype, kw, os.environ.get("MPU_BN_ATOMIC", ""), "OK" if ok else "FAILED")
+import hashlib
+h = hashlib.sha256(m1.params.cpu().numpy().tobytes() + m1.bn_state.cpu().numpy().tobytes()).hexdigest()[:16]
+print("SOAK", dtype, kw, os.environ.get("MPU_BN_ATOMIC", ""), "OK" if ok else "FAILED", "parameters after 600 steps: sha256", h)
