@@ -49,11 +49,21 @@ def test_pipeline_variants_equal_the_serial_eager_loop_bitwise(kw):
 
 
 def test_side_stream_runs_beside_a_busy_main_stream():
-    from multiplanarunet_amd.pipeline import pick_side_stream
-    st, lat = pick_side_stream(torch.device("cuda"), busy_ms=3.0)
-    assert isinstance(st, torch.cuda.Stream) and st != torch.cuda.current_stream()
+    """The fill probe of pipeline.pick_side_stream in a FRESH process (its figure depends on the streams a process has created before:
+    bench.py's e2e leg reads 6 ms for every candidate after the other legs although the loop then runs at the step's rate -- the
+    stream that matters is chosen under the real loop, test_mp_train_pipeline_delivers_at_least_090_of_the_step_rate)."""
+    import subprocess, sys, os
+    code = ("import torch\n"
+            "from multiplanarunet_amd.pipeline import pick_side_stream\n"
+            "st, lat = pick_side_stream(torch.device('cuda'), busy_ms=3.0)\n"
+            "assert isinstance(st, torch.cuda.Stream) and st != torch.cuda.current_stream()\n"
+            "print('LAT %.1f' % lat)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lat = float([l for l in r.stdout.splitlines() if l.startswith("LAT ")][-1].split()[1])
     assert np.isfinite(lat) and lat > 0
-    print("producer stream chosen: %r, probe latency %.0f us" % (st, lat))
+    print("producer stream probe latency %.0f us" % lat)
     # a stream queued BEHIND the probe's 3 ms of fills answers after >= 3000 us. Round 6 (VERDICT r5 item 7): FAIL, do not skip --
     # `mp train` on such a stream delivers 0.64 of the step rate (gpurun R5p), and a runtime update that changes the stream -> queue
     # mapping must be seen here, not in a throughput regression nobody attributes
