@@ -84,6 +84,15 @@ def test_split_bf16_step_every_conv_launch_against_fp64():
     _replay_conv_launches(4, 128, 1, dtype="bf16x3", tol_act=5e-5, tol_w=5e-5)
 
 
+@pytest.mark.parametrize("B,cf", [(16, 1), (8, 2)], ids=["configs1", "default_yaml_cf2"])
+def test_split_bf16_benchmarked_and_odd_channel_networks_every_conv_launch_against_fp64(B, cf):
+    """The same at the BENCHMARKED shape (16 slices: all input planes in one launch, eleven layers on two stored planes through the
+    grouped wgrad_taps launch, bias gradients out of the accumulators) and on the default-YAML network (complexity_factor 2:
+    90 / 181 / 362 / 724 / 1448 filters -- channel counts that are no multiples of 64: three stored planes, concat sources as
+    separate jobs, BatchNorms outside the folded kernels' shapes)."""
+    _replay_conv_launches(B, 128, cf, dtype="bf16x3", tol_act=5e-5, tol_w=5e-5)
+
+
 def _replay_conv_launches(B, dim, cf, dtype="bf16", tol_act=1.2e-2, tol_w=2e-3):
     from multiplanarunet_amd import _lib
     from multiplanarunet_amd.unet import UNet
