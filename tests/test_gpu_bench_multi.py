@@ -61,3 +61,34 @@ def test_bench_four_ranks_config3_eight_slices_per_rank():
     assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["config"]["global_batch"] == 32 and d["config"]["slices_per_gpu"] == 8
     c = d["comm"]
     assert c["buckets"] == 3 and c["comm_ms_per_step"] > 0 and d["guard"]["finite"] and d["guard"]["decreasing"]
+
+
+def test_bench_single_gpu_default_line_follows_the_driver_contract():
+    """`python bench.py` as the driver runs it at N = 1 (defaults; here with fewer steps and without the peak probes): ONE JSON line
+    with the contract's keys, the metric / unit of BASELINE.json, the roofline and cpu_baseline objects, and the legs added since
+    (predict_fuse, train_e2e, f32_mode, bf16x3_mode)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-peaks"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic" and d["value"] > 0 and d["ms_per_step"] > 0
+    assert abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]          # slices/s of 16 slices per step
+    # (BASELINE.json: "2D slices/sec/GPU (train) + voxels/sec ..."; the driver's contract wants the WHOLE-JOB aggregate as `value`)
+    assert d["unit"] == "slices/s" and d["metric"].startswith("2D slices/sec") and base["metric"].startswith("2D slices/sec")
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["launch"] in ("graph", "eager")
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["traffic"] is None or rf["traffic"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == d["unit"] and cb["sample"]
+    assert d["predict_fuse"]["value"] > 0 and d["predict_fuse"]["roofline"]["bound"] == "hbm"
+    assert 0.5 < d["train_e2e"]["fraction_of_headline"] < 1.2
+    assert d["f32_mode"]["ms_per_step"] > d["bf16x3_mode"]["ms_per_step"] > d["ms_per_step"]
+    assert d["guard"]["finite"]
