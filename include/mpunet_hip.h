@@ -234,7 +234,9 @@ int mpu_unet_forward(const mpu_unet* m, int32_t batch, const float* d_x, const f
  * per-image sample weights, gradient of the SUM over batch and pixels).
  *   d_y u8 [B,H*W] ; d_sample_weight f32 [B] ; d_grads f32 [param_floats]
  *   d_loss f32 [B,H*W] per-pixel weighted loss or NULL.
- * Must follow mpu_unet_forward(training=1) on the same workspace. */
+ * Must follow mpu_unet_forward(training=1) on the same workspace -- ONE backward pass per training forward: the forward's first
+ * launch zeroes the fixed-point BatchNorm accumulators of both passes (round 6, bf16 / bf16x3), a second backward pass on the same
+ * forward would add to the first one's sums. */
 int mpu_unet_backward(const mpu_unet* m, int32_t batch, const uint8_t* d_y,
                       const float* d_sample_weight, const float* d_params, const void* d_packed,
                       float* d_bn_state, void* d_workspace, float* d_grads, float* d_loss,
