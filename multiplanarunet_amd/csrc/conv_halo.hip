@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int tiles_n = (a.Cout + BN - 1) / BN;
     // n-tile fastest: the n-tiles of one pixel tile are neighbours in time (shared patch in L2)
-    int t = blockIdx.x;
+    const int logical = a.xcd ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;      // (kernels.h)
+    int t = logical;
     const int n0 = (t % tiles_n) * BN; t /= tiles_n;
     const int x0 = (t % tiles_x) * TW; t /= tiles_x;
     const int y0 = (t % tiles_y) * TH; const int b = t / tiles_y;
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvArgs a) {
                 red[(r0 * BN + c * EPC + e) * 2 + 1] = ssq[e];
             }
             __syncthreads();
-            const int ptile = blockIdx.x / tiles_n;                               // pixel-tile index (n-tile fastest)
+            const int ptile = logical / tiles_n;                               // pixel-tile index (n-tile fastest)
             for (int v = tid; v < BN * 2; v += 256) {
                 const int col = v >> 1, st2 = v & 1;
                 double acc = 0.0;
@@ -564,7 +565,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
     const int H = a.Ho, W = a.Wo;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int tiles_n = (a.Cout + BN - 1) / BN;
-    int t = blockIdx.x;
+    const int logical = a.xcd ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;      // (kernels.h)
+    int t = logical;
     const int n0 = (t % tiles_n) * BN; t /= tiles_n;
     const int x0 = (t % tiles_x) * TW; t /= tiles_x;
     const int y0 = (t % tiles_y) * TH; const int b = t / tiles_y;
@@ -1066,7 +1068,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo8_kernel(ConvArgs a) {
                 red[(r0 * BN + c * EPC + e) * 2 + 1] = ssq[e];
             }
             __syncthreads();
-            const int ptile = blockIdx.x / tiles_n;
+            const int ptile = logical / tiles_n;
             for (int v = tid; v < BN * 2; v += NTHR) {
                 const int col = v >> 1, st2 = v & 1;
                 double acc2 = 0.0;
@@ -1111,6 +1113,7 @@ int launch_halo8_cfg_n(const ConvArgs& a_in, hipStream_t st) {
     a.dbg_buf = stamp_buffer();
     a.dbg = 2;                                                   // (SCHED 2: s_setprio 1 in the load phase, as SCHED 1 has it compiled in)
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);
+    a.xcd = env(ENV_XCD_TILES) != 0;
     launch_k(kern, dim3((unsigned)tiles), dim3(512), Cfg::SMEM, st, a);
     if (prof_on()) prof_end(st);
     return launch_ok();
@@ -1142,6 +1145,7 @@ int launch_halo_cfg(const ConvArgs& a_in, hipStream_t st) {
     if (a.pooled && a.pooled_done && MODE == CONV3 && !a.mask && !(a.Ho & 1) && !(a.Wo & 1) && TH % 2 == 0) *a.pooled_done = 1;
     else a.pooled = nullptr;
     if (prof_on()) prof_begin(PROF_CONV, a.flops > 0 ? a.flops : 2.0 * M * a.Cout * Cfg::NT * (a.C0 + a.C1), st);
+    a.xcd = env(ENV_XCD_TILES) != 0;
     launch_k(kern, dim3((unsigned)tiles), dim3(256), Cfg::SMEM, st, a);
     if (prof_on()) prof_end(st);
     return launch_ok();

@@ -57,7 +57,8 @@ struct WsCfg {
 };
 
 template <int TH, bool HEAD>
-__global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles, unsigned magic_x, unsigned magic_y) {
+__global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles, unsigned magic_x, unsigned magic_y,
+                                                         unsigned magic_g, int xcd_chunk) {
     using Cfg = WsCfg<TH>;
     constexpr int TW = Cfg::TW, PW = Cfg::PW, PROWS = Cfg::PROWS;
     constexpr int TM = TH / 2;                                   // pixel rows per wave (2 x 2 waves: channels x rows)
@@ -77,7 +78,17 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvArgs a, int ntiles,
     const unsigned lds0 = (unsigned)(uintptr_t)smem;
     const int lrow = lane >> 3, slot = lane & 7;
 
+    // The loop below walks VIRTUAL tile indices v = blockIdx.x + round * gridDim.x. With xcd_chunk (= ntiles / 8; the launcher
+    // sets it when 8 divides the grid and the grid divides the tiles) the tile behind v is
+    //   (blockIdx.x & 7) * xcd_chunk + round * (gridDim.x / 8) + (blockIdx.x >> 3):
+    // XCD k (workgroups with id = k mod 8) owns tiles [k * xcd_chunk, (k + 1) * xcd_chunk) and the workgroups of an XCD take
+    // neighbouring tiles in the same round, so the halo rows two tiles share are fetched into that XCD's L2 once (in launch
+    // order vertical neighbours sit on different XCDs: 1.59 x the input bytes from the fabric at 4-row tiles).
     auto tile_coords = [&](int t, int& b, int& y0, int& x0) {      // exact multiply-high division (host-checked range)
+        if (xcd_chunk) {
+            const int rnd = (int)__umulhi((unsigned)t, magic_g), bid = t - rnd * (int)gridDim.x;
+            t = (bid & 7) * xcd_chunk + rnd * ((int)gridDim.x >> 3) + (bid >> 3);
+        }
         const int t1 = magic_x ? (int)__umulhi((unsigned)t, magic_x) : t;   // t / tiles_x (magic 0 = one tile column: 2^32 / 1 does not fit)
         x0 = (t - t1 * tiles_x) * TW;
         b = magic_y ? (int)__umulhi((unsigned)t1, magic_y) : t1;    // t1 / tiles_y
@@ -406,7 +417,11 @@ int launch_ws(const ConvArgs& a_in, hipStream_t st) {
     else a.pooled = nullptr;
     if (HEAD) *a.head_done = 1;
     else a.head_partial = nullptr;
-    launch_k(kern, dim3((unsigned)grid), dim3(256), Cfg::SMEM, st, a, (int)tiles, mx, my);
+    // XCD-contiguous tile ranges (MPU_XCD_TILES): only the regular case -- every workgroup runs the same number of rounds
+    // (and tiles * grid < 2^32: the multiply-high division by the grid is exact)
+    const bool xcd = env(ENV_XCD_TILES) != 0 && !(grid & 7) && grid >= 8 && tiles % grid == 0 && tiles * (long)grid < (1L << 32);
+    const unsigned mg = xcd ? (unsigned)(((1UL << 32) + grid - 1) / grid) : 0u;
+    launch_k(kern, dim3((unsigned)grid), dim3(256), Cfg::SMEM, st, a, (int)tiles, mx, my, mg, xcd ? (int)(tiles / 8) : 0);
     if (prof_on()) prof_end(st);
     return launch_ok();
 }

@@ -25,6 +25,7 @@ enum EnvKind {
     X(PIPE_DEBUG, "MPU_PIPE_DEBUG", ENV_NUM, 0, "dev aid: 32 = s_memtime stamps in conv_pipe")                                       \
     X(HALO8, "MPU_HALO8", ENV_ON, 1, "0: 192-400-workgroup grids on the 4-wave conv_halo instead of the 8-wave conv_halo8")          \
     X(HALO8_SCHED, "MPU_HALO8_SCHED", ENV_NUM, 1, "0: conv_halo8 with lockstep halves (round-3 A/B); 1: halves one phase apart")      \
+    X(XCD_TILES, "MPU_XCD_TILES", ENV_ON, 1, "0: conv_halo / conv_halo8 / conv_ws tiles dealt to workgroups in launch order instead of XCD-contiguous ranges (round-6 A/B)") \
     X(HALO_UPCONV, "MPU_HALO_UPCONV", ENV_ON, 1, "0: up-convolutions not on the low-resolution-patch conv_halo variant")             \
     X(HALO_UP8_MIN, "MPU_HALO_UP8_MIN", ENV_NUM, 2048, "grid size from which up-convolutions take 8-row tiles")                      \
     X(HALO_KNOCKOUT, "MPU_HALO_KNOCKOUT", ENV_NUM, 0, "dev aid (-DMPU_HALO_KNOCKOUT_BUILD only): knock-out mask of the predict conv kernel") \

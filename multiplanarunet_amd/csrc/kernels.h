@@ -44,10 +44,20 @@ struct ConvArgs {
     // softmax. Otherwise the caller runs launch_head_forward on the stored output.
     const float* head_w = nullptr; int head_k = 0, head_ldw = 0; float* head_partial = nullptr; int* head_done = nullptr;
     int x3 = 0;                  // f32 storage only: split-bf16 products (three bf16 MFMAs, common.h x3_mma) instead of exact-f32 MFMAs
+    int xcd = 0;                 // set by the launchers of conv_halo / conv_halo8 / conv_ws (MPU_XCD_TILES): workgroup -> tile through
+                                 //   xcd_contiguous() below, so that the tiles one XCD works on are neighbours (shared halo rows and,
+                                 //   with several filter tiles, the shared patch hit in that XCD's L2 instead of being fetched per XCD)
     int dbg = 0;                 // profiling switches of conv_pipe_kernel (MPU_PIPE_DEBUG: 1 no stores, 2 no MFMAs, 4 no DMA,
                                  //   8 no fragment reads, 16 no barrier, 32 s_memtime stamps into dbg_buf)
     unsigned long long* dbg_buf = nullptr;
 };
+// Workgroups are dealt to the eight XCDs round-robin (XCD = workgroup id & 7). xcd_contiguous maps workgroup `bid` of `nwg` to
+// a logical index such that XCD k owns the contiguous range [k * nwg / 8, (k + 1) * nwg / 8) (ragged counts: the first nwg & 7
+// XCDs take one more), in launch order inside the range. A bijection on [0, nwg).
+__device__ __forceinline__ int xcd_contiguous(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
 // One column sum of a producer's tile: a partial row (the fixed-order scheme), or -- stats_acc mode -- a fixed-point atomic add
 // into the row of THIS workgroup's XCD (hardware register XCC_ID, so the eight per-XCD L2 caches never share an address; inside an
 // XCD the L2 is the point of coherence of every compute unit, which is where a scope-less global atomic executes).
