@@ -1032,6 +1032,12 @@ static int try_pipe(const ConvArgs& a, hipStream_t st) {
             while (ks > 1 && ks * M * a.Cout > a.partial_cap) --ks;
             if (ks < 1) ks = 1;
         }
+        // Round 6 (gpurun R6at): a stride-2 data gradient (up-convolution) whose reduction would be split in TWO takes the
+        // unsplit 64 x 128 tiles of conv_glds instead when those fill the chip: at configs[1] the 256 -> 128 up-conv's data
+        // gradient (16 K output pixels, K = 1152) ran 21.3 us + a 17.2-us finish pass (33 MB of fp32 partials, BatchNorm-backward
+        // sums) against 29.3 us as ONE launch of 512 workgroups with the sums in its epilogue. With 4 or 8 splits the pair wins
+        // (30.9 against 37.4 us, 30.0 against 37.3 us on the two deeper up-convs).
+        if (MODE == CONV3S2 && ks == 2 && (long)cdiv(a.Cout, 64) * cdiv(M, 128) >= 384) return 0;
         ConvArgs b = a; b.dbg = dbg;
         const bool ragged = (a.C0 % 64) != 0 || (a.C1 % 64) != 0;
         int rc;

@@ -189,11 +189,16 @@ def test_cfg1_bf16_train_step_per_tensor_and_dispatch():
         # per cent on one deep tensor fails here even where the rel-L2 floor is tens of per cent)
         proj = float(np.vdot(a, g64) / (np.vdot(g64, g64) + 1e-300))
         proj_floor = abs(float(np.vdot(g32_, g64) / (np.vdot(g64, g64) + 1e-300)) - 1.0)
-        projs.append((abs(proj - 1.0) - 2 * proj_floor, name, proj, proj_floor))
+        projs.append((abs(proj - 1.0) - 2 * proj_floor, name, proj, proj_floor, a.size))
     print("cfg1 bf16 grads vs matched model: tightest margin at %s: rel-L2 %.3g (noise floor %.3g)" % worst)
     projs.sort(reverse=True)
     print("cfg1 bf16 grads: projection coefficient furthest from 1 (beyond twice the model's own): " +
-          ", ".join("%s %.4f (model %.4f)" % (n_, p_, f_) for _, n_, p_, f_ in projs[:4]))
+          ", ".join("%s %.4f (model %.4f)" % (n_, p_, f_) for _, n_, p_, f_, _n in projs[:4]))
+    big = [t for t in projs if t[4] >= 4096]                 # the kernels (>= 4096 elements: the noise averages out)
+    print("   ... among the %d tensors of >= 4096 elements: " % len(big) +
+          ", ".join("%s %.4f (model %.4f)" % (n_, p_, f_) for _, n_, p_, f_, _n in big[:3]))
+    for _, n_, p_, f_, _n in big:
+        assert abs(p_ - 1.0) <= 0.05 + 2 * f_, (n_, p_, f_)
     for name in ("conv2d/kernel", "conv2d/bias", "upsample_L3_BN2/gamma", "upsample_L3_BN2/beta"):
         a = _grad(m, g, name).astype(np.float64)
         print("   %-24s rel-L2 vs model %.3g (floor %.3g)" % (name, rel(a, r64["grads"][name]), rel(r32["grads"][name], r64["grads"][name])))
