@@ -47,6 +47,9 @@ struct mpu_unet {
     int cmax = 0;
     int x3 = 0;                              // MPU_F32X3: cfg.dtype holds MPU_F32 (storage, every elementwise kernel), the MFMA kernels split
     mpu_launch_tap_fn tap = nullptr; void* tap_user = nullptr;      // test aid: mpu_unet_set_launch_tap
+    // Round 6: the last training forward ran the fused head (head_bn_forward: no post-BatchNorm tensor of the last block exists);
+    // its backward pass must take head_bn_backward / head_bn_bwd_apply. A backward pass belongs to exactly one training forward.
+    mutable int head_fused_fwd = 0;
 
     // indices into conv / bn
     int enc_c1(int i) const { return 2 * i; }
@@ -156,7 +159,7 @@ Plan make_plan(const mpu_unet* m, int B) {
     const long he = (long)HEAD_BWD_MAX_BLOCKS * (m->head_C * m->cfg.n_classes + m->cfg.n_classes + 1);
     if (he > pe) pe = he;
     if (pe < (4L << 20)) pe = 4L << 20;         // room for the per-tile BN statistics rows of the fused conv epilogues
-    P.partial = take(pe * 4);
+    P.partial = take((pe + 1024) * 4);          // (+ 1024 floats the producers are never told about: T of the fused training head)
     P.partial_floats = pe;
     P.partial2 = take((long)RED_MAX_BLOCKS * m->cmax * 4);
     // Weight-gradient scratch: every layer has its OWN region (K-split partials + bias-gradient partials), because the
@@ -470,6 +473,14 @@ void tap_aux(const Run& r, int kind, int index, int lvl, int C0, int Cout, const
     r.m->tap(r.m->tap_user, &li);
 }
 
+// Round 6: the training step's head as the three head_bn_* passes (unet_ops.hip): bf16, accumulator mode, a 64-channel last block
+// feeding a softmax head, no launch tap (the replay tests check the unfused kernels launch by launch)
+bool head_train_fused_wanted(const Run& r) {
+    const mpu_unet* m = r.m;
+    return env(ENV_HEAD_TRAIN_FUSED) != 0 && r.acc_mode && !m->x3 && !m->tap && m->cfg.depth > 0 && m->cfg.softmax &&
+           m->F[0] == 64 && head_train_fused_shape_ok(m->cfg.dtype, m->head_C, m->cfg.n_classes);
+}
+
 int bn_fwd(const Run& r, const BN& b, const void* x, int lvl, int training, void* y, void* pooled, int stats_rows = 0) {
     const int H = r.m->cfg.H >> lvl, W = r.m->cfg.W >> lvl;
     const long M = (long)r.B * H * W;
@@ -570,6 +581,7 @@ int run_forward(const Run& r, const float* d_x, int training, float* d_out) {
     if (!training) return run_forward_infer(r, d_x, d_out);
     const mpu_unet* m = r.m; const int D = m->cfg.depth; const Plan& P = r.P;
     const long M0 = (long)r.B * m->cfg.H * m->cfg.W;
+    m->head_fused_fwd = 0;
     // accumulator mode of the fused BatchNorm statistics: offered where the folded kernel takes the shape; the accumulators of BOTH
     // passes are zeroed by the step's first launch (a backward pass belongs to exactly one training forward)
     RC(launch_cast_pad(m->cfg.dtype, d_x, M0, m->cfg.n_channels, m->cin_pad, r.at(P.xin), r.st,
@@ -604,13 +616,21 @@ int run_forward(const Run& r, const float* d_x, int training, float* d_out) {
         rows = 0;
         RC(conv_fwd(r, m->conv[m->up_c(j, 2)], r.at(P.c2u[j]), f, nullptr, 0, r.at(P.c3u[j]), lvl, nullptr, nullptr, &rows,
                     nullptr, nullptr, nullptr, accf(m->bn[m->up_bn(j, 1)], lvl, false)));
+        if (j == D - 1 && rows == -1 && head_train_fused_wanted(r)) { m->head_fused_fwd = 1; break; }     // (no n2 of the last block)
         RC(bn_fwd(r, m->bn[m->up_bn(j, 1)], r.at(P.c3u[j]), lvl, training, r.at(P.n2[j]), nullptr, rows));
         prev = r.at(P.n2[j]); Cprev = f;
     }
     float* out = d_out ? d_out : (float*)r.at(P.probs);
-    RC(launch_head_forward(m->cfg.dtype, prev, M0, m->head_C, m->cfg.n_classes, r.params + m->head_w,
-                           m->cfg.n_classes, r.params + m->head_b, m->cfg.softmax, out, r.st));
-    tap_aux(r, 6, -1, 0, m->head_C, m->cfg.n_classes, prev, nullptr, nullptr, nullptr, out, m->head_w, m->head_b);
+    if (m->head_fused_fwd) {
+        const BN& b = m->bn[m->up_bn(D - 1, 1)];
+        RC(launch_head_bn_forward(r.at(P.c3u[D - 1]), M0, r.acc_f(b), BN_ACC_F, r.params + b.g, r.params + b.b, r.state + b.mm,
+                                  r.state + b.mv, r.stat(b, 0), r.stat(b, 1), r.stat(b, 2), r.stat(b, 3), BN_EPS, BN_MOM,
+                                  m->cfg.n_classes, r.params + m->head_w, m->cfg.n_classes, r.params + m->head_b, m->cfg.softmax, out, r.st));
+    } else {
+        RC(launch_head_forward(m->cfg.dtype, prev, M0, m->head_C, m->cfg.n_classes, r.params + m->head_w,
+                               m->cfg.n_classes, r.params + m->head_b, m->cfg.softmax, out, r.st));
+        tap_aux(r, 6, -1, 0, m->head_C, m->cfg.n_classes, prev, nullptr, nullptr, nullptr, out, m->head_w, m->head_b);
+    }
     if (training && d_out)     // keep a copy for the backward pass
         MPU_CHECK_HIP(hipMemcpyAsync(r.at(P.probs), d_out, M0 * m->cfg.n_classes * 4, hipMemcpyDeviceToDevice, r.st));
     return MPU_OK;
@@ -644,11 +664,26 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
     const long M0 = (long)r.B * m->cfg.H * m->cfg.W;
     void* gA = r.at(P.gA); void* gB = r.at(P.gB);
     const void* last = D > 0 ? r.at(P.n2[D - 1]) : r.at(P.nb);
+    const bool head_fused = m->head_fused_fwd != 0;
+    if (head_fused) {           // (the forward pass left no n2 of the last block: head_bn_* passes over c3 instead)
+        const BN& b = m->bn[m->up_bn(D - 1, 1)];
+        const void* c3 = r.at(P.c3u[D - 1]);
+        float* tsum = (float*)r.at(P.partial) + P.partial_floats;
+        const long ppi = (long)m->cfg.H * m->cfg.W;
+        RC(launch_head_bn_backward(c3, (const float*)r.at(P.probs), d_y, d_sw, M0, ppi, m->cfg.n_classes, r.stat(b, 0), r.stat(b, 1),
+                                   (float*)r.at(P.partial), tsum, r.grads + m->head_b, d_loss, r.st,
+                                   (opt && opt->step && tail_overlap_wanted(r)) ? opt->step : nullptr, (float*)r.at(P.loss_mean)));
+        RC(launch_head_bn_bwd_apply(c3, (const float*)r.at(P.probs), d_y, d_sw, M0, ppi, m->cfg.n_classes, r.params + m->head_w,
+                                    m->cfg.n_classes, tsum, r.grads + m->head_b, r.params + b.g, r.params + b.b, r.stat(b, 0), r.stat(b, 1),
+                                    r.grads + b.g, r.grads + b.b, r.grads + m->head_w, (float*)r.at(P.coeffs),
+                                    r.at(P.dz[m->up_c(D - 1, 2)]), r.st));
+    } else {
     RC(launch_head_backward(dt, last, (const float*)r.at(P.probs), d_y, d_sw, M0, (long)m->cfg.H * m->cfg.W,
                             m->head_C, m->cfg.n_classes, r.params + m->head_w, m->cfg.n_classes,
                             (float*)r.at(P.partial), gA, r.grads + m->head_w, r.grads + m->head_b, d_loss, r.st,
                             (opt && opt->step && tail_overlap_wanted(r)) ? opt->step : nullptr, (float*)r.at(P.loss_mean)));
     tap_aux(r, 7, -1, 0, m->head_C, m->cfg.n_classes, last, r.at(P.probs), d_y, d_sw, gA, m->head_w, m->head_b);
+    }
     if (m->x3) RC(x3_presplit_inputs(r));
     int point = 0;
     RC(mark_ready(r, point++));                                                            // head
@@ -662,7 +697,8 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
         const Conv& cu = m->conv[iu]; const Conv& c2 = m->conv[i2]; const Conv& c3 = m->conv[i3];
         const void* prev = j > 0 ? r.at(P.n2[j - 1]) : r.at(P.nb);
         const int Cprev = j > 0 ? m->F[lvl + 1] : m->F[D];
-        RC(bn_bwd(r, m->bn[m->up_bn(j, 1)], gA, r.at(P.c3u[j]), lvl, DZ(i3), rowsA, 1));   // dz3
+        if (!(head_fused && j == D - 1))                                                   // (fused head: dz3 of the last block is written)
+            RC(bn_bwd(r, m->bn[m->up_bn(j, 1)], gA, r.at(P.c3u[j]), lvl, DZ(i3), rowsA, 1));   // dz3
         RC(conv_wgrad(r, c3, r.at(P.c2u[j]), f, nullptr, 0, DZ(i3), lvl));
         RC(conv_dgrad(r, c3, DZ(i3), r.at(P.c2u[j]), DZ(i2), lvl, 0, f));                  // dz2
         RC(conv_wgrad(r, c2, r.at(P.n[lvl]), f, r.at(P.n1[j]), f, DZ(i2), lvl));
@@ -696,11 +732,26 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
         // skip gradient + un-pooled gradient, and in the same pass the BN-backward sums of the result
         const BN& eb = m->bn[m->enc_bn(i)];
         int bwd_rows = 0;
+        // Round 6 (MPU_POOL_BWD_RECOMPUTE): neither the post-BatchNorm tensor n is read nor the summed gradient written -- both
+        // passes recompute them from the BatchNorm input, the skip gradient and the pooled gradient (same bits; no launch tap:
+        // the replay tests check the two-tensor kernels)
+        int fused_pool = 0;
+        // (from 4 M elements: measured R6av at configs[1] -- levels 0 / 1 / 2 50.0 -> 41.6, 28.7 -> 26.4, 17.2 -> 16.2 us; the
+        //  2 M elements x 512 channels of level 3 lose 1.6 us to the all-channel coefficient prologue of the second pass)
+        if (env(ENV_POOL_BWD_RECOMPUTE) != 0 && r.acc_mode && !(eb.C & 63) && !m->tap &&
+            (long)r.B * H * W * m->F[i] >= (env(ENV_POOL_BWD_RECOMPUTE) > 1 ? 0L : 4L << 20)) {
+            fused_pool = launch_maxpool_bwd_bn(dt, r.at(P.dskip[i]), gB, r.B, H, W, m->F[i], r.at(P.c2[i]), r.stat(eb, 0), r.stat(eb, 1),
+                                               r.stat(eb, 2), r.stat(eb, 3), r.params + eb.g, r.grads + eb.g, r.grads + eb.b,
+                                               (float*)r.at(P.coeffs), DZ(i2), r.acc_b(eb), BN_ACC_B, r.st);
+            if (fused_pool < 0) return fused_pool;
+        }
+        if (!fused_pool) {
         RC(launch_maxpool_bwd_add_stats(dt, r.at(P.n[i]), r.at(P.dskip[i]), gB, r.B, H, W, m->F[i], gA, r.at(P.c2[i]),
                                         r.stat(eb, 0), r.stat(eb, 1), (float*)r.at(P.partial), P.partial_floats, &bwd_rows,
                                         r.st, (r.acc_mode && !(eb.C & 63)) ? r.acc_b(eb) : nullptr, BN_ACC_B));
         tap_aux(r, 5, m->enc_bn(i), i, m->F[i], m->F[i], r.at(P.n[i]), r.at(P.dskip[i]), gB, nullptr, gA, 0, 0);
         RC(bn_bwd(r, eb, gA, r.at(P.c2[i]), i, DZ(i2), bwd_rows));
+        }
         RC(conv_wgrad(r, c2, r.at(P.c1[i]), m->F[i], nullptr, 0, DZ(i2), i));
         RC(conv_dgrad(r, c2, DZ(i2), r.at(P.c1[i]), DZ(i1), i, 0, m->F[i]));
         const void* xin = i > 0 ? r.at(P.p[i - 1]) : r.at(P.xin);

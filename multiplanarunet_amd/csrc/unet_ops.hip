@@ -953,21 +953,30 @@ int launch_bn_backward(int dtype, const void* dn, const void* x, long M, int C, 
 // STATS: also the BatchNorm-backward sums of the level's BN over the STORED dn (sum dn, sum dn * xhat, xhat from the BN
 // input x): the grid is sized so that a thread keeps its channel chunk over all its elements ((gridDim.x * 256) % cpr
 // == 0); per-block partial row [2][C] in the layout of colreduce<1>, which this replaces for the encoder levels.
-template <typename T, bool STATS>
+// RECOMP (round 6, with STATS): the post-BatchNorm tensor n is NOT read -- its stored values are recomputed from the BatchNorm
+// input x the kernel loads anyway (n = rounding of bn_affine(x, scale, shift), the expression and the rounding of the forward
+// pass: the same bits, hence the same arg-max) -- and dn is NOT written: maxpool_bwd_bn_fold_kernel below recomputes it.
+template <typename T, bool STATS, bool RECOMP = false>
 __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const T* __restrict__ n, const T* __restrict__ dskip,
                                                               const T* __restrict__ dp, int B, int H, int W, int C,
                                                               T* __restrict__ dn, const T* __restrict__ x,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               float* __restrict__ partial, long long* acc_out, float acc_scale0,
-                                                              float acc_scale1) {
+                                                              float acc_scale1, const float* __restrict__ scale = nullptr,
+                                                              const float* __restrict__ shift = nullptr) {
+    static_assert(!RECOMP || STATS, "RECOMP needs the BatchNorm input");
     constexpr int N = Vec<T>::N;
     const int cpr = C / N, Hp = H / 2, Wp = W / 2;
     const long total = (long)B * Hp * Wp * cpr;
-    float s0[N], s1[N], mu[N], is[N];
+    float s0[N], s1[N], mu[N], is[N], sc[RECOMP ? N : 1], sh[RECOMP ? N : 1];
     if (STATS) {
         const int c = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpr);
 #pragma unroll
         for (int i = 0; i < N; ++i) { s0[i] = 0.f; s1[i] = 0.f; mu[i] = mean[c * N + i]; is[i] = invstd[c * N + i]; }
+        if (RECOMP) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { sc[i] = scale[c * N + i]; sh[i] = shift[c * N + i]; }
+        }
     }
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int c = (int)(e % cpr); long t = e / cpr;
@@ -980,7 +989,18 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const T* __restric
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             o[d] = ((((long)b * H + 2 * py + (d >> 1)) * W + 2 * px + (d & 1)) * cpr + c) * N;
-            Vec<T>::load(n + o[d], v[d]);
+            if (!RECOMP) Vec<T>::load(n + o[d], v[d]);
+        }
+        float xv[4][N];
+        if (STATS) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) Vec<T>::load(x + o[d], xv[d]);
+        }
+        if (RECOMP) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int i = 0; i < N; ++i) v[d][i] = to_f32<T>(from_f32<T>(bn_affine(xv[d][i], sc[i], sh[i])));
         }
         int arg[N];
 #pragma unroll
@@ -1000,17 +1020,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const T* __restric
 #pragma unroll
                 for (int i = 0; i < N; ++i) sk[d][i] = 0.f;
         }
-        float xv[4][N];
-        if (STATS) {
-#pragma unroll
-            for (int d = 0; d < 4; ++d) Vec<T>::load(x + o[d], xv[d]);
-        }
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             float s[N];
 #pragma unroll
             for (int i = 0; i < N; ++i) s[i] = sk[d][i] + (arg[i] == d ? g[i] : 0.f);
-            Vec<T>::store(dn + o[d], s);
+            if (!RECOMP) Vec<T>::store(dn + o[d], s);
             if (STATS) {
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
@@ -1064,6 +1079,104 @@ int launch_maxpool_bwd_add_stats(int dtype, const void* n, const void* dskip, co
         maxpool_bwd_add_kernel<float, true><<<(unsigned)blocks, 256, 0, st>>>((const float*)n, (const float*)dskip, (const float*)dp, B, H, W, C, (float*)dn, (const float*)x, mean, invstd, partial, acc, acc ? acc_scale[0] : 0.f, acc ? acc_scale[1] : 0.f);
     *rows = acc ? -1 : (int)blocks;
     return launch_ok();
+}
+
+// Round 6, second pass of the encoder levels' backward step without the dn tensor: recomputes what maxpool_bwd_add_kernel<RECOMP>
+// summed -- dn = rounding of (skip gradient + un-pooled gradient at the arg-max of the recomputed n) -- and applies the BatchNorm
+// backward to it: dz = [x > 0] * (k1 * dn + k2 * x + k3), coefficients from the accumulators in the prologue (the arithmetic of
+// bn_bwd_fold_kernel, expression for expression: the same bits as the two-tensor form). A workgroup covers whole pixels
+// (256 % (C / N) == 0), so its coefficient table holds all C channels: [5][C] floats of LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_bn_fold_kernel(const T* __restrict__ x, const T* __restrict__ dskip,
+                                                                  const T* __restrict__ dp, int B, int H, int W, int C,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  const long long* __restrict__ acc, float inv0, float inv1, long M,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, float* dgamma, float* dbeta,
+                                                                  float* coeffs, T* __restrict__ dz) {
+    constexpr int N = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float tab[];          // [5][C]: k1, k2, k3, scale, shift
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double s = bn_acc_sum(acc, C, 0, c, inv0), sx = bn_acc_sum(acc, C, 1, c, inv1);
+        float k1f, k2f, k3f;
+        bn_bwd_coeffs(s, sx, M, gamma[c], mean[c], invstd[c], k1f, k2f, k3f);
+        tab[c] = k1f; tab[C + c] = k2f; tab[2 * C + c] = k3f; tab[3 * C + c] = scale[c]; tab[4 * C + c] = shift[c];
+        if (blockIdx.x == 0) {
+            dgamma[c] = (float)sx; dbeta[c] = (float)s;
+            coeffs[c] = k1f; coeffs[C + c] = k2f; coeffs[2 * C + c] = k3f;
+        }
+    }
+    __syncthreads();
+    const int cpr = C / N, Hp = H / 2, Wp = W / 2;
+    const long total = (long)B * Hp * Wp * cpr;
+    const int cc = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpr);     // (gridDim.x * 256) % cpr == 0: the same chunk for all items
+    float k1[N], k2[N], k3[N], sc[N], sh[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        k1[i] = tab[cc * N + i]; k2[i] = tab[C + cc * N + i]; k3[i] = tab[2 * C + cc * N + i];
+        sc[i] = tab[3 * C + cc * N + i]; sh[i] = tab[4 * C + cc * N + i];
+    }
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % cpr); long t = e / cpr;
+        const int px = (int)(t % Wp); t /= Wp;
+        const int py = (int)(t % Hp); const int b = (int)(t / Hp);
+        float g[N];
+        Vec<T>::load(dp + e * N, g);
+        float xv[4][N], sk[4][N];
+        long o[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            o[d] = ((((long)b * H + 2 * py + (d >> 1)) * W + 2 * px + (d & 1)) * cpr + c) * N;
+            Vec<T>::load(x + o[d], xv[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) Vec<T>::load(dskip + o[d], sk[d]);
+        int arg[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            int a = 0; float m = to_f32<T>(from_f32<T>(bn_affine(xv[0][i], sc[i], sh[i])));
+#pragma unroll
+            for (int d = 1; d < 4; ++d) {
+                const float v = to_f32<T>(from_f32<T>(bn_affine(xv[d][i], sc[i], sh[i])));
+                if (v > m) { m = v; a = d; }
+            }
+            arg[i] = a;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float q[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const float r = to_f32<T>(from_f32<T>(sk[d][i] + (arg[i] == d ? g[i] : 0.f)));       // the stored dn of the two-tensor form
+                q[i] = xv[d][i] > 0.f ? bn_bwd_affine(r, xv[d][i], k1[i], k2[i], k3[i]) : 0.f;
+            }
+            Vec<T>::store(dz + o[d], q);
+        }
+    }
+}
+
+// Both passes of an encoder level's backward step without the dn tensor (accumulator mode; see the two kernels). 1 = launched,
+// 0 = shape not suited (the caller runs launch_maxpool_bwd_add_stats + launch_bn_backward).
+int launch_maxpool_bwd_bn(int dtype, const void* dskip, const void* dp, int B, int H, int W, int C, const void* x,
+                          const float* mean, const float* invstd, const float* scale, const float* shift, const float* gamma,
+                          float* dgamma, float* dbeta, float* coeffs, void* dz, long long* acc, const float* acc_scale, hipStream_t st) {
+    const int N = dtype == MPU_BF16 ? 8 : 4, cpr = C / N;
+    if (!acc || !dskip || C % N || (C & 63) || cpr < 1 || cpr > 256 || 256 % cpr || (H & 1) || (W & 1) || 5L * C * 4 > 48 * 1024) return 0;
+    const long work = (long)B * (H / 2) * (W / 2) * cpr;
+    long blocks = (work + 255) / 256; if (blocks > 1024) blocks = 1024;
+    const long M = (long)B * H * W;
+    const float inv0 = 1.f / acc_scale[0], inv1 = 1.f / acc_scale[1];
+    const unsigned lds = (unsigned)(5L * C * 4);
+    if (dtype == MPU_BF16) {
+        maxpool_bwd_add_kernel<bf16_t, true, true><<<(unsigned)blocks, 256, 0, st>>>(nullptr, (const bf16_t*)dskip, (const bf16_t*)dp, B, H, W, C, nullptr, (const bf16_t*)x, mean, invstd, nullptr, acc, acc_scale[0], acc_scale[1], scale, shift);
+        maxpool_bwd_bn_fold_kernel<bf16_t><<<(unsigned)blocks, 256, lds, st>>>((const bf16_t*)x, (const bf16_t*)dskip, (const bf16_t*)dp, B, H, W, C, scale, shift, acc, inv0, inv1, M, gamma, mean, invstd, dgamma, dbeta, coeffs, (bf16_t*)dz);
+    } else {
+        maxpool_bwd_add_kernel<float, true, true><<<(unsigned)blocks, 256, 0, st>>>(nullptr, (const float*)dskip, (const float*)dp, B, H, W, C, nullptr, (const float*)x, mean, invstd, nullptr, acc, acc_scale[0], acc_scale[1], scale, shift);
+        maxpool_bwd_bn_fold_kernel<float><<<(unsigned)blocks, 256, lds, st>>>((const float*)x, (const float*)dskip, (const float*)dp, B, H, W, C, scale, shift, acc, inv0, inv1, M, gamma, mean, invstd, dgamma, dbeta, coeffs, (float*)dz);
+    }
+    if (sched_log_on()) sched_note("bn_fold bwd C=%d rows=-1 pool=1 grid=%ld", C, blocks);
+    const int rc = launch_ok();
+    return rc ? rc : 1;
 }
 
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* out) {
@@ -1586,6 +1699,358 @@ int launch_head_backward(int dtype, const void* n, const float* probs, const uin
     if (rc) return rc;
     head_bwd_finalize_kernel<<<cdiv(C * K + K + 1, FIN_COLS), 256, 0, st>>>(partial, (int)blocks, C, K, ldw, dWh, dbh, step_incr, loss_mean,
                                                                             1.0 / (double)M);
+    return launch_ok();
+}
+
+// ------------------------------------------------------------------------------------------------------------------- //
+// Round 6: the training step's head WITHOUT the post-BatchNorm tensor of the last block (bf16, 64 channels, accumulator mode).
+// The unfused chain around the head is six HBM passes over 33.5-MB tensors at configs[1] -- BN apply (c3 -> n2), head forward
+// (n2 -> probs), head backward (n2, probs -> dn2 + head gradients), column reduction (dn2, c3 -> BatchNorm-backward sums),
+// BN backward (dn2, c3 -> dz3) -- although n2 and dn2 are functions of c3 and of K numbers per pixel:
+//   n2[m][c] = bf16(scale_c * c3[m][c] + shift_c),     dn2[m][c] = sum_k dzh[m][k] * Wh[c][k]   (dzh: the CE gradient at the logits)
+// so that  sum_m dn2[m][c]          = sum_k Wh[c][k] * dbh[k]
+//          sum_m dn2[m][c] * xhat_c = sum_k Wh[c][k] * T[c][k],   T[c][k] = sum_m xhat[m][c] * dzh[m][k]
+//          dWh[c][k] = sum_m n2[m][c] * dzh[m][k] = gamma_c * T[c][k] + beta_c * dbh[k]        (n2 before its bf16 rounding)
+// Three passes over c3 remain: head_bn_forward (fold of the BatchNorm statistics + affine + 1x1 + softmax -> probs; the logits
+// are the unfused path's bit for bit: the affine result takes the same bf16 rounding the stored n2 had), head_bn_backward (probs,
+// labels, c3 -> T, dbh, loss: partial rows, summed by head_bwd_finalize_kernel) and head_bn_bwd_apply (recomputes dzh and dn2 per
+// pixel, forms the BatchNorm-backward coefficients from T / dbh / Wh in its prologue, writes dz3; its first workgroup writes
+// dgamma, dbeta and dWh). dn2 stays in fp32 registers (the unfused path rounds it to bf16 in HBM), n2 in dWh is unrounded:
+// both closer to the fp64 oracle. Switch MPU_HEAD_TRAIN_FUSED=0; not taken while a launch tap is installed (the replay tests
+// check the unfused kernels launch by launch).
+// ------------------------------------------------------------------------------------------------------------------- //
+// CE gradient at the logits of one pixel (head_backward_kernel's per-pixel part, expression for expression)
+template <int K>
+__device__ __forceinline__ void head_ce_grad(const float* __restrict__ probs, const uint8_t* __restrict__ y, const float* __restrict__ sw,
+                                             long mm, long ppi, float (&dzv)[K], float* lv) {
+    constexpr float EPS = 1e-7f;
+    float p[K], g[K];
+    const int yy = y[mm];
+    const float wt = sw[mm / ppi];
+    float S = 0.f, qy = 1.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        p[k] = probs[mm * K + k];
+        const float q = fminf(fmaxf(p[k], EPS), 1.f - EPS);
+        S += q;
+        if (k == yy) qy = q;
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const bool pass = p[k] >= EPS && p[k] <= 1.f - EPS;
+        g[k] = pass ? ((k == yy ? -1.f / qy : 0.f) + 1.f / S) * wt : 0.f;
+        dot += g[k] * p[k];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) dzv[k] = p[k] * (g[k] - dot);
+    if (lv) *lv = (-logf(qy) + logf(S)) * wt;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void head_bn_forward_kernel(const bf16_t* __restrict__ x, long M, const long long* __restrict__ acc,
+                                                              float inv0, float inv1, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* mmean, float* mvar, float* mean,
+                                                              float* invstd, float* scale, float* shift, float eps, float mom,
+                                                              const float* __restrict__ Wh, int ldw, const float* __restrict__ bh,
+                                                              int softmax, float* __restrict__ out) {
+    constexpr int N = 8, GS = 8, C = 64;
+    __shared__ double red[2][64];
+    __shared__ __attribute__((aligned(16))) float coef[2][64];
+    const int sub = threadIdx.x % GS;
+    float g_ = 0.f, b_ = 0.f, mm_ = 0.f, mv_ = 0.f;
+    if (threadIdx.x < 64) { g_ = gamma[threadIdx.x]; b_ = beta[threadIdx.x]; mm_ = mmean[threadIdx.x]; mv_ = mvar[threadIdx.x]; }
+    if (threadIdx.x < 128) {
+        const int cl = threadIdx.x & 63, st = threadIdx.x >> 6;
+        red[st][cl] = bn_acc_sum(acc, C, st, cl, st ? inv1 : inv0);
+    }
+    float wr[N][K];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int k = 0; k < K; ++k) wr[i][k] = Wh[(long)(sub * N + i) * ldw + k];
+    float bias[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) bias[k] = bh[k];
+    __syncthreads();
+    if (threadIdx.x < 64) {                                      // bn_fold_apply_kernel's prologue, expression for expression
+        const BnFwdCoef kf = bn_fwd_coeffs(red[0][threadIdx.x], red[1][threadIdx.x], M, g_, b_, mm_, mv_, eps, mom);
+        coef[0][threadIdx.x] = kf.scale; coef[1][threadIdx.x] = kf.shift;
+        if (blockIdx.x == 0) {
+            const int c = threadIdx.x;
+            mean[c] = kf.mean; invstd[c] = kf.invstd; scale[c] = kf.scale; shift[c] = kf.shift;
+            mmean[c] = kf.mmean; mvar[c] = kf.mvar;
+        }
+    }
+    __syncthreads();
+    float sc[N], sh[N];
+#pragma unroll
+    for (int i = 0; i < N; i += 4) {
+        *reinterpret_cast<float4*>(sc + i) = *reinterpret_cast<const float4*>(&coef[0][sub * N + i]);
+        *reinterpret_cast<float4*>(sh + i) = *reinterpret_cast<const float4*>(&coef[1][sub * N + i]);
+    }
+    constexpr int PPB = 256;
+    for (long m0 = ((long)blockIdx.x * (256 / GS) + threadIdx.x / GS) * GS; m0 < M; m0 += (long)gridDim.x * PPB) {
+        const long left = M - m0;
+        const int nv = left < GS ? (int)left : GS;
+        float z[GS][K];
+#pragma unroll
+        for (int h = 0; h < GS; h += 4) {
+            float v[4][N];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                Vec<bf16_t>::load(x + (m0 + (h + u < nv ? h + u : nv - 1)) * C + (long)sub * N, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int i = 0; i < N; i += 2) {                 // the stored n2: affine, then the bf16 rounding of the store
+                    const uint32_t w2 = f32x2_to_bf16x2(bn_affine(v[u][i], sc[i], sh[i]), bn_affine(v[u][i + 1], sc[i + 1], sh[i + 1]));
+                    v[u][i] = __uint_as_float(w2 << 16); v[u][i + 1] = __uint_as_float(w2 & 0xffff0000u);
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) a += v[u][i] * wr[i][k];
+                    z[h + u][k] = a;
+                }
+            }
+        }
+#pragma unroll
+        for (int s = GS / 2; s >= 1; s >>= 1) {
+            const bool upper = (sub & s) != 0;
+#pragma unroll
+            for (int q = 0; q < s; ++q)
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float keep = upper ? z[s + q][k] : z[q][k];
+                    const float send = upper ? z[q][k] : z[s + q][k];
+                    z[q][k] = keep + __shfl_xor(send, s, 64);
+                }
+        }
+        if (sub < nv) {
+            float zz[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) zz[k] = z[0][k] + bias[k];
+            if (softmax) {
+                float mx = zz[0];
+#pragma unroll
+                for (int k = 1; k < K; ++k) mx = fmaxf(mx, zz[k]);
+                float ssum = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) { zz[k] = expf(zz[k] - mx); ssum += zz[k]; }
+#pragma unroll
+                for (int k = 0; k < K; ++k) zz[k] = zz[k] / ssum;
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) out[(m0 + sub) * K + k] = zz[k];
+        }
+    }
+}
+
+// partial layout as head_backward_kernel's: [nblk][64 * K + K + 1] = T, dbh, sum of the weighted per-pixel loss
+template <int K>
+__global__ __launch_bounds__(256, 4) void head_bn_backward_kernel(const bf16_t* __restrict__ x, const float* __restrict__ probs,
+                                                                  const uint8_t* __restrict__ y, const float* __restrict__ sw, long M,
+                                                                  long ppi, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, float* __restrict__ partial,
+                                                                  float* __restrict__ loss) {
+    constexpr int N = 8, G = 8, C = 64, JR = 2;
+    __shared__ float red[C * K + K + 1];
+    for (int i = threadIdx.x; i < C * K + K + 1; i += 256) red[i] = 0.f;
+    const int sub = threadIdx.x % G;
+    const int ppb = 256 / G;
+    const int lane = threadIdx.x & 63, gbase = lane & ~(G - 1);
+    float mu[N], is[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { mu[i] = mean[sub * N + i]; is[i] = invstd[sub * N + i]; }
+    float at[N][K], ab[K];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int k = 0; k < K; ++k) at[i][k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) ab[k] = 0.f;
+    float lsum = 0.f;
+    __syncthreads();
+    for (long m0 = ((long)blockIdx.x * ppb + threadIdx.x / G) * G; m0 < M; m0 += (long)gridDim.x * ppb * G) {
+        const long mm = m0 + sub;
+        float dzv[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) dzv[k] = 0.f;
+        if (mm < M) {
+            float lv;
+            head_ce_grad<K>(probs, y, sw, mm, ppi, dzv, &lv);
+#pragma unroll
+            for (int k = 0; k < K; ++k) ab[k] += dzv[k];
+            lsum += lv;
+            if (loss) loss[mm] = lv;
+        }
+        const long left = M - m0;
+        const int nv = left < G ? (int)left : G;
+        for (int j0 = 0; j0 < nv; j0 += JR) {
+            float v[JR][N];
+#pragma unroll
+            for (int u = 0; u < JR; ++u)
+                Vec<bf16_t>::load(x + (m0 + (j0 + u < nv ? j0 + u : nv - 1)) * C + (long)sub * N, v[u]);
+#pragma unroll
+            for (int u = 0; u < JR; ++u) {
+                const bool valid = j0 + u < nv;
+                float dj[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float t = __shfl(dzv[k], gbase + ((j0 + u) & (G - 1)), 64);
+                    dj[k] = valid ? t : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const float xh = (v[u][i] - mu[i]) * is[i];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) at[i][k] += xh * dj[k];
+                }
+            }
+        }
+    }
+    for (int o = G; o < 64; o <<= 1) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int k = 0; k < K; ++k) at[i][k] += __shfl_xor(at[i][k], o, 64);
+    }
+    for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) ab[k] += __shfl_xor(ab[k], o, 64);
+        lsum += __shfl_xor(lsum, o, 64);
+    }
+    for (int wv = 0; wv < 4; ++wv) {
+        const bool mine = (int)(threadIdx.x >> 6) == wv;
+        if (mine && lane < G) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int k = 0; k < K; ++k) red[(sub * N + i) * K + k] += at[i][k];
+        }
+        if (mine && lane == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) red[C * K + k] += ab[k];
+            red[C * K + K] += lsum;
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < C * K + K + 1; i += 256) partial[(long)blockIdx.x * (C * K + K + 1) + i] = red[i];
+}
+
+template <int K>
+__global__ __launch_bounds__(256, 4) void head_bn_bwd_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ probs,
+                                                                   const uint8_t* __restrict__ y, const float* __restrict__ sw, long M,
+                                                                   long ppi, const float* __restrict__ Wh, int ldw,
+                                                                   const float* __restrict__ Tsum, const float* __restrict__ dbh,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   float* dgamma, float* dbeta, float* dWh, float* coeffs,
+                                                                   bf16_t* __restrict__ dz) {
+    constexpr int N = 8, G = 8, C = 64, JR = 2;
+    __shared__ __attribute__((aligned(16))) float coef[3][64];
+    __shared__ float w[C * K];
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;
+        const float g_ = gamma[c], b_ = beta[c];
+        double s0 = 0.0, s1 = 0.0;
+        float tr[K], db[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float wk = Wh[(long)c * ldw + k];
+            w[c * K + k] = wk; tr[k] = Tsum[c * K + k]; db[k] = dbh[k];
+            s0 += (double)wk * (double)db[k]; s1 += (double)wk * (double)tr[k];
+        }
+        float k1f, k2f, k3f;
+        bn_bwd_coeffs(s0, s1, M, g_, mean[c], invstd[c], k1f, k2f, k3f);
+        coef[0][c] = k1f; coef[1][c] = k2f; coef[2][c] = k3f;
+        if (blockIdx.x == 0) {
+            dgamma[c] = (float)s1; dbeta[c] = (float)s0;
+            coeffs[c] = k1f; coeffs[C + c] = k2f; coeffs[2 * C + c] = k3f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) dWh[(long)c * ldw + k] = (float)((double)g_ * (double)tr[k] + (double)b_ * (double)db[k]);
+        }
+    }
+    __syncthreads();
+    const int sub = threadIdx.x % G;
+    const int ppb = 256 / G;
+    const int lane = threadIdx.x & 63, gbase = lane & ~(G - 1);
+    float wr[N][K], k1[N], k2[N], k3[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) wr[i][k] = w[(sub * N + i) * K + k];
+        k1[i] = coef[0][sub * N + i]; k2[i] = coef[1][sub * N + i]; k3[i] = coef[2][sub * N + i];
+    }
+    for (long m0 = ((long)blockIdx.x * ppb + threadIdx.x / G) * G; m0 < M; m0 += (long)gridDim.x * ppb * G) {
+        const long mm = m0 + sub;
+        float dzv[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) dzv[k] = 0.f;
+        if (mm < M) head_ce_grad<K>(probs, y, sw, mm, ppi, dzv, nullptr);
+        const long left = M - m0;
+        const int nv = left < G ? (int)left : G;
+        for (int j0 = 0; j0 < nv; j0 += JR) {
+            float v[JR][N];
+#pragma unroll
+            for (int u = 0; u < JR; ++u)
+                Vec<bf16_t>::load(x + (m0 + (j0 + u < nv ? j0 + u : nv - 1)) * C + (long)sub * N, v[u]);
+#pragma unroll
+            for (int u = 0; u < JR; ++u) {
+                const bool valid = j0 + u < nv;
+                float dj[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) dj[k] = __shfl(dzv[k], gbase + ((j0 + u) & (G - 1)), 64);
+                float o[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    float dn = 0.f;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) dn += dj[k] * wr[i][k];
+                    o[i] = v[u][i] > 0.f ? bn_bwd_affine(dn, v[u][i], k1[i], k2[i], k3[i]) : 0.f;
+                }
+                if (valid) Vec<bf16_t>::store(dz + (m0 + j0 + u) * C + (long)sub * N, o);
+            }
+        }
+    }
+}
+
+bool head_train_fused_shape_ok(int dtype, int C, int K) { return dtype == MPU_BF16 && C == 64 && K >= 1 && K <= 8; }
+
+int launch_head_bn_forward(const void* x, long M, const long long* acc, const float* acc_scale, const float* gamma, const float* beta,
+                           float* mmean, float* mvar, float* mean, float* invstd, float* scale, float* shift, float eps, float momentum,
+                           int K, const float* Wh, int ldw, const float* bh, int softmax, float* out, hipStream_t st) {
+    long rb = (M + 255) / 256; if (rb > 4096) rb = 4096;
+    const float inv0 = 1.f / acc_scale[0], inv1 = 1.f / acc_scale[1];
+    MPU_HEAD_DISPATCH_K(K, (head_bn_forward_kernel<KK><<<(unsigned)rb, 256, 0, st>>>((const bf16_t*)x, M, acc, inv0, inv1, gamma, beta, mmean, mvar,
+                                                                                     mean, invstd, scale, shift, eps, momentum, Wh, ldw, bh, softmax, out)))
+    if (sched_log_on()) sched_note("bn_fold fwd C=64 rows=-1 pool=0 head=1 grid=%ld", rb);
+    return launch_ok();
+}
+
+// T (-> tsum [64][K]), dbh, mean loss; the device step counter moves in the finalizer as in launch_head_backward
+int launch_head_bn_backward(const void* x, const float* probs, const uint8_t* y, const float* sw, long M, long ppi, int K,
+                            const float* mean, const float* invstd, float* partial, float* tsum, float* dbh, float* loss,
+                            hipStream_t st, long long* step_incr, float* loss_mean) {
+    long blocks = (M + 255) / 256; if (blocks > HEAD_BWD_MAX_BLOCKS) blocks = HEAD_BWD_MAX_BLOCKS;
+    MPU_HEAD_DISPATCH_K(K, (head_bn_backward_kernel<KK><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)x, probs, y, sw, M, ppi, mean, invstd, partial, loss)))
+    int rc = launch_ok();
+    if (rc) return rc;
+    head_bwd_finalize_kernel<<<cdiv(64 * K + K + 1, FIN_COLS), 256, 0, st>>>(partial, (int)blocks, 64, K, K, tsum, dbh, step_incr, loss_mean,
+                                                                             1.0 / (double)M);
+    return launch_ok();
+}
+
+int launch_head_bn_bwd_apply(const void* x, const float* probs, const uint8_t* y, const float* sw, long M, long ppi, int K,
+                             const float* Wh, int ldw, const float* tsum, const float* dbh, const float* gamma, const float* beta,
+                             const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dWh, float* coeffs, void* dz,
+                             hipStream_t st) {
+    long blocks = (M + 255) / 256; if (blocks > 4096) blocks = 4096;
+    MPU_HEAD_DISPATCH_K(K, (head_bn_bwd_apply_kernel<KK><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)x, probs, y, sw, M, ppi, Wh, ldw, tsum, dbh, gamma,
+                                                                                          beta, mean, invstd, dgamma, dbeta, dWh, coeffs, (bf16_t*)dz)))
+    if (sched_log_on()) sched_note("bn_fold bwd C=64 rows=-1 head=1 grid=%ld", blocks);
     return launch_ok();
 }
 

@@ -616,6 +616,7 @@ n = lib.mpu_schedule_log_read(None, 0); buf = C.create_string_buffer(int(n) + 1)
 lib.mpu_schedule_log_enable(0)
 lines = buf.value.decode().splitlines()
 print("FOLD fwd=%%d bwd=%%d" %% (sum(1 for l in lines if l.startswith("bn_fold fwd")), sum(1 for l in lines if l.startswith("bn_fold bwd"))))
+print("POOLBWD %%d" %% sum(1 for l in lines if l.startswith("bn_fold bwd") and "pool=1" in l))
 m.train_step(x, y, sw, want_loss=False)
 torch.cuda.synchronize()
 np.save(sys.argv[1], np.concatenate([m.params.cpu().numpy(), m.bn_state.cpu().numpy(), m.grads.cpu().numpy()]))
@@ -681,6 +682,106 @@ def test_bn_sums_in_fixed_point_accumulators_no_finalize_launches(tmp_path):
     print("accumulator form vs partial rows after one configs[1] step: moving statistics max |diff| / max = %.2e, gradient cosine %.4f"
           % (d_state, cos))
     assert d_state < 1e-4 and cos > 0.85, (d_state, cos)       # (measured: 8e-6 and 0.915)
+
+
+def test_pool_backward_without_the_summed_gradient_tensor_is_bitwise_the_two_tensor_form(tmp_path):
+    """Round 6: at the encoder levels the backward step max-pool backward + skip add -> BatchNorm backward used to read the
+    post-BatchNorm tensor (for the arg-max), write the summed gradient and read it back. Now both passes recompute them from the
+    BatchNorm input, the skip gradient and the pooled gradient (maxpool_bwd_add_kernel<RECOMP>, maxpool_bwd_bn_fold_kernel): the
+    recomputed activations take the forward pass's expression and rounding, the recomputed gradient the rounding of the stored
+    tensor, the sums are integers -- so parameters, moving statistics and gradients after two configs[1] train steps (gammas of
+    both signs) are the SAME BITS as with MPU_POOL_BWD_RECOMPUTE=0. Two subprocesses (the switch is read once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, env in (("recompute", {"MPU_POOL_BWD_RECOMPUTE": "2"}), ("tensors", {"MPU_POOL_BWD_RECOMPUTE": "0"})):     # (2: at every level)
+        f = str(tmp_path / (tag + ".npy"))
+        r = subprocess.run([sys.executable, "-c", _FOLD_SCRIPT % root, f], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("FOLD ")][0]
+        npool = int([l for l in r.stdout.splitlines() if l.startswith("POOLBWD ")][0].split()[1])
+        out[tag] = (np.load(f), npool, line)
+    a, b = out["recompute"][0], out["tensors"][0]
+    assert out["recompute"][1] == 4 and out["tensors"][1] == 0, (out["recompute"][1], out["tensors"][1])     # the four encoder levels
+    print("pool backward recompute vs two-tensor form: %s | %s; %d values" % (out["recompute"][2], out["tensors"][2], a.size))
+    assert out["recompute"][2] == out["tensors"][2]               # the same count of folded BatchNorms in both
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
+_HEAD_FUSED_SCRIPT = r"""
+import sys, numpy as np, torch, ctypes as C
+sys.path.insert(0, %r)
+from multiplanarunet_amd.unet import UNet
+from multiplanarunet_amd import _lib
+lib = _lib.load()
+quiet = lambda *a, **k: None
+B, K, D, dim = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+m = UNet(n_classes=K, dim=dim, n_channels=1, depth=D, complexity_factor=1, dtype="bf16", logger=quiet, flatten_output=True, seed=5)
+w = m.get_weights_dict()
+rng = np.random.RandomState(3)
+for k in w:                                        # gammas of both signs, non-trivial betas
+    if k.endswith("/gamma"): w[k] = rng.uniform(-1.5, 1.5, w[k].shape).astype(np.float32)
+    if k.endswith("/beta"): w[k] = rng.uniform(-.3, .3, w[k].shape).astype(np.float32)
+m.set_weights_dict(w)
+rng = np.random.RandomState(7)
+x = torch.tensor(rng.randn(B, dim, dim, 1).astype(np.float32), device="cuda")
+y = torch.tensor(rng.randint(0, K, (B, dim * dim, 1)).astype(np.uint8), device="cuda")
+sw = torch.tensor(np.where(np.arange(B) %% 2 == 0, 0.4, 1.0).astype(np.float32), device="cuda")
+lib.mpu_schedule_log_enable(1)
+probs, loss = m.forward_backward(x, y, sw, want_loss=True)
+n = lib.mpu_schedule_log_read(None, 0); buf = C.create_string_buffer(int(n) + 1); lib.mpu_schedule_log_read(buf, n + 1)
+lib.mpu_schedule_log_enable(0)
+lines = buf.value.decode().splitlines()
+print("HEAD fused=%%d folds=%%d" %% (sum(1 for l in lines if "head=1" in l), sum(1 for l in lines if l.startswith("bn_fold"))))
+torch.cuda.synchronize()
+g = m.grads.cpu().numpy()
+def grad_of(name):
+    kind, off, ps, ls = m._tensors[name]
+    return m._from_stored(name, g[off:off + int(np.prod(ps))].reshape(ps), ps, ls)
+np.savez(sys.argv[1], probs=probs.float().cpu().numpy(), loss=loss.float().cpu().numpy(), loss_mean=np.float32(m.loss_mean().item()),
+         state=m.bn_state.cpu().numpy(), **{"g:" + k: grad_of(k) for k in m._order if m._tensors[k][0] == 0})
+"""
+
+
+@pytest.mark.parametrize("B,K,D,dim", [(3, 3, 2, 48), (2, 4, 1, 64), (16, 3, 4, 128)])
+def test_training_head_without_the_last_post_bn_tensor_equals_the_unfused_chain(tmp_path, B, K, D, dim):
+    """Round 6: in the bf16 train step the last block's BatchNorm apply, the head forward, the head backward, the column reduction
+    of the BatchNorm-backward sums and the BatchNorm backward (five passes, two 33-MB intermediates at configs[1]) run as three
+    passes over the last conv's output (head_bn_forward / head_bn_backward / head_bn_bwd_apply; MPU_HEAD_TRAIN_FUSED=0 restores
+    the chain). The forward is the same arithmetic: probabilities, per-pixel loss and moving statistics are the SAME BITS. The
+    backward keeps the head's data gradient in fp32 registers instead of a bf16 tensor and forms the head weight gradient from
+    the unrounded BatchNorm output, so gradients agree to bf16 rounding: the head's and the last BatchNorm's own tensors tightly,
+    the rest of the network through its (chaotic) amplification. Shapes: ragged pixel counts / 4 classes / the configs[1] network."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, env in (("fused", {}), ("chain", {"MPU_HEAD_TRAIN_FUSED": "0"})):
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _HEAD_FUSED_SCRIPT % root, f, str(B), str(K), str(D), str(dim)],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("HEAD ")][0]
+        nh, nfold = (int(t.split("=")[1]) for t in line.split()[1:])
+        out[tag] = (dict(np.load(f)), nh, nfold)
+    (a, nh, nf), (b, nh0, nf0) = out["fused"], out["chain"]
+    assert nh == 2 and nh0 == 0 and nf == nf0, (nh, nh0, nf, nf0)      # forward + backward pass of the last BatchNorm ride in the head passes
+    assert np.array_equal(a["probs"], b["probs"]) and np.array_equal(a["loss"], b["loss"]) and np.array_equal(a["state"], b["state"])
+    assert abs(float(a["loss_mean"]) - float(b["loss_mean"])) <= 1e-6 * abs(float(b["loss_mean"]))
+    rel = lambda u, v: float(np.linalg.norm(u.astype(np.float64) - v) / (np.linalg.norm(v.astype(np.float64)) + 1e-30))
+    last = "upsample_L%d_BN2" % (D - 1)                         # the head's own tensors and the last BatchNorm's
+    tight = {k: rel(a[k], b[k]) for k in a if k.startswith("g:") and (k[2:].split("/")[0] == last or
+                                                                      not any(t in k for t in ("encoder", "bottom", "upsample")))}
+    allr = {k: rel(a[k], b[k]) for k in a if k.startswith("g:")}
+    ga = np.concatenate([a[k].ravel() for k in sorted(allr)]).astype(np.float64)
+    gb = np.concatenate([b[k].ravel() for k in sorted(allr)]).astype(np.float64)
+    cos = float(ga @ gb / np.sqrt((ga @ ga) * (gb @ gb)))
+    print("fused head vs chain (B=%d K=%d depth=%d dim=%d): head / last-BN tensors rel-L2 %s; all gradients cosine %.5f, worst tensor %.3g"
+          % (B, K, D, dim, {k[2:]: "%.2e" % v for k, v in tight.items()}, cos, max(allr.values())))
+    assert len(tight) >= 4, list(tight)
+    for k, v in tight.items():
+        assert v <= 1e-2, (k, v)
+    assert cos >= (0.85 if D >= 4 else 0.995), cos
 
 
 def test_persistent_halo16_inference_equals_default_schedules_subprocess(tmp_path):
