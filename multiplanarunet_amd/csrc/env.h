@@ -41,6 +41,7 @@ enum EnvKind {
     X(FUSED_BN_BWD, "MPU_FUSED_BN_BWD", ENV_ON, 1, "0: max-pool backward + skip add without the fused BatchNorm-backward sums")      \
     X(HEAD_TRAIN_FUSED, "MPU_HEAD_TRAIN_FUSED", ENV_ON, 1, "0: training step with the post-BatchNorm tensor of the last block materialised (BN apply, head forward, head backward, column reduction, BN backward as five launches) instead of the three head_bn_* passes (round-6 A/B)") \
     X(POOL_BWD_RECOMPUTE, "MPU_POOL_BWD_RECOMPUTE", ENV_NUM, 1, "0: encoder levels' backward step with the post-BatchNorm tensor read and the summed gradient (skip + un-pooled) written between max-pool backward and BatchNorm backward, instead of both passes recomputing them (round-6 A/B); 1: recompute from 4 M elements per level; 2: at every level (tests)") \
+    X(POOL_BWD_BLOCKS, "MPU_POOL_BWD_BLOCKS", ENV_NUM, 0, "dev aid: cap on the workgroups of the two pool-backward recompute passes (0 = the default)") \
     X(HEAD_RS, "MPU_HEAD_RS", ENV_ON, 1, "0: head forward without the reduce-scatter variant")                                       \
     X(WGRAD_C8, "MPU_WGRAD_C8", ENV_ON, 1, "0: first-layer weight gradient not on wgrad_c8")                                         \
     X(WGRAD_TAPS, "MPU_WGRAD_TAPS", ENV_ON, 1, "0: no wgrad_taps (strip-resident weight gradients): wgrad_glds everywhere")          \

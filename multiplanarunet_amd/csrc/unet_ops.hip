@@ -1163,7 +1163,8 @@ int launch_maxpool_bwd_bn(int dtype, const void* dskip, const void* dp, int B, i
     const int N = dtype == MPU_BF16 ? 8 : 4, cpr = C / N;
     if (!acc || !dskip || C % N || (C & 63) || cpr < 1 || cpr > 256 || 256 % cpr || (H & 1) || (W & 1) || 5L * C * 4 > 48 * 1024) return 0;
     const long work = (long)B * (H / 2) * (W / 2) * cpr;
-    long blocks = (work + 255) / 256; if (blocks > 1024) blocks = 1024;
+    const long cap = env(ENV_POOL_BWD_BLOCKS) > 0 ? env(ENV_POOL_BWD_BLOCKS) : 1024;
+    long blocks = (work + 255) / 256; if (blocks > cap) blocks = cap;
     const long M = (long)B * H * W;
     const float inv0 = 1.f / acc_scale[0], inv1 = 1.f / acc_scale[1];
     const unsigned lds = (unsigned)(5L * C * 4);
@@ -1755,9 +1756,21 @@ __global__ __launch_bounds__(256) void head_bn_forward_kernel(const bf16_t* __re
                                                               const float* __restrict__ Wh, int ldw, const float* __restrict__ bh,
                                                               int softmax, float* __restrict__ out) {
     constexpr int N = 8, GS = 8, C = 64;
+    constexpr int PPB = 256;
     __shared__ double red[2][64];
     __shared__ __attribute__((aligned(16))) float coef[2][64];
     const int sub = threadIdx.x % GS;
+    // the eight chunks of the first pass are requested BEFORE the statistics (two dependent round trips + two barriers):
+    // at configs[1] a workgroup has exactly one pass
+    long m0 = ((long)blockIdx.x * (256 / GS) + threadIdx.x / GS) * GS;
+    uint4 xq[GS];
+    {
+        const long left = M - m0;
+        const int nv = left < GS ? (left > 0 ? (int)left : 1) : GS;
+        const long mb = m0 < M ? m0 : 0;
+#pragma unroll
+        for (int h = 0; h < GS; ++h) xq[h] = *(const uint4*)(x + (mb + (h < nv ? h : nv - 1)) * C + (long)sub * N);
+    }
     float g_ = 0.f, b_ = 0.f, mm_ = 0.f, mv_ = 0.f;
     if (threadIdx.x < 64) { g_ = gamma[threadIdx.x]; b_ = beta[threadIdx.x]; mm_ = mmean[threadIdx.x]; mv_ = mvar[threadIdx.x]; }
     if (threadIdx.x < 128) {
@@ -1789,8 +1802,7 @@ __global__ __launch_bounds__(256) void head_bn_forward_kernel(const bf16_t* __re
         *reinterpret_cast<float4*>(sc + i) = *reinterpret_cast<const float4*>(&coef[0][sub * N + i]);
         *reinterpret_cast<float4*>(sh + i) = *reinterpret_cast<const float4*>(&coef[1][sub * N + i]);
     }
-    constexpr int PPB = 256;
-    for (long m0 = ((long)blockIdx.x * (256 / GS) + threadIdx.x / GS) * GS; m0 < M; m0 += (long)gridDim.x * PPB) {
+    for (; m0 < M; m0 += (long)gridDim.x * PPB) {
         const long left = M - m0;
         const int nv = left < GS ? (int)left : GS;
         float z[GS][K];
@@ -1798,8 +1810,11 @@ __global__ __launch_bounds__(256) void head_bn_forward_kernel(const bf16_t* __re
         for (int h = 0; h < GS; h += 4) {
             float v[4][N];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                Vec<bf16_t>::load(x + (m0 + (h + u < nv ? h + u : nv - 1)) * C + (long)sub * N, v[u]);
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t w4[4] = {xq[h + u].x, xq[h + u].y, xq[h + u].z, xq[h + u].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[u][2 * q] = __uint_as_float(w4[q] << 16); v[u][2 * q + 1] = __uint_as_float(w4[q] & 0xffff0000u); }
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -1845,12 +1860,19 @@ __global__ __launch_bounds__(256) void head_bn_forward_kernel(const bf16_t* __re
 #pragma unroll
             for (int k = 0; k < K; ++k) out[(m0 + sub) * K + k] = zz[k];
         }
+        const long m1 = m0 + (long)gridDim.x * PPB;              // the next pass's chunks
+        if (m1 < M) {
+            const long left1 = M - m1;
+            const int nv1 = left1 < GS ? (int)left1 : GS;
+#pragma unroll
+            for (int h = 0; h < GS; ++h) xq[h] = *(const uint4*)(x + (m1 + (h < nv1 ? h : nv1 - 1)) * C + (long)sub * N);
+        }
     }
 }
 
 // partial layout as head_backward_kernel's: [nblk][64 * K + K + 1] = T, dbh, sum of the weighted per-pixel loss
 template <int K>
-__global__ __launch_bounds__(256, 4) void head_bn_backward_kernel(const bf16_t* __restrict__ x, const float* __restrict__ probs,
+__global__ __launch_bounds__(256, (K <= 4 ? 4 : 2)) void head_bn_backward_kernel(const bf16_t* __restrict__ x, const float* __restrict__ probs,
                                                                   const uint8_t* __restrict__ y, const float* __restrict__ sw, long M,
                                                                   long ppi, const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd, float* __restrict__ partial,
@@ -1888,6 +1910,7 @@ __global__ __launch_bounds__(256, 4) void head_bn_backward_kernel(const bf16_t* 
         }
         const long left = M - m0;
         const int nv = left < G ? (int)left : G;
+        // (all eight chunks requested before the per-pixel part, fully unrolled: 5-67 spilled registers at K = 3-4; this form: 92)
         for (int j0 = 0; j0 < nv; j0 += JR) {
             float v[JR][N];
 #pragma unroll
@@ -1941,7 +1964,7 @@ __global__ __launch_bounds__(256, 4) void head_bn_backward_kernel(const bf16_t* 
 }
 
 template <int K>
-__global__ __launch_bounds__(256, 4) void head_bn_bwd_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ probs,
+__global__ __launch_bounds__(256, (K <= 4 ? 4 : 2)) void head_bn_bwd_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ probs,
                                                                    const uint8_t* __restrict__ y, const float* __restrict__ sw, long M,
                                                                    long ppi, const float* __restrict__ Wh, int ldw,
                                                                    const float* __restrict__ Tsum, const float* __restrict__ dbh,

@@ -72,7 +72,7 @@ c3, c4, tr = opt("bench_line_configs3.json"), opt("bench_line_configs4.json"), o
 traffic = "not taken"
 if tr:
     step_gb = sum(k["launches"] * k["hbm_MB_per_launch"] for k in tr["kernels"].values()) / 1e3
-    steps = next(k["launches"] for n, k in tr["kernels"].items() if "head_forward" in n)      # one head per step
+    steps = next(k["launches"] for n, k in tr["kernels"].items() if "head_forward" in n or "head_bn_forward" in n)      # one head per step
     traffic = "%.2f GB per step (conv family %.1f MB per launch, weight gradients %.0f MB per launch)" % (
         step_gb / steps, tr["classes"]["conv_igemm"]["hbm_bytes_per_launch"] / 1e6, tr["classes"]["wgrad_igemm"]["hbm_bytes_per_launch"] / 1e6)
 cb = line["cpu_baseline"]

@@ -25,7 +25,7 @@ CONV = ("conv_c8", "conv_ws", "conv_halo8", "conv_halo", "conv_deepk", "conv_pip
 def short(n):
     return n.replace("_kernel", "")
 # split the sequence at head_forward: forward convs before, data gradients after
-hf = next(i for i, r in enumerate(rows) if r[0].startswith("head_forward"))
+hf = next(i for i, r in enumerate(rows) if r[0].startswith(("head_forward", "head_bn_forward")))
 tail = next(i for i, r in enumerate(rows) if r[0].startswith("wgrad_c8_kernel"))
 def conv_groups(seq):
     out = []
