@@ -293,13 +293,13 @@ int launch_maxpool_bwd_bn(int dtype, const void* dskip, const void* dp, int B, i
                           float* dgamma, float* dbeta, float* coeffs, void* dz, long long* acc, const float* acc_scale, hipStream_t st);
 // Round 6: the training step's head without the post-BatchNorm tensor of the last block (unet_ops.hip, "head_bn_*")
 bool head_train_fused_shape_ok(int dtype, int C, int K);
-int launch_head_bn_forward(const void* x, long M, const long long* acc, const float* acc_scale, const float* gamma, const float* beta,
+int launch_head_bn_forward(int dtype, const void* x, long M, const long long* acc, const float* acc_scale, const float* gamma, const float* beta,
                            float* mmean, float* mvar, float* mean, float* invstd, float* scale, float* shift, float eps, float momentum,
                            int K, const float* Wh, int ldw, const float* bh, int softmax, float* out, hipStream_t st);
-int launch_head_bn_backward(const void* x, const float* probs, const uint8_t* y, const float* sw, long M, long ppi, int K,
+int launch_head_bn_backward(int dtype, const void* x, const float* probs, const uint8_t* y, const float* sw, long M, long ppi, int K,
                             const float* mean, const float* invstd, float* partial, float* tsum, float* dbh, float* loss,
                             hipStream_t st, long long* step_incr, float* loss_mean);
-int launch_head_bn_bwd_apply(const void* x, const float* probs, const uint8_t* y, const float* sw, long M, long ppi, int K,
+int launch_head_bn_bwd_apply(int dtype, const void* x, const float* probs, const uint8_t* y, const float* sw, long M, long ppi, int K,
                              const float* Wh, int ldw, const float* tsum, const float* dbh, const float* gamma, const float* beta,
                              const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dWh, float* coeffs, void* dz,
                              hipStream_t st);

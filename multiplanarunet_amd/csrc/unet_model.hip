@@ -473,11 +473,11 @@ void tap_aux(const Run& r, int kind, int index, int lvl, int C0, int Cout, const
     r.m->tap(r.m->tap_user, &li);
 }
 
-// Round 6: the training step's head as the three head_bn_* passes (unet_ops.hip): bf16, accumulator mode, a 64-channel last block
+// Round 6: the training step's head as the three head_bn_* passes (unet_ops.hip): bf16 or bf16x3 (accumulator mode), a 64-channel last block
 // feeding a softmax head, no launch tap (the replay tests check the unfused kernels launch by launch)
 bool head_train_fused_wanted(const Run& r) {
     const mpu_unet* m = r.m;
-    return env(ENV_HEAD_TRAIN_FUSED) != 0 && r.acc_mode && !m->x3 && !m->tap && m->cfg.depth > 0 && m->cfg.softmax &&
+    return env(ENV_HEAD_TRAIN_FUSED) != 0 && r.acc_mode && !m->tap && m->cfg.depth > 0 && m->cfg.softmax &&
            m->F[0] == 64 && head_train_fused_shape_ok(m->cfg.dtype, m->head_C, m->cfg.n_classes);
 }
 
@@ -623,7 +623,7 @@ int run_forward(const Run& r, const float* d_x, int training, float* d_out) {
     float* out = d_out ? d_out : (float*)r.at(P.probs);
     if (m->head_fused_fwd) {
         const BN& b = m->bn[m->up_bn(D - 1, 1)];
-        RC(launch_head_bn_forward(r.at(P.c3u[D - 1]), M0, r.acc_f(b), BN_ACC_F, r.params + b.g, r.params + b.b, r.state + b.mm,
+        RC(launch_head_bn_forward(m->cfg.dtype, r.at(P.c3u[D - 1]), M0, r.acc_f(b), BN_ACC_F, r.params + b.g, r.params + b.b, r.state + b.mm,
                                   r.state + b.mv, r.stat(b, 0), r.stat(b, 1), r.stat(b, 2), r.stat(b, 3), BN_EPS, BN_MOM,
                                   m->cfg.n_classes, r.params + m->head_w, m->cfg.n_classes, r.params + m->head_b, m->cfg.softmax, out, r.st));
     } else {
@@ -670,10 +670,10 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
         const void* c3 = r.at(P.c3u[D - 1]);
         float* tsum = (float*)r.at(P.partial) + P.partial_floats;
         const long ppi = (long)m->cfg.H * m->cfg.W;
-        RC(launch_head_bn_backward(c3, (const float*)r.at(P.probs), d_y, d_sw, M0, ppi, m->cfg.n_classes, r.stat(b, 0), r.stat(b, 1),
+        RC(launch_head_bn_backward(dt, c3, (const float*)r.at(P.probs), d_y, d_sw, M0, ppi, m->cfg.n_classes, r.stat(b, 0), r.stat(b, 1),
                                    (float*)r.at(P.partial), tsum, r.grads + m->head_b, d_loss, r.st,
                                    (opt && opt->step && tail_overlap_wanted(r)) ? opt->step : nullptr, (float*)r.at(P.loss_mean)));
-        RC(launch_head_bn_bwd_apply(c3, (const float*)r.at(P.probs), d_y, d_sw, M0, ppi, m->cfg.n_classes, r.params + m->head_w,
+        RC(launch_head_bn_bwd_apply(dt, c3, (const float*)r.at(P.probs), d_y, d_sw, M0, ppi, m->cfg.n_classes, r.params + m->head_w,
                                     m->cfg.n_classes, tsum, r.grads + m->head_b, r.params + b.g, r.params + b.b, r.stat(b, 0), r.stat(b, 1),
                                     r.grads + b.g, r.grads + b.b, r.grads + m->head_w, (float*)r.at(P.coeffs),
                                     r.at(P.dz[m->up_c(D - 1, 2)]), r.st));

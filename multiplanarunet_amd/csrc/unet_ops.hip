@@ -1063,13 +1063,22 @@ int launch_maxpool_bwd_add(int dtype, const void* n, const void* dskip, const vo
 
 // Same, plus the BN-backward partial sums of dn against the BN input x (see the kernel). *rows = partial rows written
 // ([rows][2][C]); 0 = shape not suited (plain kernel launched, the caller runs the column reduction).
+// Workgroups of the pool-backward kernels with fused sums (both forms: the SAME partition of the elements over threads, so that their
+// per-thread fp32 partial sums -- and with them every bit downstream -- agree). The kernels hold 147-160 registers: three workgroups
+// per CU are resident, a cap of 1024 ran 1.33 rounds (R6ax: levels 0 / 1 41.0 -> 38.9 us, 26.1 -> 23.5 us at 768).
+static long pool_bwd_blocks(long work) {
+    const long cap = env(ENV_POOL_BWD_BLOCKS) > 0 ? env(ENV_POOL_BWD_BLOCKS) : 3L * device_cu_count();
+    const long blocks = (work + 255) / 256;
+    return blocks > cap ? cap : blocks;
+}
+
 int launch_maxpool_bwd_add_stats(int dtype, const void* n, const void* dskip, const void* dp, int B, int H, int W, int C,
                                  void* dn, const void* x, const float* mean, const float* invstd, float* partial,
                                  long partial_cap, int* rows, hipStream_t st, long long* acc, const float* acc_scale) {
     const bool on = env(ENV_FUSED_BN_BWD) != 0;
     const int N = dtype == MPU_BF16 ? 8 : 4, cpr = C / N;
     const long work = (long)B * (H / 2) * (W / 2) * cpr;
-    long blocks = (work + 255) / 256; if (blocks > 1024) blocks = 1024;
+    const long blocks = pool_bwd_blocks(work);
     *rows = 0;
     if (!on || C % N || cpr < 1 || cpr > 256 || 256 % cpr || blocks * 2 * C > partial_cap)
         return launch_maxpool_bwd_add(dtype, n, dskip, dp, B, H, W, C, dn, st);
@@ -1163,10 +1172,7 @@ int launch_maxpool_bwd_bn(int dtype, const void* dskip, const void* dp, int B, i
     const int N = dtype == MPU_BF16 ? 8 : 4, cpr = C / N;
     if (!acc || !dskip || C % N || (C & 63) || cpr < 1 || cpr > 256 || 256 % cpr || (H & 1) || (W & 1) || 5L * C * 4 > 48 * 1024) return 0;
     const long work = (long)B * (H / 2) * (W / 2) * cpr;
-    // (both passes hold 147 / 160 registers: three workgroups per CU are resident -- a cap of 1024 is 1.33 rounds; R6ax, levels 0 / 1:
-    //  41.0 -> 38.9 us, 26.1 -> 23.5 us at 768)
-    const long cap = env(ENV_POOL_BWD_BLOCKS) > 0 ? env(ENV_POOL_BWD_BLOCKS) : 3L * device_cu_count();
-    long blocks = (work + 255) / 256; if (blocks > cap) blocks = cap;
+    const long blocks = pool_bwd_blocks(work);
     const long M = (long)B * H * W;
     const float inv0 = 1.f / acc_scale[0], inv1 = 1.f / acc_scale[1];
     const unsigned lds = (unsigned)(5L * C * 4);
@@ -1750,29 +1756,19 @@ __device__ __forceinline__ void head_ce_grad(const float* __restrict__ probs, co
     if (lv) *lv = (-logf(qy) + logf(S)) * wt;
 }
 
-template <int K>
-__global__ __launch_bounds__(256) void head_bn_forward_kernel(const bf16_t* __restrict__ x, long M, const long long* __restrict__ acc,
+template <typename T, int K>
+__global__ __launch_bounds__(256) void head_bn_forward_kernel(const T* __restrict__ x, long M, const long long* __restrict__ acc,
                                                               float inv0, float inv1, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* mmean, float* mvar, float* mean,
                                                               float* invstd, float* scale, float* shift, float eps, float mom,
                                                               const float* __restrict__ Wh, int ldw, const float* __restrict__ bh,
                                                               int softmax, float* __restrict__ out) {
-    constexpr int N = 8, GS = 8, C = 64;
+    constexpr int N = Vec<T>::N, GS = 64 / N, C = 64;            // 8 lanes x 8 channels (bf16) / 16 lanes x 4 channels (f32 storage)
+    static_assert(GS * K <= 64, "reduce-scatter group");
     constexpr int PPB = 256;
     __shared__ double red[2][64];
     __shared__ __attribute__((aligned(16))) float coef[2][64];
     const int sub = threadIdx.x % GS;
-    // the eight chunks of the first pass are requested BEFORE the statistics (two dependent round trips + two barriers):
-    // at configs[1] a workgroup has exactly one pass
-    long m0 = ((long)blockIdx.x * (256 / GS) + threadIdx.x / GS) * GS;
-    uint4 xq[GS];
-    {
-        const long left = M - m0;
-        const int nv = left < GS ? (left > 0 ? (int)left : 1) : GS;
-        const long mb = m0 < M ? m0 : 0;
-#pragma unroll
-        for (int h = 0; h < GS; ++h) xq[h] = *(const uint4*)(x + (mb + (h < nv ? h : nv - 1)) * C + (long)sub * N);
-    }
     float g_ = 0.f, b_ = 0.f, mm_ = 0.f, mv_ = 0.f;
     if (threadIdx.x < 64) { g_ = gamma[threadIdx.x]; b_ = beta[threadIdx.x]; mm_ = mmean[threadIdx.x]; mv_ = mvar[threadIdx.x]; }
     if (threadIdx.x < 128) {
@@ -1804,7 +1800,8 @@ __global__ __launch_bounds__(256) void head_bn_forward_kernel(const bf16_t* __re
         *reinterpret_cast<float4*>(sc + i) = *reinterpret_cast<const float4*>(&coef[0][sub * N + i]);
         *reinterpret_cast<float4*>(sh + i) = *reinterpret_cast<const float4*>(&coef[1][sub * N + i]);
     }
-    for (; m0 < M; m0 += (long)gridDim.x * PPB) {
+    // (requesting the first pass's chunks before the statistics prologue measured the same, 10.7 / 11.0 us at configs[1]: R6ax)
+    for (long m0 = ((long)blockIdx.x * (256 / GS) + threadIdx.x / GS) * GS; m0 < M; m0 += (long)gridDim.x * PPB) {
         const long left = M - m0;
         const int nv = left < GS ? (int)left : GS;
         float z[GS][K];
@@ -1812,18 +1809,13 @@ __global__ __launch_bounds__(256) void head_bn_forward_kernel(const bf16_t* __re
         for (int h = 0; h < GS; h += 4) {
             float v[4][N];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t w4[4] = {xq[h + u].x, xq[h + u].y, xq[h + u].z, xq[h + u].w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { v[u][2 * q] = __uint_as_float(w4[q] << 16); v[u][2 * q + 1] = __uint_as_float(w4[q] & 0xffff0000u); }
-            }
+            for (int u = 0; u < 4; ++u)
+                Vec<T>::load(x + (m0 + (h + u < nv ? h + u : nv - 1)) * C + (long)sub * N, v[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                for (int i = 0; i < N; i += 2) {                 // the stored n2: affine, then the bf16 rounding of the store
-                    const uint32_t w2 = f32x2_to_bf16x2(bn_affine(v[u][i], sc[i], sh[i]), bn_affine(v[u][i + 1], sc[i + 1], sh[i + 1]));
-                    v[u][i] = __uint_as_float(w2 << 16); v[u][i + 1] = __uint_as_float(w2 & 0xffff0000u);
-                }
+                for (int i = 0; i < N; ++i)                      // the stored n2: affine, then the rounding of the store
+                    v[u][i] = to_f32<T>(from_f32<T>(bn_affine(v[u][i], sc[i], sh[i])));
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     float a = 0.f;
@@ -1862,24 +1854,17 @@ __global__ __launch_bounds__(256) void head_bn_forward_kernel(const bf16_t* __re
 #pragma unroll
             for (int k = 0; k < K; ++k) out[(m0 + sub) * K + k] = zz[k];
         }
-        const long m1 = m0 + (long)gridDim.x * PPB;              // the next pass's chunks
-        if (m1 < M) {
-            const long left1 = M - m1;
-            const int nv1 = left1 < GS ? (int)left1 : GS;
-#pragma unroll
-            for (int h = 0; h < GS; ++h) xq[h] = *(const uint4*)(x + (m1 + (h < nv1 ? h : nv1 - 1)) * C + (long)sub * N);
-        }
     }
 }
 
 // partial layout as head_backward_kernel's: [nblk][64 * K + K + 1] = T, dbh, sum of the weighted per-pixel loss
-template <int K>
-__global__ __launch_bounds__(256, (K <= 4 ? 4 : 2)) void head_bn_backward_kernel(const bf16_t* __restrict__ x, const float* __restrict__ probs,
+template <typename T, int K>
+__global__ __launch_bounds__(256, (K <= 4 ? 4 : 2)) void head_bn_backward_kernel(const T* __restrict__ x, const float* __restrict__ probs,
                                                                   const uint8_t* __restrict__ y, const float* __restrict__ sw, long M,
                                                                   long ppi, const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd, float* __restrict__ partial,
                                                                   float* __restrict__ loss) {
-    constexpr int N = 8, G = 8, C = 64, JR = 2;
+    constexpr int N = Vec<T>::N, G = 64 / N, C = 64, JR = 2;
     __shared__ float red[C * K + K + 1];
     for (int i = threadIdx.x; i < C * K + K + 1; i += 256) red[i] = 0.f;
     const int sub = threadIdx.x % G;
@@ -1912,12 +1897,12 @@ __global__ __launch_bounds__(256, (K <= 4 ? 4 : 2)) void head_bn_backward_kernel
         }
         const long left = M - m0;
         const int nv = left < G ? (int)left : G;
-        // (all eight chunks requested before the per-pixel part, fully unrolled: 5-67 spilled registers at K = 3-4; this form: 92)
+        // (all chunks of a pass requested before the per-pixel part, fully unrolled: 5-67 spilled registers at K = 3-4; this form: 92)
         for (int j0 = 0; j0 < nv; j0 += JR) {
             float v[JR][N];
 #pragma unroll
             for (int u = 0; u < JR; ++u)
-                Vec<bf16_t>::load(x + (m0 + (j0 + u < nv ? j0 + u : nv - 1)) * C + (long)sub * N, v[u]);
+                Vec<T>::load(x + (m0 + (j0 + u < nv ? j0 + u : nv - 1)) * C + (long)sub * N, v[u]);
 #pragma unroll
             for (int u = 0; u < JR; ++u) {
                 const bool valid = j0 + u < nv;
@@ -1965,16 +1950,16 @@ __global__ __launch_bounds__(256, (K <= 4 ? 4 : 2)) void head_bn_backward_kernel
     for (int i = threadIdx.x; i < C * K + K + 1; i += 256) partial[(long)blockIdx.x * (C * K + K + 1) + i] = red[i];
 }
 
-template <int K>
-__global__ __launch_bounds__(256, (K <= 4 ? 4 : 2)) void head_bn_bwd_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ probs,
+template <typename T, int K>
+__global__ __launch_bounds__(256, (K <= 4 ? 4 : 2)) void head_bn_bwd_apply_kernel(const T* __restrict__ x, const float* __restrict__ probs,
                                                                    const uint8_t* __restrict__ y, const float* __restrict__ sw, long M,
                                                                    long ppi, const float* __restrict__ Wh, int ldw,
                                                                    const float* __restrict__ Tsum, const float* __restrict__ dbh,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                    float* dgamma, float* dbeta, float* dWh, float* coeffs,
-                                                                   bf16_t* __restrict__ dz) {
-    constexpr int N = 8, G = 8, C = 64, JR = 2;
+                                                                   T* __restrict__ dz) {
+    constexpr int N = Vec<T>::N, G = 64 / N, C = 64, JR = 2;
     __shared__ __attribute__((aligned(16))) float coef[3][64];
     __shared__ float w[C * K];
     if (threadIdx.x < 64) {
@@ -2021,7 +2006,7 @@ __global__ __launch_bounds__(256, (K <= 4 ? 4 : 2)) void head_bn_bwd_apply_kerne
             float v[JR][N];
 #pragma unroll
             for (int u = 0; u < JR; ++u)
-                Vec<bf16_t>::load(x + (m0 + (j0 + u < nv ? j0 + u : nv - 1)) * C + (long)sub * N, v[u]);
+                Vec<T>::load(x + (m0 + (j0 + u < nv ? j0 + u : nv - 1)) * C + (long)sub * N, v[u]);
 #pragma unroll
             for (int u = 0; u < JR; ++u) {
                 const bool valid = j0 + u < nv;
@@ -2036,31 +2021,51 @@ __global__ __launch_bounds__(256, (K <= 4 ? 4 : 2)) void head_bn_bwd_apply_kerne
                     for (int k = 0; k < K; ++k) dn += dj[k] * wr[i][k];
                     o[i] = v[u][i] > 0.f ? bn_bwd_affine(dn, v[u][i], k1[i], k2[i], k3[i]) : 0.f;
                 }
-                if (valid) Vec<bf16_t>::store(dz + (m0 + j0 + u) * C + (long)sub * N, o);
+                if (valid) Vec<T>::store(dz + (m0 + j0 + u) * C + (long)sub * N, o);
             }
         }
     }
 }
 
-bool head_train_fused_shape_ok(int dtype, int C, int K) { return dtype == MPU_BF16 && C == 64 && K >= 1 && K <= 8; }
+// bf16 storage: 8 lanes per pixel, 1..8 classes; f32 storage (dtype "bf16x3"): 16 lanes per pixel, the reduce-scatter needs 16 * K <= 64
+bool head_train_fused_shape_ok(int dtype, int C, int K) {
+    return C == 64 && K >= 1 && ((dtype == MPU_BF16 && K <= 8) || (dtype == MPU_F32 && K <= 4));
+}
+#define MPU_HEAD_DISPATCH_K4(K_, CALL)                                      \
+    switch (K_) {                                                           \
+        case 1: { constexpr int KK = 1; CALL; } break;                      \
+        case 2: { constexpr int KK = 2; CALL; } break;                      \
+        case 3: { constexpr int KK = 3; CALL; } break;                      \
+        case 4: { constexpr int KK = 4; CALL; } break;                      \
+        default: return fail(MPU_EUNSUPPORTED, "%s", "fused training head in f32 storage: 1..4 classes"); \
+    }
 
-int launch_head_bn_forward(const void* x, long M, const long long* acc, const float* acc_scale, const float* gamma, const float* beta,
+int launch_head_bn_forward(int dtype, const void* x, long M, const long long* acc, const float* acc_scale, const float* gamma, const float* beta,
                            float* mmean, float* mvar, float* mean, float* invstd, float* scale, float* shift, float eps, float momentum,
                            int K, const float* Wh, int ldw, const float* bh, int softmax, float* out, hipStream_t st) {
     long rb = (M + 255) / 256; if (rb > 4096) rb = 4096;
     const float inv0 = 1.f / acc_scale[0], inv1 = 1.f / acc_scale[1];
-    MPU_HEAD_DISPATCH_K(K, (head_bn_forward_kernel<KK><<<(unsigned)rb, 256, 0, st>>>((const bf16_t*)x, M, acc, inv0, inv1, gamma, beta, mmean, mvar,
-                                                                                     mean, invstd, scale, shift, eps, momentum, Wh, ldw, bh, softmax, out)))
+    if (dtype == MPU_BF16) {
+        MPU_HEAD_DISPATCH_K(K, (head_bn_forward_kernel<bf16_t, KK><<<(unsigned)rb, 256, 0, st>>>((const bf16_t*)x, M, acc, inv0, inv1, gamma, beta, mmean, mvar,
+                                                                                                 mean, invstd, scale, shift, eps, momentum, Wh, ldw, bh, softmax, out)))
+    } else {
+        MPU_HEAD_DISPATCH_K4(K, (head_bn_forward_kernel<float, KK><<<(unsigned)rb, 256, 0, st>>>((const float*)x, M, acc, inv0, inv1, gamma, beta, mmean, mvar,
+                                                                                                 mean, invstd, scale, shift, eps, momentum, Wh, ldw, bh, softmax, out)))
+    }
     if (sched_log_on()) sched_note("bn_fold fwd C=64 rows=-1 pool=0 head=1 grid=%ld", rb);
     return launch_ok();
 }
 
 // T (-> tsum [64][K]), dbh, mean loss; the device step counter moves in the finalizer as in launch_head_backward
-int launch_head_bn_backward(const void* x, const float* probs, const uint8_t* y, const float* sw, long M, long ppi, int K,
+int launch_head_bn_backward(int dtype, const void* x, const float* probs, const uint8_t* y, const float* sw, long M, long ppi, int K,
                             const float* mean, const float* invstd, float* partial, float* tsum, float* dbh, float* loss,
                             hipStream_t st, long long* step_incr, float* loss_mean) {
     long blocks = (M + 255) / 256; if (blocks > HEAD_BWD_MAX_BLOCKS) blocks = HEAD_BWD_MAX_BLOCKS;
-    MPU_HEAD_DISPATCH_K(K, (head_bn_backward_kernel<KK><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)x, probs, y, sw, M, ppi, mean, invstd, partial, loss)))
+    if (dtype == MPU_BF16) {
+        MPU_HEAD_DISPATCH_K(K, (head_bn_backward_kernel<bf16_t, KK><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)x, probs, y, sw, M, ppi, mean, invstd, partial, loss)))
+    } else {
+        MPU_HEAD_DISPATCH_K4(K, (head_bn_backward_kernel<float, KK><<<(unsigned)blocks, 256, 0, st>>>((const float*)x, probs, y, sw, M, ppi, mean, invstd, partial, loss)))
+    }
     int rc = launch_ok();
     if (rc) return rc;
     head_bwd_finalize_kernel<<<cdiv(64 * K + K + 1, FIN_COLS), 256, 0, st>>>(partial, (int)blocks, 64, K, K, tsum, dbh, step_incr, loss_mean,
@@ -2068,13 +2073,18 @@ int launch_head_bn_backward(const void* x, const float* probs, const uint8_t* y,
     return launch_ok();
 }
 
-int launch_head_bn_bwd_apply(const void* x, const float* probs, const uint8_t* y, const float* sw, long M, long ppi, int K,
+int launch_head_bn_bwd_apply(int dtype, const void* x, const float* probs, const uint8_t* y, const float* sw, long M, long ppi, int K,
                              const float* Wh, int ldw, const float* tsum, const float* dbh, const float* gamma, const float* beta,
                              const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dWh, float* coeffs, void* dz,
                              hipStream_t st) {
     long blocks = (M + 255) / 256; if (blocks > 4096) blocks = 4096;
-    MPU_HEAD_DISPATCH_K(K, (head_bn_bwd_apply_kernel<KK><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)x, probs, y, sw, M, ppi, Wh, ldw, tsum, dbh, gamma,
-                                                                                          beta, mean, invstd, dgamma, dbeta, dWh, coeffs, (bf16_t*)dz)))
+    if (dtype == MPU_BF16) {
+        MPU_HEAD_DISPATCH_K(K, (head_bn_bwd_apply_kernel<bf16_t, KK><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)x, probs, y, sw, M, ppi, Wh, ldw, tsum, dbh, gamma,
+                                                                                                       beta, mean, invstd, dgamma, dbeta, dWh, coeffs, (bf16_t*)dz)))
+    } else {
+        MPU_HEAD_DISPATCH_K4(K, (head_bn_bwd_apply_kernel<float, KK><<<(unsigned)blocks, 256, 0, st>>>((const float*)x, probs, y, sw, M, ppi, Wh, ldw, tsum, dbh, gamma,
+                                                                                                       beta, mean, invstd, dgamma, dbeta, dWh, coeffs, (float*)dz)))
+    }
     if (sched_log_on()) sched_note("bn_fold bwd C=64 rows=-1 head=1 grid=%ld", blocks);
     return launch_ok();
 }

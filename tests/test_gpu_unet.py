@@ -717,7 +717,7 @@ from multiplanarunet_amd import _lib
 lib = _lib.load()
 quiet = lambda *a, **k: None
 B, K, D, dim = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
-m = UNet(n_classes=K, dim=dim, n_channels=1, depth=D, complexity_factor=1, dtype="bf16", logger=quiet, flatten_output=True, seed=5)
+m = UNet(n_classes=K, dim=dim, n_channels=1, depth=D, complexity_factor=1, dtype=sys.argv[6], logger=quiet, flatten_output=True, seed=5)
 w = m.get_weights_dict()
 rng = np.random.RandomState(3)
 for k in w:                                        # gammas of both signs, non-trivial betas
@@ -744,21 +744,23 @@ np.savez(sys.argv[1], probs=probs.float().cpu().numpy(), loss=loss.float().cpu()
 """
 
 
-@pytest.mark.parametrize("B,K,D,dim", [(3, 3, 2, 48), (2, 4, 1, 64), (16, 3, 4, 128)])
-def test_training_head_without_the_last_post_bn_tensor_equals_the_unfused_chain(tmp_path, B, K, D, dim):
+@pytest.mark.parametrize("B,K,D,dim,dtype", [(3, 3, 2, 48, "bf16"), (2, 4, 1, 64, "bf16"), (16, 3, 4, 128, "bf16"), (3, 3, 2, 48, "bf16x3"),
+                                             (2, 4, 1, 64, "bf16x3")])
+def test_training_head_without_the_last_post_bn_tensor_equals_the_unfused_chain(tmp_path, B, K, D, dim, dtype):
     """Round 6: in the bf16 train step the last block's BatchNorm apply, the head forward, the head backward, the column reduction
     of the BatchNorm-backward sums and the BatchNorm backward (five passes, two 33-MB intermediates at configs[1]) run as three
     passes over the last conv's output (head_bn_forward / head_bn_backward / head_bn_bwd_apply; MPU_HEAD_TRAIN_FUSED=0 restores
     the chain). The forward is the same arithmetic: probabilities, per-pixel loss and moving statistics are the SAME BITS. The
     backward keeps the head's data gradient in fp32 registers instead of a bf16 tensor and forms the head weight gradient from
     the unrounded BatchNorm output, so gradients agree to bf16 rounding: the head's and the last BatchNorm's own tensors tightly,
-    the rest of the network through its (chaotic) amplification. Shapes: ragged pixel counts / 4 classes / the configs[1] network."""
+    the rest of the network through its (chaotic) amplification. Shapes: ragged pixel counts / 4 classes / the configs[1] network;
+    dtype "bf16x3" (f32 storage: 16 lanes of 4 channels per pixel) takes the same three passes."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
     for tag, env in (("fused", {}), ("chain", {"MPU_HEAD_TRAIN_FUSED": "0"})):
         f = str(tmp_path / (tag + ".npz"))
-        r = subprocess.run([sys.executable, "-c", _HEAD_FUSED_SCRIPT % root, f, str(B), str(K), str(D), str(dim)],
+        r = subprocess.run([sys.executable, "-c", _HEAD_FUSED_SCRIPT % root, f, str(B), str(K), str(D), str(dim), dtype],
                            env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         line = [l for l in r.stdout.splitlines() if l.startswith("HEAD ")][0]
@@ -776,8 +778,8 @@ def test_training_head_without_the_last_post_bn_tensor_equals_the_unfused_chain(
     ga = np.concatenate([a[k].ravel() for k in sorted(allr)]).astype(np.float64)
     gb = np.concatenate([b[k].ravel() for k in sorted(allr)]).astype(np.float64)
     cos = float(ga @ gb / np.sqrt((ga @ ga) * (gb @ gb)))
-    print("fused head vs chain (B=%d K=%d depth=%d dim=%d): head / last-BN tensors rel-L2 %s; all gradients cosine %.5f, worst tensor %.3g"
-          % (B, K, D, dim, {k[2:]: "%.2e" % v for k, v in tight.items()}, cos, max(allr.values())))
+    print("fused head vs chain (%s B=%d K=%d depth=%d dim=%d): head / last-BN tensors rel-L2 %s; all gradients cosine %.5f, worst tensor %.3g"
+          % (dtype, B, K, D, dim, {k[2:]: "%.2e" % v for k, v in tight.items()}, cos, max(allr.values())))
     assert len(tight) >= 4, list(tight)
     for k, v in tight.items():
         assert v <= 1e-2, (k, v)
