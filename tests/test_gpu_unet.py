@@ -745,7 +745,7 @@ np.savez(sys.argv[1], probs=probs.float().cpu().numpy(), loss=loss.float().cpu()
 
 
 @pytest.mark.parametrize("B,K,D,dim,dtype", [(3, 3, 2, 48, "bf16"), (2, 4, 1, 64, "bf16"), (16, 3, 4, 128, "bf16"), (3, 3, 2, 48, "bf16x3"),
-                                             (2, 4, 1, 64, "bf16x3")])
+                                             (2, 4, 1, 64, "bf16x3"), (2, 8, 1, 32, "bf16"), (1, 2, 1, 40, "bf16"), (2, 2, 1, 32, "bf16x3")])
 def test_training_head_without_the_last_post_bn_tensor_equals_the_unfused_chain(tmp_path, B, K, D, dim, dtype):
     """Round 6: in the bf16 train step the last block's BatchNorm apply, the head forward, the head backward, the column reduction
     of the BatchNorm-backward sums and the BatchNorm backward (five passes, two 33-MB intermediates at configs[1]) run as three
