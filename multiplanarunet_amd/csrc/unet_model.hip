@@ -678,11 +678,11 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
                                     r.grads + b.g, r.grads + b.b, r.grads + m->head_w, (float*)r.at(P.coeffs),
                                     r.at(P.dz[m->up_c(D - 1, 2)]), r.st));
     } else {
-    RC(launch_head_backward(dt, last, (const float*)r.at(P.probs), d_y, d_sw, M0, (long)m->cfg.H * m->cfg.W,
-                            m->head_C, m->cfg.n_classes, r.params + m->head_w, m->cfg.n_classes,
-                            (float*)r.at(P.partial), gA, r.grads + m->head_w, r.grads + m->head_b, d_loss, r.st,
-                            (opt && opt->step && tail_overlap_wanted(r)) ? opt->step : nullptr, (float*)r.at(P.loss_mean)));
-    tap_aux(r, 7, -1, 0, m->head_C, m->cfg.n_classes, last, r.at(P.probs), d_y, d_sw, gA, m->head_w, m->head_b);
+        RC(launch_head_backward(dt, last, (const float*)r.at(P.probs), d_y, d_sw, M0, (long)m->cfg.H * m->cfg.W,
+                                m->head_C, m->cfg.n_classes, r.params + m->head_w, m->cfg.n_classes,
+                                (float*)r.at(P.partial), gA, r.grads + m->head_w, r.grads + m->head_b, d_loss, r.st,
+                                (opt && opt->step && tail_overlap_wanted(r)) ? opt->step : nullptr, (float*)r.at(P.loss_mean)));
+        tap_aux(r, 7, -1, 0, m->head_C, m->cfg.n_classes, last, r.at(P.probs), d_y, d_sw, gA, m->head_w, m->head_b);
     }
     if (m->x3) RC(x3_presplit_inputs(r));
     int point = 0;
@@ -746,11 +746,11 @@ int run_backward(const Run& r, const uint8_t* d_y, const float* d_sw, float* d_l
             if (fused_pool < 0) return fused_pool;
         }
         if (!fused_pool) {
-        RC(launch_maxpool_bwd_add_stats(dt, r.at(P.n[i]), r.at(P.dskip[i]), gB, r.B, H, W, m->F[i], gA, r.at(P.c2[i]),
-                                        r.stat(eb, 0), r.stat(eb, 1), (float*)r.at(P.partial), P.partial_floats, &bwd_rows,
-                                        r.st, (r.acc_mode && !(eb.C & 63)) ? r.acc_b(eb) : nullptr, BN_ACC_B));
-        tap_aux(r, 5, m->enc_bn(i), i, m->F[i], m->F[i], r.at(P.n[i]), r.at(P.dskip[i]), gB, nullptr, gA, 0, 0);
-        RC(bn_bwd(r, eb, gA, r.at(P.c2[i]), i, DZ(i2), bwd_rows));
+            RC(launch_maxpool_bwd_add_stats(dt, r.at(P.n[i]), r.at(P.dskip[i]), gB, r.B, H, W, m->F[i], gA, r.at(P.c2[i]),
+                                            r.stat(eb, 0), r.stat(eb, 1), (float*)r.at(P.partial), P.partial_floats, &bwd_rows,
+                                            r.st, (r.acc_mode && !(eb.C & 63)) ? r.acc_b(eb) : nullptr, BN_ACC_B));
+            tap_aux(r, 5, m->enc_bn(i), i, m->F[i], m->F[i], r.at(P.n[i]), r.at(P.dskip[i]), gB, nullptr, gA, 0, 0);
+            RC(bn_bwd(r, eb, gA, r.at(P.c2[i]), i, DZ(i2), bwd_rows));
         }
         RC(conv_wgrad(r, c2, r.at(P.c1[i]), m->F[i], nullptr, 0, DZ(i2), i));
         RC(conv_dgrad(r, c2, DZ(i2), r.at(P.c1[i]), DZ(i1), i, 0, m->F[i]));
