@@ -236,7 +236,9 @@ int mpu_unet_forward(const mpu_unet* m, int32_t batch, const float* d_x, const f
  *   d_loss f32 [B,H*W] per-pixel weighted loss or NULL.
  * Must follow mpu_unet_forward(training=1) on the same workspace -- ONE backward pass per training forward: the forward's first
  * launch zeroes the fixed-point BatchNorm accumulators of both passes (round 6, bf16 / bf16x3), a second backward pass on the same
- * forward would add to the first one's sums. */
+ * forward would add to the first one's sums. The handle remembers which form of the head the last training forward ran (with a
+ * 64-channel last block and a softmax head it leaves NO post-BatchNorm tensor of that block in the workspace; the backward pass
+ * then recomputes it): forward and backward of one step run on the same handle, not interleaved with another step's. */
 int mpu_unet_backward(const mpu_unet* m, int32_t batch, const uint8_t* d_y,
                       const float* d_sample_weight, const float* d_params, const void* d_packed,
                       float* d_bn_state, void* d_workspace, float* d_grads, float* d_loss,

@@ -77,7 +77,7 @@ if tr:
         step_gb / steps, tr["classes"]["conv_igemm"]["hbm_bytes_per_launch"] / 1e6, tr["classes"]["wgrad_igemm"]["hbm_bytes_per_launch"] / 1e6)
 cb = line["cpu_baseline"]
 N = [
-    ("train step, configs[1] (headline)", "**%.4f ms = %.0f slices/s** (launch form: %s; 2.21–2.32 ms across the boxes of the pool with the last build: `r06e` is a fast one, `r06f` a slow one; 2.27–2.42 before the last session)" % (line["ms_per_step"], line["value"], line["config"].get("launch")), "`%s_bench_line.json`" % tag),
+    ("train step, configs[1] (headline)", "**%.4f ms = %.0f slices/s** (launch form: %s; 2.21–2.32 ms across the boxes of the pool with the last build: `r06e` is a fast one, `r06g` a slow one; 2.27–2.42 before the last session)" % (line["ms_per_step"], line["value"], line["config"].get("launch")), "`%s_bench_line.json`" % tag),
     ("conv family (`roofline`)", "%.0f TFLOP/s = **%.3f** of peak, %.1f µs per launch, %.3f ms per step" % (rf["achieved"], rf["frac"], rf["avg_launch_us"], rf["kernel_ms_per_step"]), "same"),
     ("weight gradients (`wgrad`)", "%.0f TFLOP/s = %.3f of peak, %.3f ms per step" % (wg["achieved"], wg["frac"], wg["kernel_ms_per_step"]), "same"),
     ("HBM traffic of a step (PMC)", traffic, "`%s_hbm_traffic_pmc.json`" % tag),
